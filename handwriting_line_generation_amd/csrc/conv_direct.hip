@@ -1,0 +1,334 @@
+// Direct (non-MFMA) convolution kernels for the single-channel ends of the networks:
+//   c1  : C == 1 input (first layers: D 7x7, encoders 5x5, HWR 3x3) and, with flipped taps, the data gradient
+//         of K == 1 heads
+//   to1 : K <= 2 outputs (D heads, spacer head, decoder/generator output convs) and the data gradient of first layers
+//   wgrad_direct : weight gradients of both
+// These are HBM/L2-bound reductions; a GEMM formulation would waste 15/16 of the MFMA work.
+#include "hwg_common.h"
+
+namespace {
+
+struct DirK {
+  const float* x;
+  const float* w;
+  const float* bias;
+  float* y;
+  int N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, P, Q;
+  int accumulate;
+};
+
+// ---- C == 1 : each thread computes 4 consecutive q pixels x 4 channels; weights [R*S][K] staged in LDS ----
+__global__ __launch_bounds__(256) void conv_c1_kernel(DirK a, int KG, int PG) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [R*S][KG*4]
+  const int K4 = KG * 4;
+  for (int i = threadIdx.x; i < a.R * a.S * K4; i += 256) {
+    const int tap = i / K4, k = i % K4;
+    wsm[i] = (k < a.K) ? a.w[tap * a.K + k] : 0.f;
+  }
+  __syncthreads();
+  const int kg = threadIdx.x % KG;
+  const int pg = threadIdx.x / KG;
+  if (pg >= PG) return;
+  const int qtiles = (a.Q + PG * 4 - 1) / (PG * 4);
+  const int bid = blockIdx.x;
+  const int qt = bid % qtiles;
+  const int t = bid / qtiles;
+  const int p = t % a.P;
+  const int n = t / a.P;
+  const int q0 = (qt * PG + pg) * 4;
+  if (q0 >= a.Q) return;
+  float4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* xn = a.x + (long long)n * a.H * a.W;
+  for (int r = 0; r < a.R; ++r) {
+    const int ih = p * a.sh - a.ph + r * a.dh;
+    if (ih < 0 || ih >= a.H) continue;
+    const float* xr = xn + (long long)ih * a.W;
+    for (int s = 0; s < a.S; ++s) {
+      const float4 wv = *reinterpret_cast<const float4*>(wsm + (r * a.S + s) * K4 + kg * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int iw = (q0 + j) * a.sw - a.pw + s * a.dw;
+        const float xv = (iw >= 0 && iw < a.W) ? xr[iw] : 0.f;
+        acc[j].x += xv * wv.x; acc[j].y += xv * wv.y; acc[j].z += xv * wv.z; acc[j].w += xv * wv.w;
+      }
+    }
+  }
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int k0 = kg * 4;
+  if (a.bias) {
+    if (k0 + 0 < a.K) bv.x = a.bias[k0 + 0];
+    if (k0 + 1 < a.K) bv.y = a.bias[k0 + 1];
+    if (k0 + 2 < a.K) bv.z = a.bias[k0 + 2];
+    if (k0 + 3 < a.K) bv.w = a.bias[k0 + 3];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = q0 + j;
+    if (q >= a.Q) break;
+    float* yo = a.y + (((long long)n * a.P + p) * a.Q + q) * a.K + k0;
+    float v[4] = {acc[j].x + bv.x, acc[j].y + bv.y, acc[j].z + bv.z, acc[j].w + bv.w};
+    if (k0 + 3 < a.K && (a.K & 3) == 0) {
+      float4 o = make_float4(v[0], v[1], v[2], v[3]);
+      if (a.accumulate) { const float4 old = *reinterpret_cast<float4*>(yo); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+      *reinterpret_cast<float4*>(yo) = o;
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (k0 + e < a.K) yo[e] = a.accumulate ? yo[e] + v[e] : v[e];
+    }
+  }
+}
+
+// ---- K <= 2 : one wave per output pixel, lanes sweep (tap, channel/4), wave reduction ----
+__global__ __launch_bounds__(256) void conv_to1_kernel(DirK a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * 256) >> 6;
+  const int C4 = a.C >> 2;
+  const int E = a.R * a.S * C4;
+  const long long M = (long long)a.N * a.P * a.Q;
+  for (long long m = wave; m < M; m += nwaves) {
+    const int q = (int)(m % a.Q);
+    const long long t = m / a.Q;
+    const int p = (int)(t % a.P);
+    const int n = (int)(t / a.P);
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int e = lane; e < E; e += 64) {
+      const int tap = e / C4, c4 = e % C4;
+      const int r = tap / a.S, s = tap % a.S;
+      const int ih = p * a.sh - a.ph + r * a.dh;
+      const int iw = q * a.sw - a.pw + s * a.dw;
+      if (ih < 0 || ih >= a.H || iw < 0 || iw >= a.W) continue;
+      const float4 xv = *reinterpret_cast<const float4*>(a.x + (((long long)n * a.H + ih) * a.W + iw) * a.C + c4 * 4);
+      const float4 w0 = *reinterpret_cast<const float4*>(a.w + ((long long)tap * a.K + 0) * a.C + c4 * 4);
+      acc0 += xv.x * w0.x + xv.y * w0.y + xv.z * w0.z + xv.w * w0.w;
+      if (a.K > 1) {
+        const float4 w1 = *reinterpret_cast<const float4*>(a.w + ((long long)tap * a.K + 1) * a.C + c4 * 4);
+        acc1 += xv.x * w1.x + xv.y * w1.y + xv.z * w1.z + xv.w * w1.w;
+      }
+    }
+    acc0 = wave_sum(acc0);
+    if (a.K > 1) acc1 = wave_sum(acc1);
+    if (lane == 0) {
+      float v0 = acc0 + (a.bias ? a.bias[0] : 0.f);
+      float* yo = a.y + m * a.K;
+      yo[0] = a.accumulate ? yo[0] + v0 : v0;
+      if (a.K > 1) {
+        float v1 = acc1 + (a.bias ? a.bias[1] : 0.f);
+        yo[1] = a.accumulate ? yo[1] + v1 : v1;
+      }
+    }
+  }
+}
+
+// ---- direct weight gradient: one side of the contraction has <= 2 channels ----
+// big_on_anchor != 0 : u is [M][K] with K large, v is single channel (C == 1):   part[blk][tap][k]      = sum_m u[m][k] * v[g(m,tap)]
+// big_on_anchor == 0 : u is [M][K<=2],          v is [.., C] with C large:        part[blk][tap][ko][c]  = sum_m u[m][ko] * v[g(m,tap)][c]
+struct WdK {
+  const float* u;
+  const float* v;
+  float* part;
+  int N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, P, Q;
+  int Mtot, chunk;
+  int G;     // channel groups of 4 on the big side
+  int TSL;   // tap slots
+  int PL;    // pixel lanes
+  int MAXT;  // taps per thread
+};
+constexpr int WD_MAXT = 8;
+
+template <int BIG_ON_ANCHOR>
+__global__ __launch_bounds__(256) void wgrad_direct_kernel(WdK a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [PL][TSL*MAXT][NACC][G*4]
+  const int tid = threadIdx.x;
+  const int g = tid % a.G;
+  const int slot = tid / a.G;
+  const int tsl = slot % a.TSL;
+  const int pl = slot / a.TSL;
+  const bool active = pl < a.PL;
+  const int RS = a.R * a.S;
+  constexpr int NACC = BIG_ON_ANCHOR ? 1 : 2;
+  float4 acc[WD_MAXT][NACC];
+#pragma unroll
+  for (int t = 0; t < WD_MAXT; ++t)
+#pragma unroll
+    for (int e = 0; e < NACC; ++e) acc[t][e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int pb = blockIdx.x * a.chunk;
+  const int pe = min(pb + a.chunk, a.Mtot);
+  if (active) {
+    for (int m = pb + pl; m < pe; m += a.PL) {
+      const int q = m % a.Q;
+      const int tt = m / a.Q;
+      const int p = tt % a.P;
+      const int n = tt / a.P;
+      float4 ub = make_float4(0.f, 0.f, 0.f, 0.f);
+      float us0 = 0.f, us1 = 0.f;
+      if (BIG_ON_ANCHOR) {
+        ub = *reinterpret_cast<const float4*>(a.u + (long long)m * a.K + g * 4);
+      } else {
+        us0 = a.u[(long long)m * a.K];
+        if (a.K > 1) us1 = a.u[(long long)m * a.K + 1];
+      }
+#pragma unroll
+      for (int t = 0; t < WD_MAXT; ++t) {
+        const int tap = tsl + t * a.TSL;
+        if (t >= a.MAXT || tap >= RS) break;
+        const int r = tap / a.S, s = tap % a.S;
+        const int ih = p * a.sh - a.ph + r * a.dh;
+        const int iw = q * a.sw - a.pw + s * a.dw;
+        if (ih < 0 || ih >= a.H || iw < 0 || iw >= a.W) continue;
+        const long long vo = (((long long)n * a.H + ih) * a.W + iw) * a.C;
+        if (BIG_ON_ANCHOR) {
+          const float xv = a.v[vo];
+          acc[t][0].x += ub.x * xv; acc[t][0].y += ub.y * xv; acc[t][0].z += ub.z * xv; acc[t][0].w += ub.w * xv;
+        } else {
+          const float4 vv = *reinterpret_cast<const float4*>(a.v + vo + g * 4);
+          acc[t][0].x += us0 * vv.x; acc[t][0].y += us0 * vv.y; acc[t][0].z += us0 * vv.z; acc[t][0].w += us0 * vv.w;
+          if (NACC > 1) {
+            acc[t][NACC - 1].x += us1 * vv.x; acc[t][NACC - 1].y += us1 * vv.y;
+            acc[t][NACC - 1].z += us1 * vv.z; acc[t][NACC - 1].w += us1 * vv.w;
+          }
+        }
+      }
+    }
+  }
+  // reduce pixel lanes through LDS, then write part[blk][tap][ko][ch]
+  const int G4 = a.G * 4;
+  const int per_pl = a.TSL * a.MAXT * NACC * G4;
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < WD_MAXT; ++t) {
+      if (t >= a.MAXT) break;
+#pragma unroll
+      for (int e = 0; e < NACC; ++e)
+        *reinterpret_cast<float4*>(red + pl * per_pl + (((tsl * a.MAXT + t) * NACC + e) * a.G + g) * 4) = acc[t][e];
+    }
+  }
+  __syncthreads();
+  const int nko = BIG_ON_ANCHOR ? 1 : a.K;
+  const int nch = BIG_ON_ANCHOR ? a.K : a.C;  // big-side channel count (== G*4)
+  float* pout = a.part + (long long)blockIdx.x * RS * nko * nch;
+  for (int i = tid; i < RS * nko * nch; i += 256) {
+    const int ch = i % nch;
+    const int t2 = i / nch;
+    const int ko = t2 % nko;
+    const int tap = t2 / nko;
+    const int ts = tap % a.TSL, tt = tap / a.TSL;
+    float sum = 0.f;
+    for (int l = 0; l < a.PL; ++l) sum += red[l * per_pl + ((ts * a.MAXT + tt) * NACC + ko) * G4 + ch];
+    pout[i] = sum;
+  }
+}
+
+// same final reduction as the MFMA path (duplicated signature; defined in conv_mfma.hip's TU would need export)
+__global__ void wgrad_direct_reduce_kernel(const float* part, float* dw, int nblk, int RS, int S, int K, int C,
+                                           long long sa, long long sb, long long sr, long long ss, int accumulate) {
+  const long long total = (long long)RS * K * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long t = i / C;
+    const int k = (int)(t % K);
+    const int tap = (int)(t / K);
+    float sum = 0.f;
+    for (int b = 0; b < nblk; ++b) sum += part[(long long)b * total + i];
+    const long long o = k * sa + c * sb + (tap / S) * sr + (tap % S) * ss;
+    dw[o] = accumulate ? dw[o] + sum : sum;
+  }
+}
+
+struct WdPlan { int big_on_anchor, G, TSL, PL, MAXT, chunk, nblk; size_t smem; };
+bool plan_wd(const hwg_conv_desc* d, WdPlan* p) {
+  const int RS = d->R * d->S;
+  p->big_on_anchor = (d->K > 2) ? 1 : 0;
+  const int bigc = p->big_on_anchor ? d->K : d->C;
+  if (bigc % 4 != 0 || bigc > 1024) return false;
+  if (p->big_on_anchor && d->C != 1) return false;
+  p->G = bigc / 4;
+  const int slots = 256 / p->G;
+  if (slots < 1) return false;
+  p->TSL = slots < RS ? slots : RS;
+  p->PL = slots / p->TSL;
+  p->MAXT = (RS + p->TSL - 1) / p->TSL;
+  if (p->MAXT > WD_MAXT) return false;
+  const long long Mtot = (long long)d->N * d->P * d->Q;
+  long long nblk = (Mtot + 511) / 512;
+  if (nblk > 1024) nblk = 1024;
+  if (nblk < 1) nblk = 1;
+  long long chunk = (Mtot + nblk - 1) / nblk;
+  nblk = (Mtot + chunk - 1) / chunk;
+  p->chunk = (int)chunk;
+  p->nblk = (int)nblk;
+  const int NACC = p->big_on_anchor ? 1 : 2;
+  p->smem = (size_t)p->PL * p->TSL * p->MAXT * NACC * p->G * 4 * sizeof(float);
+  return p->smem <= 64 * 1024;
+}
+
+}  // namespace
+
+int hwg_conv_c1_fwd_impl(const hwg_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int accumulate, hipStream_t st) {
+  HWG_REQUIRE(d->C == 1, "conv_c1: C must be 1");
+  const int KG = (d->K + 3) / 4;
+  HWG_REQUIRE(KG <= 256, "conv_c1: K=%d too large", d->K);
+  const int PG = 256 / KG;
+  const size_t smem = (size_t)d->R * d->S * KG * 4 * sizeof(float);
+  HWG_REQUIRE(smem <= 64 * 1024, "conv_c1: weights do not fit LDS (%zu B)", smem);
+  DirK k;
+  k.x = x; k.w = w; k.bias = bias; k.y = y;
+  k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.R = d->R; k.S = d->S;
+  k.sh = d->stride_h; k.sw = d->stride_w; k.ph = d->pad_h; k.pw = d->pad_w; k.dh = d->dil_h; k.dw = d->dil_w;
+  k.P = d->P; k.Q = d->Q; k.accumulate = accumulate;
+  const int qtiles = hwg_cdiv(d->Q, PG * 4);
+  const long long blocks = (long long)d->N * d->P * qtiles;
+  hipLaunchKernelGGL(conv_c1_kernel, dim3((unsigned)blocks), dim3(256), smem, st, k, KG, PG);
+  HWG_LAUNCH_CHECK("conv_c1");
+  return HWG_OK;
+}
+
+int hwg_conv_to1_fwd_impl(const hwg_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int accumulate, hipStream_t st) {
+  HWG_REQUIRE(d->K <= 2, "conv_to1: K must be <= 2");
+  HWG_REQUIRE(d->C % 4 == 0, "conv_to1: C %% 4 != 0 (C=%d)", d->C);
+  DirK k;
+  k.x = x; k.w = w; k.bias = bias; k.y = y;
+  k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.R = d->R; k.S = d->S;
+  k.sh = d->stride_h; k.sw = d->stride_w; k.ph = d->pad_h; k.pw = d->pad_w; k.dh = d->dil_h; k.dw = d->dil_w;
+  k.P = d->P; k.Q = d->Q; k.accumulate = accumulate;
+  const long long M = (long long)d->N * d->P * d->Q;
+  long long blocks = (M + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(conv_to1_kernel, dim3((unsigned)blocks), dim3(256), 0, st, k);
+  HWG_LAUNCH_CHECK("conv_to1");
+  return HWG_OK;
+}
+
+size_t hwg_conv_wgrad_direct_workspace(const hwg_conv_desc* d) {
+  WdPlan p;
+  if (!plan_wd(d, &p)) return 0;
+  return (size_t)p.nblk * d->R * d->S * d->K * d->C * sizeof(float);
+}
+
+int hwg_conv_wgrad_direct_impl(const hwg_conv_desc* d, const float* u, const float* v, float* dw, long long sa, long long sb,
+                               long long sr, long long ss, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  WdPlan p;
+  HWG_REQUIRE(plan_wd(d, &p), "conv_wgrad(direct): unsupported shape K=%d C=%d R=%d S=%d", d->K, d->C, d->R, d->S);
+  const size_t need = hwg_conv_wgrad_direct_workspace(d);
+  if (!ws || ws_bytes < need) {
+    hwg_set_error("conv_wgrad(direct): workspace too small (%zu < %zu)", ws_bytes, need);
+    return HWG_ERR_WORKSPACE;
+  }
+  WdK k;
+  k.u = u; k.v = v; k.part = (float*)ws;
+  k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.R = d->R; k.S = d->S;
+  k.sh = d->stride_h; k.sw = d->stride_w; k.ph = d->pad_h; k.pw = d->pad_w; k.dh = d->dil_h; k.dw = d->dil_w;
+  k.P = d->P; k.Q = d->Q;
+  k.Mtot = d->N * d->P * d->Q;
+  k.chunk = p.chunk; k.G = p.G; k.TSL = p.TSL; k.PL = p.PL; k.MAXT = p.MAXT;
+  if (p.big_on_anchor) hipLaunchKernelGGL(wgrad_direct_kernel<1>, dim3(p.nblk), dim3(256), p.smem, st, k);
+  else hipLaunchKernelGGL(wgrad_direct_kernel<0>, dim3(p.nblk), dim3(256), p.smem, st, k);
+  HWG_LAUNCH_CHECK("conv_wgrad_direct");
+  const long long total = (long long)d->R * d->S * d->K * d->C;
+  hipLaunchKernelGGL(wgrad_direct_reduce_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, st, (const float*)ws, dw,
+                     p.nblk, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate);
+  HWG_LAUNCH_CHECK("conv_wgrad_direct_reduce");
+  return HWG_OK;
+}

@@ -1,0 +1,653 @@
+// Implicit-GEMM convolution on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   forward / data-gradient : conv_mfma_kernel   GEMM M = output pixels, N = out channels, K = taps x in channels
+//   weight gradient         : wgrad_mfma_kernel  GEMM M = anchor channels, N = gathered channels, K = pixels
+//
+// Activations are NHWC so a 16-byte global load fetches 4 consecutive input channels of one
+// pixel; tiles are staged through LDS ([row][k] with k fastest, row stride BK+4 floats which makes
+// ds_read_b128 fragment reads conflict free) and double buffered with register prefetch so that one
+// barrier per K step suffices. The K order inside a step is permuted identically for A and B so one
+// ds_read_b128 feeds four MFMAs (see the comment at the fragment reads).
+#include "hwg_common.h"
+
+namespace {
+
+struct ConvK {
+  const float* x;
+  const float* w;
+  const float* bias;
+  float* y;
+  int N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, P, Q;
+  int mode;        // 0: convolution gather, 1: fractionally strided (transposed, stride>1) by parity class
+  int accumulate;
+  int ntm;         // M tiles of the largest parity class
+  int ntm_pad;     // ntm rounded up to a multiple of 8 (XCD remap)
+};
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK a) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  static_assert(MI >= 1 && NI >= 1, "wave tile must be at least 32x32");
+  constexpr int LD = BK + 4;
+  constexpr int KC = BK / 4;
+  constexpr int A_F4 = BM * KC, B_F4 = BN * KC;
+  constexpr int A_IT = (A_F4 + 255) / 256, B_IT = (B_F4 + 255) / 256;
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LD];
+  float* As = smem;
+  float* Bs = smem + 2 * BM * LD;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+
+  // XCD-aware tile order: the dispatcher places block b on XCD b%8, give each XCD a contiguous run
+  // of M tiles so neighbouring tiles (shared halo rows, same weights) hit the same L2.
+  const int bid = blockIdx.x;
+  const int tile_m = (bid & 7) * (a.ntm_pad >> 3) + (bid >> 3);
+  if (tile_m >= a.ntm) return;
+  const int n0 = blockIdx.y * BN;
+
+  int cp = 0, cq = 0, Pc = a.P, Qc = a.Q;
+  int r0 = 0, s0 = 0, tr = 1, ts = 1, nr = a.R, ns = a.S;
+  int ah, bh, ch, aw, bw, cw;
+  if (a.mode == 0) {
+    ah = a.sh; bh = -a.ph; ch = a.dh;
+    aw = a.sw; bw = -a.pw; cw = a.dw;
+  } else {
+    const int cls = blockIdx.z;
+    cp = cls / a.sw; cq = cls % a.sw;
+    Pc = (a.P - cp + a.sh - 1) / a.sh;
+    Qc = (a.Q - cq + a.sw - 1) / a.sw;
+    r0 = (cp + a.ph) % a.sh; s0 = (cq + a.pw) % a.sw;
+    tr = a.sh; ts = a.sw;
+    nr = (a.R - r0 + a.sh - 1) / a.sh; if (nr < 0) nr = 0;
+    ns = (a.S - s0 + a.sw - 1) / a.sw; if (ns < 0) ns = 0;
+    ah = 1; bh = (cp + a.ph - r0) / a.sh; ch = -1;
+    aw = 1; bw = (cq + a.pw - s0) / a.sw; cw = -1;
+  }
+  if (Pc <= 0 || Qc <= 0) return;
+  const int Mc = a.N * Pc * Qc;
+  const int m0 = tile_m * BM;
+  if (m0 >= Mc) return;
+
+  // per-thread gather rows
+  int a_hb[A_IT], a_wb[A_IT], a_nb[A_IT], a_row[A_IT], a_chk[A_IT];
+  bool a_ok[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int f = tid + it * 256;
+    const int row = f / KC;
+    a_row[it] = row;
+    a_chk[it] = f % KC;
+    const int m = m0 + row;
+    const bool ok = (f < A_F4) && (m < Mc);
+    a_ok[it] = ok;
+    const int mm = ok ? m : 0;
+    const int qi = mm % Qc;
+    const int t = mm / Qc;
+    const int pi = t % Pc;
+    const int n = t / Pc;
+    a_hb[it] = ah * pi + bh;
+    a_wb[it] = aw * qi + bw;
+    a_nb[it] = n * a.H * a.W;
+  }
+  int b_row[B_IT], b_chk[B_IT];
+  bool b_ok[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int f = tid + it * 256;
+    b_row[it] = f / KC;
+    b_chk[it] = f % KC;
+    b_ok[it] = (f < B_F4) && (n0 + b_row[it] < a.K);
+  }
+
+  const int csteps = a.C / BK;
+  const int T = nr * ns * csteps;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  float4 ra[A_IT], rb[B_IT];
+  int jr = 0, js = 0, c0 = 0;  // coordinates of the tile being LOADED
+
+  auto load_tile = [&]() {
+    const int r = r0 + tr * jr, s = s0 + ts * js;
+    const int tap = r * a.S + s;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int ih = a_hb[it] + ch * jr;
+      const int iw = a_wb[it] + cw * js;
+      const bool v = a_ok[it] && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v) {
+        const long long off = ((long long)(a_nb[it] + ih * a.W + iw)) * a.C + c0 + a_chk[it] * 4;
+        val = *reinterpret_cast<const float4*>(a.x + off);
+      }
+      ra[it] = val;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b_ok[it]) {
+        const long long off = ((long long)tap * a.K + n0 + b_row[it]) * a.C + c0 + b_chk[it] * 4;
+        val = *reinterpret_cast<const float4*>(a.w + off);
+      }
+      rb[it] = val;
+    }
+    // advance to the next tile
+    c0 += BK;
+    if (c0 >= a.C) {
+      c0 = 0;
+      if (++js >= ns) { js = 0; ++jr; }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* Ab = As + buf * BM * LD;
+    float* Bb = Bs + buf * BN * LD;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it)
+      if (tid + it * 256 < A_F4) *reinterpret_cast<float4*>(Ab + a_row[it] * LD + a_chk[it] * 4) = ra[it];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+      if (tid + it * 256 < B_F4) *reinterpret_cast<float4*>(Bb + b_row[it] * LD + b_chk[it] * 4) = rb[it];
+  };
+
+  const int wm0 = (wid / WAVES_N) * WM;
+  const int wn0 = (wid % WAVES_N) * WN;
+  const int l31 = lane & 31;
+  const int lhi = lane >> 5;
+
+  if (T > 0) {
+    load_tile();
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < T) load_tile();  // global loads in flight during the MFMAs below
+    const float* Ab = As + buf * BM * LD;
+    const float* Bb = Bs + buf * BN * LD;
+#pragma unroll
+    for (int sg = 0; sg < BK / 8; ++sg) {
+      // lane (i = lane&31, half = lane>>5) reads 4 consecutive k values starting at 4*(2*sg+half); the j-th of them
+      // is the operand of the j-th MFMA of this group. A and B use the same mapping, so MFMA j contracts
+      // k = {8sg+j, 8sg+4+j}: a permutation of the K order, which the sum does not care about.
+      const int koff = 4 * (2 * sg + lhi);
+      float4 af[MI], bf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        af[mi] = *reinterpret_cast<const float4*>(Ab + (wm0 + mi * 32 + l31) * LD + koff);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        bf[ni] = *reinterpret_cast<const float4*>(Bb + (wn0 + ni * 32 + l31) * LD + koff);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const float av = j == 0 ? af[mi].x : j == 1 ? af[mi].y : j == 2 ? af[mi].z : af[mi].w;
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const float bv = j == 0 ? bf[ni].x : j == 1 ? bf[ni].y : j == 2 ? bf[ni].z : bf[ni].w;
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (t + 1 < T) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+      const int m = m0 + row;
+      if (m >= Mc) continue;
+      long long obase;
+      if (a.mode == 0) {
+        obase = (long long)m * a.K;
+      } else {
+        const int qi = m % Qc;
+        const int t2 = m / Qc;
+        const int pi = t2 % Pc;
+        const int n = t2 / Pc;
+        obase = (((long long)n * a.P + (cp + a.sh * pi)) * a.Q + (cq + a.sw * qi)) * a.K;
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int col = n0 + wn0 + ni * 32 + l31;
+        if (col < a.K) {
+          float v = acc[mi][ni][e];
+          if (a.bias) v += a.bias[col];
+          if (a.accumulate) v += a.y[obase + col];
+          a.y[obase + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct WgK {
+  const float* u;  // anchor  [Mtot][K]
+  const float* v;  // gathered [N,H,W,C]
+  float* part;     // [nsplit][R*S][K][C]
+  int N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, P, Q;
+  int Mtot, chunk, tiles_v;
+};
+
+template <int BMU, int BNV, int BKP, int WAVES_M, int WAVES_N, int WAVES_K>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgK a) {
+  static_assert(WAVES_M * WAVES_N * WAVES_K == 4, "4 waves per workgroup");
+  constexpr int WM = BMU / WAVES_M, WN = BNV / WAVES_N;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int UC = BMU / 4, VC = BNV / 4;
+  constexpr int U_F4 = BKP * UC, V_F4 = BKP * VC;
+  constexpr int U_IT = (U_F4 + 255) / 256, V_IT = (V_F4 + 255) / 256;
+  constexpr int TILE = BKP * (BMU + BNV);
+  constexpr int RED = (WAVES_K > 1) ? WAVES_K * MI * NI * 16 * 64 : 0;
+  constexpr int SM = (2 * TILE > RED) ? 2 * TILE : RED;
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  float* Us = smem;              // [2][BKP][BMU]
+  float* Vs = smem + 2 * BKP * BMU;  // [2][BKP][BNV]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tap = blockIdx.z;
+  const int r = tap / a.S, s = tap % a.S;
+  const int tu = blockIdx.y / a.tiles_v, tv = blockIdx.y % a.tiles_v;
+  const int k0 = tu * BMU, c0 = tv * BNV;
+  const int pb = blockIdx.x * a.chunk;
+  const int pe = min(pb + a.chunk, a.Mtot);
+
+  int u_kp[U_IT], u_c4[U_IT];
+  bool u_ok[U_IT];
+#pragma unroll
+  for (int it = 0; it < U_IT; ++it) {
+    const int f = tid + it * 256;
+    u_kp[it] = f / UC;
+    u_c4[it] = f % UC;
+    u_ok[it] = (f < U_F4) && (k0 + u_c4[it] * 4 < a.K);
+  }
+  int v_kp[V_IT], v_c4[V_IT];
+  bool v_ok[V_IT];
+#pragma unroll
+  for (int it = 0; it < V_IT; ++it) {
+    const int f = tid + it * 256;
+    v_kp[it] = f / VC;
+    v_c4[it] = f % VC;
+    v_ok[it] = (f < V_F4) && (c0 + v_c4[it] * 4 < a.C);
+  }
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  float4 ru[U_IT], rv[V_IT];
+  int pbase = pb;  // first pixel of the tile being loaded
+  auto load_tile = [&]() {
+#pragma unroll
+    for (int it = 0; it < U_IT; ++it) {
+      const int m = pbase + u_kp[it];
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (u_ok[it] && m < pe) val = *reinterpret_cast<const float4*>(a.u + (long long)m * a.K + k0 + u_c4[it] * 4);
+      ru[it] = val;
+    }
+#pragma unroll
+    for (int it = 0; it < V_IT; ++it) {
+      const int m = pbase + v_kp[it];
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v_ok[it] && m < pe) {
+        const int q = m % a.Q;
+        const int t = m / a.Q;
+        const int p = t % a.P;
+        const int n = t / a.P;
+        const int ih = p * a.sh - a.ph + r * a.dh;
+        const int iw = q * a.sw - a.pw + s * a.dw;
+        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+          val = *reinterpret_cast<const float4*>(a.v + (((long long)n * a.H + ih) * a.W + iw) * a.C + c0 + v_c4[it] * 4);
+      }
+      rv[it] = val;
+    }
+    pbase += BKP;
+  };
+  auto store_tile = [&](int buf) {
+    float* Ub = Us + buf * BKP * BMU;
+    float* Vb = Vs + buf * BKP * BNV;
+#pragma unroll
+    for (int it = 0; it < U_IT; ++it)
+      if (tid + it * 256 < U_F4) *reinterpret_cast<float4*>(Ub + u_kp[it] * BMU + u_c4[it] * 4) = ru[it];
+#pragma unroll
+    for (int it = 0; it < V_IT; ++it)
+      if (tid + it * 256 < V_F4) *reinterpret_cast<float4*>(Vb + v_kp[it] * BNV + v_c4[it] * 4) = rv[it];
+  };
+
+  const int T = (pe > pb) ? (pe - pb + BKP - 1) / BKP : 0;
+  int wm0, wn0, kbeg, kend;
+  if (WAVES_K == 1) {
+    wm0 = (wid / WAVES_N) * WM;
+    wn0 = (wid % WAVES_N) * WN;
+    kbeg = 0; kend = BKP;
+  } else {
+    wm0 = 0; wn0 = 0;
+    kbeg = wid * (BKP / WAVES_K);
+    kend = kbeg + BKP / WAVES_K;
+  }
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  if (T > 0) { load_tile(); store_tile(0); }
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < T) load_tile();
+    const float* Ub = Us + buf * BKP * BMU;
+    const float* Vb = Vs + buf * BKP * BNV;
+#pragma unroll
+    for (int ks = kbeg; ks < kend; ks += 2) {
+      const int kk = ks + lhi;
+      float af[MI], bf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[mi] = Ub[kk * BMU + wm0 + mi * 32 + l31];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[ni] = Vb[kk * BNV + wn0 + ni * 32 + l31];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (t + 1 < T) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (WAVES_K > 1) {
+    // cross-wave reduction of the per-wave K slices (tile buffers are free now)
+    float* red = smem;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[((wid * MI * NI + mi * NI + ni) * 16 + e) * 64 + lane] = acc[mi][ni][e];
+    __syncthreads();
+    if (wid != 0) return;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float sacc = 0.f;
+          for (int w = 0; w < WAVES_K; ++w) sacc += red[((w * MI * NI + mi * NI + ni) * 16 + e) * 64 + lane];
+          acc[mi][ni][e] = sacc;
+        }
+  }
+
+  float* pout = a.part + ((long long)blockIdx.x * (a.R * a.S) + tap) * a.K * a.C;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = k0 + wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+      if (k >= a.K) continue;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int c = c0 + wn0 + ni * 32 + l31;
+        if (c < a.C) pout[(long long)k * a.C + c] = acc[mi][ni][e];
+      }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* part, float* dw, int nsplit, int RS, int S, int K, int C,
+                                    long long sa, long long sb, long long sr, long long ss, int accumulate) {
+  const long long total = (long long)RS * K * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long t = i / C;
+    const int k = (int)(t % K);
+    const int tap = (int)(t / K);
+    float sum = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) sum += part[(long long)sp * total + i];
+    const long long o = k * sa + c * sb + (tap / S) * sr + (tap % S) * ss;
+    dw[o] = accumulate ? dw[o] + sum : sum;
+  }
+}
+
+__global__ void pack_weight_kernel(const float* src, float* dst, int A, int B, int Bpad, int R, int S,
+                                   long long sa, long long sb, long long sr, long long ss, int flip) {
+  const long long total = (long long)R * S * A * Bpad;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i % Bpad);
+    const long long t = i / Bpad;
+    const int aa = (int)(t % A);
+    const int tap = (int)(t / A);
+    int r = tap / S, s = tap % S;
+    if (flip) { r = R - 1 - r; s = S - 1 - s; }
+    dst[i] = (b < B) ? src[aa * sa + b * sb + r * sr + s * ss] : 0.f;
+  }
+}
+
+// column sums: x[rows][C] -> part[chunks][C]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, long long rows, int C, float* part, long long rows_per_chunk) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const long long rb = blockIdx.x * rows_per_chunk;
+  const long long re = min(rb + rows_per_chunk, rows);
+  float s = 0.f;
+  if (c < C)
+    for (long long rr = rb + rl; rr < re; rr += 4) s += x[rr * C + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) part[(long long)blockIdx.x * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+__global__ void colsum_final_kernel(const float* part, int chunks, int C, float* out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int i = 0; i < chunks; ++i) s += part[(long long)i * C + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+template <int BM, int BN, int BK, int WM_, int WN_>
+void launch_conv(const ConvK& k, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_>), grid, dim3(256), 0, st, k);
+}
+
+struct WgPlan {
+  int cfg;      // 0: 128x128, 1: 64x64, 2: 32x32 (k-split waves)
+  int bmu, bnv, bkp;
+  int tiles_u, tiles_v, nsplit, chunk;
+};
+WgPlan plan_wgrad(const hwg_conv_desc* d) {
+  WgPlan p;
+  const int K = d->K, C = d->C;
+  if (K >= 128 && C >= 128) { p.cfg = 0; p.bmu = 128; p.bnv = 128; p.bkp = 16; }
+  else if (K > 32 || C > 32) { p.cfg = 1; p.bmu = 64; p.bnv = 64; p.bkp = 32; }
+  else { p.cfg = 2; p.bmu = 32; p.bnv = 32; p.bkp = 32; }
+  p.tiles_u = hwg_cdiv(K, p.bmu);
+  p.tiles_v = hwg_cdiv(C, p.bnv);
+  const long long Mtot = (long long)d->N * d->P * d->Q;
+  const long long base = (long long)d->R * d->S * p.tiles_u * p.tiles_v;
+  long long ns = (1024 + base - 1) / base;
+  const long long max_ns = (Mtot + 4LL * p.bkp - 1) / (4LL * p.bkp);  // at least 4 k-steps per split
+  if (ns > max_ns) ns = max_ns;
+  if (ns < 1) ns = 1;
+  long long chunk = (Mtot + ns - 1) / ns;
+  chunk = (chunk + p.bkp - 1) / p.bkp * p.bkp;
+  ns = (Mtot + chunk - 1) / chunk;
+  if (ns < 1) ns = 1;
+  p.nsplit = (int)ns;
+  p.chunk = (int)chunk;
+  return p;
+}
+
+}  // namespace
+
+extern "C" int hwg_conv_pack_weight(const float* src, float* dst, int A, int B, int Bpad, int R, int S,
+                                    long long sa, long long sb, long long sr, long long ss, int flip, void* stream) {
+  HWG_REQUIRE(src && dst && A > 0 && B > 0 && Bpad >= B && R > 0 && S > 0, "conv_pack_weight: bad arguments");
+  const long long total = (long long)R * S * A * Bpad;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     src, dst, A, B, Bpad, R, S, sa, sb, sr, ss, flip);
+  HWG_LAUNCH_CHECK("conv_pack_weight");
+  return HWG_OK;
+}
+
+// direct kernels for single-channel ends live in conv_direct.hip
+int hwg_conv_c1_fwd_impl(const hwg_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int accumulate, hipStream_t st);
+int hwg_conv_to1_fwd_impl(const hwg_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int accumulate, hipStream_t st);
+int hwg_conv_wgrad_direct_impl(const hwg_conv_desc* d, const float* u, const float* v, float* dw, long long sa, long long sb,
+                               long long sr, long long ss, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+size_t hwg_conv_wgrad_direct_workspace(const hwg_conv_desc* d);
+
+static int check_desc(const hwg_conv_desc* d, const char* who) {
+  HWG_REQUIRE(d, "%s: null descriptor", who);
+  HWG_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0 && d->P > 0 && d->Q > 0,
+              "%s: non-positive dimension", who);
+  HWG_REQUIRE(d->stride_h > 0 && d->stride_w > 0 && d->dil_h > 0 && d->dil_w > 0, "%s: bad stride/dilation", who);
+  return HWG_OK;
+}
+
+extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                            int accumulate, void* stream) {
+  int rc = check_desc(d, "conv_fwd");
+  if (rc) return rc;
+  HWG_REQUIRE(x && w && y, "conv_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (!d->transposed) {
+    // geometry must be consistent
+    const int Pexp = (d->H + 2 * d->pad_h - d->dil_h * (d->R - 1) - 1) / d->stride_h + 1;
+    const int Qexp = (d->W + 2 * d->pad_w - d->dil_w * (d->S - 1) - 1) / d->stride_w + 1;
+    HWG_REQUIRE(Pexp == d->P && Qexp == d->Q, "conv_fwd: output size %dx%d does not match geometry (%dx%d)", d->P, d->Q, Pexp, Qexp);
+    if (d->K <= 2) return hwg_conv_to1_fwd_impl(d, x, w, bias, y, accumulate, st);
+    if (d->C == 1) return hwg_conv_c1_fwd_impl(d, x, w, bias, y, accumulate, st);
+  } else {
+    HWG_REQUIRE(d->dil_h == 1 && d->dil_w == 1, "conv_fwd: transposed mode needs dilation 1");
+    const int Pexp = (d->H - 1) * d->stride_h - 2 * d->pad_h + d->R;
+    const int Qexp = (d->W - 1) * d->stride_w - 2 * d->pad_w + d->S;
+    HWG_REQUIRE(Pexp <= d->P && d->P < Pexp + d->stride_h && Qexp <= d->Q && d->Q < Qexp + d->stride_w,
+                "conv_fwd: transposed output size %dx%d inconsistent with geometry (%dx%d)", d->P, d->Q, Pexp, Qexp);
+  }
+  HWG_REQUIRE(d->C % 16 == 0, "conv_fwd: MFMA path needs C %% 16 == 0 (got C=%d); pad the channels", d->C);
+
+  ConvK k;
+  k.x = x; k.w = w; k.bias = bias; k.y = y;
+  k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.R = d->R; k.S = d->S;
+  k.sh = d->stride_h; k.sw = d->stride_w; k.ph = d->pad_h; k.pw = d->pad_w; k.dh = d->dil_h; k.dw = d->dil_w;
+  k.P = d->P; k.Q = d->Q;
+  k.mode = d->transposed ? 1 : 0;
+  k.accumulate = accumulate;
+  const int classes = d->transposed ? d->stride_h * d->stride_w : 1;
+  long long Mc = (long long)d->N * d->P * d->Q;
+  if (d->transposed) Mc = (long long)d->N * hwg_cdiv(d->P, d->stride_h) * hwg_cdiv(d->Q, d->stride_w);
+
+  // tile selection
+  int bn = d->K >= 96 ? 128 : (d->K > 32 ? 64 : 32);
+  int bm = 128;
+  if (bn == 128 || bn == 64) {
+    const long long blocks = (long long)hwg_cdiv(Mc, 128) * hwg_cdiv(d->K, bn) * classes;
+    if (blocks < 256) { bm = 64; bn = 64; }
+  }
+  const int bk = (d->C % 32 == 0) ? 32 : 16;
+  k.ntm = hwg_cdiv(Mc, bm);
+  k.ntm_pad = (k.ntm + 7) / 8 * 8;
+  dim3 grid(k.ntm_pad, hwg_cdiv(d->K, bn), classes);
+#define HWG_CONV_CASE(BM_, BN_, WMW, WNW)                                   \
+  if (bm == BM_ && bn == BN_) {                                             \
+    if (bk == 32) launch_conv<BM_, BN_, 32, WMW, WNW>(k, grid, st);         \
+    else launch_conv<BM_, BN_, 16, WMW, WNW>(k, grid, st);                  \
+  } else
+  HWG_CONV_CASE(128, 128, 2, 2)
+  HWG_CONV_CASE(128, 64, 2, 2)
+  HWG_CONV_CASE(128, 32, 4, 1)
+  HWG_CONV_CASE(64, 64, 2, 2)
+  { hwg_set_error("conv_fwd: no tile config for bm=%d bn=%d", bm, bn); return HWG_ERR_ARG; }
+#undef HWG_CONV_CASE
+  HWG_LAUNCH_CHECK("conv_fwd");
+  return HWG_OK;
+}
+
+static bool wgrad_is_direct(const hwg_conv_desc* d) { return d->K <= 2 || d->C <= 2; }
+
+extern "C" size_t hwg_conv_wgrad_workspace(const hwg_conv_desc* d) {
+  if (!d) return 0;
+  if (wgrad_is_direct(d)) return hwg_conv_wgrad_direct_workspace(d);
+  WgPlan p = plan_wgrad(d);
+  return (size_t)p.nsplit * d->R * d->S * d->K * d->C * sizeof(float);
+}
+
+extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const float* v, float* dw,
+                              long long sa, long long sb, long long sr, long long ss, int accumulate,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_desc(d, "conv_wgrad");
+  if (rc) return rc;
+  HWG_REQUIRE(u && v && dw, "conv_wgrad: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (wgrad_is_direct(d)) return hwg_conv_wgrad_direct_impl(d, u, v, dw, sa, sb, sr, ss, accumulate, workspace, workspace_bytes, st);
+  HWG_REQUIRE(d->K % 4 == 0 && d->C % 4 == 0, "conv_wgrad: channels must be multiples of 4 (K=%d C=%d)", d->K, d->C);
+  const size_t need = hwg_conv_wgrad_workspace(d);
+  if (!workspace || workspace_bytes < need) {
+    hwg_set_error("conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return HWG_ERR_WORKSPACE;
+  }
+  WgPlan p = plan_wgrad(d);
+  WgK k;
+  k.u = u; k.v = v; k.part = (float*)workspace;
+  k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.R = d->R; k.S = d->S;
+  k.sh = d->stride_h; k.sw = d->stride_w; k.ph = d->pad_h; k.pw = d->pad_w; k.dh = d->dil_h; k.dw = d->dil_w;
+  k.P = d->P; k.Q = d->Q;
+  k.Mtot = d->N * d->P * d->Q;
+  k.chunk = p.chunk;
+  k.tiles_v = p.tiles_v;
+  dim3 grid(p.nsplit, p.tiles_u * p.tiles_v, d->R * d->S);
+  if (p.cfg == 0) hipLaunchKernelGGL((wgrad_mfma_kernel<128, 128, 16, 2, 2, 1>), grid, dim3(256), 0, st, k);
+  else if (p.cfg == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<64, 64, 32, 2, 2, 1>), grid, dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((wgrad_mfma_kernel<32, 32, 32, 1, 1, 4>), grid, dim3(256), 0, st, k);
+  HWG_LAUNCH_CHECK("conv_wgrad");
+  const long long total = (long long)d->R * d->S * d->K * d->C;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
+                     p.nsplit, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate);
+  HWG_LAUNCH_CHECK("conv_wgrad_reduce");
+  return HWG_OK;
+}
+
+static long long colsum_chunks(long long rows) {
+  long long chunks = (rows + 255) / 256;
+  if (chunks > 512) chunks = 512;
+  if (chunks < 1) chunks = 1;
+  return chunks;
+}
+extern "C" size_t hwg_colsum_workspace(long long rows, int C) { return (size_t)colsum_chunks(rows) * C * sizeof(float); }
+
+extern "C" int hwg_colsum(const float* x, long long rows, int C, float* out, int accumulate,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  HWG_REQUIRE(x && out && rows > 0 && C > 0, "colsum: bad arguments");
+  const size_t need = hwg_colsum_workspace(rows, C);
+  if (!workspace || workspace_bytes < need) {
+    hwg_set_error("colsum: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return HWG_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const long long chunks = colsum_chunks(rows);
+  const long long rpc = (rows + chunks - 1) / chunks;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)chunks, hwg_cdiv(C, 64)), dim3(256), 0, st, x, rows, C, (float*)workspace, rpc);
+  HWG_LAUNCH_CHECK("colsum_partial");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(hwg_cdiv(C, 256)), dim3(256), 0, st, (const float*)workspace, (int)chunks, C, out, accumulate);
+  HWG_LAUNCH_CHECK("colsum_final");
+  return HWG_OK;
+}

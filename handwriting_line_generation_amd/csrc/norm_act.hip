@@ -1,0 +1,553 @@
+// Normalisation + activation epilogues on NHWC tensors (HBM-bound streaming kernels).
+//   InstanceNorm / GroupNorm / BatchNorm(train) share one three-stage pipeline:
+//     partial moments per (n, pixel chunk, c)  ->  finalize per statistic group  ->  apply (+affine, channel mask, activation)
+//   and the mirrored backward. The generator's NoiseInjection -> LeakyReLU -> AdaIN chain
+//   (model/pure_gen.py:205-214) is fused into the first/last stage of the InstanceNorm pipeline.
+// Moments are accumulated in fp64 across threads so var = E[x^2]-E[x]^2 is safe.
+#include "hwg_common.h"
+
+namespace {
+
+enum { MODE_IN = 0, MODE_GN = 1, MODE_BN = 2 };
+
+struct Geo {
+  int N, HW, C, C4, L, PP, chunks, cs;
+};
+Geo make_geo(int N, int HW, int C) {
+  Geo g;
+  g.N = N; g.HW = HW; g.C = C; g.C4 = C / 4;
+  g.L = g.C4;                 // float4 lanes per pixel (<= 256)
+  g.PP = 256 / g.L;           // pixels per pass
+  int chunks = (HW + 255) / 256;
+  if (chunks > 64) chunks = 64;
+  while (chunks > 1 && (long long)chunks * N > 2048) chunks >>= 1;
+  if (chunks < 1) chunks = 1;
+  g.cs = (HW + chunks - 1) / chunks;
+  g.chunks = (HW + g.cs - 1) / g.cs;
+  return g;
+}
+
+// Reduce NV float4 accumulators over the pixel lanes of the block and write part[n][chunk][c][NV] (double)
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(const float4 (&acc)[NV], const Geo& g, double* part, double* sm) {
+  const int tid = threadIdx.x;
+  const int cl = tid % g.L, pl = tid / g.L;
+  const bool active = pl < g.PP;
+  // sm layout [pl][c][NV]
+  if (active) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      double* o = sm + ((size_t)pl * g.C + cl * 4) * NV + v;
+      o[0 * NV] = acc[v].x; o[1 * NV] = acc[v].y; o[2 * NV] = acc[v].z; o[3 * NV] = acc[v].w;
+    }
+  }
+  __syncthreads();
+  double* po = part + (((size_t)blockIdx.y * g.chunks + blockIdx.x) * g.C) * NV;
+  for (int i = tid; i < g.C * NV; i += 256) {
+    double s = 0.0;
+    for (int p = 0; p < g.PP; ++p) s += sm[(size_t)p * g.C * NV + i];
+    po[i] = s;
+  }
+}
+
+// ---------------- forward stage 1: moments of x (optionally of u = lrelu(x + nw*noise), which is also written) -------------
+template <bool NOISE>
+__global__ __launch_bounds__(256) void moments_fwd_kernel(const float* x, Geo g, double* part,
+                                                          const float* noise, const float* nw, float nscale, float slope, float* u) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int tid = threadIdx.x;
+  const int cl = tid % g.L, pl = tid / g.L;
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * g.cs, p1 = min(p0 + g.cs, g.HW);
+  float4 acc[2];
+  acc[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+  acc[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (NOISE && pl < g.PP) {
+    w4 = *reinterpret_cast<const float4*>(nw + cl * 4);
+    w4.x *= nscale; w4.y *= nscale; w4.z *= nscale; w4.w *= nscale;
+  }
+  if (pl < g.PP) {
+    for (int p = p0 + pl; p < p1; p += g.PP) {
+      const size_t off = ((size_t)n * g.HW + p) * g.C + cl * 4;
+      float4 v = *reinterpret_cast<const float4*>(x + off);
+      if (NOISE) {
+        const float4 nz = *reinterpret_cast<const float4*>(noise + off);
+        v.x += w4.x * nz.x; v.y += w4.y * nz.y; v.z += w4.z * nz.z; v.w += w4.w * nz.w;
+        v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+        v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+        *reinterpret_cast<float4*>(u + off) = v;
+      }
+      acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+      acc[1].x += v.x * v.x; acc[1].y += v.y * v.y; acc[1].z += v.z * v.z; acc[1].w += v.w * v.w;
+    }
+  }
+  block_reduce_store<2>(acc, g, part, sm);
+}
+
+// ---------------- forward stage 2: statistics per group -> mean[N][C], rstd[N][C] ---------------------------------------
+__global__ void finalize_fwd_kernel(const double* part, Geo g, int mode, int groups, float eps, float* mean, float* rstd,
+                                    float* running_mean, float* running_var, float momentum) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mode == MODE_BN) {
+    if (idx >= g.C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < g.N; ++n)
+      for (int k = 0; k < g.chunks; ++k) {
+        const double* p = part + (((size_t)n * g.chunks + k) * g.C + idx) * 2;
+        s1 += p[0]; s2 += p[1];
+      }
+    const double cnt = (double)g.N * g.HW;
+    const double m = s1 / cnt;
+    double var = s2 / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    const float r = (float)(1.0 / sqrt(var + (double)eps));
+    for (int n = 0; n < g.N; ++n) { mean[n * g.C + idx] = (float)m; rstd[n * g.C + idx] = r; }
+    if (running_mean) {
+      const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+      running_mean[idx] = (1.f - momentum) * running_mean[idx] + momentum * (float)m;
+      running_var[idx] = (1.f - momentum) * running_var[idx] + momentum * (float)unb;
+    }
+    return;
+  }
+  if (idx >= g.N * g.C) return;
+  const int n = idx / g.C, c = idx % g.C;
+  int cb = c, ce = c + 1;
+  if (mode == MODE_GN) {
+    const int cpg = g.C / groups;
+    cb = (c / cpg) * cpg; ce = cb + cpg;
+  }
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < g.chunks; ++k)
+    for (int cc = cb; cc < ce; ++cc) {
+      const double* p = part + (((size_t)n * g.chunks + k) * g.C + cc) * 2;
+      s1 += p[0]; s2 += p[1];
+    }
+  const double cnt = (double)g.HW * (ce - cb);
+  const double m = s1 / cnt;
+  double var = s2 / cnt - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[idx] = (float)m;
+  rstd[idx] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// ---------------- forward stage 3: y = act(mask * (gamma * xhat + beta)) -----------------------------------------------
+__global__ __launch_bounds__(256) void apply_fwd_kernel(const float* x, float* y, Geo g, const float* mean, const float* rstd,
+                                                        const float* gamma, const float* beta, int per_sample,
+                                                        const float* mask, int act, float slope) {
+  const int tid = threadIdx.x;
+  const int cl = tid % g.L, pl = tid / g.L;
+  if (pl >= g.PP) return;
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * g.cs, p1 = min(p0 + g.cs, g.HW);
+  const int c = cl * 4;
+  const float4 m4 = *reinterpret_cast<const float4*>(mean + n * g.C + c);
+  const float4 r4 = *reinterpret_cast<const float4*>(rstd + n * g.C + c);
+  float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ao = per_sample ? n * g.C + c : c;
+  if (gamma) g4 = *reinterpret_cast<const float4*>(gamma + ao);
+  if (beta) b4 = *reinterpret_cast<const float4*>(beta + ao);
+  float4 k4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (mask) k4 = *reinterpret_cast<const float4*>(mask + n * g.C + c);
+  // y = act(k*(g*(x-m)*r + b)) = act(x*sc + sh)
+  float4 sc, sh;
+  sc.x = k4.x * g4.x * r4.x; sh.x = k4.x * (b4.x - g4.x * r4.x * m4.x);
+  sc.y = k4.y * g4.y * r4.y; sh.y = k4.y * (b4.y - g4.y * r4.y * m4.y);
+  sc.z = k4.z * g4.z * r4.z; sh.z = k4.z * (b4.z - g4.z * r4.z * m4.z);
+  sc.w = k4.w * g4.w * r4.w; sh.w = k4.w * (b4.w - g4.w * r4.w * m4.w);
+  for (int p = p0 + pl; p < p1; p += g.PP) {
+    const size_t off = ((size_t)n * g.HW + p) * g.C + c;
+    const float4 v = *reinterpret_cast<const float4*>(x + off);
+    float4 o;
+    // keep the reference's operation order (normalise, then affine) for rounding parity
+    o.x = act_apply(k4.x * (g4.x * ((v.x - m4.x) * r4.x) + b4.x), act, slope);
+    o.y = act_apply(k4.y * (g4.y * ((v.y - m4.y) * r4.y) + b4.y), act, slope);
+    o.z = act_apply(k4.z * (g4.z * ((v.z - m4.z) * r4.z) + b4.z), act, slope);
+    o.w = act_apply(k4.w * (g4.w * ((v.w - m4.w) * r4.w) + b4.w), act, slope);
+    (void)sc; (void)sh;
+    *reinterpret_cast<float4*>(y + off) = o;
+  }
+}
+
+// ---------------- backward stage 1: partial sums of g and g*xhat, g = dy * act'(y) * mask ---------------------------------
+__global__ __launch_bounds__(256) void moments_bwd_kernel(const float* dy, const float* x, const float* y, Geo g, double* part,
+                                                          const float* mean, const float* rstd, const float* mask, int act, float slope) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int tid = threadIdx.x;
+  const int cl = tid % g.L, pl = tid / g.L;
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * g.cs, p1 = min(p0 + g.cs, g.HW);
+  float4 acc[2];
+  acc[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+  acc[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pl < g.PP) {
+    const int c = cl * 4;
+    const float4 m4 = *reinterpret_cast<const float4*>(mean + n * g.C + c);
+    const float4 r4 = *reinterpret_cast<const float4*>(rstd + n * g.C + c);
+    float4 k4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (mask) k4 = *reinterpret_cast<const float4*>(mask + n * g.C + c);
+    for (int p = p0 + pl; p < p1; p += g.PP) {
+      const size_t off = ((size_t)n * g.HW + p) * g.C + c;
+      float4 d = *reinterpret_cast<const float4*>(dy + off);
+      const float4 v = *reinterpret_cast<const float4*>(x + off);
+      if (act != 0) {
+        const float4 o = *reinterpret_cast<const float4*>(y + off);
+        d.x *= act_grad_from_out(o.x, act, slope); d.y *= act_grad_from_out(o.y, act, slope);
+        d.z *= act_grad_from_out(o.z, act, slope); d.w *= act_grad_from_out(o.w, act, slope);
+      }
+      d.x *= k4.x; d.y *= k4.y; d.z *= k4.z; d.w *= k4.w;
+      acc[0].x += d.x; acc[0].y += d.y; acc[0].z += d.z; acc[0].w += d.w;
+      acc[1].x += d.x * ((v.x - m4.x) * r4.x); acc[1].y += d.y * ((v.y - m4.y) * r4.y);
+      acc[1].z += d.z * ((v.z - m4.z) * r4.z); acc[1].w += d.w * ((v.w - m4.w) * r4.w);
+    }
+  }
+  block_reduce_store<2>(acc, g, part, sm);
+}
+
+// ---------------- backward stage 2: per group coefficients c1,c2 [N][C] and parameter gradients ---------------------------
+// dx = rstd * (g*gamma - c1 - xhat*c2),  c1 = mean_grp(g*gamma), c2 = mean_grp(g*gamma*xhat)
+__global__ void finalize_bwd_kernel(const double* part, Geo g, int mode, int groups, const float* gamma, int per_sample,
+                                    float* c1, float* c2, float* dgamma, float* dbeta, int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mode == MODE_BN) {
+    if (idx >= g.C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < g.N; ++n)
+      for (int k = 0; k < g.chunks; ++k) {
+        const double* p = part + (((size_t)n * g.chunks + k) * g.C + idx) * 2;
+        s1 += p[0]; s2 += p[1];
+      }
+    const double cnt = (double)g.N * g.HW;
+    const double gm = gamma ? (double)gamma[idx] : 1.0;
+    for (int n = 0; n < g.N; ++n) { c1[n * g.C + idx] = (float)(gm * s1 / cnt); c2[n * g.C + idx] = (float)(gm * s2 / cnt); }
+    if (dgamma) dgamma[idx] = (accumulate ? dgamma[idx] : 0.f) + (float)s2;
+    if (dbeta) dbeta[idx] = (accumulate ? dbeta[idx] : 0.f) + (float)s1;
+    return;
+  }
+  if (idx >= g.N * g.C) return;
+  const int n = idx / g.C, c = idx % g.C;
+  int cb = c, ce = c + 1;
+  if (mode == MODE_GN) {
+    const int cpg = g.C / groups;
+    cb = (c / cpg) * cpg; ce = cb + cpg;
+  }
+  double a1 = 0.0, a2 = 0.0;
+  for (int cc = cb; cc < ce; ++cc) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < g.chunks; ++k) {
+      const double* p = part + (((size_t)n * g.chunks + k) * g.C + cc) * 2;
+      s1 += p[0]; s2 += p[1];
+    }
+    const double gm = gamma ? (double)gamma[per_sample ? n * g.C + cc : cc] : 1.0;
+    a1 += gm * s1; a2 += gm * s2;
+    if (cc == c && per_sample) {
+      if (dgamma) dgamma[idx] = (accumulate ? dgamma[idx] : 0.f) + (float)s2;
+      if (dbeta) dbeta[idx] = (accumulate ? dbeta[idx] : 0.f) + (float)s1;
+    }
+  }
+  const double cnt = (double)g.HW * (ce - cb);
+  c1[idx] = (float)(a1 / cnt);
+  c2[idx] = (float)(a2 / cnt);
+}
+// per-channel parameter gradients for IN/GN with shared (per-channel) affine: sum over n and chunks
+__global__ void param_grad_kernel(const double* part, Geo g, float* dgamma, float* dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= g.C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int n = 0; n < g.N; ++n)
+    for (int k = 0; k < g.chunks; ++k) {
+      const double* p = part + (((size_t)n * g.chunks + k) * g.C + c) * 2;
+      s1 += p[0]; s2 += p[1];
+    }
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+}
+
+// ---------------- backward stage 3 -----------------------------------------------------------------------------------------
+// PRE != 0 additionally back-propagates through u = lrelu(x + nw*noise): dt = du * lrelu'(u); writes dx = dt and
+// accumulates per-channel partials of dt (conv bias grad) and dt*noise (noise weight grad) into part2[n][chunk][c][2].
+template <bool PRE>
+__global__ __launch_bounds__(256) void apply_bwd_kernel(const float* dy, const float* x, const float* y, float* dx, Geo g,
+                                                        const float* mean, const float* rstd, const float* gamma, int per_sample,
+                                                        const float* c1, const float* c2, const float* mask, int act, float slope,
+                                                        const float* noise, float pre_slope, double* part2) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int tid = threadIdx.x;
+  const int cl = tid % g.L, pl = tid / g.L;
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * g.cs, p1 = min(p0 + g.cs, g.HW);
+  float4 acc[2];
+  acc[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+  acc[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pl < g.PP) {
+    const int c = cl * 4;
+    const float4 m4 = *reinterpret_cast<const float4*>(mean + n * g.C + c);
+    const float4 r4 = *reinterpret_cast<const float4*>(rstd + n * g.C + c);
+    const float4 a4 = *reinterpret_cast<const float4*>(c1 + n * g.C + c);
+    const float4 b4 = *reinterpret_cast<const float4*>(c2 + n * g.C + c);
+    float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (gamma) g4 = *reinterpret_cast<const float4*>(gamma + (per_sample ? n * g.C + c : c));
+    float4 k4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (mask) k4 = *reinterpret_cast<const float4*>(mask + n * g.C + c);
+    for (int p = p0 + pl; p < p1; p += g.PP) {
+      const size_t off = ((size_t)n * g.HW + p) * g.C + c;
+      float4 d = *reinterpret_cast<const float4*>(dy + off);
+      const float4 v = *reinterpret_cast<const float4*>(x + off);
+      if (act != 0) {
+        const float4 o = *reinterpret_cast<const float4*>(y + off);
+        d.x *= act_grad_from_out(o.x, act, slope); d.y *= act_grad_from_out(o.y, act, slope);
+        d.z *= act_grad_from_out(o.z, act, slope); d.w *= act_grad_from_out(o.w, act, slope);
+      }
+      float4 o;
+      o.x = r4.x * (d.x * k4.x * g4.x - a4.x - ((v.x - m4.x) * r4.x) * b4.x);
+      o.y = r4.y * (d.y * k4.y * g4.y - a4.y - ((v.y - m4.y) * r4.y) * b4.y);
+      o.z = r4.z * (d.z * k4.z * g4.z - a4.z - ((v.z - m4.z) * r4.z) * b4.z);
+      o.w = r4.w * (d.w * k4.w * g4.w - a4.w - ((v.w - m4.w) * r4.w) * b4.w);
+      if (PRE) {
+        // x here is u (the lrelu output that was normalised)
+        o.x *= v.x > 0.f ? 1.f : pre_slope; o.y *= v.y > 0.f ? 1.f : pre_slope;
+        o.z *= v.z > 0.f ? 1.f : pre_slope; o.w *= v.w > 0.f ? 1.f : pre_slope;
+        const float4 nz = *reinterpret_cast<const float4*>(noise + off);
+        acc[0].x += o.x; acc[0].y += o.y; acc[0].z += o.z; acc[0].w += o.w;
+        acc[1].x += o.x * nz.x; acc[1].y += o.y * nz.y; acc[1].z += o.z * nz.z; acc[1].w += o.w * nz.w;
+      }
+      *reinterpret_cast<float4*>(dx + off) = o;
+    }
+  }
+  if (PRE) block_reduce_store<2>(acc, g, part2, sm);
+}
+
+// dbias[c] = sum part2[...][c][0];  dnoise_w[c] = nscale * sum part2[...][c][1]
+__global__ void adain_param_grad_kernel(const double* part2, Geo g, float nscale, float* dbias, float* dnw, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= g.C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int n = 0; n < g.N; ++n)
+    for (int k = 0; k < g.chunks; ++k) {
+      const double* p = part2 + (((size_t)n * g.chunks + k) * g.C + c) * 2;
+      s1 += p[0]; s2 += p[1];
+    }
+  if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)s1;
+  if (dnw) dnw[c] = (accumulate ? dnw[c] : 0.f) + (float)(s2 * (double)nscale);
+}
+
+// ---------------- plain elementwise: y = act(mask * (x + bias)) and its backward ----------------------------------------------
+__global__ void bias_act_fwd_kernel(const float* x, const float* bias, const float* mask, float* y, long long rows, int HW, int C,
+                                    int act, float slope) {
+  const long long total4 = rows * C / 4;
+  const int C4 = C / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const long long row = i / C4;
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+    if (mask) {
+      const float4 k = *reinterpret_cast<const float4*>(mask + (row / HW) * C + c);
+      v.x *= k.x; v.y *= k.y; v.z *= k.z; v.w *= k.w;
+    }
+    v.x = act_apply(v.x, act, slope); v.y = act_apply(v.y, act, slope);
+    v.z = act_apply(v.z, act, slope); v.w = act_apply(v.w, act, slope);
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+}
+__global__ void bias_act_bwd_kernel(const float* dy, const float* y, const float* mask, float* dx, long long rows, int HW, int C,
+                                    int act, float slope) {
+  const long long total4 = rows * C / 4;
+  const int C4 = C / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const long long row = i / C4;
+    float4 d = reinterpret_cast<const float4*>(dy)[i];
+    if (act != 0) {
+      const float4 o = reinterpret_cast<const float4*>(y)[i];
+      d.x *= act_grad_from_out(o.x, act, slope); d.y *= act_grad_from_out(o.y, act, slope);
+      d.z *= act_grad_from_out(o.z, act, slope); d.w *= act_grad_from_out(o.w, act, slope);
+    }
+    if (mask) {
+      const float4 k = *reinterpret_cast<const float4*>(mask + (row / HW) * C + c);
+      d.x *= k.x; d.y *= k.y; d.z *= k.z; d.w *= k.w;
+    }
+    reinterpret_cast<float4*>(dx)[i] = d;
+  }
+}
+// scalar-tail versions for C % 4 != 0 (tiny tensors only)
+__global__ void bias_act_fwd_scalar_kernel(const float* x, const float* bias, const float* mask, float* y, long long rows, int HW, int C,
+                                           int act, float slope) {
+  const long long total = rows * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long row = i / C;
+    float v = x[i];
+    if (bias) v += bias[c];
+    if (mask) v *= mask[(row / HW) * C + c];
+    y[i] = act_apply(v, act, slope);
+  }
+}
+__global__ void bias_act_bwd_scalar_kernel(const float* dy, const float* y, const float* mask, float* dx, long long rows, int HW, int C,
+                                           int act, float slope) {
+  const long long total = rows * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long row = i / C;
+    float d = dy[i];
+    if (act != 0) d *= act_grad_from_out(y[i], act, slope);
+    if (mask) d *= mask[(row / HW) * C + c];
+    dx[i] = d;
+  }
+}
+
+int check_geo(int N, int HW, int C, const char* who) {
+  HWG_REQUIRE(N > 0 && HW > 0 && C > 0, "%s: non-positive size", who);
+  HWG_REQUIRE(C % 4 == 0 && C <= 1024, "%s: C must be a multiple of 4 and <= 1024 (C=%d)", who, C);
+  return HWG_OK;
+}
+size_t part_bytes(const Geo& g) { return (size_t)g.N * g.chunks * g.C * 2 * sizeof(double); }
+size_t red_smem(const Geo& g) { return (size_t)g.PP * g.C * 2 * sizeof(double); }
+
+}  // namespace
+
+extern "C" size_t hwg_norm_workspace(int N, int HW, int C) {
+  if (N <= 0 || HW <= 0 || C <= 0 || C % 4) return 0;
+  Geo g = make_geo(N, HW, C);
+  // two partial buffers (moments + adain param partials) and c1/c2 coefficient arrays
+  return 2 * part_bytes(g) + 2 * (size_t)N * C * sizeof(float) + 256;
+}
+
+extern "C" int hwg_norm_fwd(const float* x, float* y, int N, int HW, int C, int mode, int groups, float eps,
+                            const float* gamma, const float* beta, int affine_per_sample, const float* chan_mask,
+                            int act, float slope, float* mean, float* rstd, float* running_mean, float* running_var,
+                            float momentum, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_geo(N, HW, C, "norm_fwd");
+  if (rc) return rc;
+  HWG_REQUIRE(x && y && mean && rstd, "norm_fwd: null pointer");
+  HWG_REQUIRE(mode >= 0 && mode <= 2, "norm_fwd: bad mode %d", mode);
+  if (mode == MODE_GN) HWG_REQUIRE(groups > 0 && C % groups == 0, "norm_fwd: C=%d not divisible by groups=%d", C, groups);
+  Geo g = make_geo(N, HW, C);
+  if (!ws || ws_bytes < hwg_norm_workspace(N, HW, C)) { hwg_set_error("norm_fwd: workspace too small"); return HWG_ERR_WORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)ws;
+  dim3 grid(g.chunks, N);
+  hipLaunchKernelGGL(moments_fwd_kernel<false>, grid, dim3(256), red_smem(g), st, x, g, part, nullptr, nullptr, 0.f, 0.f, nullptr);
+  HWG_LAUNCH_CHECK("norm_fwd.moments");
+  const int nfin = (mode == MODE_BN) ? C : N * C;
+  hipLaunchKernelGGL(finalize_fwd_kernel, dim3(hwg_cdiv(nfin, 128)), dim3(128), 0, st, (const double*)part, g, mode, groups, eps, mean, rstd,
+                     running_mean, running_var, momentum);
+  HWG_LAUNCH_CHECK("norm_fwd.finalize");
+  hipLaunchKernelGGL(apply_fwd_kernel, grid, dim3(256), 0, st, x, y, g, (const float*)mean, (const float*)rstd, gamma, beta,
+                     affine_per_sample, chan_mask, act, slope);
+  HWG_LAUNCH_CHECK("norm_fwd.apply");
+  return HWG_OK;
+}
+
+extern "C" int hwg_norm_bwd(const float* dy, const float* x, const float* y, float* dx, int N, int HW, int C, int mode, int groups,
+                            const float* gamma, int affine_per_sample, const float* chan_mask, int act, float slope,
+                            const float* mean, const float* rstd, float* dgamma, float* dbeta, int accumulate,
+                            void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_geo(N, HW, C, "norm_bwd");
+  if (rc) return rc;
+  HWG_REQUIRE(dy && x && dx && mean && rstd, "norm_bwd: null pointer");
+  HWG_REQUIRE(act == 0 || y, "norm_bwd: y required when an activation is fused");
+  Geo g = make_geo(N, HW, C);
+  if (!ws || ws_bytes < hwg_norm_workspace(N, HW, C)) { hwg_set_error("norm_bwd: workspace too small"); return HWG_ERR_WORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)ws;
+  float* c1 = (float*)((char*)ws + 2 * part_bytes(g));
+  float* c2 = c1 + (size_t)N * C;
+  dim3 grid(g.chunks, N);
+  hipLaunchKernelGGL(moments_bwd_kernel, grid, dim3(256), red_smem(g), st, dy, x, y, g, part, mean, rstd, chan_mask, act, slope);
+  HWG_LAUNCH_CHECK("norm_bwd.moments");
+  const int nfin = (mode == MODE_BN) ? C : N * C;
+  hipLaunchKernelGGL(finalize_bwd_kernel, dim3(hwg_cdiv(nfin, 128)), dim3(128), 0, st, (const double*)part, g, mode, groups, gamma,
+                     affine_per_sample, c1, c2, dgamma, dbeta, accumulate);
+  HWG_LAUNCH_CHECK("norm_bwd.finalize");
+  if (mode != MODE_BN && !affine_per_sample && (dgamma || dbeta)) {
+    hipLaunchKernelGGL(param_grad_kernel, dim3(hwg_cdiv(C, 128)), dim3(128), 0, st, (const double*)part, g, dgamma, dbeta, accumulate);
+    HWG_LAUNCH_CHECK("norm_bwd.param_grad");
+  }
+  hipLaunchKernelGGL(apply_bwd_kernel<false>, grid, dim3(256), 0, st, dy, x, y, dx, g, mean, rstd, gamma, affine_per_sample,
+                     (const float*)c1, (const float*)c2, chan_mask, act, slope, nullptr, 0.f, nullptr);
+  HWG_LAUNCH_CHECK("norm_bwd.apply");
+  return HWG_OK;
+}
+
+extern "C" int hwg_adain_fwd(const float* x, const float* noise, const float* noise_w, float noise_scale, float slope,
+                             const float* gamma, const float* beta, float eps, float* u, float* y, float* mean, float* rstd,
+                             int N, int HW, int C, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_geo(N, HW, C, "adain_fwd");
+  if (rc) return rc;
+  HWG_REQUIRE(x && noise && noise_w && gamma && beta && u && y && mean && rstd, "adain_fwd: null pointer");
+  Geo g = make_geo(N, HW, C);
+  if (!ws || ws_bytes < hwg_norm_workspace(N, HW, C)) { hwg_set_error("adain_fwd: workspace too small"); return HWG_ERR_WORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)ws;
+  dim3 grid(g.chunks, N);
+  hipLaunchKernelGGL(moments_fwd_kernel<true>, grid, dim3(256), red_smem(g), st, x, g, part, noise, noise_w, noise_scale, slope, u);
+  HWG_LAUNCH_CHECK("adain_fwd.moments");
+  hipLaunchKernelGGL(finalize_fwd_kernel, dim3(hwg_cdiv(N * C, 128)), dim3(128), 0, st, (const double*)part, g, (int)MODE_IN, 1, eps, mean, rstd,
+                     (float*)nullptr, (float*)nullptr, 0.f);
+  HWG_LAUNCH_CHECK("adain_fwd.finalize");
+  hipLaunchKernelGGL(apply_fwd_kernel, grid, dim3(256), 0, st, (const float*)u, y, g, (const float*)mean, (const float*)rstd, gamma, beta, 1,
+                     (const float*)nullptr, 0, 0.f);
+  HWG_LAUNCH_CHECK("adain_fwd.apply");
+  return HWG_OK;
+}
+
+extern "C" int hwg_adain_bwd(const float* dy, const float* u, const float* noise, float noise_scale, float slope,
+                             const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
+                             float* dnoise_w, float* dbias, int accumulate_params, int N, int HW, int C,
+                             void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_geo(N, HW, C, "adain_bwd");
+  if (rc) return rc;
+  HWG_REQUIRE(dy && u && noise && gamma && mean && rstd && dx && dgamma && dbeta, "adain_bwd: null pointer");
+  Geo g = make_geo(N, HW, C);
+  if (!ws || ws_bytes < hwg_norm_workspace(N, HW, C)) { hwg_set_error("adain_bwd: workspace too small"); return HWG_ERR_WORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)ws;
+  double* part2 = (double*)((char*)ws + part_bytes(g));
+  float* c1 = (float*)((char*)ws + 2 * part_bytes(g));
+  float* c2 = c1 + (size_t)N * C;
+  dim3 grid(g.chunks, N);
+  hipLaunchKernelGGL(moments_bwd_kernel, grid, dim3(256), red_smem(g), st, dy, u, (const float*)nullptr, g, part, mean, rstd,
+                     (const float*)nullptr, 0, 0.f);
+  HWG_LAUNCH_CHECK("adain_bwd.moments");
+  // dgamma/dbeta are per (n,c) and are NOT accumulated (they feed the style Linear's backward)
+  hipLaunchKernelGGL(finalize_bwd_kernel, dim3(hwg_cdiv(N * C, 128)), dim3(128), 0, st, (const double*)part, g, (int)MODE_IN, 1, gamma, 1,
+                     c1, c2, dgamma, dbeta, 0);
+  HWG_LAUNCH_CHECK("adain_bwd.finalize");
+  hipLaunchKernelGGL(apply_bwd_kernel<true>, grid, dim3(256), red_smem(g), st, dy, u, (const float*)nullptr, dx, g, mean, rstd, gamma, 1,
+                     (const float*)c1, (const float*)c2, (const float*)nullptr, 0, 0.f, noise, slope, part2);
+  HWG_LAUNCH_CHECK("adain_bwd.apply");
+  if (dnoise_w || dbias) {
+    hipLaunchKernelGGL(adain_param_grad_kernel, dim3(hwg_cdiv(C, 128)), dim3(128), 0, st, (const double*)part2, g, noise_scale, dbias, dnoise_w,
+                       accumulate_params);
+    HWG_LAUNCH_CHECK("adain_bwd.param_grad");
+  }
+  return HWG_OK;
+}
+
+extern "C" int hwg_bias_act_fwd(const float* x, const float* bias, const float* chan_mask, float* y, long long rows, int HW, int C,
+                                int act, float slope, void* stream) {
+  HWG_REQUIRE(x && y && rows > 0 && C > 0 && HW > 0, "bias_act_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (C % 4 == 0) {
+    hipLaunchKernelGGL(bias_act_fwd_kernel, dim3(hwg_stream_grid(rows * C / 4, 256)), dim3(256), 0, st, x, bias, chan_mask, y, rows, HW, C, act, slope);
+  } else {
+    hipLaunchKernelGGL(bias_act_fwd_scalar_kernel, dim3(hwg_stream_grid(rows * C, 256)), dim3(256), 0, st, x, bias, chan_mask, y, rows, HW, C, act, slope);
+  }
+  HWG_LAUNCH_CHECK("bias_act_fwd");
+  return HWG_OK;
+}
+
+extern "C" int hwg_bias_act_bwd(const float* dy, const float* y, const float* chan_mask, float* dx, long long rows, int HW, int C,
+                                int act, float slope, void* stream) {
+  HWG_REQUIRE(dy && dx && rows > 0 && C > 0 && HW > 0, "bias_act_bwd: bad arguments");
+  HWG_REQUIRE(act == 0 || y, "bias_act_bwd: y required when an activation is fused");
+  hipStream_t st = (hipStream_t)stream;
+  if (C % 4 == 0) {
+    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(hwg_stream_grid(rows * C / 4, 256)), dim3(256), 0, st, dy, y, chan_mask, dx, rows, HW, C, act, slope);
+  } else {
+    hipLaunchKernelGGL(bias_act_bwd_scalar_kernel, dim3(hwg_stream_grid(rows * C, 256)), dim3(256), 0, st, dy, y, chan_mask, dx, rows, HW, C, act, slope);
+  }
+  HWG_LAUNCH_CHECK("bias_act_bwd");
+  return HWG_OK;
+}

@@ -1,0 +1,233 @@
+// Multi-tensor optimizer-side kernels (gradient stash / balance / clip / Adam / NaN scan over the ~1.3k
+// parameter tensors, trainer/hw_with_style_trainer.py:300-391) and the Philox random number kernels that
+// replace torch.randn_like / Dropout2d masks (model/pure_gen.py:206,212; nn.Dropout2d sites).
+//
+// Tensor lists are described by device tables built once on the host:
+//   ptrs*      : int64 array of device addresses, one per tensor (0 = tensor absent -> chunk skipped)
+//   chunk_tensor / chunk_off : one entry per fixed-size chunk of a tensor, so one launch covers all tensors.
+#include "hwg_common.h"
+
+namespace {
+
+struct MtArgs {
+  const long long* pa;
+  const long long* pb;
+  const long long* pc;
+  const long long* pd;
+  const long long* numel;
+  const int* chunk_tensor;
+  const long long* chunk_off;
+  int chunk;
+};
+
+__global__ __launch_bounds__(256) void mt_abs_sum_kernel(MtArgs a, double* out) {
+  __shared__ double sm[16];
+  const int t = a.chunk_tensor[blockIdx.x];
+  const float* g = reinterpret_cast<const float*>(a.pa[t]);
+  if (!g) return;
+  const long long off = a.chunk_off[blockIdx.x];
+  const long long end = min(off + (long long)a.chunk, a.numel[t]);
+  double s = 0.0;
+  for (long long i = off + threadIdx.x; i < end; i += 256) s += (double)fabsf(g[i]);
+  s = block_sum_d(s, sm);
+  if (threadIdx.x == 0) atomicAdd(out + t, s);
+}
+
+// coefficients of the balanced add:  coef[k][t] = x_k * D_t / R_kt   (0 when the stashed tensor is absent or all-zero)
+// D_t = mean|grad_t|, zero means are replaced by the mean of the non-zero ones (trainer :341-359)
+__global__ __launch_bounds__(256) void mt_balance_coef_kernel(const double* sumD, const double* sumR /*[nsets][nt]*/, const long long* numel,
+                                                              const long long* ptr_grad, const long long* ptr_R /*[nsets][nt]*/, const float* xs,
+                                                              int nsets, int nt, float* coef /*[nsets][nt]*/) {
+  __shared__ double sm[16];
+  __shared__ double s_nonzero;
+  double zs = 0.0, zc = 0.0;
+  for (int t = threadIdx.x; t < nt; t += 256) {
+    if (!ptr_grad[t]) continue;
+    const float m = (float)(sumD[t] / (double)numel[t]);
+    if (m != 0.f) { zs += (double)m; zc += 1.0; }
+  }
+  zs = block_sum_d(zs, sm);
+  zc = block_sum_d(zc, sm);
+  if (threadIdx.x == 0) s_nonzero = zc > 0.0 ? (double)((float)zs / (float)zc) : 0.0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < nsets * nt; i += 256) {
+    const int t = i % nt, k = i / nt;
+    float c = 0.f;
+    if (ptr_grad[t] && ptr_R[i]) {
+      float d = (float)(sumD[t] / (double)numel[t]);
+      if (d == 0.f && zc > 0.0) d = (float)s_nonzero;
+      const float r = (float)(sumR[i] / (double)numel[t]);
+      if (r != 0.f) c = xs[k] * (d / r);
+    }
+    coef[i] = c;
+  }
+}
+
+// dst += coef[t] * src
+__global__ __launch_bounds__(256) void mt_axpy_kernel(MtArgs a, const float* coef) {
+  const int t = a.chunk_tensor[blockIdx.x];
+  float* dst = reinterpret_cast<float*>(a.pa[t]);
+  const float* src = reinterpret_cast<const float*>(a.pb[t]);
+  if (!dst || !src) return;
+  const float c = coef ? coef[t] : 1.f;
+  if (c == 0.f) return;
+  const long long off = a.chunk_off[blockIdx.x];
+  const long long end = min(off + (long long)a.chunk, a.numel[t]);
+  for (long long i = off + threadIdx.x; i < end; i += 256) dst[i] += c * src[i];
+}
+
+// op 0: a = 0 ; 1: a = clamp(a, -c, c) ; 2: flag |= any(!finite(a)) ; 3: b = a (copy) ; 4: b = a, a = 0 (stash)
+__global__ __launch_bounds__(256) void mt_unary_kernel(MtArgs a, int op, float c, int* flag) {
+  const int t = a.chunk_tensor[blockIdx.x];
+  float* x = reinterpret_cast<float*>(a.pa[t]);
+  if (!x) return;
+  float* y = a.pb ? reinterpret_cast<float*>(a.pb[t]) : nullptr;
+  const long long off = a.chunk_off[blockIdx.x];
+  const long long end = min(off + (long long)a.chunk, a.numel[t]);
+  bool bad = false;
+  for (long long i = off + threadIdx.x; i < end; i += 256) {
+    const float v = x[i];
+    if (op == 0) x[i] = 0.f;
+    else if (op == 1) x[i] = fminf(fmaxf(v, -c), c);
+    else if (op == 2) bad |= !isfinite(v);
+    else if (op == 3) { if (y) y[i] = v; }
+    else { if (y) y[i] = v; x[i] = 0.f; }
+  }
+  if (op == 2 && bad) atomicOr(flag, 1);
+}
+
+// torch.optim.Adam (no amsgrad / weight decay) with the trainer's clip_grad_value_ fused into the gradient read
+__global__ __launch_bounds__(256) void mt_adam_kernel(MtArgs a, const float* step_size, const float* bc2_sqrt, float beta1, float beta2, float eps,
+                                                      float clip) {
+  const int t = a.chunk_tensor[blockIdx.x];
+  float* p = reinterpret_cast<float*>(a.pa[t]);
+  float* g = reinterpret_cast<float*>(a.pb[t]);
+  float* m = reinterpret_cast<float*>(a.pc[t]);
+  float* v = reinterpret_cast<float*>(a.pd[t]);
+  if (!p || !g || !m || !v) return;
+  const float ss = step_size[t], b2 = bc2_sqrt[t];
+  const long long off = a.chunk_off[blockIdx.x];
+  const long long end = min(off + (long long)a.chunk, a.numel[t]);
+  for (long long i = off + threadIdx.x; i < end; i += 256) {
+    float gi = g[i];
+    if (clip > 0.f) { gi = fminf(fmaxf(gi, -clip), clip); g[i] = gi; }
+    // exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / b2 + eps;
+    p[i] = p[i] - ss * (mi / denom);
+  }
+}
+
+// ---------------- Philox4x32-10 ----------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+  const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+  c[0] = hi1 ^ c[1] ^ k[0]; c[1] = lo1; c[2] = hi0 ^ c[3] ^ k[1]; c[3] = lo0;
+  k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) philox_round(c, k);
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.f / 16777216.f); }  // (0,1)
+
+__global__ void randn_kernel(float* out, long long n, uint64_t seed, uint64_t offset) {
+  const long long n4 = (n + 3) / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4(seed, offset + (uint64_t)i, r);
+    const float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]), u3 = u01(r[3]);
+    const float ra = sqrtf(-2.f * logf(u0)), rb = sqrtf(-2.f * logf(u2));
+    float s0, c0, s1, c1;
+    sincosf(6.2831853071795864f * u1, &s0, &c0);
+    sincosf(6.2831853071795864f * u3, &s1, &c1);
+    const float v[4] = {ra * c0, ra * s0, rb * c1, rb * s1};
+    for (int e = 0; e < 4; ++e)
+      if (i * 4 + e < n) out[i * 4 + e] = v[e];
+  }
+}
+// out[i] = (u >= p) ? 1/(1-p) : 0     (feature-dropout channel masks)
+__global__ void dropmask_kernel(float* out, long long n, float p, uint64_t seed, uint64_t offset) {
+  const long long n4 = (n + 3) / 4;
+  const float keep = 1.f / (1.f - p);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4(seed, offset + (uint64_t)i, r);
+    for (int e = 0; e < 4; ++e)
+      if (i * 4 + e < n) out[i * 4 + e] = (u01(r[e]) >= p) ? keep : 0.f;
+  }
+}
+
+MtArgs make_mt(const void* pa, const void* pb, const void* pc, const void* pd, const void* numel, const void* ct, const void* co, int chunk) {
+  MtArgs a;
+  a.pa = (const long long*)pa; a.pb = (const long long*)pb; a.pc = (const long long*)pc; a.pd = (const long long*)pd;
+  a.numel = (const long long*)numel; a.chunk_tensor = (const int*)ct; a.chunk_off = (const long long*)co; a.chunk = chunk;
+  return a;
+}
+
+}  // namespace
+
+extern "C" int hwg_mt_abs_sum(const void* ptrs, const void* numel, const void* chunk_tensor, const void* chunk_off, int nchunks, int chunk,
+                              double* out_sums, void* stream) {
+  HWG_REQUIRE(ptrs && numel && chunk_tensor && chunk_off && out_sums && nchunks > 0 && chunk > 0, "mt_abs_sum: bad arguments");
+  MtArgs a = make_mt(ptrs, nullptr, nullptr, nullptr, numel, chunk_tensor, chunk_off, chunk);
+  hipLaunchKernelGGL(mt_abs_sum_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a, out_sums);
+  HWG_LAUNCH_CHECK("mt_abs_sum");
+  return HWG_OK;
+}
+extern "C" int hwg_mt_balance_coef(const double* sumD, const double* sumR, const void* numel, const void* ptr_grad, const void* ptr_R,
+                                   const float* xs, int nsets, int nt, float* coef, void* stream) {
+  HWG_REQUIRE(sumD && sumR && numel && ptr_grad && ptr_R && xs && coef && nsets > 0 && nt > 0, "mt_balance_coef: bad arguments");
+  hipLaunchKernelGGL(mt_balance_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sumD, sumR, (const long long*)numel,
+                     (const long long*)ptr_grad, (const long long*)ptr_R, xs, nsets, nt, coef);
+  HWG_LAUNCH_CHECK("mt_balance_coef");
+  return HWG_OK;
+}
+extern "C" int hwg_mt_axpy(const void* ptrs_dst, const void* ptrs_src, const float* coef, const void* numel, const void* chunk_tensor,
+                           const void* chunk_off, int nchunks, int chunk, void* stream) {
+  HWG_REQUIRE(ptrs_dst && ptrs_src && numel && chunk_tensor && chunk_off && nchunks > 0 && chunk > 0, "mt_axpy: bad arguments");
+  MtArgs a = make_mt(ptrs_dst, ptrs_src, nullptr, nullptr, numel, chunk_tensor, chunk_off, chunk);
+  hipLaunchKernelGGL(mt_axpy_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a, coef);
+  HWG_LAUNCH_CHECK("mt_axpy");
+  return HWG_OK;
+}
+extern "C" int hwg_mt_unary(const void* ptrs_a, const void* ptrs_b, int op, float c, int* flag, const void* numel, const void* chunk_tensor,
+                            const void* chunk_off, int nchunks, int chunk, void* stream) {
+  HWG_REQUIRE(ptrs_a && numel && chunk_tensor && chunk_off && nchunks > 0 && chunk > 0 && op >= 0 && op <= 4, "mt_unary: bad arguments");
+  HWG_REQUIRE(op != 2 || flag, "mt_unary: nan scan needs a flag");
+  MtArgs a = make_mt(ptrs_a, ptrs_b, nullptr, nullptr, numel, chunk_tensor, chunk_off, chunk);
+  hipLaunchKernelGGL(mt_unary_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a, op, c, flag);
+  HWG_LAUNCH_CHECK("mt_unary");
+  return HWG_OK;
+}
+extern "C" int hwg_mt_adam(const void* ptrs_p, const void* ptrs_g, const void* ptrs_m, const void* ptrs_v, const float* step_size,
+                           const float* bc2_sqrt, float beta1, float beta2, float eps, float clip, const void* numel, const void* chunk_tensor,
+                           const void* chunk_off, int nchunks, int chunk, void* stream) {
+  HWG_REQUIRE(ptrs_p && ptrs_g && ptrs_m && ptrs_v && step_size && bc2_sqrt && numel && chunk_tensor && chunk_off && nchunks > 0 && chunk > 0,
+              "mt_adam: bad arguments");
+  MtArgs a = make_mt(ptrs_p, ptrs_g, ptrs_m, ptrs_v, numel, chunk_tensor, chunk_off, chunk);
+  hipLaunchKernelGGL(mt_adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a, step_size, bc2_sqrt, beta1, beta2, eps, clip);
+  HWG_LAUNCH_CHECK("mt_adam");
+  return HWG_OK;
+}
+
+extern "C" int hwg_randn(float* out, long long n, unsigned long long seed, unsigned long long offset, void* stream) {
+  HWG_REQUIRE(out && n > 0, "randn: bad arguments");
+  hipLaunchKernelGGL(randn_kernel, dim3(hwg_stream_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n, (uint64_t)seed, (uint64_t)offset);
+  HWG_LAUNCH_CHECK("randn");
+  return HWG_OK;
+}
+extern "C" int hwg_dropmask(float* out, long long n, float p, unsigned long long seed, unsigned long long offset, void* stream) {
+  HWG_REQUIRE(out && n > 0 && p >= 0.f && p < 1.f, "dropmask: bad arguments");
+  hipLaunchKernelGGL(dropmask_kernel, dim3(hwg_stream_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n, p, (uint64_t)seed,
+                     (uint64_t)offset);
+  HWG_LAUNCH_CHECK("dropmask");
+  return HWG_OK;
+}

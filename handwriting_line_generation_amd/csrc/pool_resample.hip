@@ -1,0 +1,393 @@
+// Pooling / resampling / padding / concatenation kernels on NHWC tensors. All HBM-bound; every kernel is
+// a grid-stride loop over output vectors of V channels (V = 4 when C % 4 == 0, else 1).
+#include "hwg_common.h"
+
+namespace {
+
+template <int V> struct VecT { float v[V]; };
+template <int V> __device__ __forceinline__ VecT<V> vload(const float* p) {
+  VecT<V> r;
+  if (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p); r.v[0] = t.x; r.v[1 % V] = t.y; r.v[2 % V] = t.z; r.v[3 % V] = t.w; }
+  else r.v[0] = p[0];
+  return r;
+}
+template <int V> __device__ __forceinline__ void vstore(float* p, const VecT<V>& r) {
+  if (V == 4) *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1 % V], r.v[2 % V], r.v[3 % V]);
+  else p[0] = r.v[0];
+}
+template <int V> __device__ __forceinline__ VecT<V> vzero() { VecT<V> r; for (int i = 0; i < V; ++i) r.v[i] = 0.f; return r; }
+
+#define GRID_STRIDE(i, total) \
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (total); i += (long long)gridDim.x * blockDim.x)
+
+// ---------------- average pooling (kernel == stride, no padding, floor) ----------------
+template <int V>
+__global__ void avgpool_fwd_kernel(const float* x, float* y, int N, int H, int W, int C, int kh, int kw, int P, int Q) {
+  const int CV = C / V;
+  const long long total = (long long)N * P * Q * CV;
+  const float inv = 1.f / (kh * kw);
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int q = (int)(t % Q); t /= Q;
+    const int p = (int)(t % P); const int n = (int)(t / P);
+    VecT<V> acc = vzero<V>();
+    for (int a = 0; a < kh; ++a)
+      for (int b = 0; b < kw; ++b) {
+        const VecT<V> v = vload<V>(x + (((long long)n * H + p * kh + a) * W + q * kw + b) * C + c);
+        for (int e = 0; e < V; ++e) acc.v[e] += v.v[e];
+      }
+    for (int e = 0; e < V; ++e) acc.v[e] *= inv;
+    vstore<V>(y + i * V, acc);
+  }
+}
+template <int V>
+__global__ void avgpool_bwd_kernel(const float* dy, float* dx, int N, int H, int W, int C, int kh, int kw, int P, int Q) {
+  const int CV = C / V;
+  const long long total = (long long)N * H * W * CV;
+  const float inv = 1.f / (kh * kw);
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); const int n = (int)(t / H);
+    const int p = h / kh, q = w / kw;
+    VecT<V> r = vzero<V>();
+    if (p < P && q < Q) {
+      r = vload<V>(dy + (((long long)n * P + p) * Q + q) * C + c);
+      for (int e = 0; e < V; ++e) r.v[e] *= inv;
+    }
+    vstore<V>(dx + i * V, r);
+  }
+}
+
+// ---------------- max pooling (general kernel/stride/padding), argmax saved as h*W+w ----------------
+template <int V>
+__global__ void maxpool_fwd_kernel(const float* x, float* y, int* idx, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
+                                   int ph, int pw, int P, int Q) {
+  const int CV = C / V;
+  const long long total = (long long)N * P * Q * CV;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int q = (int)(t % Q); t /= Q;
+    const int p = (int)(t % P); const int n = (int)(t / P);
+    VecT<V> best; int bi[V];
+    for (int e = 0; e < V; ++e) { best.v[e] = -INFINITY; bi[e] = -1; }
+    for (int a = 0; a < kh; ++a) {
+      const int h = p * sh - ph + a;
+      if (h < 0 || h >= H) continue;
+      for (int b = 0; b < kw; ++b) {
+        const int w = q * sw - pw + b;
+        if (w < 0 || w >= W) continue;
+        const VecT<V> v = vload<V>(x + (((long long)n * H + h) * W + w) * C + c);
+        // same update rule as ATen's max_pool2d: first maximum wins, NaN propagates
+        for (int e = 0; e < V; ++e)
+          if (v.v[e] > best.v[e] || v.v[e] != v.v[e] || bi[e] < 0) { best.v[e] = v.v[e]; bi[e] = h * W + w; }
+      }
+    }
+    vstore<V>(y + i * V, best);
+    for (int e = 0; e < V; ++e) idx[i * V + e] = bi[e];
+  }
+}
+template <int V>
+__global__ void maxpool_bwd_kernel(const float* dy, const int* idx, float* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
+                                   int ph, int pw, int P, int Q) {
+  const int CV = C / V;
+  const long long total = (long long)N * H * W * CV;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); const int n = (int)(t / H);
+    const int me = h * W + w;
+    VecT<V> acc = vzero<V>();
+    // output rows p with p*sh-ph <= h <= p*sh-ph+kh-1
+    int pmin = (h + ph - kh + 1 + sh - 1); pmin = pmin > 0 ? pmin / sh : 0;
+    int pmax = (h + ph) / sh; if (pmax > P - 1) pmax = P - 1;
+    int qmin = (w + pw - kw + 1 + sw - 1); qmin = qmin > 0 ? qmin / sw : 0;
+    int qmax = (w + pw) / sw; if (qmax > Q - 1) qmax = Q - 1;
+    for (int p = pmin; p <= pmax; ++p)
+      for (int q = qmin; q <= qmax; ++q) {
+        const long long o = (((long long)n * P + p) * Q + q) * C + c;
+        for (int e = 0; e < V; ++e)
+          if (idx[o + e] == me) acc.v[e] += dy[o + e];
+      }
+    vstore<V>(dx + i * V, acc);
+  }
+}
+
+// ---------------- nearest upsample by integer factors ----------------
+template <int V>
+__global__ void upsample_fwd_kernel(const float* x, float* y, int N, int H, int W, int C, int fh, int fw) {
+  const int CV = C / V;
+  const int P = H * fh, Q = W * fw;
+  const long long total = (long long)N * P * Q * CV;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int q = (int)(t % Q); t /= Q;
+    const int p = (int)(t % P); const int n = (int)(t / P);
+    vstore<V>(y + i * V, vload<V>(x + (((long long)n * H + p / fh) * W + q / fw) * C + c));
+  }
+}
+template <int V>
+__global__ void upsample_bwd_kernel(const float* dy, float* dx, int N, int H, int W, int C, int fh, int fw) {
+  const int CV = C / V;
+  const int P = H * fh, Q = W * fw;
+  const long long total = (long long)N * H * W * CV;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); const int n = (int)(t / H);
+    VecT<V> acc = vzero<V>();
+    for (int a = 0; a < fh; ++a)
+      for (int b = 0; b < fw; ++b) {
+        const VecT<V> v = vload<V>(dy + (((long long)n * P + h * fh + a) * Q + w * fw + b) * C + c);
+        for (int e = 0; e < V; ++e) acc.v[e] += v.v[e];
+      }
+    vstore<V>(dx + i * V, acc);
+  }
+}
+
+// ---------------- depthwise 3x3 binomial blur, zero padding 1 (symmetric: forward == backward) ----------------
+template <int V>
+__global__ void blur3_kernel(const float* x, float* y, int N, int H, int W, int C) {
+  const int CV = C / V;
+  const long long total = (long long)N * H * W * CV;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); const int n = (int)(t / H);
+    VecT<V> acc = vzero<V>();
+    // accumulate in the same tap order as the 3x3 correlation (row major)
+    for (int a = -1; a <= 1; ++a) {
+      const int hh = h + a;
+      if (hh < 0 || hh >= H) continue;
+      for (int b = -1; b <= 1; ++b) {
+        const int ww = w + b;
+        if (ww < 0 || ww >= W) continue;
+        const float k = ((a == 0 ? 2.f : 1.f) * (b == 0 ? 2.f : 1.f)) * (1.f / 16.f);
+        const VecT<V> v = vload<V>(x + (((long long)n * H + hh) * W + ww) * C + c);
+        for (int e = 0; e < V; ++e) acc.v[e] += k * v.v[e];
+      }
+    }
+    vstore<V>(y + i * V, acc);
+  }
+}
+
+// ---------------- 2-D padding: mode 0 constant(value), mode 1 replicate ----------------
+template <int V>
+__global__ void pad2d_fwd_kernel(const float* x, float* y, int N, int H, int W, int C, int pt, int pb, int pl, int pr, int mode, float value) {
+  const int CV = C / V;
+  const int P = H + pt + pb, Q = W + pl + pr;
+  const long long total = (long long)N * P * Q * CV;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int q = (int)(t % Q); t /= Q;
+    const int p = (int)(t % P); const int n = (int)(t / P);
+    int h = p - pt, w = q - pl;
+    VecT<V> r;
+    if (mode == 1) {
+      h = h < 0 ? 0 : (h >= H ? H - 1 : h);
+      w = w < 0 ? 0 : (w >= W ? W - 1 : w);
+      r = vload<V>(x + (((long long)n * H + h) * W + w) * C + c);
+    } else if (h >= 0 && h < H && w >= 0 && w < W) {
+      r = vload<V>(x + (((long long)n * H + h) * W + w) * C + c);
+    } else {
+      for (int e = 0; e < V; ++e) r.v[e] = value;
+    }
+    vstore<V>(y + i * V, r);
+  }
+}
+template <int V>
+__global__ void pad2d_bwd_kernel(const float* dy, float* dx, int N, int H, int W, int C, int pt, int pb, int pl, int pr, int mode) {
+  const int CV = C / V;
+  const int P = H + pt + pb, Q = W + pl + pr;
+  const long long total = (long long)N * H * W * CV;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); const int n = (int)(t / H);
+    int p0 = h + pt, p1 = h + pt, q0 = w + pl, q1 = w + pl;
+    if (mode == 1) {
+      if (h == 0) p0 = 0;
+      if (h == H - 1) p1 = P - 1;
+      if (w == 0) q0 = 0;
+      if (w == W - 1) q1 = Q - 1;
+    }
+    VecT<V> acc = vzero<V>();
+    for (int p = p0; p <= p1; ++p)
+      for (int q = q0; q <= q1; ++q) {
+        if (p < 0 || p >= P || q < 0 || q >= Q) continue;  // negative pads (crop)
+        const VecT<V> v = vload<V>(dy + (((long long)n * P + p) * Q + q) * C + c);
+        for (int e = 0; e < V; ++e) acc.v[e] += v.v[e];
+      }
+    vstore<V>(dx + i * V, acc);
+  }
+}
+
+// ---------------- channel slice copies (concat / split), with optional per-sample broadcast over HW ----------------
+// dst[row][doff + c] = src[(bcast ? row / HW : row)][soff + c],  c < Cn
+__global__ void copy_channels_kernel(const float* src, int Cs, int soff, float* dst, int Cd, int doff, int Cn, long long rows, int HW, int bcast,
+                                     int accumulate) {
+  const long long total = rows * Cn;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % Cn);
+    const long long row = i / Cn;
+    const long long srow = bcast ? row / HW : row;
+    const float v = src[srow * Cs + soff + c];
+    float* d = dst + row * Cd + doff + c;
+    *d = accumulate ? *d + v : v;
+  }
+}
+// out[n][c] (+)= sum_hw src[n*HW + hw][soff + c]   (backward of the broadcast)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* src, int Cs, int soff, float* out, int Cn, int HW, int accumulate) {
+  __shared__ float red[256];
+  const int n = blockIdx.x;
+  const int c = blockIdx.y;
+  float s = 0.f;
+  for (int p = threadIdx.x; p < HW; p += 256) s += src[((long long)n * HW + p) * Cs + soff + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[n * Cn + c] = accumulate ? out[n * Cn + c] + red[0] : red[0];
+}
+
+// one-hot rows: label is [L][B] (time major, as the reference passes it); out is [B][L][ncls]
+__global__ void onehot_kernel(const int* label, float* out, int L, int B, int ncls, int Cd, int doff) {
+  const long long total = (long long)B * L * ncls;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % ncls);
+    const long long t = i / ncls;
+    const int l = (int)(t % L), b = (int)(t / L);
+    out[((long long)b * L + l) * Cd + doff + c] = (label[l * B + b] == c) ? 1.f : 0.f;
+  }
+}
+
+// generic strided 4-d permute copy: out[i0][i1][i2][i3] (contiguous) = in[i0*s0 + i1*s1 + i2*s2 + i3*s3]
+__global__ void permute4_kernel(const float* in, float* out, int d0, int d1, int d2, int d3, long long s0, long long s1, long long s2, long long s3) {
+  const long long total = (long long)d0 * d1 * d2 * d3;
+  GRID_STRIDE(i, total) {
+    const int i3 = (int)(i % d3); long long t = i / d3;
+    const int i2 = (int)(t % d2); t /= d2;
+    const int i1 = (int)(t % d1); const int i0 = (int)(t / d1);
+    out[i] = in[i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3];
+  }
+}
+
+#define LAUNCH_V(kern, total_of_v, C, ...)                                                                         \
+  do {                                                                                                               \
+    if ((C) % 4 == 0) hipLaunchKernelGGL(kern<4>, dim3(hwg_stream_grid((total_of_v) / 4, 256)), dim3(256), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern<1>, dim3(hwg_stream_grid((total_of_v), 256)), dim3(256), 0, st, __VA_ARGS__);           \
+  } while (0)
+
+}  // namespace
+
+extern "C" int hwg_avgpool_fwd(const float* x, float* y, int N, int H, int W, int C, int kh, int kw, void* stream) {
+  HWG_REQUIRE(x && y && N > 0 && H >= kh && W >= kw && C > 0 && kh > 0 && kw > 0, "avgpool_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int P = H / kh, Q = W / kw;
+  LAUNCH_V(avgpool_fwd_kernel, (long long)N * P * Q * C, C, x, y, N, H, W, C, kh, kw, P, Q);
+  HWG_LAUNCH_CHECK("avgpool_fwd");
+  return HWG_OK;
+}
+extern "C" int hwg_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, int C, int kh, int kw, void* stream) {
+  HWG_REQUIRE(dy && dx && N > 0 && H >= kh && W >= kw && C > 0 && kh > 0 && kw > 0, "avgpool_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int P = H / kh, Q = W / kw;
+  LAUNCH_V(avgpool_bwd_kernel, (long long)N * H * W * C, C, dy, dx, N, H, W, C, kh, kw, P, Q);
+  HWG_LAUNCH_CHECK("avgpool_bwd");
+  return HWG_OK;
+}
+
+extern "C" int hwg_maxpool_fwd(const float* x, float* y, int* idx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+                               int P, int Q, void* stream) {
+  HWG_REQUIRE(x && y && idx && N > 0 && C > 0 && P > 0 && Q > 0, "maxpool_fwd: bad arguments");
+  HWG_REQUIRE(P == (H + 2 * ph - kh) / sh + 1 && Q == (W + 2 * pw - kw) / sw + 1, "maxpool_fwd: inconsistent output size");
+  hipStream_t st = (hipStream_t)stream;
+  LAUNCH_V(maxpool_fwd_kernel, (long long)N * P * Q * C, C, x, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q);
+  HWG_LAUNCH_CHECK("maxpool_fwd");
+  return HWG_OK;
+}
+extern "C" int hwg_maxpool_bwd(const float* dy, const int* idx, float* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph,
+                               int pw, int P, int Q, void* stream) {
+  HWG_REQUIRE(dy && dx && idx && N > 0 && C > 0 && P > 0 && Q > 0, "maxpool_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  LAUNCH_V(maxpool_bwd_kernel, (long long)N * H * W * C, C, dy, idx, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q);
+  HWG_LAUNCH_CHECK("maxpool_bwd");
+  return HWG_OK;
+}
+
+extern "C" int hwg_upsample_nearest_fwd(const float* x, float* y, int N, int H, int W, int C, int fh, int fw, void* stream) {
+  HWG_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && fh > 0 && fw > 0, "upsample_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  LAUNCH_V(upsample_fwd_kernel, (long long)N * H * fh * W * fw * C, C, x, y, N, H, W, C, fh, fw);
+  HWG_LAUNCH_CHECK("upsample_fwd");
+  return HWG_OK;
+}
+extern "C" int hwg_upsample_nearest_bwd(const float* dy, float* dx, int N, int H, int W, int C, int fh, int fw, void* stream) {
+  HWG_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && fh > 0 && fw > 0, "upsample_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  LAUNCH_V(upsample_bwd_kernel, (long long)N * H * W * C, C, dy, dx, N, H, W, C, fh, fw);
+  HWG_LAUNCH_CHECK("upsample_bwd");
+  return HWG_OK;
+}
+
+extern "C" int hwg_blur3(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  HWG_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "blur3: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  LAUNCH_V(blur3_kernel, (long long)N * H * W * C, C, x, y, N, H, W, C);
+  HWG_LAUNCH_CHECK("blur3");
+  return HWG_OK;
+}
+
+extern "C" int hwg_pad2d_fwd(const float* x, float* y, int N, int H, int W, int C, int pt, int pb, int pl, int pr, int mode, float value,
+                             void* stream) {
+  HWG_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "pad2d_fwd: bad arguments");
+  HWG_REQUIRE(H + pt + pb > 0 && W + pl + pr > 0, "pad2d_fwd: empty output");
+  HWG_REQUIRE(mode == 0 || (pt >= 0 && pb >= 0 && pl >= 0 && pr >= 0), "pad2d_fwd: replicate needs non-negative pads");
+  hipStream_t st = (hipStream_t)stream;
+  LAUNCH_V(pad2d_fwd_kernel, (long long)N * (H + pt + pb) * (W + pl + pr) * C, C, x, y, N, H, W, C, pt, pb, pl, pr, mode, value);
+  HWG_LAUNCH_CHECK("pad2d_fwd");
+  return HWG_OK;
+}
+extern "C" int hwg_pad2d_bwd(const float* dy, float* dx, int N, int H, int W, int C, int pt, int pb, int pl, int pr, int mode, void* stream) {
+  HWG_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "pad2d_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  LAUNCH_V(pad2d_bwd_kernel, (long long)N * H * W * C, C, dy, dx, N, H, W, C, pt, pb, pl, pr, mode);
+  HWG_LAUNCH_CHECK("pad2d_bwd");
+  return HWG_OK;
+}
+
+extern "C" int hwg_copy_channels(const float* src, int Cs, int soff, float* dst, int Cd, int doff, int Cn, long long rows, int HW, int bcast,
+                                 int accumulate, void* stream) {
+  HWG_REQUIRE(src && dst && rows > 0 && Cn > 0 && soff >= 0 && doff >= 0 && soff + Cn <= Cs && doff + Cn <= Cd && HW > 0,
+              "copy_channels: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(hwg_stream_grid(rows * Cn, 256)), dim3(256), 0, st, src, Cs, soff, dst, Cd, doff, Cn, rows, HW,
+                     bcast, accumulate);
+  HWG_LAUNCH_CHECK("copy_channels");
+  return HWG_OK;
+}
+extern "C" int hwg_reduce_rows(const float* src, int Cs, int soff, float* out, int Cn, int N, int HW, int accumulate, void* stream) {
+  HWG_REQUIRE(src && out && N > 0 && HW > 0 && Cn > 0 && soff >= 0 && soff + Cn <= Cs, "reduce_rows: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(N, Cn), dim3(256), 0, st, src, Cs, soff, out, Cn, HW, accumulate);
+  HWG_LAUNCH_CHECK("reduce_rows");
+  return HWG_OK;
+}
+extern "C" int hwg_onehot(const int* label, float* out, int L, int B, int ncls, int Cd, int doff, void* stream) {
+  HWG_REQUIRE(label && out && L > 0 && B > 0 && ncls > 0 && doff >= 0 && doff + ncls <= Cd, "onehot: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(onehot_kernel, dim3(hwg_stream_grid((long long)B * L * ncls, 256)), dim3(256), 0, st, label, out, L, B, ncls, Cd, doff);
+  HWG_LAUNCH_CHECK("onehot");
+  return HWG_OK;
+}
+extern "C" int hwg_permute4(const float* in, float* out, int d0, int d1, int d2, int d3, long long s0, long long s1, long long s2, long long s3,
+                            void* stream) {
+  HWG_REQUIRE(in && out && d0 > 0 && d1 > 0 && d2 > 0 && d3 > 0, "permute4: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(permute4_kernel, dim3(hwg_stream_grid((long long)d0 * d1 * d2 * d3, 256)), dim3(256), 0, st, in, out, d0, d1, d2, d3, s0, s1,
+                     s2, s3);
+  HWG_LAUNCH_CHECK("permute4");
+  return HWG_OK;
+}

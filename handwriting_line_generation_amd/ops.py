@@ -1,0 +1,842 @@
+"""torch.autograd wrappers around the hwg C-ABI kernels.
+
+All activations handled here are NHWC fp32 CUDA(HIP) tensors ([N,H,W,C], C fastest). Parameters keep the
+PyTorch layouts of the reference's state-dict (Conv [O,I,R,S], ConvTranspose [I,O,R,S], Linear [O,I]) so
+released checkpoints load; the kernels read/write those layouts directly through strides.
+
+Nothing in this module computes on the CPU or through ATen math kernels: every op is a call into
+libhwg_hip.so on torch's current stream. torch is used for memory, autograd bookkeeping and views.
+"""
+import ctypes
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+NORM_IN, NORM_GN, NORM_BN = 0, 1, 2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Shared scratch buffer (stream ordered, contents are dead once the call that used it returns)."""
+    nbytes = int(nbytes)
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _chk(t, name, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise L.HwgError("%s must live on the GPU (no CPU fallback exists)" % name)
+    if t.dtype != dtype:
+        raise L.HwgError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise L.HwgError("%s must be contiguous" % name)
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+# ----------------------------------------------------------------------------------------------
+# convolution
+# ----------------------------------------------------------------------------------------------
+def _desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed=0):
+    d = L.ConvDesc()
+    d.N, d.H, d.W, d.C, d.K, d.R, d.S = N, H, W, C, K, R, S
+    d.stride_h, d.stride_w = stride
+    d.pad_h, d.pad_w = pad
+    d.dil_h, d.dil_w = dil
+    d.P, d.Q = P, Q
+    d.transposed = transposed
+    return d
+
+
+def _pack(weight, A, B, R, S, sa, sb, flip, Bpad=None):
+    Bpad = B if Bpad is None else Bpad
+    out = torch.empty((R * S, A, Bpad), dtype=torch.float32, device=weight.device)
+    L.call("hwg_conv_pack_weight", weight, out, A, B, Bpad, R, S, sa, sb, S, 1, int(flip), _stream())
+    return out
+
+
+def _pad_channels(x, Cpad):
+    N, H, W, C = x.shape
+    out = torch.zeros((N, H, W, Cpad), dtype=x.dtype, device=x.device)
+    L.call("hwg_copy_channels", x, C, 0, out, Cpad, 0, C, N * H * W, 1, 0, 0, _stream())
+    return out
+
+
+def _run_conv(x, wp, bias, N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed):
+    y = torch.empty((N, P, Q, K), dtype=torch.float32, device=x.device)
+    d = _desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed)
+    L.call("hwg_conv_fwd", ctypes.byref(d), x, wp, bias, y, 0, _stream())
+    return y
+
+
+def _needs_cpad(C, K):
+    # the MFMA path wants the contraction channels in multiples of 16; the direct kernels (C==1 / K<=2) do not
+    return C != 1 and K > 2 and C % 16 != 0
+
+
+class _Conv2d(Function):
+    """y = conv2d(x, w) (+b) or conv_transpose2d(x, w) (+b); x NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation, transposed, output_padding):
+        _chk(x, "conv input"); _chk(weight, "conv weight"); _chk(bias, "conv bias")
+        N, H, W, C = x.shape
+        R, S = weight.shape[2], weight.shape[3]
+        sh, sw = stride; ph, pw = padding; dh, dw = dilation
+        if not transposed:
+            K = weight.shape[0]
+            assert weight.shape[1] == C, "conv: weight expects %d input channels, got %d" % (weight.shape[1], C)
+            P = (H + 2 * ph - dh * (R - 1) - 1) // sh + 1
+            Q = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
+            Cp = (C + 15) // 16 * 16 if _needs_cpad(C, K) else C
+            xin = _pad_channels(x, Cp) if Cp != C else x
+            wp = _pack(weight, K, C, R, S, C * R * S, R * S, flip=0, Bpad=Cp)
+            y = _run_conv(xin, wp, bias, N, H, W, Cp, K, R, S, (sh, sw), (ph, pw), (dh, dw), P, Q, 0)
+        else:
+            K = weight.shape[1]
+            assert weight.shape[0] == C, "conv_transpose: weight expects %d input channels, got %d" % (weight.shape[0], C)
+            oph, opw = output_padding
+            P = (H - 1) * sh - 2 * ph + dh * (R - 1) + 1 + oph
+            Q = (W - 1) * sw - 2 * pw + dw * (S - 1) + 1 + opw
+            Cp = (C + 15) // 16 * 16 if _needs_cpad(C, K) else C
+            xin = _pad_channels(x, Cp) if Cp != C else x
+            if sh == 1 and sw == 1:
+                # stride-1 transposed conv == correlation with mirrored taps and padding dil*(R-1)-pad
+                wp = _pack(weight, K, C, R, S, R * S, K * R * S, flip=1, Bpad=Cp)
+                y = _run_conv(xin, wp, bias, N, H, W, Cp, K, R, S, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), P, Q, 0)
+            else:
+                assert dh == 1 and dw == 1, "strided conv_transpose needs dilation 1"
+                wp = _pack(weight, K, C, R, S, R * S, K * R * S, flip=0, Bpad=Cp)
+                y = _run_conv(xin, wp, bias, N, H, W, Cp, K, R, S, (sh, sw), (ph, pw), (1, 1), P, Q, 1)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.geom = (stride, padding, dilation, transposed, P, Q)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, padding, dilation, transposed, P, Q = ctx.geom
+        dy = dy.contiguous()
+        N, H, W, C = x.shape
+        R, S = weight.shape[2], weight.shape[3]
+        sh, sw = stride; ph, pw = padding; dh, dw = dilation
+        K = dy.shape[3]
+        dx = dw_ = db = None
+        st = _stream()
+        if ctx.needs_input_grad[0]:
+            # data gradient: contraction over K (dy's channels) producing C channels
+            Kp = (K + 15) // 16 * 16 if _needs_cpad(K, C) else K
+            dyin = _pad_channels(dy, Kp) if Kp != K else dy
+            if not transposed:
+                if sh == 1 and sw == 1:
+                    wp = _pack(weight, C, K, R, S, R * S, C * R * S, flip=1, Bpad=Kp)
+                    dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), H, W, 0)
+                else:
+                    assert dh == 1 and dw == 1, "strided conv backward needs dilation 1"
+                    wp = _pack(weight, C, K, R, S, R * S, C * R * S, flip=0, Bpad=Kp)
+                    dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (sh, sw), (ph, pw), (1, 1), H, W, 1)
+            else:
+                # gradient of a transposed conv is an ordinary (strided) correlation of dy
+                wp = _pack(weight, C, K, R, S, K * R * S, R * S, flip=0, Bpad=Kp)
+                dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (sh, sw), (ph, pw), (dh, dw), H, W, 0)
+        if ctx.needs_input_grad[1]:
+            dw_ = torch.empty_like(weight)
+            if not transposed:
+                d = _desc(N, H, W, C, K, R, S, (sh, sw), (ph, pw), (dh, dw), P, Q)
+                u, v = dy, x
+                sa, sb = C * R * S, R * S
+            else:
+                d = _desc(N, P, Q, K, C, R, S, (sh, sw), (ph, pw), (dh, dw), H, W)
+                u, v = x, dy
+                sa, sb = K * R * S, R * S
+            need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
+            ws = workspace(need, x.device)
+            L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 0, ws, ws.numel(), st)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy.view(-1, K))
+        return dx, dw_, db, None, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
+    return _Conv2d.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(dilation), False, (0, 0))
+
+
+def conv_transpose2d(x, weight, bias=None, stride=1, padding=0, output_padding=0, dilation=1):
+    return _Conv2d.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(dilation), True, _pair(output_padding))
+
+
+def conv1d(x, weight, bias=None, stride=1, padding=0, dilation=1):
+    """x [N,1,L,C]; weight in Conv1d layout [O,I,S]"""
+    return conv2d(x, weight.unsqueeze(2), bias, (1, stride), (0, padding), (1, dilation))
+
+
+def linear(x, weight, bias=None):
+    """x [rows, I] -> [rows, O]; weight [O, I]"""
+    rows, I = x.shape
+    y = conv2d(x.view(rows, 1, 1, I), weight.view(weight.shape[0], I, 1, 1), bias)
+    return y.view(rows, weight.shape[0])
+
+
+def colsum(x2d, out=None, accumulate=False):
+    rows, C = x2d.shape
+    if out is None:
+        out = torch.empty((C,), dtype=torch.float32, device=x2d.device)
+    need = L.query("hwg_colsum_workspace", rows, C)
+    ws = workspace(need, x2d.device)
+    L.call("hwg_colsum", x2d, rows, C, out, int(accumulate), ws, ws.numel(), _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# normalisation + activation
+# ----------------------------------------------------------------------------------------------
+class _Norm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mode, groups, eps, mask, act, slope, running_mean, running_var, momentum):
+        _chk(x, "norm input"); _chk(gamma, "norm weight"); _chk(beta, "norm bias"); _chk(mask, "channel mask")
+        N, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (N * C)
+        y = torch.empty_like(x)
+        mean = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = workspace(L.query("hwg_norm_workspace", N, HW, C), x.device)
+        L.call("hwg_norm_fwd", x, y, N, HW, C, mode, groups, eps, gamma, beta, 0, mask, act, slope, mean, rstd,
+               running_mean, running_var, momentum, ws, ws.numel(), _stream())
+        ctx.save_for_backward(x, y, gamma, mask, mean, rstd)
+        ctx.cfg = (mode, groups, act, slope, N, HW, C, beta is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mask, mean, rstd = ctx.saved_tensors
+        mode, groups, act, slope, N, HW, C, has_beta = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=x.device) if gamma is not None else None
+        dbeta = torch.empty((C,), dtype=torch.float32, device=x.device) if has_beta else None
+        ws = workspace(L.query("hwg_norm_workspace", N, HW, C), x.device)
+        L.call("hwg_norm_bwd", dy, x, y, dx, N, HW, C, mode, groups, gamma, 0, mask, act, slope, mean, rstd, dgamma, dbeta, 0,
+               ws, ws.numel(), _stream())
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+def group_norm(x, groups, gamma, beta, eps=1e-5, mask=None, act=ACT_NONE, slope=0.0):
+    return _Norm.apply(x, gamma, beta, NORM_GN, groups, eps, mask, act, slope, None, None, 0.0)
+
+
+def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, act=ACT_NONE, slope=0.0):
+    return _Norm.apply(x, gamma, beta, NORM_BN, 1, eps, None, act, slope, running_mean, running_var, momentum)
+
+
+def instance_norm(x, eps=1e-5):
+    return _Norm.apply(x, None, None, NORM_IN, 1, eps, None, ACT_NONE, 0.0, None, None, 0.0)
+
+
+class _AdaIN(Function):
+    """(x, noise, noise_weight_orig, gamma, beta) -> gamma*IN(lrelu(x + w*noise)) + beta  (+ folded conv-bias gradient)"""
+
+    @staticmethod
+    def forward(ctx, x, noise, noise_w, gamma, beta, noise_scale, slope, eps):
+        for t, n in ((x, "x"), (noise, "noise"), (noise_w, "noise weight"), (gamma, "gamma"), (beta, "beta")):
+            _chk(t, "adain " + n)
+        N, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (N * C)
+        u = torch.empty_like(x)
+        y = torch.empty_like(x)
+        mean = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = workspace(L.query("hwg_norm_workspace", N, HW, C), x.device)
+        L.call("hwg_adain_fwd", x, noise, noise_w, noise_scale, slope, gamma, beta, eps, u, y, mean, rstd, N, HW, C, ws, ws.numel(), _stream())
+        ctx.save_for_backward(u, noise, gamma, mean, rstd)
+        ctx.cfg = (noise_scale, slope, N, HW, C, noise_w.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, noise, gamma, mean, rstd = ctx.saved_tensors
+        noise_scale, slope, N, HW, C, wshape = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(u)
+        dgamma = torch.empty((N, C), dtype=torch.float32, device=u.device)
+        dbeta = torch.empty_like(dgamma)
+        dnw = torch.empty((C,), dtype=torch.float32, device=u.device)
+        ws = workspace(L.query("hwg_norm_workspace", N, HW, C), u.device)
+        L.call("hwg_adain_bwd", dy, u, noise, noise_scale, slope, gamma, mean, rstd, dx, dgamma, dbeta, dnw, None, 0, N, HW, C,
+               ws, ws.numel(), _stream())
+        return dx, None, dnw.view(wshape), dgamma, dbeta, None, None, None
+
+
+def adain_epilogue(x, noise, noise_w, gamma, beta, noise_scale, slope=0.2, eps=1e-5):
+    return _AdaIN.apply(x, noise, noise_w, gamma, beta, noise_scale, slope, eps)
+
+
+class _BiasAct(Function):
+    @staticmethod
+    def forward(ctx, x, bias, mask, act, slope):
+        _chk(x, "bias_act input"); _chk(bias, "bias"); _chk(mask, "channel mask")
+        C = x.shape[-1]
+        N = x.shape[0]
+        rows = x.numel() // C
+        HW = rows // N
+        y = torch.empty_like(x)
+        L.call("hwg_bias_act_fwd", x, bias, mask, y, rows, HW, C, act, slope, _stream())
+        ctx.save_for_backward(y, mask)
+        ctx.cfg = (act, slope, rows, HW, C, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, mask = ctx.saved_tensors
+        act, slope, rows, HW, C, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        L.call("hwg_bias_act_bwd", dy, y, mask, dx, rows, HW, C, act, slope, _stream())
+        db = colsum(dx.view(rows, C)) if has_bias and ctx.needs_input_grad[1] else None
+        return dx, db, None, None, None
+
+
+def bias_act(x, bias=None, mask=None, act=ACT_NONE, slope=0.0):
+    return _BiasAct.apply(x, bias, mask, act, slope)
+
+
+def relu(x):
+    return _BiasAct.apply(x, None, None, ACT_RELU, 0.0)
+
+
+def leaky_relu(x, slope):
+    return _BiasAct.apply(x, None, None, ACT_LRELU, slope)
+
+
+class _Tanh(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x, "tanh input")
+        y = torch.empty_like(x)
+        L.call("hwg_tanh_fwd", x, y, x.numel(), _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        L.call("hwg_tanh_bwd", dy.contiguous(), y, dx, y.numel(), _stream())
+        return dx
+
+
+def tanh(x):
+    return _Tanh.apply(x)
+
+
+class _PixelNorm(Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        _chk(x, "pixelnorm input")
+        rows, C = x.shape
+        y = torch.empty_like(x)
+        L.call("hwg_pixelnorm_fwd", x, y, rows, C, eps, _stream())
+        ctx.save_for_backward(x)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        L.call("hwg_pixelnorm_bwd", dy.contiguous(), x, dx, x.shape[0], x.shape[1], ctx.eps, _stream())
+        return dx, None
+
+
+def pixel_norm(x, eps=1e-8):
+    return _PixelNorm.apply(x, eps)
+
+
+# ----------------------------------------------------------------------------------------------
+# pooling / resampling / padding / concat
+# ----------------------------------------------------------------------------------------------
+class _AvgPool(Function):
+    @staticmethod
+    def forward(ctx, x, kh, kw):
+        _chk(x, "avgpool input")
+        N, H, W, C = x.shape
+        y = torch.empty((N, H // kh, W // kw, C), dtype=torch.float32, device=x.device)
+        L.call("hwg_avgpool_fwd", x, y, N, H, W, C, kh, kw, _stream())
+        ctx.cfg = (N, H, W, C, kh, kw)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C, kh, kw = ctx.cfg
+        dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
+        L.call("hwg_avgpool_bwd", dy.contiguous(), dx, N, H, W, C, kh, kw, _stream())
+        return dx, None, None
+
+
+def avg_pool2d(x, kernel):
+    kh, kw = _pair(kernel)
+    return _AvgPool.apply(x, kh, kw)
+
+
+class _MaxPool(Function):
+    @staticmethod
+    def forward(ctx, x, kernel, stride, padding):
+        _chk(x, "maxpool input")
+        N, H, W, C = x.shape
+        kh, kw = kernel; sh, sw = stride; ph, pw = padding
+        P = (H + 2 * ph - kh) // sh + 1
+        Q = (W + 2 * pw - kw) // sw + 1
+        y = torch.empty((N, P, Q, C), dtype=torch.float32, device=x.device)
+        idx = torch.empty((N, P, Q, C), dtype=torch.int32, device=x.device)
+        L.call("hwg_maxpool_fwd", x, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q, _stream())
+        ctx.save_for_backward(idx)
+        ctx.cfg = (N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q = ctx.cfg
+        dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
+        L.call("hwg_maxpool_bwd", dy.contiguous(), idx, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q, _stream())
+        return dx, None, None, None
+
+
+def max_pool2d(x, kernel, stride=None, padding=0):
+    kernel = _pair(kernel)
+    stride = kernel if stride is None else _pair(stride)
+    return _MaxPool.apply(x, kernel, stride, _pair(padding))
+
+
+class _Upsample(Function):
+    @staticmethod
+    def forward(ctx, x, fh, fw):
+        _chk(x, "upsample input")
+        N, H, W, C = x.shape
+        y = torch.empty((N, H * fh, W * fw, C), dtype=torch.float32, device=x.device)
+        L.call("hwg_upsample_nearest_fwd", x, y, N, H, W, C, fh, fw, _stream())
+        ctx.cfg = (N, H, W, C, fh, fw)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C, fh, fw = ctx.cfg
+        dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
+        L.call("hwg_upsample_nearest_bwd", dy.contiguous(), dx, N, H, W, C, fh, fw, _stream())
+        return dx, None, None
+
+
+def upsample_nearest(x, scale):
+    fh, fw = _pair(scale)
+    return _Upsample.apply(x, fh, fw)
+
+
+class _Blur(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x, "blur input")
+        N, H, W, C = x.shape
+        y = torch.empty_like(x)
+        L.call("hwg_blur3", x, y, N, H, W, C, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _Blur.apply(dy.contiguous())  # symmetric kernel; differentiable again like the reference's BlurFunctionBackward
+
+
+def blur3(x):
+    return _Blur.apply(x)
+
+
+class _Pad2d(Function):
+    @staticmethod
+    def forward(ctx, x, pt, pb, pl, pr, mode, value):
+        _chk(x, "pad input")
+        N, H, W, C = x.shape
+        y = torch.empty((N, H + pt + pb, W + pl + pr, C), dtype=torch.float32, device=x.device)
+        L.call("hwg_pad2d_fwd", x, y, N, H, W, C, pt, pb, pl, pr, mode, value, _stream())
+        ctx.cfg = (N, H, W, C, pt, pb, pl, pr, mode)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C, pt, pb, pl, pr, mode = ctx.cfg
+        dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
+        L.call("hwg_pad2d_bwd", dy.contiguous(), dx, N, H, W, C, pt, pb, pl, pr, mode, _stream())
+        return dx, None, None, None, None, None, None
+
+
+def pad2d(x, left, right, top=0, bottom=0, mode="constant", value=0.0):
+    if left == 0 and right == 0 and top == 0 and bottom == 0:
+        return x
+    return _Pad2d.apply(x, top, bottom, left, right, 1 if mode == "replicate" else 0, float(value))
+
+
+class _CatChannels(Function):
+    """concatenate along C; parts that are 2-D [N, c] are broadcast over the pixels of sample n"""
+
+    @staticmethod
+    def forward(ctx, ref_shape, *parts):
+        N, H, W = ref_shape
+        rows = N * H * W
+        widths = [p.shape[-1] for p in parts]
+        Ct = sum(widths)
+        out = torch.empty((N, H, W, Ct), dtype=torch.float32, device=parts[0].device)
+        off = 0
+        st = _stream()
+        for p, c in zip(parts, widths):
+            _chk(p, "cat part")
+            bcast = 1 if p.dim() == 2 else 0
+            L.call("hwg_copy_channels", p, c, 0, out, Ct, off, c, rows, H * W, bcast, 0, st)
+            off += c
+        ctx.cfg = (N, H, W, widths, [p.dim() == 2 for p in parts])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, widths, bc = ctx.cfg
+        dy = dy.contiguous()
+        Ct = sum(widths)
+        rows = N * H * W
+        grads = []
+        off = 0
+        st = _stream()
+        for i, (c, b) in enumerate(zip(widths, bc)):
+            if not ctx.needs_input_grad[1 + i]:
+                grads.append(None)
+            elif b:
+                g = torch.empty((N, c), dtype=torch.float32, device=dy.device)
+                L.call("hwg_reduce_rows", dy, Ct, off, g, c, N, H * W, 0, st)
+                grads.append(g)
+            else:
+                g = torch.empty((N, H, W, c), dtype=torch.float32, device=dy.device)
+                L.call("hwg_copy_channels", dy, Ct, off, g, c, 0, c, rows, H * W, 0, 0, st)
+                grads.append(g)
+            off += c
+        return (None,) + tuple(grads)
+
+
+def cat_channels(parts, spatial):
+    """parts: list of [N,H,W,c] or [N,c] (broadcast) tensors; spatial = (N,H,W)"""
+    return _CatChannels.apply(tuple(spatial), *parts)
+
+
+def onehot_rows(label_LB, ncls):
+    """label int32 [L,B] (device) -> float [B,1,L,ncls]"""
+    Lr, B = label_LB.shape
+    _chk(label_LB, "label", torch.int32)
+    out = torch.empty((B, 1, Lr, ncls), dtype=torch.float32, device=label_LB.device)
+    L.call("hwg_onehot", label_LB, out, Lr, B, ncls, ncls, 0, _stream())
+    return out
+
+
+def permute4(x, dims, strides):
+    out = torch.empty(tuple(dims), dtype=torch.float32, device=x.device)
+    L.call("hwg_permute4", x, out, dims[0], dims[1], dims[2], dims[3], strides[0], strides[1], strides[2], strides[3], _stream())
+    return out
+
+
+class _ToNCHW(Function):
+    """layout change at the module boundary (NHWC -> NCHW copy); only used for multi-channel boundary tensors"""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W, C = x.shape
+        return permute4(x, (N, C, H, W), (H * W * C, 1, W * C, C))
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W = dy.shape
+        return permute4(dy.contiguous(), (N, H, W, C), (C * H * W, W, 1, H * W))
+
+
+class _ToNHWC(Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        return permute4(x, (N, H, W, C), (C * H * W, W, 1, H * W))
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C = dy.shape
+        return permute4(dy.contiguous(), (N, C, H, W), (H * W * C, 1, W * C, C))
+
+
+def to_nchw(x):
+    return x.reshape(x.shape[0], 1, x.shape[1], x.shape[2]) if x.shape[3] == 1 else _ToNCHW.apply(x)
+
+
+def to_nhwc(x):
+    return x.reshape(x.shape[0], x.shape[2], x.shape[3], 1) if x.shape[1] == 1 else _ToNHWC.apply(x.contiguous())
+
+
+# ----------------------------------------------------------------------------------------------
+# sequence ops
+# ----------------------------------------------------------------------------------------------
+class _LogSoftmaxTB(Function):
+    """x [B,1,T,C] (NHWC) -> log-probs [T,B,C]"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x, "log_softmax input")
+        B, _, T, C = x.shape
+        y = torch.empty((T, B, C), dtype=torch.float32, device=x.device)
+        L.call("hwg_log_softmax_fwd", x, y, B * T, C, B, T, 1, _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        T, B, C = y.shape
+        dx = torch.empty((B, 1, T, C), dtype=torch.float32, device=y.device)
+        L.call("hwg_log_softmax_bwd", dy.contiguous(), y, dx, B * T, C, B, T, 1, _stream())
+        return dx
+
+
+def log_softmax_tbc(x):
+    return _LogSoftmaxTB.apply(x)
+
+
+class _CTC(Function):
+    @staticmethod
+    def forward(ctx, log_probs, targets, in_len, tg_len):
+        _chk(log_probs, "ctc log_probs")
+        for t, n in ((targets, "targets"), (in_len, "input lengths"), (tg_len, "target lengths")):
+            _chk(t, "ctc " + n, torch.int32)
+        T, B, C = log_probs.shape
+        Lmax = targets.shape[1]
+        nbytes = L.query("hwg_ctc_workspace", T, B, Lmax)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=log_probs.device)  # kept for backward
+        loss = torch.empty((), dtype=torch.float32, device=log_probs.device)
+        L.call("hwg_ctc_fwd", log_probs, targets, in_len, tg_len, T, B, C, Lmax, loss, ws, ws.numel(), _stream())
+        ctx.save_for_backward(log_probs, targets, in_len, tg_len, ws)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        log_probs, targets, in_len, tg_len, ws = ctx.saved_tensors
+        T, B, C = log_probs.shape
+        grad = torch.empty_like(log_probs)
+        L.call("hwg_ctc_bwd", log_probs, targets, in_len, tg_len, T, B, C, targets.shape[1], gout.contiguous(), grad, ws, ws.numel(), _stream())
+        return grad, None, None, None
+
+
+def ctc_loss(log_probs, targets, input_lengths, target_lengths):
+    """F.ctc_loss(blank=0, reduction='mean') with an infinite result reported as 0 (model/loss.py:28-30).
+    targets [B, Lmax]; lengths may be host tensors / lists (they are host data in the reference too)."""
+    dev = log_probs.device
+    targets = targets.to(device=dev, dtype=torch.int32).contiguous()
+    il = torch.as_tensor(input_lengths, dtype=torch.int32).to(dev)
+    tl = torch.as_tensor(target_lengths, dtype=torch.int32).to(dev)
+    return _CTC.apply(log_probs.contiguous(), targets, il, tl)
+
+
+def dtw_align(pred_TBC, label_LB):
+    """correct_pred: returns (aligned int64 [maxlen,B], lens[B]); one D2H sync for the path length."""
+    _chk(pred_TBC, "dtw pred")
+    T, B, C = pred_TBC.shape
+    label = label_LB.to(device=pred_TBC.device, dtype=torch.int32).contiguous()
+    Lr = label.shape[0]
+    out = torch.empty((T + 2 * Lr + 1, B), dtype=torch.int64, device=pred_TBC.device)
+    lens = torch.empty((B,), dtype=torch.int32, device=pred_TBC.device)
+    ws = workspace(L.query("hwg_dtw_workspace", T, B, Lr), pred_TBC.device)
+    L.call("hwg_dtw_align", pred_TBC, label, T, B, C, Lr, out, lens, ws, ws.numel(), _stream())
+    maxlen = int(lens.max().item())
+    return out[:maxlen].contiguous(), lens
+
+
+def gt_counts(index_spaced, label_LB):
+    """run-length scan of an aligned label sequence -> (gt_counts [L,B,2], min pos)"""
+    Tp, B = index_spaced.shape
+    label = label_LB.to(device=index_spaced.device, dtype=torch.int32).contiguous()
+    Lr = label.shape[0]
+    gt = torch.zeros((Lr, B, 2), dtype=torch.float32, device=index_spaced.device)
+    meta = torch.tensor([2 ** 31 - 1, 0], dtype=torch.int32, device=index_spaced.device)
+    L.call("hwg_gt_counts", index_spaced.contiguous(), label, Tp, B, Lr, gt, meta[0:1], meta[1:2], _stream())
+    return gt, meta
+
+
+def argmax_rows(x2d):
+    rows, C = x2d.shape
+    out = torch.empty((rows,), dtype=torch.int32, device=x2d.device)
+    L.call("hwg_argmax_rows", x2d, out, rows, C, _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------------
+LOSS_L1, LOSS_MSE, LOSS_MEAN, LOSS_HINGE_REAL, LOSS_HINGE_FAKE = 0, 1, 2, 3, 4
+
+
+class _Loss(Function):
+    @staticmethod
+    def forward(ctx, a, b, mode, scale):
+        _chk(a, "loss input"); _chk(b, "loss target")
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        ws = workspace(L.query("hwg_loss_workspace"), a.device)
+        L.call("hwg_loss_fwd", a, b, a.numel(), mode, scale, out, 0, ws, ws.numel(), _stream())
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (mode, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        mode, scale = ctx.cfg
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if (b is not None and ctx.needs_input_grad[1]) else None
+        if da is None and db is None:
+            return None, None, None, None
+        L.call("hwg_loss_bwd", a, b, a.numel(), mode, scale, gout.contiguous(), da, db, 0, _stream())
+        return da, db, None, None
+
+
+def l1_loss(a, b):
+    return _Loss.apply(a.contiguous(), b.contiguous(), LOSS_L1, 1.0)
+
+
+def mse_loss(a, b):
+    return _Loss.apply(a.contiguous(), b.contiguous(), LOSS_MSE, 1.0)
+
+
+def mean_loss(a, mode=LOSS_MEAN, scale=1.0):
+    return _Loss.apply(a.contiguous(), None, mode, scale)
+
+
+# ----------------------------------------------------------------------------------------------
+# spectral norm
+# ----------------------------------------------------------------------------------------------
+class _SpectralScale(Function):
+    """W_sn = W_bar / sigma with sigma = u^T W v treated as a function of W_bar (u, v constants) - discriminator_ap.py:31-32"""
+
+    @staticmethod
+    def forward(ctx, w_bar, u, v, sigma, inv_sigma):
+        out = torch.empty_like(w_bar)
+        L.call("hwg_scale_by_ptr", w_bar, inv_sigma, out, w_bar.numel(), _stream())
+        ctx.save_for_backward(w_bar, u, v, sigma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dwsn):
+        w_bar, u, v, sigma = ctx.saved_tensors
+        R = w_bar.shape[0]
+        K = w_bar.numel() // R
+        dwbar = torch.empty_like(w_bar)
+        ws = workspace(L.query("hwg_spectral_workspace", R, K), w_bar.device)
+        L.call("hwg_spectral_bwd", dwsn.contiguous(), w_bar, u, v, sigma, dwbar, R, K, 0, ws, ws.numel(), _stream())
+        return dwbar, None, None, None, None
+
+
+def spectral_normalize(w_bar, u, v, eps=1e-12):
+    """one power iteration (u, v updated in place, like the reference does on every forward) and W/sigma"""
+    R = w_bar.shape[0]
+    K = w_bar.numel() // R
+    sig = torch.empty((2,), dtype=torch.float32, device=w_bar.device)
+    ws = workspace(L.query("hwg_spectral_workspace", R, K), w_bar.device)
+    with torch.no_grad():
+        L.call("hwg_spectral_update", w_bar.detach(), u, v, R, K, eps, sig[0:1], sig[1:2], ws, ws.numel(), _stream())
+    return _SpectralScale.apply(w_bar, u.detach().clone(), v.detach().clone(), sig[0:1], sig[1:2])
+
+
+# ----------------------------------------------------------------------------------------------
+# style extraction helpers
+# ----------------------------------------------------------------------------------------------
+class _GatherWindows(Function):
+    @staticmethod
+    def forward(ctx, x, idx_b, idx_pos, window):
+        _chk(x, "window source")
+        B, Wx, C = x.shape
+        n = idx_b.numel()
+        out = torch.empty((n, 1, 2 * window + 1, C), dtype=torch.float32, device=x.device)
+        L.call("hwg_gather_windows", x, B, Wx, C, idx_b, idx_pos, n, window, out, _stream())
+        ctx.save_for_backward(idx_b, idx_pos)
+        ctx.cfg = (B, Wx, C, n, window)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx_b, idx_pos = ctx.saved_tensors
+        B, Wx, C, n, window = ctx.cfg
+        dx = torch.zeros((B, Wx, C), dtype=torch.float32, device=dy.device)
+        L.call("hwg_scatter_windows", dy.contiguous(), B, Wx, C, idx_b, idx_pos, n, window, dx, _stream())
+        return dx, None, None, None
+
+
+def gather_windows(x_BWC, idx_b, idx_pos, window):
+    return _GatherWindows.apply(x_BWC, idx_b, idx_pos, window)
+
+
+class _SegMean(Function):
+    @staticmethod
+    def forward(ctx, v, wgt, seg, B):
+        n, C = v.shape
+        out = torch.empty((B, C), dtype=torch.float32, device=v.device)
+        wsum = torch.empty((B,), dtype=torch.float32, device=v.device)
+        L.call("hwg_segment_weighted_mean", v, wgt, seg, n, C, B, out, wsum, _stream())
+        ctx.save_for_backward(wgt, seg, wsum)
+        ctx.cfg = (n, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        wgt, seg, wsum = ctx.saved_tensors
+        n, C = ctx.cfg
+        dv = torch.empty((n, C), dtype=torch.float32, device=dout.device)
+        L.call("hwg_segment_weighted_mean_bwd", dout.contiguous(), wgt, seg, wsum, n, C, dv, _stream())
+        return dv, None, None, None
+
+
+def segment_weighted_mean(v, wgt, seg, B):
+    return _SegMean.apply(v.contiguous(), wgt, seg, B)
+
+
+def gather_scores(x_BWC, idx_b, idx_pos, idx_cls):
+    n = idx_b.numel()
+    out = torch.empty((n,), dtype=torch.float32, device=x_BWC.device)
+    B, Wx, C = x_BWC.shape
+    L.call("hwg_gather_scores", x_BWC, B, Wx, C, idx_b, idx_pos, idx_cls, n, out, _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# random numbers (device Philox; parity tests inject host-drawn tensors instead)
+# ----------------------------------------------------------------------------------------------
+class DeviceRNG:
+    def __init__(self, seed=0):
+        self.seed = int(seed)
+        self.offset = 0
+
+    def randn(self, shape, device):
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+        n = out.numel()
+        L.call("hwg_randn", out, n, self.seed, self.offset, _stream())
+        self.offset += (n + 3) // 4
+        return out
+
+    def dropmask(self, shape, p, device):
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+        n = out.numel()
+        L.call("hwg_dropmask", out, n, float(p), self.seed, self.offset, _stream())
+        self.offset += (n + 3) // 4
+        return out

@@ -1,0 +1,228 @@
+/*
+ * hwg.h — C-ABI of libhwg_hip.so, the MI355X (gfx950) kernel library behind the
+ * GAN training hot path of herobd/handwriting_line_generation.
+ *
+ * The reference has no FFI layer: every op below replaces an ATen
+ * call made by the reference's Python modules; the reference call site each entry
+ * point stands in for is cited next to it (paths relative to the reference root).
+ *
+ * Conventions
+ *  - all tensors are device pointers to contiguous fp32, activations are NHWC
+ *    ([N,H,W,C], C fastest) unless stated otherwise; integer tensors are int32/int64
+ *    as stated;
+ *  - the caller owns every buffer (including workspaces); the library never
+ *    allocates device memory and never synchronises, all work is enqueued on
+ *    `stream` (a hipStream_t passed as void*);
+ *  - every function returns HWG_OK (0) or a negative hwg_status; the message is
+ *    available from hwg_last_error() (thread local). Nothing throws across the ABI.
+ */
+#ifndef HWG_H_
+#define HWG_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum hwg_status {
+  HWG_OK = 0,
+  HWG_ERR_ARG = -1,      /* unsupported / inconsistent arguments */
+  HWG_ERR_LAUNCH = -2,   /* hipLaunch / runtime failure */
+  HWG_ERR_WORKSPACE = -3 /* workspace too small */
+} hwg_status;
+
+const char* hwg_last_error(void);
+/* library/ABI version, bumped when a signature changes */
+int hwg_abi_version(void);
+/* 1 when a HIP device is present and usable */
+int hwg_device_ok(void);
+
+/* activation codes used by fused epilogues */
+enum { HWG_ACT_NONE = 0, HWG_ACT_RELU = 1, HWG_ACT_LRELU = 2, HWG_ACT_TANH = 3 };
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution engine (implicit GEMM on fp32 MFMA, direct kernels for 1-channel ends).
+ * Replaces nn.Conv2d / nn.Conv1d / nn.ConvTranspose2d / F.conv_transpose2d / nn.Linear at
+ * model/pure_gen.py:161-197,268-278,286; model/discriminator_ap.py:77-131;
+ * model/cnn_only_hwr.py:31-32,78-92; model/char_style.py:65-71,90-93,162-168;
+ * model/count_cnn.py:12-23; model/autoencoder.py:307-330,346-395,601-617.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hwg_conv_desc {
+  int N, H, W, C;             /* gathered tensor  [N,H,W,C]            */
+  int K, R, S;                /* K channels on the anchor grid, RxS taps */
+  int stride_h, stride_w;
+  int pad_h, pad_w;
+  int dil_h, dil_w;
+  int P, Q;                   /* anchor grid     [N,P,Q,K]             */
+  int transposed;             /* 0: anchor(p,q) <-> gathered(p*stride-pad+r*dil)   (convolution)
+                                 1: fractionally strided gather (conv-transpose with stride>1), dil must be 1:
+                                    out(p,q) += x(ih,iw) * w(r,s)  where  ih*stride-pad+r == p            */
+} hwg_conv_desc;
+
+/* Re-layout a weight tensor into the engine's [R*S][A][Bpad] form (b fastest, zero padded to Bpad).
+ * src element (a,b,r,s) lives at src[a*sa + b*sb + r*sr + s*ss]; flip!=0 mirrors the taps. */
+int hwg_conv_pack_weight(const float* src, float* dst, int A, int B, int Bpad, int R, int S,
+                         long long sa, long long sb, long long sr, long long ss, int flip, void* stream);
+
+/* y[N,P,Q,K] = gather-conv(x[N,H,W,C], w[R*S][K][C]) (+ bias[K] if bias != NULL).
+ * transposed==0: standard convolution. transposed==1: conv-transpose with stride>1.
+ * accumulate!=0 adds into y instead of overwriting it. */
+int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                 int accumulate, void* stream);
+
+/* weight gradient: dw(k,c,r,s) = sum_{n,p,q} u[n,p,q,k] * v[n, p*stride-pad+r*dil, q*stride-pad+s*dil, c]
+ * written to dw[k*sa + c*sb + r*sr + s*ss] (so it lands directly in the PyTorch parameter layout).
+ * u is the tensor living on the anchor grid [N,P,Q,K], v the gathered one [N,H,W,C]; d->transposed is ignored.
+ * accumulate!=0 adds into dw. */
+size_t hwg_conv_wgrad_workspace(const hwg_conv_desc* d);
+int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const float* v, float* dw,
+                   long long sa, long long sb, long long sr, long long ss, int accumulate,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[C] (+)= sum over rows of x[rows][C]  (bias gradients, channel sums) */
+size_t hwg_colsum_workspace(long long rows, int C);
+int hwg_colsum(const float* x, long long rows, int C, float* out, int accumulate,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Normalisation + activation epilogues (NHWC, x is [N][HW][C]).
+ * mode: 0 InstanceNorm, 1 GroupNorm(groups), 2 BatchNorm in training mode (batch statistics,
+ * running stats updated with `momentum` when running_mean != NULL).
+ * y = act(mask[n,c] * (gamma * xhat + beta)); gamma/beta are [C] or, with affine_per_sample, [N][C].
+ * Replaces nn.GroupNorm (+Dropout2d +ReLU/LeakyReLU) at model/discriminator_ap.py:78-79,103-104,
+ * model/autoencoder.py:346-395,307-330, model/char_style.py:41,91,100,166, model/count_cnn.py:13-21;
+ * nn.BatchNorm2d/1d at model/cnn_only_hwr.py:36,80-89; nn.InstanceNorm2d at model/pure_gen.py:56.
+ * mean/rstd are [N][C] outputs kept for the backward pass.
+ * ------------------------------------------------------------------------------------------ */
+size_t hwg_norm_workspace(int N, int HW, int C);
+int hwg_norm_fwd(const float* x, float* y, int N, int HW, int C, int mode, int groups, float eps,
+                 const float* gamma, const float* beta, int affine_per_sample, const float* chan_mask,
+                 int act, float slope, float* mean, float* rstd, float* running_mean, float* running_var,
+                 float momentum, void* ws, size_t ws_bytes, void* stream);
+int hwg_norm_bwd(const float* dy, const float* x, const float* y, float* dx, int N, int HW, int C, int mode, int groups,
+                 const float* gamma, int affine_per_sample, const float* chan_mask, int act, float slope,
+                 const float* mean, const float* rstd, float* dgamma, float* dbeta, int accumulate,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* Generator epilogue, model/pure_gen.py:205-214 (NoiseInjection -> LeakyReLU -> AdaptiveInstanceNorm):
+ *   u = lrelu(x + noise_w[c]*noise_scale*noise, slope);  y = gamma[n,c] * IN(u) + beta[n,c]
+ * backward also returns the conv-bias gradient (sum of d/dx) and the raw noise-weight gradient. */
+int hwg_adain_fwd(const float* x, const float* noise, const float* noise_w, float noise_scale, float slope,
+                  const float* gamma, const float* beta, float eps, float* u, float* y, float* mean, float* rstd,
+                  int N, int HW, int C, void* ws, size_t ws_bytes, void* stream);
+int hwg_adain_bwd(const float* dy, const float* u, const float* noise, float noise_scale, float slope,
+                  const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
+                  float* dnoise_w, float* dbias, int accumulate_params, int N, int HW, int C,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* y = act(mask[row/HW][c] * (x + bias[c])) on x[rows][C]; backward takes y (nn.ReLU / nn.LeakyReLU / nn.Dropout2d sites) */
+int hwg_bias_act_fwd(const float* x, const float* bias, const float* chan_mask, float* y, long long rows, int HW, int C,
+                     int act, float slope, void* stream);
+int hwg_bias_act_bwd(const float* dy, const float* y, const float* chan_mask, float* dx, long long rows, int HW, int C,
+                     int act, float slope, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pooling / resampling / padding / concatenation (NHWC).
+ * nn.AvgPool2d (discriminator_ap.py:88-127, autoencoder.py:350-389), nn.MaxPool2d/1d (cnn_only_hwr.py:45-55,
+ * char_style.py:164), nn.Upsample nearest (pure_gen.py:176-178), Blur (pure_gen.py:80-137),
+ * F.pad / ReplicationPad2d (char_style.py:19-21,198-202; trainer :590-595,727-737,771-795), torch.cat.
+ * ------------------------------------------------------------------------------------------ */
+int hwg_avgpool_fwd(const float* x, float* y, int N, int H, int W, int C, int kh, int kw, void* stream);
+int hwg_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, int C, int kh, int kw, void* stream);
+int hwg_maxpool_fwd(const float* x, float* y, int* idx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+                    int P, int Q, void* stream);
+int hwg_maxpool_bwd(const float* dy, const int* idx, float* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph,
+                    int pw, int P, int Q, void* stream);
+int hwg_upsample_nearest_fwd(const float* x, float* y, int N, int H, int W, int C, int fh, int fw, void* stream);
+int hwg_upsample_nearest_bwd(const float* dy, float* dx, int N, int H, int W, int C, int fh, int fw, void* stream);
+int hwg_blur3(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* mode 0 constant(value) (negative pads crop), 1 replicate */
+int hwg_pad2d_fwd(const float* x, float* y, int N, int H, int W, int C, int pt, int pb, int pl, int pr, int mode, float value, void* stream);
+int hwg_pad2d_bwd(const float* dy, float* dx, int N, int H, int W, int C, int pt, int pb, int pl, int pr, int mode, void* stream);
+/* dst[row][doff+c] (+)= src[bcast ? row/HW : row][soff+c], c < Cn */
+int hwg_copy_channels(const float* src, int Cs, int soff, float* dst, int Cd, int doff, int Cn, long long rows, int HW, int bcast,
+                      int accumulate, void* stream);
+/* out[n][c] (+)= sum_hw src[n*HW+hw][soff+c] */
+int hwg_reduce_rows(const float* src, int Cs, int soff, float* out, int Cn, int N, int HW, int accumulate, void* stream);
+/* label [L][B] int32 -> out[b][l][doff + cls] one-hot rows of width ncls inside rows of width Cd (HWWithStyle.onehot, hw_with_style.py:333-337) */
+int hwg_onehot(const int* label, float* out, int L, int B, int ncls, int Cd, int doff, void* stream);
+int hwg_permute4(const float* in, float* out, int d0, int d1, int d2, int d3, long long s0, long long s1, long long s2, long long s3, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sequence ops: LogSoftmax (cnn_only_hwr.py:92, autoencoder.py:617), F.ctc_loss (model/loss.py:28-30),
+ * DTW alignment correct_pred (model/hw_with_style.py:18-74), gt-count scan (trainer :670-697).
+ * ------------------------------------------------------------------------------------------ */
+/* rows of x are (b,t) ordered; with transpose_bt the output rows are (t,b) ordered ([T][B][C], what F.ctc_loss takes) */
+int hwg_log_softmax_fwd(const float* x, float* y, long long rows, int C, int B, int T, int transpose_bt, void* stream);
+int hwg_log_softmax_bwd(const float* dy, const float* y, float* dx, long long rows, int C, int B, int T, int transpose_bt, void* stream);
+/* log_probs [T][B][C]; targets [B][Lmax] int32 (blank = 0); reduction 'mean'; an infinite mean is reported as 0.
+ * hwg_ctc_bwd must be called with the same workspace contents hwg_ctc_fwd left behind. */
+size_t hwg_ctc_workspace(int T, int B, int Lmax);
+int hwg_ctc_fwd(const float* log_probs, const int* targets, const int* input_lengths, const int* target_lengths, int T, int B, int C,
+                int Lmax, float* loss, void* ws, size_t ws_bytes, void* stream);
+int hwg_ctc_bwd(const float* log_probs, const int* targets, const int* input_lengths, const int* target_lengths, int T, int B, int C,
+                int Lmax, const float* grad_out, float* grad, void* ws, size_t ws_bytes, void* stream);
+/* pred [T][B][C] log-probs, label [L][B] int32 -> out int64 [T+2L+1][B] zero padded, lens[B] path lengths (bit exact) */
+size_t hwg_dtw_workspace(int T, int B, int L);
+int hwg_dtw_align(const float* pred, const int* label, int T, int B, int C, int L, long long* out, int* lens, void* ws, size_t ws_bytes,
+                  void* stream);
+/* index_spaced int64 [Tp][B], label int32 [L][B] -> gt [L][B][2] (caller zero-fills), minpos (caller sets to INT_MAX), mismatch counter */
+int hwg_gt_counts(const long long* index_spaced, const int* label, int Tp, int B, int L, float* gt, int* minpos, int* mismatch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Spectral norm (model/discriminator_ap.py:11-65), losses (model/loss.py:16-27, trainer :797-821),
+ * PixelNorm (pure_gen.py:306-311) and small vector helpers.
+ * ------------------------------------------------------------------------------------------ */
+size_t hwg_spectral_workspace(int R, int K);
+int hwg_spectral_update(const float* W, float* u, float* v, int R, int K, float eps, float* sigma, float* inv_sigma, void* ws,
+                        size_t ws_bytes, void* stream);
+int hwg_scale_by_ptr(const float* x, const float* scale, float* out, long long n, void* stream);
+int hwg_spectral_bwd(const float* dWsn, const float* Wbar, const float* u, const float* v, const float* sigma, float* dWbar, int R, int K,
+                     int accumulate, void* ws, size_t ws_bytes, void* stream);
+size_t hwg_loss_workspace(void);
+/* out (+)= scale * mean(term); mode 0 |a-b|, 1 (a-b)^2, 2 a, 3 relu(1-a), 4 relu(1+a) */
+int hwg_loss_fwd(const float* a, const float* b, long long n, int mode, float scale, float* out, int accumulate, void* ws, size_t ws_bytes,
+                 void* stream);
+int hwg_loss_bwd(const float* a, const float* b, long long n, int mode, float scale, const float* grad_out, float* da, float* db,
+                 int accumulate, void* stream);
+int hwg_pixelnorm_fwd(const float* x, float* y, int rows, int C, float eps, void* stream);
+int hwg_pixelnorm_bwd(const float* dy, const float* x, float* dx, int rows, int C, float eps, void* stream);
+int hwg_axpby(const float* x, float a, const float* y, float b, float* out, long long n, void* stream);
+int hwg_tanh_fwd(const float* x, float* y, long long n, void* stream);
+int hwg_tanh_bwd(const float* dy, const float* y, float* dx, long long n, void* stream);
+int hwg_argmax_rows(const float* x, int* out, long long rows, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Character-specific style extraction helpers (model/char_style.py:204-235,286).
+ * ------------------------------------------------------------------------------------------ */
+int hwg_gather_windows(const float* x, int B, int Wx, int C, const int* idx_b, const int* idx_pos, int n, int window, float* patches, void* stream);
+int hwg_scatter_windows(const float* dpatches, int B, int Wx, int C, const int* idx_b, const int* idx_pos, int n, int window, float* dx, void* stream);
+int hwg_segment_weighted_mean(const float* v, const float* wgt, const int* seg, int n, int C, int B, float* out, float* wsum, void* stream);
+int hwg_segment_weighted_mean_bwd(const float* dout, const float* wgt, const int* seg, const float* wsum, int n, int C, float* dv, void* stream);
+int hwg_gather_scores(const float* x, int B, int Wx, int C, const int* idx_b, const int* idx_pos, const int* idx_cls, int n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-tensor optimizer-side ops (trainer/hw_with_style_trainer.py:300-391) and RNG.
+ * Tensor lists are device tables: ptrs (int64 addresses, 0 = absent), numel (int64), and a chunk table
+ * (chunk_tensor int32, chunk_off int64) with `chunk` elements per entry.
+ * ------------------------------------------------------------------------------------------ */
+int hwg_mt_abs_sum(const void* ptrs, const void* numel, const void* chunk_tensor, const void* chunk_off, int nchunks, int chunk,
+                   double* out_sums, void* stream);
+int hwg_mt_balance_coef(const double* sumD, const double* sumR, const void* numel, const void* ptr_grad, const void* ptr_R,
+                        const float* xs, int nsets, int nt, float* coef, void* stream);
+int hwg_mt_axpy(const void* ptrs_dst, const void* ptrs_src, const float* coef, const void* numel, const void* chunk_tensor,
+                const void* chunk_off, int nchunks, int chunk, void* stream);
+/* op 0: a=0, 1: clamp(a,-c,c), 2: flag |= any non-finite, 3: b=a, 4: b=a then a=0 */
+int hwg_mt_unary(const void* ptrs_a, const void* ptrs_b, int op, float c, int* flag, const void* numel, const void* chunk_tensor,
+                 const void* chunk_off, int nchunks, int chunk, void* stream);
+int hwg_mt_adam(const void* ptrs_p, const void* ptrs_g, const void* ptrs_m, const void* ptrs_v, const float* step_size,
+                const float* bc2_sqrt, float beta1, float beta2, float eps, float clip, const void* numel, const void* chunk_tensor,
+                const void* chunk_off, int nchunks, int chunk, void* stream);
+int hwg_randn(float* out, long long n, unsigned long long seed, unsigned long long offset, void* stream);
+int hwg_dropmask(float* out, long long n, float p, unsigned long long seed, unsigned long long offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HWG_H_ */

@@ -1,0 +1,375 @@
+"""Per-kernel numerics: every HIP op (through the C-ABI) against a plain PyTorch fp32 CPU reference of the same op.
+Tolerance: 1e-4 of the reference's max magnitude (BASELINE.json north_star: fp32 1e-4); integer outputs exact."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _close(got, ref, name, tol=TOL):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, "%s: shape %s vs %s" % (name, tuple(got.shape), tuple(ref.shape))
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale + 1e-6, "%s: max err %.3e (scale %.3e)" % (name, err, scale)
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # name, N,H,W,C,K,R,S, stride, pad, dil, transposed
+    ("mfma128x128_bk32", 4, 32, 260, 32, 128, 3, 3, (1, 1), (1, 1), (1, 1), False),
+    ("mfma128x64_bk16", 4, 32, 260, 16, 64, 3, 3, (1, 1), (0, 1), (1, 1), False),
+    ("mfma128x32", 2, 20, 70, 32, 16, 3, 3, (1, 1), (1, 1), (1, 1), False),
+    ("mfma64x64_smallM", 2, 4, 50, 128, 128, 3, 3, (1, 1), (1, 1), (1, 1), False),
+    ("mfma_k80_edge", 2, 1, 61, 64, 80, 1, 3, (1, 1), (0, 0), (1, 1), False),
+    ("mfma_c208", 2, 1, 40, 208, 128, 1, 3, (1, 1), (0, 1), (1, 1), False),
+    ("dil4_conv1d", 2, 1, 60, 64, 64, 1, 3, (1, 1), (0, 4), (1, 4), False),
+    ("stride2_4x4", 2, 16, 40, 32, 64, 4, 4, (2, 2), (1, 1), (1, 1), False),
+    ("stride21_4x4", 2, 8, 30, 32, 32, 4, 4, (2, 1), (0, 1), (1, 1), False),
+    ("k63_5x5", 1, 9, 20, 16, 48, 5, 5, (1, 1), (2, 2), (1, 1), False),
+    ("c1_7x7", 2, 20, 50, 1, 64, 7, 7, (1, 1), (0, 3), (1, 1), False),
+    ("c1_5x5", 2, 16, 40, 1, 32, 5, 5, (1, 1), (2, 2), (1, 1), False),
+    ("c1_3x3", 2, 16, 41, 1, 64, 3, 3, (1, 1), (1, 1), (1, 1), False),
+    ("to1_3x3", 3, 3, 20, 256, 1, 3, 3, (1, 1), (0, 1), (1, 1), False),
+    ("to1_1x1", 3, 1, 20, 256, 1, 1, 1, (1, 1), (0, 0), (1, 1), False),
+    ("to2_1x1", 3, 1, 20, 32, 2, 1, 1, (1, 1), (0, 0), (1, 1), False),
+    ("to1_16", 2, 16, 40, 16, 1, 1, 1, (1, 1), (0, 0), (1, 1), False),
+    ("convT_lift_4x3", 2, 1, 30, 208, 256, 4, 3, (1, 1), (0, 1), (1, 1), True),
+    ("convT_s2_4x4", 2, 8, 20, 64, 32, 4, 4, (2, 2), (1, 1), (1, 1), True),
+    ("convT_s1_3x3", 2, 6, 20, 32, 32, 3, 3, (1, 1), (1, 1), (1, 1), True),
+    ("convT_6x3", 2, 1, 12, 32, 64, 6, 3, (1, 1), (0, 0), (1, 1), True),
+    ("convT_to1", 2, 8, 20, 32, 1, 3, 3, (1, 1), (1, 1), (1, 1), True),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_bwd(cuda, case):
+    from handwriting_line_generation_amd import ops
+    name, N, H, W, C, K, R, S, stride, pad, dil, transposed = case
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    x = torch.randn(N, C, H, W, generator=g)
+    if transposed:
+        w = torch.randn(C, K, R, S, generator=g) * (1.0 / (C * R * S) ** 0.5)
+    else:
+        w = torch.randn(K, C, R, S, generator=g) * (1.0 / (C * R * S) ** 0.5)
+    b = torch.randn(K, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    if transposed:
+        yr = F.conv_transpose2d(xr, wr, br, stride=stride, padding=pad, dilation=dil)
+    else:
+        yr = F.conv2d(xr, wr, br, stride=stride, padding=pad, dilation=dil)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xg = nhwc(x).to(cuda).requires_grad_(True)
+    wg = w.to(cuda).requires_grad_(True)
+    bg = b.to(cuda).requires_grad_(True)
+    if transposed:
+        yg = ops.conv_transpose2d(xg, wg, bg, stride=stride, padding=pad, dilation=dil)
+    else:
+        yg = ops.conv2d(xg, wg, bg, stride=stride, padding=pad, dilation=dil)
+    _close(nchw(yg), yr, name + ".y")
+    yg.backward(nhwc(gy).to(cuda))
+    _close(nchw(xg.grad), xr.grad, name + ".dx")
+    _close(wg.grad, wr.grad, name + ".dw")
+    _close(bg.grad, br.grad, name + ".db")
+
+
+def test_linear(cuda):
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 128, generator=g); w = torch.randn(256, 128, generator=g) * 0.1; b = torch.randn(256, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.linear(xr, wr, br)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xg, wg, bg = (t.to(cuda).requires_grad_(True) for t in (x, w, b))
+    yg = ops.linear(xg, wg, bg)
+    _close(yg, yr, "linear.y")
+    yg.backward(gy.to(cuda))
+    _close(xg.grad, xr.grad, "linear.dx"); _close(wg.grad, wr.grad, "linear.dw"); _close(bg.grad, br.grad, "linear.db")
+
+
+NORM_CASES = [
+    ("gn8_lrelu", 3, 10, 33, 64, "gn", 8, "lrelu", 0.1, False),
+    ("gn8_relu_mask", 3, 6, 20, 32, "gn", 8, "relu", 0.0, True),
+    ("gn4_c16", 2, 5, 17, 16, "gn", 4, "none", 0.0, False),
+    ("gn8_big", 2, 58, 256, 64, "gn", 8, "lrelu", 0.1, False),
+    ("gn8_c512_1d", 2, 1, 60, 512, "gn", 8, "relu", 0.0, False),
+    ("bn_relu", 4, 8, 30, 256, "bn", 1, "relu", 0.0, False),
+    ("bn1d", 4, 1, 61, 512, "bn", 1, "relu", 0.0, False),
+    ("in_plain", 2, 7, 19, 32, "in", 1, "none", 0.0, False),
+]
+
+
+@pytest.mark.parametrize("case", NORM_CASES, ids=[c[0] for c in NORM_CASES])
+def test_norm_fwd_bwd(cuda, case):
+    from handwriting_line_generation_amd import ops
+    name, N, H, W, C, kind, groups, act, slope, use_mask = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, C, H, W, generator=g) * 2 + 0.5
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g)
+    mask = None
+    if use_mask:
+        mask = (torch.rand(N, C, generator=g) > 0.3).float() / 0.7
+    xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    rm = torch.zeros(C); rv = torch.ones(C)
+    if kind == "gn":
+        yr = F.group_norm(xr, groups, gr, br, 1e-5)
+    elif kind == "bn":
+        yr = F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5)
+    else:
+        yr = F.instance_norm(xr, eps=1e-5)
+    if mask is not None:
+        yr = yr * mask[:, :, None, None]
+    if act == "relu":
+        yr = F.relu(yr)
+    elif act == "lrelu":
+        yr = F.leaky_relu(yr, slope)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xg = nhwc(x).to(cuda).requires_grad_(True)
+    gg = gamma.to(cuda).requires_grad_(True); bg = beta.to(cuda).requires_grad_(True)
+    actc = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU}[act]
+    mg = mask.to(cuda) if mask is not None else None
+    if kind == "gn":
+        yg = ops.group_norm(xg, groups, gg, bg, 1e-5, mask=mg, act=actc, slope=slope)
+    elif kind == "bn":
+        rmg = torch.zeros(C, device=cuda); rvg = torch.ones(C, device=cuda)
+        yg = ops.batch_norm_train(xg, gg, bg, rmg, rvg, 0.1, 1e-5, act=actc, slope=slope)
+        _close(rmg, rm, name + ".running_mean"); _close(rvg, rv, name + ".running_var")
+    else:
+        yg = ops.instance_norm(xg, 1e-5)
+    _close(nchw(yg), yr, name + ".y")
+    yg.backward(nhwc(gy).to(cuda))
+    _close(nchw(xg.grad), xr.grad, name + ".dx", tol=2e-4)
+    if kind != "in":
+        _close(gg.grad, gr.grad, name + ".dgamma", tol=2e-4); _close(bg.grad, br.grad, name + ".dbeta", tol=2e-4)
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 61, 256), (2, 16, 40, 64), (3, 64, 100, 16)])
+def test_adain_epilogue(cuda, shape):
+    from handwriting_line_generation_amd import ops
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, C, H, W, generator=g)
+    noise = torch.randn(N, C, H, W, generator=g)
+    nw = torch.randn(1, C, 1, 1, generator=g) * 0.5
+    gamma = torch.randn(N, C, generator=g) + 1
+    beta = torch.randn(N, C, generator=g)
+    scale = (2.0 / C) ** 0.5
+    xr, nwr, gr, br = (t.clone().requires_grad_(True) for t in (x, nw, gamma, beta))
+    t = xr + (nwr * scale) * noise
+    u = F.leaky_relu(t, 0.2)
+    yr = gr[:, :, None, None] * F.instance_norm(u, eps=1e-5) + br[:, :, None, None]
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xg = nhwc(x).to(cuda).requires_grad_(True)
+    nwg = nw.to(cuda).requires_grad_(True)
+    gg = gamma.to(cuda).requires_grad_(True); bg = beta.to(cuda).requires_grad_(True)
+    yg = ops.adain_epilogue(xg, nhwc(noise).to(cuda), nwg, gg, bg, scale, 0.2, 1e-5)
+    _close(nchw(yg), yr, "adain.y")
+    yg.backward(nhwc(gy).to(cuda))
+    _close(nchw(xg.grad), xr.grad, "adain.dx", tol=2e-4)
+    _close(nwg.grad, nwr.grad, "adain.dnoise_w", tol=2e-4)
+    _close(gg.grad, gr.grad, "adain.dgamma", tol=2e-4); _close(bg.grad, br.grad, "adain.dbeta", tol=2e-4)
+
+
+def test_bias_act_and_tanh(cuda):
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 32, 5, 9, generator=g); b = torch.randn(32, generator=g)
+    mask = (torch.rand(2, 32, generator=g) > 0.2).float() / 0.8
+    xr = x.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    yr = F.leaky_relu((xr + br[None, :, None, None]) * mask[:, :, None, None], 0.1)
+    gy = torch.randn(yr.shape, generator=g); yr.backward(gy)
+    xg = nhwc(x).to(cuda).requires_grad_(True); bg = b.to(cuda).requires_grad_(True)
+    yg = ops.bias_act(xg, bg, mask.to(cuda), ops.ACT_LRELU, 0.1)
+    _close(nchw(yg), yr, "bias_act.y"); yg.backward(nhwc(gy).to(cuda))
+    _close(nchw(xg.grad), xr.grad, "bias_act.dx"); _close(bg.grad, br.grad, "bias_act.db")
+    # odd channel count takes the scalar path
+    x3 = torch.randn(2, 7, 3, generator=g)
+    y3 = ops.relu(x3.to(cuda))
+    _close(y3, F.relu(x3), "relu.scalar")
+    xt = torch.randn(3, 50, generator=g).requires_grad_(True)
+    yt = torch.tanh(xt); gt = torch.randn(3, 50, generator=g); yt.backward(gt)
+    xtg = xt.detach().to(cuda).requires_grad_(True)
+    ytg = ops.tanh(xtg); _close(ytg, yt, "tanh.y"); ytg.backward(gt.to(cuda)); _close(xtg.grad, xt.grad, "tanh.dx")
+
+
+def test_pixelnorm(cuda):
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(6, 128, generator=g).requires_grad_(True)
+    y = x / torch.sqrt(torch.mean(x ** 2, dim=1, keepdim=True) + 1e-8)
+    gy = torch.randn(6, 128, generator=g); y.backward(gy)
+    xg = x.detach().to(cuda).requires_grad_(True)
+    yg = ops.pixel_norm(xg); _close(yg, y, "pixelnorm.y"); yg.backward(gy.to(cuda)); _close(xg.grad, x.grad, "pixelnorm.dx")
+
+
+def test_pools_resample(cuda):
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 32, 11, 23, generator=g)
+
+    def check(fn_ref, fn_gpu, name, xx=x):
+        xr = xx.clone().requires_grad_(True)
+        yr = fn_ref(xr); gy = torch.randn(yr.shape, generator=g); yr.backward(gy)
+        xg = nhwc(xx).to(cuda).requires_grad_(True)
+        yg = fn_gpu(xg); _close(nchw(yg), yr, name + ".y"); yg.backward(nhwc(gy).to(cuda)); _close(nchw(xg.grad), xr.grad, name + ".dx")
+
+    check(lambda t: F.avg_pool2d(t, 2), lambda t: ops.avg_pool2d(t, 2), "avgpool2")
+    check(lambda t: F.avg_pool2d(t, (1, 2)), lambda t: ops.avg_pool2d(t, (1, 2)), "avgpool1x2")
+    check(lambda t: F.max_pool2d(t, 2, 2), lambda t: ops.max_pool2d(t, 2, 2), "maxpool2")
+    check(lambda t: F.max_pool2d(t, (2, 2), (2, 1), (0, 1)), lambda t: ops.max_pool2d(t, (2, 2), (2, 1), (0, 1)), "maxpool_s21_p01")
+    check(lambda t: F.max_pool2d(t, (1, 2), (1, 2)), lambda t: ops.max_pool2d(t, (1, 2), (1, 2)), "maxpool1d")
+    check(lambda t: F.interpolate(t, scale_factor=(2, 1), mode="nearest"), lambda t: ops.upsample_nearest(t, (2, 1)), "upsample21")
+    k = torch.tensor([[1., 2, 1], [2, 4, 2], [1, 2, 1]]) / 16
+    check(lambda t: F.conv2d(t, k.view(1, 1, 3, 3).repeat(32, 1, 1, 1), padding=1, groups=32), ops.blur3, "blur3")
+    check(lambda t: F.pad(t, (2, 3, 1, 1), mode="replicate"), lambda t: ops.pad2d(t, 2, 3, 1, 1, "replicate"), "pad_replicate")
+    check(lambda t: F.pad(t, (0, 5), value=-1.0), lambda t: ops.pad2d(t, 0, 5, 0, 0, "constant", -1.0), "pad_const")
+    x1 = torch.randn(2, 1, 8, 13, generator=g)
+    check(lambda t: F.pad(t, (0, 4, 0, 0), mode="replicate"), lambda t: ops.pad2d(t, 0, 4, 0, 0, "replicate"), "pad_replicate_c1", x1)
+    check(lambda t: F.max_pool2d(t, 2, 2), lambda t: ops.max_pool2d(t, 2, 2), "maxpool_c1", x1)
+
+
+def test_cat_onehot_layout(cuda):
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(2, 1, 7, 80, generator=g); s = torch.randn(2, 128, generator=g)
+    ar = a.clone().requires_grad_(True); sr = s.clone().requires_grad_(True)
+    yr = torch.cat((ar, sr[:, None, None, :].expand(-1, 1, 7, -1)), dim=3)
+    gy = torch.randn(yr.shape, generator=g); yr.backward(gy)
+    ag = a.to(cuda).requires_grad_(True); sg = s.to(cuda).requires_grad_(True)
+    yg = ops.cat_channels([ag, sg], (2, 1, 7))
+    _close(yg, yr, "cat.y"); yg.backward(gy.to(cuda)); _close(ag.grad, ar.grad, "cat.da"); _close(sg.grad, sr.grad, "cat.ds")
+    lab = torch.randint(0, 80, (9, 3), generator=g, dtype=torch.int32)
+    oh = ops.onehot_rows(lab.to(cuda), 80)
+    ref = F.one_hot(lab.long().t(), 80).float().view(3, 1, 9, 80)
+    assert torch.equal(oh.cpu(), ref)
+    x = torch.randn(2, 5, 4, 6, generator=g).requires_grad_(True)  # NCHW
+    xg = x.detach().to(cuda).requires_grad_(True)
+    yg = ops.to_nhwc(xg); _close(yg, x.permute(0, 2, 3, 1), "to_nhwc")
+    zg = ops.to_nchw(yg); _close(zg, x, "roundtrip")
+    zg.sum().backward(); _close(xg.grad, torch.ones_like(x), "layout.grad")
+
+
+def test_log_softmax_ctc(cuda):
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(10)
+    B, T, C, Lm = 3, 40, 80, 12
+    x = torch.randn(B, 1, T, C, generator=g)
+    xr = x.clone().requires_grad_(True)
+    lp = F.log_softmax(xr.view(B, T, C), dim=2).permute(1, 0, 2)
+    targets = torch.randint(1, C, (B, Lm), generator=g)
+    targets[1, 3] = targets[1, 2]  # repeated character
+    tl = torch.tensor([12, 7, 1]); il = torch.tensor([T, T, T])
+    loss_r = F.ctc_loss(lp, targets, il, tl)
+    loss_r.backward()
+    xg = x.to(cuda).requires_grad_(True)
+    lpg = ops.log_softmax_tbc(xg)
+    _close(lpg, lp, "log_softmax")
+    loss_g = ops.ctc_loss(lpg, targets, il, tl)
+    _close(loss_g, loss_r, "ctc.loss")
+    loss_g.backward()
+    _close(xg.grad, xr.grad, "ctc.dlogits", tol=2e-4)
+    # impossible alignment -> infinite loss is reported as 0 (model/loss.py:28-30)
+    tl2 = torch.tensor([12, 12, 12]); il2 = torch.tensor([5, 5, 5])
+    bad = ops.ctc_loss(lpg.detach(), targets, il2, tl2)
+    assert bad.item() == 0.0
+
+
+def test_losses_spectral(cuda):
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(12)
+    a = torch.randn(4, 1, 64, 100, generator=g); b = torch.randn(4, 1, 64, 100, generator=g)
+    for nm, fr, fg in (("l1", F.l1_loss, ops.l1_loss), ("mse", F.mse_loss, ops.mse_loss)):
+        ar = a.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+        lr_ = fr(ar, br); (lr_ * 0.5).backward()
+        ag = a.to(cuda).requires_grad_(True); bg = b.to(cuda).requires_grad_(True)
+        lg = fg(ag, bg); _close(lg, lr_, nm); (lg * 0.5).backward()
+        _close(ag.grad, ar.grad, nm + ".da"); _close(bg.grad, br.grad, nm + ".db")
+    p = torch.randn(8, 64, generator=g)
+    for mode, ref in ((ops.LOSS_MEAN, lambda t: t.mean()), (ops.LOSS_HINGE_REAL, lambda t: F.relu(1.0 - t).mean()),
+                      (ops.LOSS_HINGE_FAKE, lambda t: F.relu(1.0 + t).mean())):
+        pr = p.clone().requires_grad_(True); lr_ = ref(pr); lr_.backward()
+        pg = p.to(cuda).requires_grad_(True); lg = ops.mean_loss(pg, mode); _close(lg, lr_, "mean%d" % mode); lg.backward()
+        _close(pg.grad, pr.grad, "mean%d.grad" % mode)
+    # spectral norm: one power iteration + gradient through sigma
+    w = torch.randn(64, 32, 3, 3, generator=g); u = F.normalize(torch.randn(64, generator=g), dim=0); v = F.normalize(torch.randn(288, generator=g), dim=0)
+    wr = w.clone().requires_grad_(True)
+    wm = wr.view(64, -1)
+    v2 = torch.mv(wm.t().detach(), u); v2 = v2 / (v2.norm() + 1e-12)
+    u2 = torch.mv(wm.detach(), v2); u2 = u2 / (u2.norm() + 1e-12)
+    sigma = u2.dot(wm.mv(v2))
+    wsn = wr / sigma
+    gw = torch.randn(w.shape, generator=g); wsn.backward(gw)
+    wg = w.to(cuda).requires_grad_(True); ug = u.to(cuda); vg = v.to(cuda)
+    wsng = ops.spectral_normalize(wg, ug, vg)
+    _close(ug, u2, "sn.u"); _close(vg, v2, "sn.v"); _close(wsng, wsn, "sn.w")
+    wsng.backward(gw.to(cuda)); _close(wg.grad, wr.grad, "sn.dw", tol=2e-4)
+
+
+def test_dtw_matches_python_restatement(cuda):
+    """bit-exact integer output vs the oracle's restatement of correct_pred"""
+    from handwriting_line_generation_amd import ops
+    from oracle import seq_oracle
+    g = torch.Generator().manual_seed(13)
+    for (T, B, Lr) in ((30, 3, 9), (20, 2, 30), (61, 4, 12)):
+        pred = F.log_softmax(torch.randn(T, B, 20, generator=g) * 3, dim=2)
+        label = torch.randint(1, 20, (Lr, B), generator=g)
+        label[Lr - 2:, 0] = 0  # padded tail
+        ref = seq_oracle.correct_pred(pred, label)
+        got, lens = ops.dtw_align(pred.to(cuda), label.to(cuda))
+        assert got.dtype == torch.int64 and torch.equal(got.cpu(), ref), "dtw mismatch T=%d L=%d" % (T, Lr)
+        gt_ref, pos_ref = seq_oracle.gt_counts(ref, label)
+        gt, meta = ops.gt_counts(got, label.to(cuda))
+        assert torch.equal(gt.cpu(), gt_ref) and int(meta[0].item()) == pos_ref and int(meta[1].item()) == 0
+
+
+def test_style_helpers_rng(cuda):
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(2, 30, 16, generator=g)
+    ib = torch.tensor([0, 0, 1, 1], dtype=torch.int32); ip = torch.tensor([0, 7, 29, 8], dtype=torch.int32)
+    xr = x.clone().requires_grad_(True)
+    pads = F.pad(xr, (0, 0, 2, 2))
+    pr = torch.stack([pads[ib[i], ip[i]:ip[i] + 5] for i in range(4)])
+    gy = torch.randn(pr.shape, generator=g); pr.backward(gy)
+    xg = x.to(cuda).requires_grad_(True)
+    pg = ops.gather_windows(xg, ib.to(cuda), ip.to(cuda), 2)
+    _close(pg.view(4, 5, 16), pr, "windows"); pg.backward(gy.view(4, 1, 5, 16).to(cuda)); _close(xg.grad, xr.grad, "windows.dx")
+    v = torch.randn(4, 16, generator=g); wgt = torch.rand(4, generator=g); seg = torch.tensor([0, 0, 2, 0], dtype=torch.int32)
+    vr = v.clone().requires_grad_(True)
+    tot = torch.zeros(3, 16); ws = torch.zeros(3)
+    for i in range(4):
+        tot[seg[i]] = tot[seg[i]] + wgt[i] * vr[i]; ws[seg[i]] += wgt[i]
+    ref = torch.where(ws[:, None] != 0, tot / ws[:, None], tot)
+    gy = torch.randn(3, 16, generator=g); ref.backward(gy)
+    vg = v.to(cuda).requires_grad_(True)
+    og = ops.segment_weighted_mean(vg, wgt.to(cuda), seg.to(cuda), 3)
+    _close(og, ref, "segmean"); og.backward(gy.to(cuda)); _close(vg.grad, vr.grad, "segmean.dv")
+    rng = ops.DeviceRNG(1)
+    z = rng.randn((1000, 1000), cuda)
+    assert abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1) < 5e-3
+    z2 = rng.randn((1000, 1000), cuda)
+    assert not torch.equal(z, z2)
+    m = rng.dropmask((1000, 1000), 0.1, cuda)
+    assert abs((m == 0).float().mean().item() - 0.1) < 5e-3 and abs(m.max().item() - 1 / 0.9) < 1e-6
+    am = ops.argmax_rows(x.view(60, 16).to(cuda))
+    assert torch.equal(am.cpu().long(), x.view(60, 16).argmax(1))
