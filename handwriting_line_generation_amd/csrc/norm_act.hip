@@ -396,6 +396,15 @@ __global__ void bias_act_bwd_scalar_kernel(const float* dy, const float* y, cons
   }
 }
 
+// frozen (eval-mode BatchNorm) statistics expanded to [N][C]
+__global__ void frozen_stats_kernel(const float* rm, const float* rv, float eps, int N, int C, float* mean, float* rstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int c = i % C;
+  mean[i] = rm[c];
+  rstd[i] = 1.f / sqrtf(rv[c] + eps);
+}
+
 int check_geo(int N, int HW, int C, const char* who) {
   HWG_REQUIRE(N > 0 && HW > 0 && C > 0, "%s: non-positive size", who);
   HWG_REQUIRE(C % 4 == 0 && C <= 1024, "%s: C must be a multiple of 4 and <= 1024 (C=%d)", who, C);
@@ -549,5 +558,21 @@ extern "C" int hwg_bias_act_bwd(const float* dy, const float* y, const float* ch
     hipLaunchKernelGGL(bias_act_bwd_scalar_kernel, dim3(hwg_stream_grid(rows * C, 256)), dim3(256), 0, st, dy, y, chan_mask, dx, rows, HW, C, act, slope);
   }
   HWG_LAUNCH_CHECK("bias_act_bwd");
+  return HWG_OK;
+}
+
+// y = act(gamma * (x - running_mean) / sqrt(running_var + eps) + beta)   (BatchNorm in eval mode; no statistics pass)
+extern "C" int hwg_norm_frozen_fwd(const float* x, float* y, int N, int HW, int C, const float* running_mean, const float* running_var, float eps,
+                                   const float* gamma, const float* beta, int act, float slope, float* mean, float* rstd, void* stream) {
+  int rc = check_geo(N, HW, C, "norm_frozen_fwd");
+  if (rc) return rc;
+  HWG_REQUIRE(x && y && running_mean && running_var && mean && rstd, "norm_frozen_fwd: null pointer");
+  Geo g = make_geo(N, HW, C);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(frozen_stats_kernel, dim3(hwg_cdiv(N * C, 128)), dim3(128), 0, st, running_mean, running_var, eps, N, C, mean, rstd);
+  HWG_LAUNCH_CHECK("norm_frozen.stats");
+  hipLaunchKernelGGL(apply_fwd_kernel, dim3(g.chunks, N), dim3(256), 0, st, x, y, g, (const float*)mean, (const float*)rstd, gamma, beta, 0,
+                     (const float*)nullptr, act, slope);
+  HWG_LAUNCH_CHECK("norm_frozen.apply");
   return HWG_OK;
 }

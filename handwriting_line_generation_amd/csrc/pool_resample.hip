@@ -274,6 +274,35 @@ __global__ void permute4_kernel(const float* in, float* out, int d0, int d1, int
   }
 }
 
+// FusedUpsample weight (model/pure_gen.py:268-276): w4 = avg of the four 1-shifted copies of pad(w3*mult, 1); [A][B][3][3] -> [A][B][4][4]
+__global__ void fused_up_weight_fwd_kernel(const float* w3, float* w4, long long AB, float mult) {
+  const long long total = AB * 16;
+  GRID_STRIDE(i, total) {
+    const int s = (int)(i % 4), r = (int)((i / 4) % 4);
+    const long long ab = i / 16;
+    float acc = 0.f;
+    // padded index (r+dr, s+ds) for dr,ds in {0,1}; padded[p][q] = w3[p-1][q-1]
+    for (int dr = 0; dr < 2; ++dr)
+      for (int ds = 0; ds < 2; ++ds) {
+        const int p = r + dr - 1, q = s + ds - 1;
+        if (p >= 0 && p < 3 && q >= 0 && q < 3) acc += w3[ab * 9 + p * 3 + q] * mult;
+      }
+    w4[i] = acc / 4.f;
+  }
+}
+__global__ void fused_up_weight_bwd_kernel(const float* dw4, float* dw3, long long AB, float mult) {
+  const long long total = AB * 9;
+  GRID_STRIDE(i, total) {
+    const int q = (int)(i % 3), p = (int)((i / 3) % 3);
+    const long long ab = i / 9;
+    float acc = 0.f;
+    // w3[p][q] contributes to w4[r][s] with r = p+1-dr, s = q+1-ds
+    for (int dr = 0; dr < 2; ++dr)
+      for (int ds = 0; ds < 2; ++ds) acc += dw4[ab * 16 + (p + 1 - dr) * 4 + (q + 1 - ds)];
+    dw3[i] = acc * mult / 4.f;
+  }
+}
+
 #define LAUNCH_V(kern, total_of_v, C, ...)                                                                         \
   do {                                                                                                               \
     if ((C) % 4 == 0) hipLaunchKernelGGL(kern<4>, dim3(hwg_stream_grid((total_of_v) / 4, 256)), dim3(256), 0, st, __VA_ARGS__); \
@@ -389,5 +418,18 @@ extern "C" int hwg_permute4(const float* in, float* out, int d0, int d1, int d2,
   hipLaunchKernelGGL(permute4_kernel, dim3(hwg_stream_grid((long long)d0 * d1 * d2 * d3, 256)), dim3(256), 0, st, in, out, d0, d1, d2, d3, s0, s1,
                      s2, s3);
   HWG_LAUNCH_CHECK("permute4");
+  return HWG_OK;
+}
+
+extern "C" int hwg_fused_upsample_weight_fwd(const float* w3, float* w4, long long AB, float mult, void* stream) {
+  HWG_REQUIRE(w3 && w4 && AB > 0, "fused_upsample_weight_fwd: bad arguments");
+  hipLaunchKernelGGL(fused_up_weight_fwd_kernel, dim3(hwg_stream_grid(AB * 16, 256)), dim3(256), 0, (hipStream_t)stream, w3, w4, AB, mult);
+  HWG_LAUNCH_CHECK("fused_upsample_weight_fwd");
+  return HWG_OK;
+}
+extern "C" int hwg_fused_upsample_weight_bwd(const float* dw4, float* dw3, long long AB, float mult, void* stream) {
+  HWG_REQUIRE(dw4 && dw3 && AB > 0, "fused_upsample_weight_bwd: bad arguments");
+  hipLaunchKernelGGL(fused_up_weight_bwd_kernel, dim3(hwg_stream_grid(AB * 9, 256)), dim3(256), 0, (hipStream_t)stream, dw4, dw3, AB, mult);
+  HWG_LAUNCH_CHECK("fused_upsample_weight_bwd");
   return HWG_OK;
 }

@@ -190,6 +190,18 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* x, int* o
   if (lane == 0) out[r] = bi;
 }
 
+// y[r][c] = x[r][c] * scale[c] + shift[c]
+__global__ void channel_affine_kernel(const float* x, const float* scale, const float* shift, float* y, long long rows, int C) {
+  const long long n = rows * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    y[i] = x[i] * (scale ? scale[c] : 1.f) + (shift ? shift[c] : 0.f);
+  }
+}
+__global__ void mul_kernel(const float* a, const float* b, float* out, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
+}
+
 int dot_parts(long long n) { long long p = (n + 4095) / 4096; if (p > 512) p = 512; if (p < 1) p = 1; return (int)p; }
 
 }  // namespace
@@ -295,5 +307,18 @@ extern "C" int hwg_argmax_rows(const float* x, int* out, long long rows, int C, 
   HWG_REQUIRE(x && out && rows > 0 && C > 0, "argmax_rows: bad arguments");
   hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, out, rows, C);
   HWG_LAUNCH_CHECK("argmax_rows");
+  return HWG_OK;
+}
+
+extern "C" int hwg_channel_affine(const float* x, const float* scale, const float* shift, float* y, long long rows, int C, void* stream) {
+  HWG_REQUIRE(x && y && rows > 0 && C > 0, "channel_affine: bad arguments");
+  hipLaunchKernelGGL(channel_affine_kernel, dim3(hwg_stream_grid(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, rows, C);
+  HWG_LAUNCH_CHECK("channel_affine");
+  return HWG_OK;
+}
+extern "C" int hwg_mul(const float* a, const float* b, float* out, long long n, void* stream) {
+  HWG_REQUIRE(a && b && out && n > 0, "mul: bad arguments");
+  hipLaunchKernelGGL(mul_kernel, dim3(hwg_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  HWG_LAUNCH_CHECK("mul");
   return HWG_OK;
 }

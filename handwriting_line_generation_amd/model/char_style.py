@@ -1,0 +1,165 @@
+"""Character-specific style extractor on HIP kernels (reference: model/char_style.py:9-311, single-style mode).
+
+Trunk: seven replicate-padded conv blocks collapse an author's concatenated lines [B',1,64,Wc] to a feature row
+[B',1,Wc/4-2,256]. For every non-blank class found by arg-max over the recogniser's log-probs a 5-column window
+(zero padded at the row ends) goes through that class's expert net; the expert outputs are averaged per author
+weighted by exp(log-prob). A second branch (1-D convs over relu(features) ++ log-probs) gives a global vector and
+a 2-layer MLP fuses both into the style vector.
+
+The only host round trip is the arg-max map (B' x W' int32) that decides which experts run - the reference does a
+`.item()` per found character here. Windows are listed in (class, author, column) order, which is the
+reference's accumulation order, so the weighted sums round identically.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from .layers import Conv1d, Conv2d, GroupNorm, Linear, Marker, group_count
+
+
+class Conv2dBlock(nn.Module):
+    """pad (replicate) -> conv -> GroupNorm -> ReLU; child names `conv` / `norm` as in the reference"""
+
+    def __init__(self, input_dim, output_dim, kernel_size, stride, padding=0, norm="none", activation="relu", pad_type="replicate"):
+        super().__init__()
+        if pad_type not in ("replicate", "zero"):
+            raise NotImplementedError("pad_type %r is not used by any shipped config" % pad_type)
+        if isinstance(padding, int):
+            padding = (padding,) * 4
+        self.padding = tuple(padding)  # (left, right, top, bottom)
+        self.pad_mode = "replicate" if pad_type == "replicate" else "constant"
+        if norm == "group":
+            self.norm = GroupNorm(group_count(output_dim), output_dim)
+        elif norm == "none":
+            self.norm = None
+        else:
+            raise NotImplementedError("norm %r is not used by any shipped config" % norm)
+        if activation not in ("relu", "none", "lrelu"):
+            raise NotImplementedError("activation %r is not used by any shipped config" % activation)
+        self.activation = activation
+        self.conv = Conv2d(input_dim, output_dim, kernel_size, stride)
+
+    def forward(self, x):
+        l, r, t, b = self.padding
+        x = ops.pad2d(x, l, r, t, b, self.pad_mode)
+        x = self.conv(x)
+        slope = 0.2 if self.activation == "lrelu" else 0.0
+        if self.norm is not None:
+            return self.norm(x, self.activation, slope)
+        if self.activation != "none":
+            return ops.bias_act(x, None, None, ops.ACT_RELU if self.activation == "relu" else ops.ACT_LRELU, slope)
+        return x
+
+
+class CharExtractor(nn.Module):
+    def __init__(self, input_dim, dim, style_dim, num_fc=1, small=False):
+        super().__init__()
+        if not small or num_fc != 1:
+            raise NotImplementedError("only the window<3 ('small') single-fc expert of the shipped configs is built")
+        self.conv1 = nn.Sequential(Marker("relu"), Conv1d(input_dim, dim, 3, padding=1), GroupNorm(group_count(dim), dim), Marker("relu"),
+                                   Conv1d(dim, input_dim, 3, padding=1))
+        self.conv2 = nn.Sequential(Marker("relu"), Conv1d(input_dim, 2 * dim, 1), GroupNorm(group_count(2 * dim), 2 * dim), Marker("relu"))
+        self.fc = nn.Sequential(Linear(2 * dim, 2 * dim), Marker("relu"), Linear(2 * dim, style_dim))
+
+    def forward(self, x):
+        """x [n,1,5,C] windows -> [n, style_dim]"""
+        n, _, wlen, _ = x.shape
+        h = ops.relu(x)
+        h = self.conv1[2](self.conv1[1](h), "relu")
+        h = self.conv1[4](h)
+        h = ops.relu(ops.add(h, x))
+        h = self.conv2[2](self.conv2[1](h), "relu")
+        h = ops.avg_pool2d(h, (1, wlen)).reshape(n, -1)
+        h = ops.bias_act(ops.linear(h, self.fc[0].weight, None), self.fc[0].bias, None, ops.ACT_RELU)
+        return self.fc[2](h)
+
+
+class CharStyleEncoder(nn.Module):
+    def __init__(self, input_dim, dim, style_dim, char_dim, char_style_dim, norm, activ, pad_type, n_class, global_pool=False,
+                 average_found_char_style=0, num_final_g_spacing_style=1, num_char_fc=1, vae=False, window=6, small=False):
+        super().__init__()
+        if vae or char_style_dim > 0 or small or num_final_g_spacing_style != 1:
+            raise NotImplementedError("only the single-style char-spec extractor of the shipped GAN configs is built (char_style_dim=0, no VAE)")
+        self.n_class = n_class
+        self.char_style_dim = style_dim
+        self.single_style = True
+        self.window = window
+        down = [Conv2dBlock(input_dim, dim, 5, 1, 2, norm=norm, activation=activ, pad_type=pad_type)]
+        for _ in range(2):
+            down.append(Conv2dBlock(dim, 2 * dim, 4, 2, 1, norm=norm, activation=activ, pad_type=pad_type))
+            dim *= 2
+            down.append(Conv2dBlock(dim, dim, 3, 1, (1, 1, 0, 0), norm=norm, activation=activ, pad_type=pad_type))
+        down.append(Conv2dBlock(dim, dim, 4, (2, 1), (1, 1, 0, 0), norm=norm, activation=activ, pad_type=pad_type))
+        down.append(Conv2dBlock(dim, dim, 4, (2, 1), (1, 1, 0, 0), norm="none", activation="none", pad_type=pad_type))
+        self.down = nn.Sequential(*down)
+        self.feat_dim = dim
+        self.prep = nn.Sequential(
+            Conv1d(dim + n_class, dim, 5, 1, 2), Marker("relu"), Marker("maxpool1d 2"),
+            Conv1d(dim, dim, 3, 1, 1), GroupNorm(group_count(dim), dim), Marker("relu"),
+            Conv1d(dim, dim, 3, 1, 1), Marker("relu"))
+        self.final_g_spacing_style = nn.Sequential(Linear(dim + style_dim, dim), Marker("relu"), Linear(dim, style_dim))
+        self.char_extractor = nn.ModuleList([CharExtractor(dim, char_dim, style_dim, num_char_fc, window < 3) for _ in range(n_class)])
+
+    @staticmethod
+    def _align(x, recog):
+        """replicate-pad the shorter of the feature row / log-prob row so both have the same length (char_style.py:198-202)"""
+        diff = x.shape[2] - recog.shape[2]
+        if diff > 0:
+            recog = ops.pad2d(recog, diff // 2, diff // 2 + diff % 2, 0, 0, "replicate")
+        elif diff < 0:
+            d = -diff
+            x = ops.pad2d(x, d // 2, d // 2 + d % 2, 0, 0, "replicate")
+        return x, recog
+
+    def forward(self, x, recog):
+        """x: NCHW [B',1,64,Wc] author image; recog: [B',n_class,Tc] log-probs (channel major, as the reference passes) or NHWC [B',1,Tc,n_class]"""
+        B = x.shape[0]
+        feat = ops.to_nhwc(x)
+        for blk in self.down:
+            feat = blk(feat)
+        if feat.shape[1] != 1:
+            raise ValueError("style extractor expects 64-pixel-high lines (feature height %d != 1)" % feat.shape[1])
+        if recog.dim() == 3:
+            recog = ops.permute(recog, (0, 2, 1)).unsqueeze(1)  # [B,1,T,n_class]
+        feat, recog = self._align(feat, recog)
+        Wf = feat.shape[2]
+        C = feat.shape[3]
+        dev = feat.device
+
+        # which classes were recognised where (one small D2H copy)
+        pred = ops.argmax_rows(recog.reshape(B * Wf, self.n_class)).view(B, Wf).cpu().numpy()
+        cls_list, b_list, pos_list = [], [], []
+        for c in range(1, self.n_class):
+            bb, pp = np.nonzero(pred == c)   # row-major: author, then column - the reference's loop order
+            if bb.size:
+                cls_list.append(np.full(bb.size, c, dtype=np.int32)); b_list.append(bb.astype(np.int32)); pos_list.append(pp.astype(np.int32))
+        feat_rows = feat.reshape(B, Wf, C)
+        if cls_list:
+            cls_np = np.concatenate(cls_list); b_np = np.concatenate(b_list); pos_np = np.concatenate(pos_list)
+            idx = torch.from_numpy(np.stack([b_np, pos_np, cls_np])).to(dev)
+            idx_b, idx_pos, idx_cls = idx[0].contiguous(), idx[1].contiguous(), idx[2].contiguous()
+            patches = ops.gather_windows(feat_rows, idx_b, idx_pos, self.window)        # [n,1,2w+1,C]
+            scores = ops.gather_scores(recog.reshape(B, Wf, self.n_class), idx_b, idx_pos, idx_cls)
+            outs = []
+            start = 0
+            for chunk in cls_list:
+                n_c = chunk.size
+                outs.append(self.char_extractor[int(chunk[0])](patches[start:start + n_c]))
+                start += n_c
+            char_styles = torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+            avg_char_style = ops.segment_weighted_mean(char_styles, scores, idx_b, B)
+        else:
+            avg_char_style = torch.zeros((B, self.char_style_dim), dtype=torch.float32, device=dev)
+
+        xr = ops.cat_channels([ops.relu(feat), recog], (B, 1, Wf))
+        p = self.prep
+        xr = ops.bias_act(ops.conv1d(xr, p[0].weight, None, 1, 2, 1), p[0].bias, None, ops.ACT_RELU)
+        xr = ops.max_pool2d(xr, (1, 2), (1, 2))
+        xr = p[4](p[3](xr), "relu")
+        xr = ops.bias_act(ops.conv1d(xr, p[6].weight, None, 1, 1, 1), p[6].bias, None, ops.ACT_RELU)
+        xr = ops.avg_pool2d(xr, (1, xr.shape[2])).reshape(B, -1)
+        comb = ops.cat_channels([xr.view(B, 1, 1, -1), avg_char_style.view(B, 1, 1, -1)], (B, 1, 1)).reshape(B, -1)
+        f = self.final_g_spacing_style
+        comb = ops.bias_act(ops.linear(comb, f[0].weight, None), f[0].bias, None, ops.ACT_RELU)
+        return f[2](comb)

@@ -1,0 +1,213 @@
+"""`HWWithStyle`: the model container the trainer drives (reference: model/hw_with_style.py:81-337).
+
+Same constructor config keys (including the substring-matched free-text options), same attributes
+(`generator, discriminator, style_extractor, hwr, spacer, pred, spaced_label, counts, ...`) and the same
+method surface (`forward, autoencode, extract_style, insert_spaces, onehot`), with every sub-network running on
+the HIP kernels. `correct_pred` is the DTW alignment kernel instead of the reference's host double loop.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..base.base_model import BaseModel
+from .char_style import CharStyleEncoder
+from .cnn_only_hwr import CNNOnlyHWR
+from .count_cnn import CountCNN
+from .discriminator_ap import DiscriminatorAP
+from .pure_gen import SpacedGenerator
+
+
+def correct_pred(pred, label):
+    """Optimal (DTW) alignment of the label to the recogniser output: int64 [T' >= T, B] (hw_with_style.py:18-74)."""
+    out, _ = ops.dtw_align(pred.detach().contiguous(), label)
+    return out
+
+
+class HWWithStyle(BaseModel):
+    def __init__(self, config):
+        super().__init__(config)
+        g = config.get
+        self.count_std = g("count_std", 0.1)
+        self.dup_std = g("dup_std", 0.03)
+        self.image_height = 64
+        style_dim = g("style_dim", 256)
+        dim = config["style_dim"] // 4 if "style_dim" in config else 64
+        self.style_dim = style_dim
+        self.char_style_dim = g("char_style_dim", 0)
+        norm = g("style_norm", "none")
+        activ = g("style_activ", "lrelu")
+        pad_type = g("pad_type", "replicate")
+        self.max_gen_length = g("max_gen_length", 500)
+        self.num_class = num_class = config["num_class"]
+        self.vae = False
+
+        style_type = g("style", "normal")
+        if "char" in style_type:
+            dim = g("style_extractor_dim", dim)
+            self.style_extractor = CharStyleEncoder(
+                1, dim, style_dim, g("char_style_extractor_dim", dim * 2), self.char_style_dim, norm, activ, pad_type, num_class,
+                global_pool=g("style_global_pool", False), average_found_char_style=config["average_found_char_style"],
+                num_final_g_spacing_style=1, num_char_fc=1, vae=False, window=g("char_style_window", 6), small=False)
+        else:
+            self.style_extractor = None
+
+        hwr_type = g("hwr", "CRNN")
+        if "CNNOnly" in hwr_type:
+            pad = "pad" in hwr_type
+            if pad and "pad less" in hwr_type:
+                pad = "less"
+            self.hwr = CNNOnlyHWR(num_class, norm="group" if "group" in hwr_type else "batch", small="small" in hwr_type, pad=pad)
+        elif "none" in hwr_type:
+            self.hwr = None
+        else:
+            raise NotImplementedError("recogniser %r: only the CNN-only CTC recogniser is on the accelerated path" % hwr_type)
+        self.hwr_frozen = False
+        pre = g("pretrained_hwr")
+        if pre is not None:
+            if os.path.exists(pre):
+                snap = torch.load(pre, map_location="cpu", weights_only=False)
+                sd = {k[4:]: v for k, v in snap["state_dict"].items() if k.startswith("hwr.")} or snap["state_dict"]
+                self.hwr.load_state_dict(sd)
+            elif not g("RUN"):
+                raise FileNotFoundError("Could not open pretrained HWR weights at " + pre)
+
+        gen = g("generator")
+        if gen == "none":
+            self.generator = None
+        elif gen is not None and "Pure" in gen:
+            self.generator = SpacedGenerator(num_class, style_dim, g("gen_dim", 256), n_style_trans=g("n_style_trans", 6),
+                                             emb_dropout=g("style_emb_dropout", False), append_style=g("gen_append_style", False),
+                                             small="small" in gen)
+        else:
+            raise NotImplementedError("unknown generator: %r" % gen)
+
+        if g("discriminator") is not None:
+            d = config["discriminator"]
+            self.discriminator = DiscriminatorAP(g("disc_dim", 64), use_low="use low" in d, use_med="no med" not in d, small="small" in d)
+
+        if g("spacer"):
+            self.count_duplicates = isinstance(config["spacer"], str) and "duplicate" in config["spacer"]
+            self.spacer = CountCNN(num_class, style_dim, g("spacer_dim", 128), 2 if self.count_duplicates else 1)
+        else:
+            self.spacer = None
+
+        self.create_mask = None
+        self.style_from_normal = None
+        self.guide_hwr = None
+        self.style_discriminator = None
+        self.use_hwr_pred_for_style = g("use_hwr_pred_for_style", True)
+        self.pred = None
+        self.spaced_label = None
+        self.spacing_pred = None
+        self.mask_pred = None
+        self.gen_spaced = None
+        self.spaced_style = None
+        self.counts = None
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, label, label_lengths, style, spaced=None):
+        if spaced is None:
+            label_onehot = self.onehot(label)
+            self.counts = self.spacer(label_onehot, style)
+            spaced, padded = self.insert_spaces(label, label_lengths, self.counts)
+            spaced = spaced.to(label.device)
+            self.gen_padded = padded
+            spaced = self._clip_spaced(spaced)
+            self.gen_spaced = spaced
+        return self.generator(spaced, style)
+
+    def _clip_spaced(self, spaced):
+        """trim blank columns so the generator sees at most max_gen_length steps (hw_with_style.py:241-261)"""
+        if spaced.size(0) > self.max_gen_length:
+            diff = self.max_gen_length - spaced.size(0)
+            chars = spaced.argmax(2).cpu().numpy()
+            x = spaced.size(0) - 1
+            for x in range(spaced.size(0) - 1, 0, -1):  # last non-blank column (1 when there is none, like the reference's loop)
+                if (chars[x] > 0).any():
+                    break
+            to_remove = min(diff, spaced.size(0) - x + 2)
+            if to_remove > 0:
+                spaced = spaced[:-to_remove]
+        if spaced.size(0) > self.max_gen_length:
+            diff = self.max_gen_length - spaced.size(0)
+            chars = spaced.argmax(2).cpu().numpy()
+            x = 0
+            while x < spaced.size(0) - 1 and not (chars[x] > 0).any():
+                x += 1
+            to_remove = max(min(diff, x - 2), 0)
+            if to_remove > 0:
+                spaced = spaced[to_remove:]
+        return spaced
+
+    def autoencode(self, image, label, a_batch_size=None, stop_grad_extractor=False):
+        style = self.extract_style(image, label, a_batch_size)
+        if stop_grad_extractor:
+            style = style.detach()
+        if self.spaced_label is None:
+            self.spaced_label = self.onehot(correct_pred(self.pred, label))
+        recon = self.forward(label, None, style, self.spaced_label)
+        return recon, style
+
+    def extract_style(self, image, label, a_batch_size=None):
+        if self.pred is None:
+            self.pred = self.hwr(image, None)
+        batch_size, feats, h, w = image.shape
+        if a_batch_size is None:
+            a_batch_size = batch_size
+        if self.use_hwr_pred_for_style:
+            spaced = self.pred                                   # [T,B,C]
+        else:
+            if self.spaced_label is None:
+                self.spaced_label = self.onehot(correct_pred(self.pred, label))
+            spaced = self.spaced_label
+        T = spaced.shape[0]
+        n_auth = batch_size // a_batch_size
+        # lay the lines of one author side by side (image columns and recogniser time steps alike)
+        if a_batch_size == 1:
+            collapsed_image = image
+        else:
+            assert feats == 1
+            collapsed_image = ops.permute(image.reshape(n_auth, a_batch_size, h, w), (0, 2, 1, 3)).reshape(n_auth, 1, h, a_batch_size * w)
+        # [T,B,C] -> [B,T,C] -> [n_auth, A*T, C] -> NHWC rows [n_auth,1,A*T,C]
+        collapsed_recog = ops.permute(spaced, (1, 0, 2)).reshape(n_auth, 1, a_batch_size * T, spaced.shape[2])
+        style = self.style_extractor(collapsed_image, collapsed_recog)
+        if a_batch_size == 1:
+            return style
+        return ops.repeat_rows(style, a_batch_size)
+
+    def insert_spaces(self, label, label_lengths, counts):
+        """expand text to per-column one-hot content using the predicted blank / duplicate counts
+        (host logic with numpy noise and Python banker's rounding, exactly as hw_with_style.py:302-328)"""
+        cn = counts.detach().cpu().numpy()
+        lab = label.cpu().numpy()
+        batch_size = lab.shape[1]
+        max_count = max(math.ceil(float(cn.max())), 3)
+        lines = []
+        for b in range(batch_size):
+            line = []
+            for i in range(int(label_lengths[b])):
+                count = round(np.random.normal(cn[i, b, 0].item(), self.count_std))
+                duplicates = round(np.random.normal(cn[i, b, 1].item(), self.dup_std)) if self.count_duplicates else 1
+                line += [0] * count + [int(lab[i, b])] * duplicates
+            lines.append(line)
+        T = max(len(l) for l in lines) + max_count
+        idx = np.zeros((T, batch_size), dtype=np.int64)
+        padded = []
+        for b, line in enumerate(lines):
+            idx[: len(line), b] = line
+            padded.append((T - len(line)) / T)
+        spaced = torch.zeros(T, batch_size, self.num_class)
+        spaced.view(-1, self.num_class)[torch.arange(T * batch_size), torch.from_numpy(idx).view(-1)] = 1
+        return spaced, padded
+
+    def onehot(self, label):
+        """[L,B] int labels -> [L,B,num_class] float one-hot on the labels' device"""
+        if label.is_cuda:
+            rows = ops.onehot_rows(label.to(torch.int32).contiguous(), self.num_class)      # [B,1,L,C]
+            return ops.permute_bl_to_lb(rows)
+        out = torch.zeros(label.size(0), label.size(1), self.num_class)
+        out.view(-1, self.num_class)[torch.arange(label.numel()), label.reshape(-1).long()] = 1
+        return out

@@ -1,0 +1,148 @@
+"""StyleGAN-like line generator on HIP kernels - behaviour of the reference's model/pure_gen.py:12-311.
+
+Data flow (NHWC): content one-hot rows [B,1,T,n_class] (+ embedded style broadcast on the channel axis)
+  -> ConvTranspose (4,3): 1 row -> 4 rows -> two vertical-only nearest-upsample blocks -> two fused stride-2
+  transposed-conv blocks -> 1x1 equal-lr conv -> tanh, giving a 64 x 4T image.
+Every block is conv -> [noise, LeakyReLU(0.2), InstanceNorm, style affine] twice; the bracketed chain is one
+fused kernel pipeline (ops.adain_epilogue). State-dict keys/shapes are those of the reference.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import ops, rng
+from .layers import BlurBuffers, Conv2d, ConvTranspose2d, Linear, Marker
+
+
+class _NoiseWeight(nn.Module):
+    """per-channel noise gain; equal-lr parametrisation: effective = weight_orig * sqrt(2 / C) (pure_gen.py:72-79,218-247)"""
+
+    def __init__(self, channel):
+        super().__init__()
+        self.weight_orig = nn.Parameter(torch.full((1, channel, 1, 1), 0.01))
+        self.scale = math.sqrt(2.0 / channel)
+
+
+class _StyleAffine(nn.Module):
+    """style -> (gamma, beta) per channel; bias starts at gamma=1, beta=0 (pure_gen.py:52-69)"""
+
+    def __init__(self, channel, style_dim):
+        super().__init__()
+        self.channel = channel
+        self.style = Linear(style_dim, 2 * channel)
+        with torch.no_grad():
+            self.style.bias[:channel] = 1
+            self.style.bias[channel:] = 0
+
+    def forward(self, style):
+        gb = self.style(style)
+        return ops.split_cols(gb, [self.channel, self.channel])
+
+
+class FusedUpsample(nn.Module):
+    """3x3 weight -> averaged 4x4 -> stride-2 transposed conv (pure_gen.py:250-279)"""
+
+    def __init__(self, in_channel, out_channel, kernel_size=3, padding=1):
+        super().__init__()
+        assert kernel_size == 3
+        self.weight = nn.Parameter(torch.randn(in_channel, out_channel, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.zeros(out_channel))
+        self.multiplier = math.sqrt(2.0 / (in_channel * kernel_size * kernel_size))
+        self.pad = padding
+
+    def forward(self, x):
+        w4 = ops.fused_upsample_weight(self.weight, self.multiplier)
+        return ops.conv_transpose2d(x, w4, self.bias, stride=2, padding=self.pad)
+
+
+class StyledConvBlock(nn.Module):
+    def __init__(self, in_channel, out_channel, style_dim, initial=False, upsample=False, only_vertical=False, fused=False):
+        super().__init__()
+        self.kind = "initial" if initial else ("fused" if (upsample and fused) else ("up" if upsample else "plain"))
+        if initial:
+            self.conv1 = ConvTranspose2d(in_channel, out_channel, (4, 3), padding=(0, 1))
+        elif upsample and fused:
+            self.conv1 = nn.Sequential(FusedUpsample(in_channel, out_channel, 3, padding=1), BlurBuffers(out_channel))
+        elif upsample:
+            self.up_scale = (2, 1) if only_vertical else (2, 2)
+            self.conv1 = nn.Sequential(Marker("nearest upsample"), Conv2d(in_channel, out_channel, 3, padding=1), BlurBuffers(out_channel))
+        else:
+            self.conv1 = Conv2d(in_channel, out_channel, 3, padding=1)
+        self.noise1 = _NoiseWeight(out_channel)
+        self.adain1 = _StyleAffine(out_channel, style_dim)
+        self.conv2 = Conv2d(out_channel, out_channel, 3, padding=1)
+        self.noise2 = _NoiseWeight(out_channel)
+        self.adain2 = _StyleAffine(out_channel, style_dim)
+
+    def _first(self, x):
+        if self.kind == "initial" or self.kind == "plain":
+            return self.conv1(x)
+        if self.kind == "fused":
+            return self.conv1[1](self.conv1[0](x))
+        return self.conv1[2](self.conv1[1](ops.upsample_nearest(x, self.up_scale)))
+
+    def forward(self, x, style):
+        h = self._first(x)
+        g, b = self.adain1(style)
+        h = ops.adain_epilogue(h, rng.noise_like_nhwc(h), self.noise1.weight_orig, g, b, self.noise1.scale, 0.2)
+        h = self.conv2(h)
+        g, b = self.adain2(style)
+        return ops.adain_epilogue(h, rng.noise_like_nhwc(h), self.noise2.weight_orig, g, b, self.noise2.scale, 0.2)
+
+
+class _EqualConv1x1(nn.Module):
+    """1x1 conv with run-time weight scaling sqrt(2/fan_in) (pure_gen.py:281-291)"""
+
+    def __init__(self, in_channel, out_channel):
+        super().__init__()
+        self.conv = nn.Module()
+        self.conv.weight_orig = nn.Parameter(torch.randn(out_channel, in_channel, 1, 1))
+        self.conv.bias = nn.Parameter(torch.zeros(out_channel))
+        self.scale = math.sqrt(2.0 / in_channel)
+
+    def forward(self, x):
+        return ops.conv2d(x, ops.scale(self.conv.weight_orig, self.scale), self.conv.bias)
+
+
+class SpacedGenerator(nn.Module):
+    def __init__(self, n_class, style_size, dim=256, output_dim=1, n_style_trans=6, emb_dropout=False, append_style=False, small=False):
+        super().__init__()
+        if emb_dropout:
+            raise NotImplementedError("style_emb dropout is not used by any shipped config")
+        self.append_style = append_style
+        in_ch = n_class + style_size if append_style else n_class
+        self.conv = nn.Sequential(
+            StyledConvBlock(in_ch, dim, style_size, initial=True),
+            StyledConvBlock(dim, dim // 2, style_size, upsample=True, only_vertical=True),
+            StyledConvBlock(dim // 2, dim // 4, style_size, upsample=True, only_vertical=True),
+            StyledConvBlock(dim // 4, dim // 8, style_size, upsample=True, fused=True),
+            StyledConvBlock(dim // 8, dim // 16, style_size, upsample=not small, fused=True),
+        )
+        self.out = nn.Sequential(_EqualConv1x1(dim // 16, output_dim), Marker("tanh"))
+        emb = [Marker("pixel norm")]
+        for _ in range(n_style_trans):
+            emb += [Linear(style_size, style_size), Marker("leaky relu 0.2")]
+        self.style_emb = nn.Sequential(*emb)
+        self.gen = self.conv  # alias present in the reference's state-dict
+
+    def embed_style(self, style):
+        h = ops.pixel_norm(style.contiguous())
+        for m in self.style_emb:
+            if isinstance(m, Linear):
+                h = ops.bias_act(ops.linear(h, m.weight, None), m.bias, None, ops.ACT_LRELU, 0.2)
+        return h
+
+    def forward(self, content, style, return_intermediate=False):
+        """content [T,B,n_class] (time major, as in the reference) or NHWC [B,1,T,n_class]; style [B,style]; -> NCHW [B,1,64,4T]"""
+        if content.dim() == 3:
+            T, B, C = content.shape
+            content = ops.permute4(content.contiguous(), (B, 1, T, C), (C, 0, B * C, 1)) if not content.requires_grad else \
+                ops.to_nhwc(content.permute(1, 2, 0).unsqueeze(2))
+        B, _, T, _ = content.shape
+        emb = self.embed_style(style)
+        x = ops.cat_channels([content, emb], (B, 1, T)) if self.append_style else content
+        for blk in self.conv:
+            x = blk(x, emb)
+        y = ops.tanh(self.out[0](x))
+        return ops.to_nchw(y)

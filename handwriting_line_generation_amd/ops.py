@@ -840,3 +840,245 @@ class DeviceRNG:
         L.call("hwg_dropmask", out, n, float(p), self.seed, self.offset, _stream())
         self.offset += (n + 3) // 4
         return out
+
+
+# ----------------------------------------------------------------------------------------------
+# frozen BatchNorm (eval) and the FusedUpsample weight transform
+# ----------------------------------------------------------------------------------------------
+def norm_apply_frozen(x, running_mean, running_var, eps, gamma, beta, act=ACT_NONE, slope=0.0):
+    if torch.is_grad_enabled() and (x.requires_grad or (gamma is not None and gamma.requires_grad)):
+        raise L.HwgError("eval-mode BatchNorm has no backward kernel; run it under torch.no_grad()")
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * C)
+    y = torch.empty_like(x)
+    mean = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    L.call("hwg_norm_frozen_fwd", x, y, N, HW, C, running_mean, running_var, eps, gamma, beta, act, slope, mean, rstd, _stream())
+    return y
+
+
+class _FusedUpWeight(Function):
+    """[A,B,3,3] -> [A,B,4,4]: the averaged-shift weight of the reference's FusedUpsample (model/pure_gen.py:268-276)"""
+
+    @staticmethod
+    def forward(ctx, w3, mult):
+        _chk(w3, "fused upsample weight")
+        A, B = w3.shape[0], w3.shape[1]
+        w4 = torch.empty((A, B, 4, 4), dtype=torch.float32, device=w3.device)
+        L.call("hwg_fused_upsample_weight_fwd", w3, w4, A * B, mult, _stream())
+        ctx.cfg = (A, B, mult)
+        return w4
+
+    @staticmethod
+    def backward(ctx, dw4):
+        A, B, mult = ctx.cfg
+        dw3 = torch.empty((A, B, 3, 3), dtype=torch.float32, device=dw4.device)
+        L.call("hwg_fused_upsample_weight_bwd", dw4.contiguous(), dw3, A * B, mult, _stream())
+        return dw3, None
+
+
+def fused_upsample_weight(w3, mult):
+    return _FusedUpWeight.apply(w3, float(mult))
+
+
+class _Scale(Function):
+    """y = x * c with a python constant (EqualLR weight scaling, loss weights)"""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        y = torch.empty_like(x)
+        L.call("hwg_axpby", x, float(c), None, 0.0, y, x.numel(), _stream())
+        ctx.c = float(c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = torch.empty_like(dy)
+        L.call("hwg_axpby", dy.contiguous(), ctx.c, None, 0.0, dx, dy.numel(), _stream())
+        return dx, None
+
+
+def scale(x, c):
+    return _Scale.apply(x.contiguous(), c)
+
+
+class _Add(Function):
+    """z = a*x + b*y (residual adds, loss sums)"""
+
+    @staticmethod
+    def forward(ctx, x, y, a, b):
+        z = torch.empty_like(x)
+        L.call("hwg_axpby", x, float(a), y, float(b), z, x.numel(), _stream())
+        ctx.ab = (float(a), float(b))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        a, b = ctx.ab
+        dz = dz.contiguous()
+        dx = dz if a == 1.0 else scale(dz, a)
+        dy = dz if b == 1.0 else scale(dz, b)
+        return dx, dy, None, None
+
+
+def add(x, y, a=1.0, b=1.0):
+    assert x.shape == y.shape
+    return _Add.apply(x.contiguous(), y.contiguous(), a, b)
+
+
+class _SplitCols(Function):
+    """x [rows, sum(widths)] -> tuple of contiguous [rows, w_i] column blocks"""
+
+    @staticmethod
+    def forward(ctx, x, *widths):
+        _chk(x, "split input")
+        rows, Ct = x.shape
+        outs = []
+        off = 0
+        st = _stream()
+        for w in widths:
+            o = torch.empty((rows, w), dtype=torch.float32, device=x.device)
+            L.call("hwg_copy_channels", x, Ct, off, o, w, 0, w, rows, 1, 0, 0, st)
+            outs.append(o)
+            off += w
+        ctx.cfg = (rows, Ct, widths)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        rows, Ct, widths = ctx.cfg
+        dx = torch.empty((rows, Ct), dtype=torch.float32, device=grads[0].device)
+        off = 0
+        st = _stream()
+        for g, w in zip(grads, widths):
+            L.call("hwg_copy_channels", g.contiguous(), w, 0, dx, Ct, off, w, rows, 1, 0, 0, st)
+            off += w
+        return (dx,) + (None,) * len(widths)
+
+
+def split_cols(x, widths):
+    assert sum(widths) == x.shape[1]
+    return _SplitCols.apply(x.contiguous(), *widths)
+
+
+class _ChannelAffine(Function):
+    """y = x * scale[c] + shift[c] over the last dim"""
+
+    @staticmethod
+    def forward(ctx, x, scale_, shift):
+        _chk(x, "channel_affine input"); _chk(scale_, "scale"); _chk(shift, "shift")
+        C = x.shape[-1]
+        y = torch.empty_like(x)
+        L.call("hwg_channel_affine", x, scale_, shift, y, x.numel() // C, C, _stream())
+        ctx.save_for_backward(x, scale_)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale_ = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        st = _stream()
+        dx = torch.empty_like(x)
+        L.call("hwg_channel_affine", dy, scale_, None, dx, rows, C, st)
+        prod = torch.empty_like(x)
+        L.call("hwg_mul", dy, x, prod, x.numel(), st)
+        ds = colsum(prod.view(rows, C))
+        dm = colsum(dy.view(rows, C))
+        return dx, ds, dm
+
+
+def channel_affine(x, scale_, shift):
+    return _ChannelAffine.apply(x.contiguous(), scale_.contiguous(), shift.contiguous())
+
+
+class _Permute(Function):
+    """contiguous copy of x.permute(perm) for tensors of rank <= 4 (one strided-gather kernel)"""
+
+    @staticmethod
+    def forward(ctx, x, perm):
+        _chk(x, "permute input")
+        nd = x.dim()
+        assert nd <= 4 and sorted(perm) == list(range(nd))
+        shape = list(x.shape)
+        strides = [1] * nd
+        for i in range(nd - 2, -1, -1):
+            strides[i] = strides[i + 1] * shape[i + 1]
+        odims = [shape[p] for p in perm]
+        ostr = [strides[p] for p in perm]
+        pad = 4 - nd
+        out = permute4(x, [1] * pad + odims, [0] * pad + ostr).view(odims)
+        ctx.perm = perm
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        perm = ctx.perm
+        inv = [0] * len(perm)
+        for i, p in enumerate(perm):
+            inv[p] = i
+        return _Permute.apply(dy.contiguous(), tuple(inv)), None
+
+
+def permute(x, perm):
+    return _Permute.apply(x.contiguous(), tuple(perm))
+
+
+def permute_bl_to_lb(x):
+    """[B,1,L,C] -> [L,B,C]"""
+    B, _, Lr, C = x.shape
+    return permute(x.view(B, Lr, C), (1, 0, 2))
+
+
+def permute_lb_to_bl(x):
+    """[L,B,C] -> [B,1,L,C]"""
+    Lr, B, C = x.shape
+    return permute(x, (1, 0, 2)).view(B, 1, Lr, C)
+
+
+class _MulConst(Function):
+    """y = x * m with m a constant tensor of the same shape (elementwise dropout masks)"""
+
+    @staticmethod
+    def forward(ctx, x, m):
+        _chk(x, "mul input"); _chk(m, "mul mask")
+        y = torch.empty_like(x)
+        L.call("hwg_mul", x, m, y, x.numel(), _stream())
+        ctx.save_for_backward(m)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (m,) = ctx.saved_tensors
+        dx = torch.empty_like(m)
+        L.call("hwg_mul", dy.contiguous(), m, dx, m.numel(), _stream())
+        return dx, None
+
+
+def mul_const(x, m):
+    return _MulConst.apply(x.contiguous(), m)
+
+
+class _RepeatRows(Function):
+    """[n, C] -> [n*k, C], every row repeated k times consecutively (style per author -> per line)"""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        _chk(x, "repeat_rows input")
+        n, C = x.shape
+        out = torch.empty((n * k, C), dtype=torch.float32, device=x.device)
+        L.call("hwg_copy_channels", x, C, 0, out, C, 0, C, n * k, k, 1, 0, _stream())
+        ctx.cfg = (n, C, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, C, k = ctx.cfg
+        dx = torch.empty((n, C), dtype=torch.float32, device=dy.device)
+        L.call("hwg_reduce_rows", dy.contiguous(), C, 0, dx, C, n, k, 0, _stream())
+        return dx, None
+
+
+def repeat_rows(x, k):
+    return _RepeatRows.apply(x.contiguous(), int(k))

@@ -105,6 +105,10 @@ int hwg_norm_bwd(const float* dy, const float* x, const float* y, float* dx, int
                  const float* mean, const float* rstd, float* dgamma, float* dbeta, int accumulate,
                  void* ws, size_t ws_bytes, void* stream);
 
+/* BatchNorm in eval mode (running statistics); mean/rstd are [N][C] scratch outputs */
+int hwg_norm_frozen_fwd(const float* x, float* y, int N, int HW, int C, const float* running_mean, const float* running_var, float eps,
+                        const float* gamma, const float* beta, int act, float slope, float* mean, float* rstd, void* stream);
+
 /* Generator epilogue, model/pure_gen.py:205-214 (NoiseInjection -> LeakyReLU -> AdaptiveInstanceNorm):
  *   u = lrelu(x + noise_w[c]*noise_scale*noise, slope);  y = gamma[n,c] * IN(u) + beta[n,c]
  * backward also returns the conv-bias gradient (sum of d/dx) and the raw noise-weight gradient. */
@@ -147,6 +151,9 @@ int hwg_copy_channels(const float* src, int Cs, int soff, float* dst, int Cd, in
 int hwg_reduce_rows(const float* src, int Cs, int soff, float* out, int Cn, int N, int HW, int accumulate, void* stream);
 /* label [L][B] int32 -> out[b][l][doff + cls] one-hot rows of width ncls inside rows of width Cd (HWWithStyle.onehot, hw_with_style.py:333-337) */
 int hwg_onehot(const int* label, float* out, int L, int B, int ncls, int Cd, int doff, void* stream);
+/* FusedUpsample weight transform, model/pure_gen.py:268-276: [A][B][3][3] -> [A][B][4][4] (AB = A*B) and its adjoint */
+int hwg_fused_upsample_weight_fwd(const float* w3, float* w4, long long AB, float mult, void* stream);
+int hwg_fused_upsample_weight_bwd(const float* dw4, float* dw3, long long AB, float mult, void* stream);
 int hwg_permute4(const float* in, float* out, int d0, int d1, int d2, int d3, long long s0, long long s1, long long s2, long long s3, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -189,6 +196,9 @@ int hwg_loss_bwd(const float* a, const float* b, long long n, int mode, float sc
 int hwg_pixelnorm_fwd(const float* x, float* y, int rows, int C, float eps, void* stream);
 int hwg_pixelnorm_bwd(const float* dy, const float* x, float* dx, int rows, int C, float eps, void* stream);
 int hwg_axpby(const float* x, float a, const float* y, float b, float* out, long long n, void* stream);
+/* y = x*scale[c] + shift[c] on x[rows][C] (CountCNN output scaling, count_cnn.py:44); out = a*b elementwise */
+int hwg_channel_affine(const float* x, const float* scale, const float* shift, float* y, long long rows, int C, void* stream);
+int hwg_mul(const float* a, const float* b, float* out, long long n, void* stream);
 int hwg_tanh_fwd(const float* x, float* y, long long n, void* stream);
 int hwg_tanh_bwd(const float* dy, const float* y, float* dx, long long n, void* stream);
 int hwg_argmax_rows(const float* x, int* out, long long rows, int C, void* stream);

@@ -1,0 +1,82 @@
+"""ORACLE (test infrastructure only). Module-level parity cases shared by tools/gen_golden.py (reference side),
+tests/test_oracle_golden.py (oracle vs reference goldens) and tests/test_modules_gpu.py (HIP vs oracle vs goldens).
+
+A case is defined by constructor arguments, a weight seed and input seeds; weights and inputs are regenerated from the
+seeds on every side (torch's CPU generator is deterministic), so only outputs and gradient fingerprints are stored."""
+import torch
+import torch.nn.functional as F
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def peaked_logprobs(T, B, C, seed, blank_frac=0.6):
+    """recogniser-like output: mostly blanks, confident characters elsewhere -> log-softmax [T,B,C]"""
+    g = _g(seed)
+    cls = torch.randint(1, C, (T, B), generator=g)
+    cls[torch.rand(T, B, generator=g) < blank_frac] = 0
+    logits = torch.randn(T, B, C, generator=g) + 6.0 * F.one_hot(cls, C).float()
+    return F.log_softmax(logits, dim=2)
+
+
+CASES = {
+    "generator": dict(ctor=dict(n_class=80, style_size=128, dim=64, n_style_trans=6, append_style=True), wseed=11,
+                      T=12, B=2, n_class=80, style=128),
+    "discriminator": dict(ctor=dict(dim=16, use_low=True, use_med=True), wseed=12, N=3, W=96),
+    "hwr": dict(ctor=dict(nclass=80, norm="batch", small=False, pad=False), wseed=13, B=2, W=64),
+    "spacer": dict(ctor=dict(class_size=80, style_size=128, hidden_size=128, n_out=2), wseed=14, L=9, B=3),
+    "style_extractor": dict(ctor=dict(input_dim=1, dim=16, style_dim=32, char_dim=32, char_style_dim=0, norm="group", activ="relu",
+                                      pad_type="replicate", n_class=80, global_pool=True, average_found_char_style=1.0, window=2),
+                            wseed=15, B=2, W=128),
+    "encoder2": dict(ctor=dict(out_dim=32), wseed=16, N=2, W=64),
+    "decoder": dict(ctor=dict(input_dim=32), wseed=17, N=2, Wc=4),
+    "e_hwr": dict(ctor=dict(n_class=80, n_in=32), wseed=18, N=2, Wc=9),
+}
+
+
+def inputs(name):
+    c = CASES[name]
+    if name == "generator":
+        g = _g(101)
+        idx = torch.randint(0, c["n_class"], (c["T"], c["B"]), generator=g)
+        content = F.one_hot(idx, c["n_class"]).float()
+        style = torch.randn(c["B"], c["style"], generator=g)
+        return dict(content=content, style=style)
+    if name == "discriminator":
+        return dict(x=torch.rand(c["N"], 1, 64, c["W"], generator=_g(102)) * 2 - 1)
+    if name == "hwr":
+        return dict(image=torch.rand(c["B"], 1, 64, c["W"], generator=_g(103)) * 2 - 1)
+    if name == "spacer":
+        g = _g(104)
+        idx = torch.randint(0, 80, (c["L"], c["B"]), generator=g)
+        return dict(onehot=F.one_hot(idx, 80).float(), style=torch.randn(c["B"], 128, generator=g))
+    if name == "style_extractor":
+        g = _g(105)
+        x = torch.rand(c["B"], 1, 64, c["W"], generator=g) * 2 - 1
+        T = c["W"] // 4 - 6
+        recog = peaked_logprobs(T, c["B"], 80, 205).permute(1, 2, 0).contiguous()   # [B,C,T]
+        return dict(x=x, recog=recog)
+    if name == "encoder2":
+        return dict(x=torch.rand(c["N"], 1, 64, c["W"], generator=_g(106)) * 2 - 1)
+    if name == "decoder":
+        return dict(x=torch.randn(c["N"], 32, 1, c["Wc"], generator=_g(107)))
+    if name == "e_hwr":
+        return dict(x=torch.randn(c["N"], 32, 1, c["Wc"], generator=_g(108)))
+    raise KeyError(name)
+
+
+FWD_SEED = 4242  # torch.manual_seed before each forward (noise / dropout draws)
+
+
+def probe_weights(outs, seed=999):
+    """fixed random cotangents so that loss = sum_i <out_i, w_i> exercises the whole backward"""
+    g = _g(seed)
+    return [torch.randn(o.shape, generator=g) for o in outs]
+
+
+def fingerprint(named_grads):
+    """per-tensor (sum, abs-sum) gradient fingerprint, ordered by name"""
+    names = sorted(named_grads)
+    vals = torch.tensor([[float(named_grads[n].double().sum()), float(named_grads[n].double().abs().sum())] for n in names], dtype=torch.float64)
+    return names, vals

@@ -1,0 +1,93 @@
+"""CPU: the oracle restatement (oracle/) reproduces the golden vectors that tools/gen_golden.py recorded from the
+reference itself. This is what pins the oracle; the GPU tests then compare the HIP path with the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, seq_oracle, torch_ref
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+ORACLE_FWD = {
+    "generator": lambda sd, i: [torch_ref.generator(sd, i["content"], i["style"])],
+    "discriminator": lambda sd, i: torch_ref.discriminator(sd, i["x"]),
+    "hwr": lambda sd, i: [torch_ref.hwr(sd, i["image"])],
+    "spacer": lambda sd, i: [torch_ref.spacer(sd, i["onehot"], i["style"])],
+    "style_extractor": lambda sd, i: [torch_ref.style_extractor(sd, i["x"], i["recog"])],
+    "encoder2": lambda sd, i: list(torch_ref.encoder2(sd, i["x"])),
+    "decoder": lambda sd, i: [torch_ref.decoder_noskip(sd, i["x"])],
+    "e_hwr": lambda sd, i: [torch_ref.e_hwr(sd, i["x"])],
+}
+GRAD_INPUTS = {"generator": ["style"], "discriminator": ["x"], "hwr": ["image"], "spacer": ["style"], "style_extractor": ["recog"],
+               "encoder2": ["x"], "decoder": ["x"], "e_hwr": ["x"]}
+
+
+def product_module(name):
+    """the product's module class, used here on CPU only for its parameter names/shapes (no forward is run)"""
+    from handwriting_line_generation_amd import model as M
+    cls = dict(generator=M.SpacedGenerator, discriminator=M.DiscriminatorAP, hwr=M.CNNOnlyHWR, spacer=M.CountCNN,
+               style_extractor=M.CharStyleEncoder, encoder2=M.Encoder2, decoder=M.DecoderNoSkip, e_hwr=M.E_HWR)[name]
+    return cls(**cases.CASES[name]["ctor"])
+
+
+def oracle_run(name, sd):
+    inp = cases.inputs(name)
+    for k in GRAD_INPUTS[name]:
+        inp[k] = inp[k].clone().requires_grad_(True)
+    torch.manual_seed(cases.FWD_SEED)
+    outs = ORACLE_FWD[name](sd, inp)
+    ws = cases.probe_weights(outs)
+    sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+    return outs, {k: inp[k].grad for k in GRAD_INPUTS[name]}
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).double(); b = torch.as_tensor(b).double()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-6))
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_oracle_matches_reference_golden(name):
+    gold = np.load(os.path.join(GOLD, "module_%s.npz" % name))
+    m = product_module(name)
+    sd = torch_ref.seeded_state_dict(m, cases.CASES[name]["wseed"])
+    pnames = [k for k, p in m.named_parameters() if p.requires_grad]
+    for k in pnames:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    outs, igr = oracle_run(name, sd)
+    for i, o in enumerate(outs):
+        assert rel(o.detach(), gold["out%d" % i]) < 2e-5, "%s out%d" % (name, i)
+    for k, g in igr.items():
+        assert rel(g, gold["igrad_" + k]) < 2e-5, "%s d%s" % (name, k)
+    names = json.loads(str(gold["pgrad_names"]))
+    assert sorted(pnames) == names, "parameter names differ from the reference's"
+    grads = {k: (sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])) for k in pnames}
+    _, fp = cases.fingerprint(grads)
+    ref = torch.from_numpy(gold["pgrad_fp"])
+    scale = ref[:, 1].clamp_min(1e-6)
+    assert float(((fp - ref).abs() / scale[:, None]).max()) < 1e-4, name
+
+
+def test_state_dict_schema_matches_reference():
+    """full-size HWWithStyle: the 1411 state-dict entries / 47,358,027 parameters of the reference"""
+    from handwriting_line_generation_amd.model import HWWithStyle
+    cfg = json.load(open(os.path.join(GOLD, "model_config_iam.json")))
+    m = HWWithStyle(cfg)
+    schema = json.load(open(os.path.join(GOLD, "state_dict_schema_iam.json")))
+    got = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert got == schema
+    assert sum(p.numel() for p in m.parameters()) == 47358027 and len(list(m.parameters())) == 1324
+
+
+def test_seq_known_answers():
+    kat = np.load(os.path.join(GOLD, "seq_kat.npz"))
+    for n in range(5):
+        pred = torch.from_numpy(kat["dtw%d_pred" % n]); label = torch.from_numpy(kat["dtw%d_label" % n])
+        out = seq_oracle.correct_pred(pred, label)
+        assert np.array_equal(out.numpy(), kat["dtw%d_out" % n])
+        dec = json.loads(str(kat["dec%d" % n]))
+        for b in range(pred.shape[1]):
+            assert seq_oracle.naive_decode(pred[:, b].numpy())[0] == dec[b]
