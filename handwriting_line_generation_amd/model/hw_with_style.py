@@ -101,6 +101,7 @@ class HWWithStyle(BaseModel):
         self.use_hwr_pred_for_style = g("use_hwr_pred_for_style", True)
         self.pred = None
         self.spaced_label = None
+        self.spaced_label_index = None
         self.spacing_pred = None
         self.mask_pred = None
         self.gen_spaced = None
@@ -147,7 +148,8 @@ class HWWithStyle(BaseModel):
         if stop_grad_extractor:
             style = style.detach()
         if self.spaced_label is None:
-            self.spaced_label = self.onehot(correct_pred(self.pred, label))
+            self.spaced_label_index = correct_pred(self.pred, label)
+            self.spaced_label = self.onehot(self.spaced_label_index)
         recon = self.forward(label, None, style, self.spaced_label)
         return recon, style
 
@@ -161,7 +163,8 @@ class HWWithStyle(BaseModel):
             spaced = self.pred                                   # [T,B,C]
         else:
             if self.spaced_label is None:
-                self.spaced_label = self.onehot(correct_pred(self.pred, label))
+                self.spaced_label_index = correct_pred(self.pred, label)
+                self.spaced_label = self.onehot(self.spaced_label_index)
             spaced = self.spaced_label
         T = spaced.shape[0]
         n_auth = batch_size // a_batch_size

@@ -1082,3 +1082,24 @@ class _RepeatRows(Function):
 
 def repeat_rows(x, k):
     return _RepeatRows.apply(x.contiguous(), int(k))
+
+
+class _ZeroRowsFrom(Function):
+    """y = x with x[pos:] = 0 along dim 0 (the in-place `counts[pos:] = 0` of trainer :697)"""
+
+    @staticmethod
+    def forward(ctx, x, pos):
+        y = x.clone()
+        y[pos:].zero_()
+        ctx.pos = pos
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = dy.clone()
+        dx[ctx.pos:].zero_()
+        return dx, None
+
+
+def zero_rows_from(x, pos):
+    return _ZeroRowsFrom.apply(x, int(pos))

@@ -1,0 +1,221 @@
+"""Flat gradient storage + multi-tensor optimizer ops for the GAN trainer.
+
+The reference walks `model.parameters()` (1324 tensors) in Python for every gradient stash, abs-mean, balanced add,
+clip, NaN assert and Adam update (trainer/hw_with_style_trainer.py:300-391), each with its own kernel launches and
+host syncs. Here every parameter's `.grad` is a persistent view into one flat fp32 buffer, ordered
+[main-optimizer params | discriminator-optimizer params | the rest], so that
+
+  * zeroing / stashing a gradient set is one memset / memcpy,
+  * per-tensor statistics and updates are single launches of the hwg multi-tensor kernels over static chunk tables,
+  * a data-parallel all-reduce is one collective over the flat buffer.
+
+`None` gradients matter in the reference (Adam skips them, stashes record them, the balance ignores them). That state is
+tracked on the host in `touched` (set by post-accumulate-grad hooks, cleared by zero_grad) and turned into pointer masks
+for the kernels, so the semantics are identical without any device->host traffic.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from .. import ops
+
+CHUNK = 65536
+
+
+class FlatParams:
+    def __init__(self, params, groups):
+        """params: list of all model parameters (model.parameters() order); groups: dict name -> list of params (disjoint).
+        Parameters in no group form the group 'rest'."""
+        self.params = list(params)
+        self.device = self.params[0].device
+        ids = {id(p): i for i, p in enumerate(self.params)}
+        order, self.group_range = [], {}
+        seen = set()
+        for name, plist in groups.items():
+            start = len(order)
+            for p in plist:
+                order.append(ids[id(p)]); seen.add(ids[id(p)])
+            self.group_range[name] = (start, len(order))
+        start = len(order)
+        order += [i for i in range(len(self.params)) if i not in seen]
+        self.group_range["rest"] = (start, len(order))
+        self.order = order                      # flat position -> index in self.params
+        self.pos = {pi: k for k, pi in enumerate(order)}   # param index -> flat position
+        self.nt = len(order)
+        numel = np.array([self.params[i].numel() for i in order], dtype=np.int64)
+        # 16-byte aligned segments
+        padded = (numel + 3) // 4 * 4
+        self.offsets = np.concatenate([[0], np.cumsum(padded)[:-1]]).astype(np.int64)
+        self.total = int(padded.sum())
+        self.numel = numel
+        self.flat_grad = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.touched = np.zeros(self.nt, dtype=bool)
+        for k, pi in enumerate(order):
+            p = self.params[pi]
+            if not p.requires_grad:
+                continue
+            p.grad = self.flat_grad[self.offsets[k]: self.offsets[k] + numel[k]].view_as(p)
+            p.register_post_accumulate_grad_hook(self._make_hook(k))
+        # static tables
+        ct, co = [], []
+        for k in range(self.nt):
+            for off in range(0, int(numel[k]), CHUNK):
+                ct.append(k); co.append(off)
+        self.nchunks = len(ct)
+        self.d_chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=self.device)
+        self.d_chunk_off = torch.tensor(co, dtype=torch.int64, device=self.device)
+        self.d_numel = torch.from_numpy(numel).to(self.device)
+        self._param_ptrs = np.array([self.params[i].data_ptr() for i in order], dtype=np.int64)
+        self.d_param_ptrs = torch.from_numpy(self._param_ptrs).to(self.device)
+        self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._stash_pool = []
+
+    def _make_hook(self, k):
+        def hook(p):
+            self.touched[k] = True
+        return hook
+
+    # -- pointer tables -----------------------------------------------------------------------------
+    def base_ptrs(self, flat):
+        return flat.data_ptr() + self.offsets * 4
+
+    def masked_ptrs(self, flat, mask):
+        return torch.from_numpy(self.base_ptrs(flat) * mask.astype(np.int64)).to(self.device)
+
+    def group_mask(self, name):
+        m = np.zeros(self.nt, dtype=bool)
+        a, b = self.group_range[name]
+        m[a:b] = True
+        return m
+
+    def group_slice(self, flat, name):
+        a, b = self.group_range[name]
+        if a == b:
+            return flat[0:0]
+        end = self.offsets[b - 1] + (self.numel[b - 1] + 3) // 4 * 4
+        return flat[self.offsets[a]: end]
+
+    def _st(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    # -- the reference's gradient bookkeeping, vectorised ------------------------------------------------
+    def zero_grad(self, group):
+        """optimizer.zero_grad() of torch >= 2.0 (set_to_none): gradients of that optimizer's parameters become None"""
+        self.group_slice(self.flat_grad, group).zero_()
+        a, b = self.group_range[group]
+        self.touched[a:b] = False
+
+    def stash(self):
+        """clone every non-None gradient and zero it in place (trainer :305-311, :316-322, :331-338)"""
+        buf = self._stash_pool.pop() if self._stash_pool else torch.empty_like(self.flat_grad)
+        buf.copy_(self.flat_grad)
+        self.flat_grad.zero_()
+        return (buf, self.touched.copy())
+
+    def release(self, stash):
+        self._stash_pool.append(stash[0])
+
+    def abs_sums(self, flat, mask):
+        out = torch.zeros(self.nt, dtype=torch.float64, device=self.device)
+        L.call("hwg_mt_abs_sum", self.masked_ptrs(flat, mask), self.d_numel, self.d_chunk_tensor, self.d_chunk_off, self.nchunks, CHUNK, out, self._st())
+        return out
+
+    def balance(self, stashes, multipliers):
+        """p.grad += x_k * R_k * mean|p.grad| / mean|R_k| for every stashed set k (trainer :340-377)"""
+        if not stashes:
+            return
+        sumD = self.abs_sums(self.flat_grad, self.touched)
+        ns = len(stashes)
+        sumR = torch.empty((ns, self.nt), dtype=torch.float64, device=self.device)
+        ptrR = np.zeros((ns, self.nt), dtype=np.int64)
+        for k, (buf, tm) in enumerate(stashes):
+            sumR[k] = self.abs_sums(buf, tm)
+            ptrR[k] = self.base_ptrs(buf) * tm.astype(np.int64)
+            if (tm & ~self.touched).any():
+                raise RuntimeError("a stashed gradient exists for a parameter whose current gradient is None (the reference would raise here too)")
+        d_ptrR = torch.from_numpy(ptrR).to(self.device)
+        d_ptrG = self.masked_ptrs(self.flat_grad, self.touched)
+        xs = torch.tensor([float(multipliers[k]) for k in range(ns)], dtype=torch.float32, device=self.device)
+        coef = torch.empty((ns, self.nt), dtype=torch.float32, device=self.device)
+        L.call("hwg_mt_balance_coef", sumD, sumR, self.d_numel, d_ptrG, d_ptrR, xs, ns, self.nt, coef, self._st())
+        for k in range(ns):
+            L.call("hwg_mt_axpy", d_ptrG, d_ptrR[k].contiguous(), coef[k].contiguous(), self.d_numel, self.d_chunk_tensor, self.d_chunk_off,
+                   self.nchunks, CHUNK, self._st())
+
+    def clip_(self, value):
+        """torch.nn.utils.clip_grad_value_ over every parameter that has a gradient"""
+        L.call("hwg_mt_unary", self.masked_ptrs(self.flat_grad, self.touched), None, 1, float(value), None, self.d_numel, self.d_chunk_tensor,
+               self.d_chunk_off, self.nchunks, CHUNK, self._st())
+
+    def params_nonfinite_flag(self):
+        """device flag (int32[1]) set when any parameter holds NaN/inf - the reference asserts per tensor with a host sync each"""
+        self._flag.zero_()
+        L.call("hwg_mt_unary", self.d_param_ptrs, None, 2, 0.0, self._flag, self.d_numel, self.d_chunk_tensor, self.d_chunk_off, self.nchunks, CHUNK,
+               self._st())
+        return self._flag
+
+
+class HipAdam:
+    """torch.optim.Adam (betas, eps, no weight decay / amsgrad) over one parameter group of a FlatParams, as a single
+    multi-tensor kernel launch. Tensors whose gradient is None are skipped and their step count does not advance."""
+
+    def __init__(self, flat, group, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **unused):
+        if weight_decay:
+            raise NotImplementedError("weight decay is 0 in every shipped config")
+        self.flat, self.group = flat, group
+        self.lr, self.betas, self.eps = lr, tuple(betas), eps
+        self.exp_avg = torch.zeros_like(flat.flat_grad)
+        self.exp_avg_sq = torch.zeros_like(flat.flat_grad)
+        self.steps = np.zeros(flat.nt, dtype=np.int64)
+        self.mask = flat.group_mask(group)
+        self.param_groups = [{"lr": lr, "betas": self.betas, "eps": eps, "params": [flat.params[flat.order[k]] for k in np.nonzero(self.mask)[0]]}]
+
+    def zero_grad(self):
+        self.flat.zero_grad(self.group)
+
+    def step(self):
+        f = self.flat
+        active = self.mask & f.touched
+        if not active.any():
+            return
+        self.steps[active] += 1
+        lr = self.param_groups[0]["lr"]
+        b1, b2 = self.betas
+        t = np.maximum(self.steps, 1).astype(np.float64)
+        step_size = (lr / (1.0 - b1 ** t)).astype(np.float32)
+        bc2 = np.sqrt(1.0 - b2 ** t).astype(np.float32)
+        d_ss = torch.from_numpy(step_size).to(f.device)
+        d_bc = torch.from_numpy(bc2).to(f.device)
+        am = active.astype(np.int64)
+        tab = np.stack([f._param_ptrs * am, f.base_ptrs(f.flat_grad) * am, f.base_ptrs(self.exp_avg) * am, f.base_ptrs(self.exp_avg_sq) * am])
+        d_tab = torch.from_numpy(tab).to(f.device)
+        L.call("hwg_mt_adam", d_tab[0], d_tab[1], d_tab[2], d_tab[3], d_ss, d_bc, float(b1), float(b2), float(self.eps), 0.0, f.d_numel,
+               f.d_chunk_tensor, f.d_chunk_off, f.nchunks, CHUNK, f._st())
+
+    # checkpoint format of torch.optim.Adam (state keyed by parameter index within the group)
+    def state_dict(self):
+        f = self.flat
+        state = {}
+        for j, k in enumerate(np.nonzero(self.mask)[0]):
+            if self.steps[k] == 0:
+                continue
+            p = f.params[f.order[k]]
+            sl = slice(int(f.offsets[k]), int(f.offsets[k] + f.numel[k]))
+            state[j] = {"step": torch.tensor(float(self.steps[k])), "exp_avg": self.exp_avg[sl].view_as(p).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[sl].view_as(p).clone()}
+        return {"state": state, "param_groups": [{"lr": self.param_groups[0]["lr"], "betas": self.betas, "eps": self.eps, "weight_decay": 0,
+                                                  "amsgrad": False, "params": list(range(int(self.mask.sum())))}]}
+
+    def load_state_dict(self, sd):
+        f = self.flat
+        ks = np.nonzero(self.mask)[0]
+        for j, st in sd["state"].items():
+            k = ks[int(j)]
+            sl = slice(int(f.offsets[k]), int(f.offsets[k] + f.numel[k]))
+            self.exp_avg[sl].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[sl].copy_(st["exp_avg_sq"].reshape(-1))
+            self.steps[k] = int(float(st["step"]))
+        if sd.get("param_groups"):
+            self.param_groups[0]["lr"] = sd["param_groups"][0].get("lr", self.param_groups[0]["lr"])
