@@ -1,0 +1,143 @@
+#!/usr/bin/env python
+"""bench.py - G+D train steps/sec of the GAN curriculum (BASELINE.json metric) on N MI355X GPUs of one node.
+
+  python bench.py --gpus 1 --steps 14 --warmup 7
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one `HWWithStyleTrainer._train_iteration` (one lesson of the 7-lesson curriculum: count / gen / auto / disc ...)
+on one rank's synthetic author batch; steps are timed in whole curriculum cycles where possible. Data parallel runs give every rank
+its own author shard (weak scaling) and all-reduce the gradient sets over RCCL; `value` = N*K / max-over-ranks elapsed time.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # per-GPU shape of BASELINE.json configs[3] (DDP: 4 authors per GPU, a_batch_size 2 -> 8 lines of 64x512), used at every N
+    "iam_gan_b4a2_w512": dict(which="iam_gan", batch_size=4, a_batch_size=2, width=512, label_len=30),
+    # BASELINE.json configs[2] exactly as SURVEY 8d reads it (one author, one line per step)
+    "iam_gan_b1a1_w512": dict(which="iam_gan", batch_size=1, a_batch_size=1, width=512, label_len=30),
+    # the shipped config's own batch (2 authors x 2 lines) - the shape of the survey's CPU measurement
+    "iam_gan_b2a2_w512": dict(which="iam_gan", batch_size=2, a_batch_size=2, width=512, label_len=30),
+    # BASELINE.json configs[4]: RIMES, variable widths 256..1024 padded per batch
+    "rimes_gan_b4a2_w256_1024": dict(which="rimes_gan", batch_size=4, a_batch_size=2, width=1024, min_width=256, label_len=40),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 256 CU x 2.4 GHz
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=14)
+    ap.add_argument("--warmup", type=int, default=7)
+    ap.add_argument("--workload", default="iam_gan_b4a2_w512", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for the oracle baseline")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+
+    from handwriting_line_generation_amd import ops, rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+
+    wl = WORKLOADS[args.workload]
+    torch.manual_seed(1234 + rank); np.random.seed(1234 + rank); random.seed(1234 + rank)
+    rng.set_mode("device", seed=99 + rank)
+    # identical initial weights on every rank (seeded init before the rank-dependent seeds matter): build under a fixed seed
+    torch.manual_seed(0)
+    trainer, cfg = build_gan_trainer(wl["which"], wl["batch_size"], wl["a_batch_size"], width=wl["width"], label_len=wl["label_len"],
+                                     min_width=wl.get("min_width"), gpu=local, rank=rank, world=world)
+    torch.manual_seed(1234 + rank)
+    if world > 1:
+        for p in trainer.model.parameters():
+            dist.broadcast(p.data, 0)
+        for b in trainer.model.buffers():
+            dist.broadcast(b.data, 0)
+
+    it = 0
+    for _ in range(args.warmup):
+        trainer._train_iteration(it); it += 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ops.CONV_PROF = [] if rank == 0 else None
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer._train_iteration(it); it += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, ops.CONV_PROF = ops.CONV_PROF, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        fam = {}
+        for kind, flops, e0, e1 in prof:
+            f = fam.setdefault(kind, [0.0, 0.0, 0])
+            f[0] += flops; f[1] += e0.elapsed_time(e1) * 1e-3; f[2] += 1
+        dom = max(fam, key=lambda k: fam[k][1]) if fam else None
+        roofline = None
+        if dom:
+            fl, sec, n = fam[dom]
+            ach = fl / sec / 1e12
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "launches": n, "avg_launch_us": round(sec / n * 1e6, 2),
+                        "gflop_per_launch": round(fl / n / 1e9, 4),
+                        "other_kernels": {k: {"achieved": round(v[0] / v[1] / 1e12, 3), "launches": v[2], "time_frac_of_step": round(v[1] / elapsed, 3)}
+                                          for k, v in fam.items() if k != dom},
+                        "time_frac_of_step": round(sec / elapsed, 3)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import cycle_ref
+            ncores = os.cpu_count() or 1
+            torch.set_num_threads(ncores)
+            m = trainer.model
+            sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+            trainable = {k for k, p in m.named_parameters() if p.requires_grad}
+            enc = {k: v.detach().cpu() for k, v in trainer.encoder.state_dict().items()}
+            B = wl["batch_size"] * wl["a_batch_size"]
+            sps, nsteps, secs = cycle_ref.time_cycles(sd, trainable, enc, B, wl["a_batch_size"], wl["width"], wl["label_len"],
+                                                      budget_s=args.cpu_budget, max_cycles=1)
+            cpu = {"value": round(sps, 4), "unit": "steps/s", "cores": ncores, "kind": "port",
+                   "sample": "%d steps (one 7-lesson cycle) of oracle/cycle_ref.py, torch %s fp32 CPU, same batch shape, %.1f s" % (nsteps, torch.__version__, secs)}
+        out = {
+            "metric": "G+D train steps/sec", "value": round(world * args.steps / elapsed, 4), "unit": "steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "config_file": cfg["name"], "lines_per_gpu_step": wl["batch_size"] * wl["a_batch_size"],
+                       "authors_per_gpu": wl["batch_size"], "a_batch_size": wl["a_batch_size"], "line_px": "64x%d" % wl["width"],
+                       "curriculum": "count,gen,auto,disc,gen,auto,disc", "parallelism": "dp%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

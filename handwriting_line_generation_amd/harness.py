@@ -57,9 +57,7 @@ def build_gan_trainer(which="iam_gan", batch_size=None, a_batch_size=None, width
     tr = cfg["trainer"]
     if not os.path.exists(tr["encoder_weights"]):
         ae = Autoencoder({"type": tr.get("encoder_type", "2tight"), "hwr": cfg["model"]["num_class"]})
-        sd = ae.state_dict()
-        if encoder_state is not None:
-            sd = {("encoder." + k): v for k, v in encoder_state.items()}
+        sd = encoder_state if encoder_state is not None else ae.state_dict()   # keys 'encoder.*' are the ones the trainer reads
         torch.save({"state_dict": sd}, tr["encoder_weights"])
     model = HWWithStyle(cfg["model"])
     if model_state is not None:

@@ -80,10 +80,36 @@ def _pad_channels(x, Cpad):
     return out
 
 
+# Optional per-launch timing of the MFMA conv kernels (bench.py's roofline measurement): when CONV_PROF is a list every MFMA
+# launch appends (kind, flops, start_event, end_event); events are recorded on the launch stream.
+CONV_PROF = None
+
+
+def _prof_begin():
+    if CONV_PROF is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(kind, flops, e0):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        CONV_PROF.append((kind, flops, e0, e1))
+
+
 def _run_conv(x, wp, bias, N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed):
     y = torch.empty((N, P, Q, K), dtype=torch.float32, device=x.device)
     d = _desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed)
+    mfma = C != 1 and K > 2
+    e0 = _prof_begin() if mfma else None
     L.call("hwg_conv_fwd", ctypes.byref(d), x, wp, bias, y, 0, _stream())
+    if e0 is not None:
+        # algorithmic work: every output pixel x K x C x taps (transposed: every input pixel feeds RxS outputs)
+        pix = N * H * W if transposed else N * P * Q
+        _prof_end("conv_mfma_kernel", 2.0 * pix * K * C * R * S, e0)
     return y
 
 
@@ -170,7 +196,9 @@ class _Conv2d(Function):
                 sa, sb = K * R * S, R * S
             need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
             ws = workspace(need, x.device)
+            e0 = _prof_begin() if (d.K > 2 and d.C > 2) else None
             L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 0, ws, ws.numel(), st)
+            _prof_end("wgrad_mfma_kernel", 2.0 * d.N * d.P * d.Q * d.K * d.C * R * S, e0)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy.view(-1, K))
         return dx, dw_, db, None, None, None, None, None

@@ -120,3 +120,41 @@ def naive_decode(logits):
     raw = np.argmax(logits, axis=1)
     out = [int(raw[i]) for i in range(len(raw)) if raw[i] != 0 and not (i > 0 and raw[i] == raw[i - 1])]
     return out, list(raw)
+
+
+# ---- the same two algorithms through the C restatement (oracle/seq_oracle.c), for full-size checks ----
+def _clib():
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libseq_oracle.so")
+    if not os.path.exists(path):
+        raise RuntimeError("oracle/libseq_oracle.so missing: run `make -C oracle` (or __graft_entry__.build())")
+    lib = ctypes.CDLL(path)
+    lib.oracle_correct_pred.restype = ctypes.c_int
+    lib.oracle_gt_counts.restype = ctypes.c_int
+    return lib
+
+
+def correct_pred_c(pred, label):
+    import ctypes
+    lib = _clib()
+    p = np.ascontiguousarray(pred.detach().cpu().float().numpy())
+    lab = np.ascontiguousarray(label.cpu().numpy().astype(np.int32))
+    T, B, C = p.shape
+    L = lab.shape[0]
+    out = np.zeros((T + 2 * L + 1, B), dtype=np.int64)
+    lens = np.zeros(B, dtype=np.int32)
+    vp = ctypes.c_void_p
+    n = lib.oracle_correct_pred(vp(p.ctypes.data), vp(lab.ctypes.data), T, B, C, L, vp(out.ctypes.data), vp(lens.ctypes.data))
+    return torch.from_numpy(out[:n].copy())
+
+
+def gt_counts_c(index_spaced, label):
+    import ctypes
+    lib = _clib()
+    idx = np.ascontiguousarray(index_spaced.cpu().numpy().astype(np.int64))
+    lab = np.ascontiguousarray(label.cpu().numpy().astype(np.int32))
+    gt = np.zeros((lab.shape[0], lab.shape[1], 2), dtype=np.float32)
+    vp = ctypes.c_void_p
+    pos = lib.oracle_gt_counts(vp(idx.ctypes.data), vp(lab.ctypes.data), idx.shape[0], idx.shape[1], lab.shape[0], vp(gt.ctypes.data))
+    return torch.from_numpy(gt), pos

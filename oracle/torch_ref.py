@@ -52,7 +52,7 @@ def _noise(x, s):  # pure_gen.py:72-79 + EqualLR :218-247
 def _blur(x):  # pure_gen.py:80-137
     C = x.shape[1]
     k = torch.tensor([[1., 2., 1.], [2., 4., 2.], [1., 2., 1.]])
-    k = (k / k.sum()).view(1, 1, 3, 3).repeat(C, 1, 1, 1)
+    k = (k / k.sum()).view(1, 1, 3, 3).repeat(C, 1, 1, 1).to(x.dtype)
     return F.conv2d(x, k, padding=1, groups=C)
 
 
