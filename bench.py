@@ -113,18 +113,18 @@ def main():
                         "time_frac_of_step": round(sec / elapsed, 3)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import cycle_ref
-            ncores = os.cpu_count() or 1
-            torch.set_num_threads(ncores)
-            m = trainer.model
-            sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
-            trainable = {k for k, p in m.named_parameters() if p.requires_grad}
-            enc = {k: v.detach().cpu() for k, v in trainer.encoder.state_dict().items()}
+            # the oracle's CPU cycle runs in a child process (it never touches the GPU) under a hard timeout
+            import subprocess
             B = wl["batch_size"] * wl["a_batch_size"]
-            sps, nsteps, secs = cycle_ref.time_cycles(sd, trainable, enc, B, wl["a_batch_size"], wl["width"], wl["label_len"],
-                                                      budget_s=args.cpu_budget, max_cycles=1)
-            cpu = {"value": round(sps, 4), "unit": "steps/s", "cores": ncores, "kind": "port",
-                   "sample": "%d steps (one 7-lesson cycle) of oracle/cycle_ref.py, torch %s fp32 CPU, same batch shape, %.1f s" % (nsteps, torch.__version__, secs)}
+            cmd = [sys.executable, "-m", "oracle.cycle_ref", str(B), str(wl["a_batch_size"]), str(wl["width"]), str(wl["label_len"]), str(args.cpu_budget)]
+            try:
+                r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=max(240.0, 10 * args.cpu_budget))
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+                cpu = {"value": round(j["steps_per_sec"], 4), "unit": "steps/s", "cores": j["cores"], "kind": "port",
+                       "sample": "%d steps (whole 7-lesson cycles) of oracle/cycle_ref.py, torch %s fp32 CPU, same batch shape (%d lines 64x%d), %.1f s"
+                                 % (j["steps"], j["torch"], B, wl["width"], j["seconds"])}
+            except Exception as e:  # noqa: BLE001 - the baseline is a reported extra, never a reason to lose the GPU number
+                cpu = {"value": None, "unit": "steps/s", "cores": None, "kind": "port", "sample": "cpu baseline failed: %r" % (e,)}
         out = {
             "metric": "G+D train steps/sec", "value": round(world * args.steps / elapsed, 4), "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,

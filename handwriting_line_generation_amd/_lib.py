@@ -8,6 +8,8 @@ import ctypes
 import os
 import re
 
+import torch  # noqa: F401  (must be loaded first: its bundled HIP runtime has to be the one libhwg_hip.so binds to)
+
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _REPO_DIR = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.path.join(_PKG_DIR, "libhwg_hip.so")

@@ -146,3 +146,39 @@ def time_cycles(model_sd, trainable, encoder_sd, B, A, W, label_len, budget_s=25
             break
     dt = time.perf_counter() - t0
     return 7 * n / dt, 7 * n, dt
+
+
+def effective_cores():
+    """CPUs this process may really use: min(affinity mask, cgroup CPU quota)"""
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+if __name__ == "__main__":
+    # CLI used by bench.py's cpu_baseline leg (child process, never touches the GPU):
+    #   python -m oracle.cycle_ref B A W label_len budget_seconds
+    import json
+    import sys
+    import warnings
+    warnings.filterwarnings("ignore")
+    B, A, W, Lr = (int(v) for v in sys.argv[1:5])
+    budget = float(sys.argv[5])
+    cores = effective_cores()
+    torch.set_num_threads(cores)
+    from handwriting_line_generation_amd.model import Autoencoder, HWWithStyle   # parameter shapes only; nothing is executed through it
+    import os
+    cfg = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "model_config_iam.json")))
+    torch.manual_seed(0)
+    m = HWWithStyle(cfg)
+    ae = Autoencoder({"type": "2tight", "hwr": cfg["num_class"]})
+    trainable = {k for k, p in m.named_parameters() if p.requires_grad}
+    enc = {k[8:]: v for k, v in ae.state_dict().items() if k.startswith("encoder.")}
+    sps, nsteps, secs = time_cycles(m.state_dict(), trainable, enc, B, A, W, Lr, budget_s=budget, max_cycles=2)
+    print(json.dumps({"steps_per_sec": sps, "steps": nsteps, "seconds": secs, "cores": cores, "torch": torch.__version__}))
