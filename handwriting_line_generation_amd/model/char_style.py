@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 from .. import ops
+from . import expert_bank
 from .layers import Conv1d, Conv2d, GroupNorm, Linear, Marker, group_count
 
 
@@ -100,6 +101,7 @@ class CharStyleEncoder(nn.Module):
             Conv1d(dim, dim, 3, 1, 1), Marker("relu"))
         self.final_g_spacing_style = nn.Sequential(Linear(dim + style_dim, dim), Marker("relu"), Linear(dim, style_dim))
         self.char_extractor = nn.ModuleList([CharExtractor(dim, char_dim, style_dim, num_char_fc, window < 3) for _ in range(n_class)])
+        self._bank = None   # pointer tables over the experts' parameters, built on first use (after the module sits on its device)
 
     @staticmethod
     def _align(x, recog):
@@ -129,25 +131,21 @@ class CharStyleEncoder(nn.Module):
 
         # which classes were recognised where (one small D2H copy)
         pred = ops.argmax_rows(recog.reshape(B * Wf, self.n_class)).view(B, Wf).cpu().numpy()
-        cls_list, b_list, pos_list = [], [], []
-        for c in range(1, self.n_class):
-            bb, pp = np.nonzero(pred == c)   # row-major: author, then column - the reference's loop order
-            if bb.size:
-                cls_list.append(np.full(bb.size, c, dtype=np.int32)); b_list.append(bb.astype(np.int32)); pos_list.append(pp.astype(np.int32))
+        bb, pp = np.nonzero(pred > 0)                 # row-major: author, then column
         feat_rows = feat.reshape(B, Wf, C)
-        if cls_list:
-            cls_np = np.concatenate(cls_list); b_np = np.concatenate(b_list); pos_np = np.concatenate(pos_list)
+        if bb.size:
+            cls_all = pred[bb, pp]
+            order = np.argsort(cls_all, kind="stable")   # class-major, then (author, column): the reference's loop order
+            cls_np = cls_all[order].astype(np.int32); b_np = bb[order].astype(np.int32); pos_np = pp[order].astype(np.int32)
             idx = torch.from_numpy(np.stack([b_np, pos_np, cls_np])).to(dev)
             idx_b, idx_pos, idx_cls = idx[0].contiguous(), idx[1].contiguous(), idx[2].contiguous()
             patches = ops.gather_windows(feat_rows, idx_b, idx_pos, self.window)        # [n,1,2w+1,C]
             scores = ops.gather_scores(recog.reshape(B, Wf, self.n_class), idx_b, idx_pos, idx_cls)
-            outs = []
-            start = 0
-            for chunk in cls_list:
-                n_c = chunk.size
-                outs.append(self.char_extractor[int(chunk[0])](patches[start:start + n_c]))
-                start += n_c
-            char_styles = torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+            if self._bank is None:
+                self._bank = expert_bank.ExpertBank(list(self.char_extractor))
+            plan = expert_bank.make_plan(cls_np, dev)
+            ex0 = self.char_extractor[0]
+            char_styles = expert_bank.run_experts(self._bank, patches, plan, ex0.conv1[2].num_groups, ex0.conv2[2].num_groups)
             avg_char_style = ops.segment_weighted_mean(char_styles, scores, idx_b, B)
         else:
             avg_char_style = torch.zeros((B, self.char_style_dim), dtype=torch.float32, device=dev)

@@ -1,0 +1,159 @@
+"""All character-style experts evaluated together (reference: model/char_style.py:84-124 run once per class, :210-235).
+
+The 79 `CharExtractor` modules keep their own parameters (state-dict compatible), but the forward/backward for ALL recognised
+windows is a fixed sequence of grouped kernels that read each window's expert weights through device pointer tables
+(csrc/expert_bank.hip). Parameter gradients are accumulated by the kernels directly into each expert's `.grad` buffer; experts
+without a window in the batch are never touched, which preserves the reference's "gradient is None" state for them.
+"""
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from .. import _lib as L
+from .. import ops
+
+# (attribute path, is_bias) of every parameter kind of one expert
+KINDS = {
+    "w1": ("conv1", 1, "weight"), "b1": ("conv1", 1, "bias"), "g1": ("conv1", 2, "weight"), "be1": ("conv1", 2, "bias"),
+    "w2": ("conv1", 4, "weight"), "b2": ("conv1", 4, "bias"),
+    "w3": ("conv2", 1, "weight"), "b3": ("conv2", 1, "bias"), "g2": ("conv2", 2, "weight"), "be2": ("conv2", 2, "bias"),
+    "w4": ("fc", 0, "weight"), "b4": ("fc", 0, "bias"), "w5": ("fc", 2, "weight"), "b5": ("fc", 2, "bias"),
+}
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class ExpertBank:
+    """pointer tables over the experts' parameters and gradient buffers"""
+
+    def __init__(self, experts):
+        self.experts = experts
+        self.E = len(experts)
+        self.params = {k: [getattr(getattr(ex, seq)[idx], leaf) for ex in experts] for k, (seq, idx, leaf) in KINDS.items()}
+        self._pptr = None
+        self._pkey = None
+        self._gptr_host = {k: np.zeros(self.E, dtype=np.int64) for k in KINDS}
+        self._gptr_dev = {}
+
+    def param_ptrs(self, device):
+        key = (self.params["w1"][1].data_ptr(), str(device))
+        if self._pkey != key:
+            host = np.array([[p.data_ptr() for p in self.params[k]] for k in KINDS], dtype=np.int64)
+            dev = torch.from_numpy(host).to(device)
+            self._pptr = {k: dev[i] for i, k in enumerate(KINDS)}
+            self._pkey = key
+        return self._pptr
+
+    def grad_ptrs(self, present, device):
+        """gradient-buffer tables; allocates / marks-as-touched the buffers of the experts present in this batch"""
+        changed = False
+        for k in KINDS:
+            plist = self.params[k]
+            hp = self._gptr_host[k]
+            for e in present:
+                g = ops._grad_buffer(plist[e])
+                a = g.data_ptr()
+                if hp[e] != a:
+                    hp[e] = a
+                    changed = True
+        if changed or not self._gptr_dev:
+            dev = torch.from_numpy(np.stack([self._gptr_host[k] for k in KINDS])).to(device)
+            self._gptr_dev = {k: dev[i] for i, k in enumerate(KINDS)}
+        return self._gptr_dev
+
+
+class _GroupedConv1d(Function):
+    @staticmethod
+    def forward(ctx, x, bank, wk, bk, plan, S, pad):
+        n, _, R, Cin = x.shape
+        Cout = bank.params[wk][1].shape[0]
+        pp = bank.param_ptrs(x.device)
+        y = torch.empty((n, 1, R, Cout), dtype=torch.float32, device=x.device)
+        L.call("hwg_grouped_conv1d_fwd", x, plan["eid"], pp[wk], pp[bk], y, n, R, Cin, Cout, S, pad, _st())
+        ctx.save_for_backward(x)
+        ctx.cfg = (bank, wk, bk, plan, S, pad, n, R, Cin, Cout)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        bank, wk, bk, plan, S, pad, n, R, Cin, Cout = ctx.cfg
+        dy = dy.contiguous()
+        pp = bank.param_ptrs(x.device)
+        gp = bank.grad_ptrs(plan["present"], x.device)
+        st = _st()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.call("hwg_grouped_conv1d_dgrad", dy, plan["eid"], pp[wk], dx, n, R, Cin, Cout, S, pad, st)
+        L.call("hwg_grouped_conv1d_wgrad", dy, x, plan["seg_start"], plan["seg_eid"], plan["G"], gp[wk], gp[bk], R, Cin, Cout, S, pad, st)
+        return dx, None, None, None, None, None, None
+
+
+class _GroupedGN(Function):
+    """GroupNorm + ReLU with each window's affine parameters taken from its expert"""
+
+    @staticmethod
+    def forward(ctx, x, bank, gk, bk, plan, groups, eps):
+        n, _, R, C = x.shape
+        pp = bank.param_ptrs(x.device)
+        st = _st()
+        gamma = torch.empty((n, C), dtype=torch.float32, device=x.device)
+        beta = torch.empty((n, C), dtype=torch.float32, device=x.device)
+        L.call("hwg_gather_rows_ptr", pp[gk], plan["eid"], gamma, n, C, st)
+        L.call("hwg_gather_rows_ptr", pp[bk], plan["eid"], beta, n, C, st)
+        y = torch.empty_like(x)
+        mean = torch.empty((n, C), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = ops.workspace(L.query("hwg_norm_workspace", n, R, C), x.device)
+        L.call("hwg_norm_fwd", x, y, n, R, C, ops.NORM_GN, groups, eps, gamma, beta, 1, None, ops.ACT_RELU, 0.0, mean, rstd, None, None, 0.0,
+               ws, ws.numel(), st)
+        ctx.save_for_backward(x, y, gamma, mean, rstd)
+        ctx.cfg = (bank, gk, bk, plan, groups, n, R, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, rstd = ctx.saved_tensors
+        bank, gk, bk, plan, groups, n, R, C = ctx.cfg
+        dy = dy.contiguous()
+        st = _st()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty((n, C), dtype=torch.float32, device=x.device)
+        dbeta = torch.empty_like(dgamma)
+        ws = ops.workspace(L.query("hwg_norm_workspace", n, R, C), x.device)
+        L.call("hwg_norm_bwd", dy, x, y, dx, n, R, C, ops.NORM_GN, groups, gamma, 1, None, ops.ACT_RELU, 0.0, mean, rstd, dgamma, dbeta, 0,
+               ws, ws.numel(), st)
+        gp = bank.grad_ptrs(plan["present"], x.device)
+        L.call("hwg_segment_accumulate_ptr", dgamma, plan["seg_start"], plan["seg_eid"], plan["G"], gp[gk], C, st)
+        L.call("hwg_segment_accumulate_ptr", dbeta, plan["seg_start"], plan["seg_eid"], plan["G"], gp[bk], C, st)
+        return dx, None, None, None, None, None, None
+
+
+def make_plan(cls_sorted_np, device):
+    """cls_sorted_np: int array of the expert id of every window, sorted ascending"""
+    n = cls_sorted_np.size
+    change = np.nonzero(np.diff(cls_sorted_np))[0] + 1
+    starts = np.concatenate([[0], change, [n]]).astype(np.int32)
+    seg_eid = cls_sorted_np[starts[:-1]].astype(np.int32)
+    packed = torch.from_numpy(np.concatenate([cls_sorted_np.astype(np.int32), starts, seg_eid])).to(device)
+    return {"eid": packed[:n], "seg_start": packed[n:n + starts.size], "seg_eid": packed[n + starts.size:], "G": int(seg_eid.size),
+            "present": [int(e) for e in seg_eid], "n": n}
+
+
+def run_experts(bank, patches, plan, groups1, groups2, eps=1e-5):
+    """patches [n,1,R,C] -> per-window styles [n, style_dim]; the network of char_style.py:118-124 (window < 3 variant)"""
+    n, _, R, _ = patches.shape
+    h = ops.relu(patches)
+    h = _GroupedConv1d.apply(h, bank, "w1", "b1", plan, 3, 1)
+    h = _GroupedGN.apply(h, bank, "g1", "be1", plan, groups1, eps)
+    h = _GroupedConv1d.apply(h, bank, "w2", "b2", plan, 3, 1)
+    h = ops.relu(ops.add(h, patches))
+    h = _GroupedConv1d.apply(h, bank, "w3", "b3", plan, 1, 0)
+    h = _GroupedGN.apply(h, bank, "g2", "be2", plan, groups2, eps)
+    h = ops.avg_pool2d(h, (1, R))                                   # [n,1,1,C]
+    h = ops.relu(_GroupedConv1d.apply(h, bank, "w4", "b4", plan, 1, 0))
+    h = _GroupedConv1d.apply(h, bank, "w5", "b5", plan, 1, 0)
+    return h.reshape(n, -1)

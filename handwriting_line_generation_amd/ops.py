@@ -52,6 +52,25 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
 
+# Parameter gradients are accumulated by the kernels straight into `param.grad` (the trainer keeps those as views of one flat
+# buffer) instead of being returned to autograd, which would allocate a temporary and launch an extra add kernel per tensor.
+DIRECT_PARAM_GRADS = True
+
+
+def _direct(p):
+    return DIRECT_PARAM_GRADS and p is not None and p.is_leaf and p.requires_grad
+
+
+def _grad_buffer(p):
+    """the buffer parameter gradients accumulate into (zero-initialised on first use)"""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    touch = getattr(p, "_hwg_touch", None)
+    if touch is not None:
+        touch()
+    return p.grad
+
+
 # ----------------------------------------------------------------------------------------------
 # convolution
 # ----------------------------------------------------------------------------------------------
@@ -154,6 +173,7 @@ class _Conv2d(Function):
                 y = _run_conv(xin, wp, bias, N, H, W, Cp, K, R, S, (sh, sw), (ph, pw), (1, 1), P, Q, 1)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.param_refs = (weight, bias)
         ctx.geom = (stride, padding, dilation, transposed, P, Q)
         return y
 
@@ -184,8 +204,10 @@ class _Conv2d(Function):
                 # gradient of a transposed conv is an ordinary (strided) correlation of dy
                 wp = _pack(weight, C, K, R, S, K * R * S, R * S, flip=0, Bpad=Kp)
                 dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (sh, sw), (ph, pw), (dh, dw), H, W, 0)
+        wref, bref = ctx.param_refs
         if ctx.needs_input_grad[1]:
-            dw_ = torch.empty_like(weight)
+            direct = _direct(wref)
+            dw_ = _grad_buffer(wref) if direct else torch.empty_like(weight)
             if not transposed:
                 d = _desc(N, H, W, C, K, R, S, (sh, sw), (ph, pw), (dh, dw), P, Q)
                 u, v = dy, x
@@ -197,10 +219,15 @@ class _Conv2d(Function):
             need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
             ws = workspace(need, x.device)
             e0 = _prof_begin() if (d.K > 2 and d.C > 2) else None
-            L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 0, ws, ws.numel(), st)
+            L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 1 if direct else 0, ws, ws.numel(), st)
             _prof_end("wgrad_mfma_kernel", 2.0 * d.N * d.P * d.Q * d.K * d.C * R * S, e0)
+            if direct:
+                dw_ = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy.view(-1, K))
+            if _direct(bref):
+                colsum(dy.view(-1, K), out=_grad_buffer(bref), accumulate=True)
+            else:
+                db = colsum(dy.view(-1, K))
         return dx, dw_, db, None, None, None, None, None
 
 
@@ -251,6 +278,7 @@ class _Norm(Function):
                running_mean, running_var, momentum, ws, ws.numel(), _stream())
         ctx.save_for_backward(x, y, gamma, mask, mean, rstd)
         ctx.cfg = (mode, groups, act, slope, N, HW, C, beta is not None)
+        ctx.param_refs = (gamma, beta)
         return y
 
     @staticmethod
@@ -259,11 +287,19 @@ class _Norm(Function):
         mode, groups, act, slope, N, HW, C, has_beta = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dgamma = torch.empty((C,), dtype=torch.float32, device=x.device) if gamma is not None else None
-        dbeta = torch.empty((C,), dtype=torch.float32, device=x.device) if has_beta else None
+        gref, bref = ctx.param_refs
+        direct = (gamma is None or _direct(gref)) and (not has_beta or _direct(bref))
+        if direct:
+            dgamma = _grad_buffer(gref) if gamma is not None else None
+            dbeta = _grad_buffer(bref) if has_beta else None
+        else:
+            dgamma = torch.empty((C,), dtype=torch.float32, device=x.device) if gamma is not None else None
+            dbeta = torch.empty((C,), dtype=torch.float32, device=x.device) if has_beta else None
         ws = workspace(L.query("hwg_norm_workspace", N, HW, C), x.device)
-        L.call("hwg_norm_bwd", dy, x, y, dx, N, HW, C, mode, groups, gamma, 0, mask, act, slope, mean, rstd, dgamma, dbeta, 0,
+        L.call("hwg_norm_bwd", dy, x, y, dx, N, HW, C, mode, groups, gamma, 0, mask, act, slope, mean, rstd, dgamma, dbeta, 1 if direct else 0,
                ws, ws.numel(), _stream())
+        if direct:
+            dgamma = dbeta = None
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
@@ -296,6 +332,7 @@ class _AdaIN(Function):
         L.call("hwg_adain_fwd", x, noise, noise_w, noise_scale, slope, gamma, beta, eps, u, y, mean, rstd, N, HW, C, ws, ws.numel(), _stream())
         ctx.save_for_backward(u, noise, gamma, mean, rstd)
         ctx.cfg = (noise_scale, slope, N, HW, C, noise_w.shape)
+        ctx.param_refs = (noise_w,)
         return y
 
     @staticmethod
@@ -306,11 +343,13 @@ class _AdaIN(Function):
         dx = torch.empty_like(u)
         dgamma = torch.empty((N, C), dtype=torch.float32, device=u.device)
         dbeta = torch.empty_like(dgamma)
-        dnw = torch.empty((C,), dtype=torch.float32, device=u.device)
+        (nwref,) = ctx.param_refs
+        direct = _direct(nwref)
+        dnw = _grad_buffer(nwref) if direct else torch.empty((C,), dtype=torch.float32, device=u.device)
         ws = workspace(L.query("hwg_norm_workspace", N, HW, C), u.device)
-        L.call("hwg_adain_bwd", dy, u, noise, noise_scale, slope, gamma, mean, rstd, dx, dgamma, dbeta, dnw, None, 0, N, HW, C,
+        L.call("hwg_adain_bwd", dy, u, noise, noise_scale, slope, gamma, mean, rstd, dx, dgamma, dbeta, dnw, None, 1 if direct else 0, N, HW, C,
                ws, ws.numel(), _stream())
-        return dx, None, dnw.view(wshape), dgamma, dbeta, None, None, None
+        return dx, None, (None if direct else dnw.view(wshape)), dgamma, dbeta, None, None, None
 
 
 def adain_epilogue(x, noise, noise_w, gamma, beta, noise_scale, slope=0.2, eps=1e-5):
@@ -329,6 +368,7 @@ class _BiasAct(Function):
         L.call("hwg_bias_act_fwd", x, bias, mask, y, rows, HW, C, act, slope, _stream())
         ctx.save_for_backward(y, mask)
         ctx.cfg = (act, slope, rows, HW, C, bias is not None)
+        ctx.param_refs = (bias,)
         return y
 
     @staticmethod
@@ -338,7 +378,13 @@ class _BiasAct(Function):
         dy = dy.contiguous()
         dx = torch.empty_like(y)
         L.call("hwg_bias_act_bwd", dy, y, mask, dx, rows, HW, C, act, slope, _stream())
-        db = colsum(dx.view(rows, C)) if has_bias and ctx.needs_input_grad[1] else None
+        db = None
+        if has_bias and ctx.needs_input_grad[1]:
+            (bref,) = ctx.param_refs
+            if _direct(bref):
+                colsum(dx.view(rows, C), out=_grad_buffer(bref), accumulate=True)
+            else:
+                db = colsum(dx.view(rows, C))
         return dx, db, None, None, None
 
 

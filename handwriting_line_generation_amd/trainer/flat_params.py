@@ -57,7 +57,8 @@ class FlatParams:
             if not p.requires_grad:
                 continue
             p.grad = self.flat_grad[self.offsets[k]: self.offsets[k] + numel[k]].view_as(p)
-            p.register_post_accumulate_grad_hook(self._make_hook(k))
+            p.register_post_accumulate_grad_hook(self._make_hook(k))   # gradients that still arrive through autograd
+            p._hwg_touch = self._make_touch(k)                            # gradients the kernels accumulate in place (ops._grad_buffer)
         # static tables
         ct, co = [], []
         for k in range(self.nt):
@@ -71,6 +72,11 @@ class FlatParams:
         self.d_param_ptrs = torch.from_numpy(self._param_ptrs).to(self.device)
         self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._stash_pool = []
+
+    def _make_touch(self, k):
+        def touch():
+            self.touched[k] = True
+        return touch
 
     def _make_hook(self, k):
         def hook(p):

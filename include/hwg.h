@@ -212,6 +212,19 @@ int hwg_segment_weighted_mean(const float* v, const float* wgt, const int* seg, 
 int hwg_segment_weighted_mean_bwd(const float* dout, const float* wgt, const int* seg, const float* wsum, int n, int C, float* dv, void* stream);
 int hwg_gather_scores(const float* x, int B, int Wx, int C, const int* idx_b, const int* idx_pos, const int* idx_cls, int n, float* out, void* stream);
 
+/* Grouped "one expert per window" layers for the 79 character-style experts (model/char_style.py:84-124, 210-235).
+ * x [n][R][Cin] -> y [n][R][Cout]; eid[n] selects the expert of each window; wptr/bptr are device tables (int64 addresses, one per
+ * expert) of weights in the Conv1d layout [Cout][Cin][S] and biases; R <= 8. Windows are sorted by expert: seg_start[G+1] / seg_eid[G]
+ * describe the runs. wgrad and segment_accumulate ADD into the buffers addressed by the grad-pointer tables. */
+int hwg_grouped_conv1d_fwd(const float* x, const int* eid, const void* wptr, const void* bptr, float* y, int n, int R, int Cin, int Cout,
+                           int S, int pad, void* stream);
+int hwg_grouped_conv1d_dgrad(const float* dy, const int* eid, const void* wptr, float* dx, int n, int R, int Cin, int Cout, int S, int pad,
+                             void* stream);
+int hwg_grouped_conv1d_wgrad(const float* dy, const float* x, const int* seg_start, const int* seg_eid, int G, const void* gwptr,
+                             const void* gbptr, int R, int Cin, int Cout, int S, int pad, void* stream);
+int hwg_gather_rows_ptr(const void* ptrs, const int* eid, float* out, int n, int C, void* stream);
+int hwg_segment_accumulate_ptr(const float* rows, const int* seg_start, const int* seg_eid, int G, const void* gptrs, int C, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Multi-tensor optimizer-side ops (trainer/hw_with_style_trainer.py:300-391) and RNG.
  * Tensor lists are device tables: ptrs (int64 addresses, 0 = absent), numel (int64), and a chunk table
