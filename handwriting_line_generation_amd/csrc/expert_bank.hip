@@ -82,12 +82,15 @@ __global__ __launch_bounds__(256) void gconv_dgrad_kernel(const float* dy, const
 }
 
 // dW[e][co][ci][s] += sum_{i in run} sum_p dy[i][p][co] * x[i][p+s-pad][ci];  db[e][co] += sum dy
-// block = (run of one expert, tile of output channels); a wave owns one output channel at a time, lanes own (ci,s) entries
+// block = (run of one expert, tile of CPB output channels). A lane owns up to WG_MAXJ (ci,s) entries; for every window it
+// first pulls the R shifted x values of its entries into registers, then reuses them for all channels of the tile, so the
+// inner loop is one LDS broadcast read (dy) per R*WG_MAXJ FMAs.
 constexpr int WG_MAXJ = 12;  // (Cin*S)/64 <= 12  (256*3/64)
+constexpr int WG_CPB = 16;   // output channels per block
+template <int R>
 __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const float* dy, const float* x, const int* seg_start, const int* seg_eid,
-                                                          const long long* gwptr, const long long* gbptr, int R, int Cin, int Cout, int S, int pad,
-                                                          int co_per_block) {
-  extern __shared__ float sm[];  // xs [R][Cin] | dys [R][co_per_block]
+                                                          const long long* gwptr, const long long* gbptr, int Cin, int Cout, int S, int pad) {
+  extern __shared__ float sm[];  // xs [R][Cin] | dys [R][WG_CPB]
   float* xs = sm;
   float* dys = sm + R * Cin;
   const int g = blockIdx.x;
@@ -97,10 +100,9 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const float* dy, const
   float* db = gbptr ? reinterpret_cast<float*>(gbptr[e]) : nullptr;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int KS = Cin * S;
-  const int co0 = blockIdx.y * co_per_block;
-  const int nco = min(co_per_block, Cout - co0);
-  // every wave handles channels wid, wid+4, ... of the tile; accumulators live in registers across the windows of the run
-  constexpr int MAXC = 8;  // co_per_block / 4 <= 8
+  const int co0 = blockIdx.y * WG_CPB;
+  const int nco = min(WG_CPB, Cout - co0);
+  constexpr int MAXC = WG_CPB / 4;
   float acc[MAXC][WG_MAXJ];
   float bacc[MAXC];
 #pragma unroll
@@ -109,47 +111,55 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const float* dy, const
 #pragma unroll
     for (int j = 0; j < WG_MAXJ; ++j) acc[c][j] = 0.f;
   }
+  // the (ci, s) entries this lane owns
+  int ent_ci[WG_MAXJ], ent_s[WG_MAXJ];
+#pragma unroll
+  for (int jj = 0; jj < WG_MAXJ; ++jj) {
+    const int j = lane + 64 * jj;
+    ent_ci[jj] = (j < KS) ? j / S : 0;
+    ent_s[jj] = (j < KS) ? j % S : 0;
+  }
   for (int i = i0; i < i1; ++i) {
     __syncthreads();
     for (int t = threadIdx.x; t < R * Cin; t += 256) xs[t] = x[(long long)i * R * Cin + t];
     for (int t = threadIdx.x; t < R * nco; t += 256) {
       const int p = t / nco, c = t - p * nco;
-      dys[p * co_per_block + c] = dy[((long long)i * R + p) * Cout + co0 + c];
+      dys[p * WG_CPB + c] = dy[((long long)i * R + p) * Cout + co0 + c];
     }
     __syncthreads();
+    float xv[WG_MAXJ][R];
+#pragma unroll
+    for (int jj = 0; jj < WG_MAXJ; ++jj)
+#pragma unroll
+      for (int p = 0; p < R; ++p) {
+        const int q = p + ent_s[jj] - pad;
+        xv[jj][p] = (lane + 64 * jj < KS && q >= 0 && q < R) ? xs[q * Cin + ent_ci[jj]] : 0.f;
+      }
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       const int cl = wid + 4 * c;
-      if (cl >= nco) break;
-#pragma unroll
-      for (int jj = 0; jj < WG_MAXJ; ++jj) {
-        const int j = lane + 64 * jj;
-        if (j >= KS) break;
-        const int ci = j / S, s = j - ci * S;
-        float a = 0.f;
-        for (int p = 0; p < R; ++p) {
-          const int q = p + s - pad;
-          if (q >= 0 && q < R) a += dys[p * co_per_block + cl] * xs[q * Cin + ci];
-        }
-        acc[c][jj] += a;
-      }
-      if (lane == 0) {
+      if (cl < nco) {
+        float d[R];
         float b = 0.f;
-        for (int p = 0; p < R; ++p) b += dys[p * co_per_block + cl];
+#pragma unroll
+        for (int p = 0; p < R; ++p) { d[p] = dys[p * WG_CPB + cl]; b += d[p]; }
         bacc[c] += b;
+#pragma unroll
+        for (int jj = 0; jj < WG_MAXJ; ++jj)
+#pragma unroll
+          for (int p = 0; p < R; ++p) acc[c][jj] += d[p] * xv[jj][p];
       }
     }
   }
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
     const int cl = wid + 4 * c;
-    if (cl >= nco) break;
+    if (cl >= nco) continue;
     float* wr = dW + (long long)(co0 + cl) * KS;
 #pragma unroll
     for (int jj = 0; jj < WG_MAXJ; ++jj) {
       const int j = lane + 64 * jj;
-      if (j >= KS) break;
-      wr[j] += acc[c][jj];
+      if (j < KS) wr[j] += acc[c][jj];
     }
     if (lane == 0 && db) db[co0 + cl] += bacc[c];
   }
@@ -201,10 +211,19 @@ extern "C" int hwg_grouped_conv1d_wgrad(const float* dy, const float* x, const i
                                         const void* gbptr, int R, int Cin, int Cout, int S, int pad, void* stream) {
   HWG_REQUIRE(dy && x && seg_start && seg_eid && gwptr && G > 0 && R > 0 && R <= MAXR && Cin > 0 && Cout > 0 && S > 0, "grouped_conv1d_wgrad: bad arguments");
   HWG_REQUIRE(Cin * S <= 64 * WG_MAXJ, "grouped_conv1d_wgrad: Cin*S=%d too large", Cin * S);
-  const int cpb = 32;
-  const size_t smem = ((size_t)R * Cin + (size_t)R * cpb) * sizeof(float);
-  hipLaunchKernelGGL(gconv_wgrad_kernel, dim3(G, hwg_cdiv(Cout, cpb)), dim3(256), smem, (hipStream_t)stream, dy, x, seg_start, seg_eid,
-                     (const long long*)gwptr, (const long long*)gbptr, R, Cin, Cout, S, pad, cpb);
+  const size_t smem = ((size_t)R * Cin + (size_t)R * WG_CPB) * sizeof(float);
+  dim3 grid(G, hwg_cdiv(Cout, WG_CPB));
+  hipStream_t st = (hipStream_t)stream;
+#define HWG_WG_CASE(RR)                                                                                                              \
+  case RR:                                                                                                                           \
+    hipLaunchKernelGGL(gconv_wgrad_kernel<RR>, grid, dim3(256), smem, st, dy, x, seg_start, seg_eid, (const long long*)gwptr,        \
+                       (const long long*)gbptr, Cin, Cout, S, pad);                                                                  \
+    break;
+  switch (R) {
+    HWG_WG_CASE(1) HWG_WG_CASE(2) HWG_WG_CASE(3) HWG_WG_CASE(4) HWG_WG_CASE(5) HWG_WG_CASE(6) HWG_WG_CASE(7) HWG_WG_CASE(8)
+    default: break;
+  }
+#undef HWG_WG_CASE
   HWG_LAUNCH_CHECK("grouped_conv1d_wgrad");
   return HWG_OK;
 }

@@ -154,17 +154,23 @@ __global__ __launch_bounds__(256) void ctc_beta_grad_kernel(const float* lp, con
       }
       cur[s] = v;
     }
-    for (int c = threadIdx.x; c < C; c += 256) lcab[c] = NEG;
+    float* lmax = lcab;        // [C] running maximum of alpha+beta per class
+    float* lsum = lcab + C;    // [C] sum of exp(alpha+beta - max)
+    for (int c = threadIdx.x; c < C; c += 256) { lmax[c] = NEG; lsum[c] = 0.f; }
     __syncthreads();
-    // log-sum of alpha*beta per class: thread c scans the extended target
+    // log-sum of alpha*beta per class, one thread per extended-target state (two LDS-atomic passes: max, then sum)
+    for (int s = threadIdx.x; s < NS; s += 256) {
+      const float v = la[(long long)t * NSmax + s] + cur[s];
+      if (v != NEG) atomicMax(&lmax[ctc_ext(tg, s)], v);
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < NS; s += 256) {
+      const float v = la[(long long)t * NSmax + s] + cur[s];
+      if (v != NEG) { const int c = ctc_ext(tg, s); atomicAdd(&lsum[c], expf(v - lmax[c])); }
+    }
+    __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-      float acc = NEG;
-      for (int s = 0; s < NS; ++s) {
-        if (ctc_ext(tg, s) != c) continue;
-        const float v = la[(long long)t * NSmax + s] + cur[s];
-        if (acc == NEG) acc = v;
-        else { const float m = fmaxf(acc, v); acc = (m == NEG) ? NEG : logf(expf(acc - m) + expf(v - m)) + m; }
-      }
+      const float acc = (lsum[c] > 0.f) ? logf(lsum[c]) + lmax[c] : NEG;
       const float l = lp[((long long)t * B + b) * C + c];
       float g = (expf(l) - expf(acc + nl - l)) * gr;
       if (bad) g = 0.f;
@@ -315,7 +321,7 @@ extern "C" int hwg_ctc_bwd(const float* log_probs, const int* targets, const int
   float* lb = la + (size_t)B * T * NS;
   float* nll = lb + (size_t)B * 2 * NS;
   int* flag = (int*)(nll + B);
-  hipLaunchKernelGGL(ctc_beta_grad_kernel, dim3(B), dim3(256), C * sizeof(float), st, log_probs, targets, input_lengths, target_lengths, T, B, C,
+  hipLaunchKernelGGL(ctc_beta_grad_kernel, dim3(B), dim3(256), 2 * C * sizeof(float), st, log_probs, targets, input_lengths, target_lengths, T, B, C,
                      Lmax, (const float*)la, (const float*)nll, grad_out, (const int*)flag, lb, grad);
   HWG_LAUNCH_CHECK("ctc_beta_grad");
   return HWG_OK;
