@@ -163,6 +163,24 @@ class FlatParams:
         return self._flag
 
 
+def allreduce_gradient_sets(flat, stashes, world, device):
+    """Data-parallel averaging of the current gradient set and of every stashed set.
+    The None-masks are OR-ed first (int32 MAX): a tensor that received a gradient on any rank exists, possibly as zeros, on all."""
+    import torch.distributed as dist
+    if world == 1:
+        return
+    masks = [flat.touched] + [s[1] for s in stashes]
+    m = torch.from_numpy(np.stack(masks).astype(np.int32)).to(device)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    m = m.cpu().numpy().astype(bool)
+    flat.touched[:] = m[0]
+    for k, s in enumerate(stashes):
+        s[1][:] = m[1 + k]
+    for buf in [flat.flat_grad] + [s[0] for s in stashes]:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        buf.div_(world)
+
+
 class HipAdam:
     """torch.optim.Adam (betas, eps, no weight decay / amsgrad) over one parameter group of a FlatParams, as a single
     multi-tensor kernel launch. Tensors whose gradient is None are skipped and their step count does not advance."""

@@ -19,6 +19,7 @@ import torch.distributed as dist
 
 from .. import ops
 from ..base.base_trainer import BaseTrainer
+from .flat_params import allreduce_gradient_sets
 from ..data.text_data import TextData
 from ..model.autoencoder import Encoder2
 from ..model.hw_with_style import correct_pred
@@ -123,20 +124,7 @@ class HWWithStyleTrainer(BaseTrainer):
             return next(self.data_loader_iter)
 
     def _allreduce_grads(self, stashes=()):
-        """average gradient sets over the data-parallel ranks; None-masks are OR-ed (a tensor touched on any rank exists on all)"""
-        if self.world == 1:
-            return
-        f = self.flat
-        masks = [f.touched] + [s[1] for s in stashes]
-        m = torch.from_numpy(np.stack(masks).astype(np.int32)).to(self.gpu)
-        dist.all_reduce(m, op=dist.ReduceOp.MAX)
-        m = m.cpu().numpy().astype(bool)
-        f.touched[:] = m[0]
-        for k, s in enumerate(stashes):
-            s[1][:] = m[1 + k]
-        for buf in [f.flat_grad] + [s[0] for s in stashes]:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-            buf.div_(self.world)
+        allreduce_gradient_sets(self.flat, stashes, self.world, self.gpu)
 
     def _train_iteration(self, iteration):
         self.model.train()

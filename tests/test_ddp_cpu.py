@@ -1,0 +1,57 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient exchange of the trainer (flat buffer + stashes averaged, None-masks
+OR-ed) equals what a single process would get by averaging the two ranks' gradient sets."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from handwriting_line_generation_amd.trainer.flat_params import FlatParams, allreduce_gradient_sets
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3), torch.nn.Linear(3, 2))
+    params = list(net.parameters())
+    flat = FlatParams(params, {"main": params[:4], "disc": params[4:]})
+    g = torch.Generator().manual_seed(10 + rank)
+    # rank 0 touches tensors {0,1,2}, rank 1 touches {1,2,5}; one stash each with different masks
+    touch = [{0, 1, 2}, {1, 2, 5}][rank]
+    for k in touch:
+        params[flat.order[k]].grad.copy_(torch.randn(params[flat.order[k]].shape, generator=g))
+        flat.touched[k] = True
+    stash_buf = torch.randn(flat.total, generator=g)
+    stash_mask = np.zeros(flat.nt, dtype=bool); stash_mask[[3, 4][rank]] = True
+    stashes = [(stash_buf.clone(), stash_mask.copy())]
+    mine = flat.flat_grad.clone()
+    allreduce_gradient_sets(flat, stashes, world, torch.device("cpu"))
+    # gather every rank's original sets to rank-independent expectation
+    gl = [torch.zeros_like(mine) for _ in range(world)]; dist.all_gather(gl, mine)
+    sl = [torch.zeros_like(stash_buf) for _ in range(world)]; dist.all_gather(sl, stash_buf)
+    ok = torch.allclose(flat.flat_grad, sum(gl) / world) and torch.allclose(stashes[0][0], sum(sl) / world)
+    ok = ok and flat.touched.tolist() == [True, True, True, False, False, True] and stashes[0][1].tolist() == [False, False, False, True, True, False]
+    # parameter .grad views still alias the flat buffer
+    ok = ok and params[flat.order[1]].grad.data_ptr() == flat.flat_grad[flat.offsets[1]:].data_ptr()
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange():
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get(0) and out.get(1), dict(out)

@@ -1,0 +1,90 @@
+"""CPU: host-side logic of the product path (no kernel is executed) and the C-ABI export check."""
+import json
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    from handwriting_line_generation_amd import _lib
+    out = subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T hwg_" in l}
+    assert set(_lib.DECLS) <= exported, sorted(set(_lib.DECLS) - exported)
+    assert exported <= set(_lib.DECLS), "exported but undeclared: %s" % sorted(exported - set(_lib.DECLS))
+    assert _lib.abi_version() == 1 and len(_lib.DECLS) >= 70
+
+
+def test_kernels_refuse_cpu_tensors():
+    from handwriting_line_generation_amd import _lib, ops
+    with pytest.raises(_lib.HwgError):
+        ops.conv2d(torch.zeros(1, 4, 4, 16), torch.zeros(16, 16, 3, 3))
+
+
+def test_curriculum_cycle_of_the_shipped_gan_config():
+    from handwriting_line_generation_amd.harness import load_config
+    from handwriting_line_generation_amd.utils.curriculum import Curriculum
+    cur = Curriculum(load_config("iam_gan")["trainer"]["curriculum"])
+    got = [cur.getLesson(i) for i in range(9)]
+    cyc = [["count"], ["no-step", "gen"], ["auto", "auto-gen"], ["disc"], ["no-step", "gen"], ["auto", "auto-gen"], ["disc"]]
+    assert got == cyc + cyc[:2]
+    assert set(cur.getValid()) == {"count", "auto", "no-step", "valid"} and "valid" in cur.getValid()
+    c2 = Curriculum({"0": [[2, "a"], ["b"]], "5": [["c"]]})
+    assert [c2.getLesson(i) for i in range(7)] == [["a"], ["a"], ["b"], ["a"], ["a"], ["c"], ["c"]]
+
+
+def test_insert_spaces_matches_oracle_and_reference_rounding():
+    from handwriting_line_generation_amd.model import HWWithStyle
+    from oracle import seq_oracle
+    cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "model_config_iam.json")))
+    m = HWWithStyle(cfg)
+    g = torch.Generator().manual_seed(3)
+    label = torch.randint(1, 80, (9, 3), generator=g)
+    counts = torch.rand(9, 3, 2, generator=g) * 3
+    lens = [9, 7, 4]
+    np.random.seed(5)
+    a, pa = m.insert_spaces(label, lens, counts)
+    np.random.seed(5)
+    b, pb = seq_oracle.insert_spaces(label, lens, counts, 80, m.count_std, m.dup_std)
+    assert torch.equal(a, b) and pa == pb
+    # and the vector recorded from the reference's own insert_spaces (tests/golden/seq_kat.npz)
+    kat = np.load(os.path.join(ROOT, "tests", "golden", "seq_kat.npz"))
+    np.random.seed(int(kat["ins_seed"]))
+    c, pc = m.insert_spaces(torch.from_numpy(kat["ins_label"]), kat["ins_lens"].tolist(), torch.from_numpy(kat["ins_counts"]))
+    assert np.array_equal(c.numpy(), kat["ins_spaced"]) and np.allclose(pc, kat["ins_padded"])
+
+
+def test_text_data_and_string_utils(tmp_path):
+    from handwriting_line_generation_amd.data.synthetic import write_synthetic_corpus
+    from handwriting_line_generation_amd.data.text_data import TextData
+    from handwriting_line_generation_amd.harness import CHAR_FILES
+    from handwriting_line_generation_amd.utils import string_utils as su
+    corpus = str(tmp_path / "c.txt")
+    write_synthetic_corpus(corpus, CHAR_FILES["iam"], 5000)
+    td = TextData(corpus, CHAR_FILES["iam"], batch_size=4, max_len=20)
+    random.seed(1); np.random.seed(1)
+    inst = td.getInstance()
+    assert inst["image"] is None and inst["label"].dtype == torch.int32 and inst["label"].shape[1] == 4
+    assert all(17 <= len(t) <= 20 for t in inst["gt"]) and inst["label_lengths"].tolist() == [len(t) for t in inst["gt"]]
+    logits = np.full((6, 4), -5.0); logits[[0, 1, 2, 3, 4, 5], [1, 1, 0, 2, 2, 1]] = 0
+    assert su.naive_decode(logits)[0] == [1, 2, 1]
+    assert su.cer("abc", "abd") == pytest.approx(1 / 3) and su.wer("a b", "a c") == 0.5 and su.cer("", "xy") == 2
+
+
+def test_flat_params_bookkeeping_on_cpu():
+    from handwriting_line_generation_amd.trainer.flat_params import FlatParams
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    ps = list(net.parameters())
+    f = FlatParams(ps, {"main": ps[:2], "disc": ps[2:]})
+    net(torch.randn(5, 4)).sum().backward()
+    assert f.touched.all() and float(f.flat_grad.abs().sum()) > 0
+    st = f.stash()
+    assert float(f.flat_grad.abs().sum()) == 0 and st[1].all() and float(st[0].abs().sum()) > 0
+    f.zero_grad("main")
+    assert f.touched.tolist() == [False, False, True, True]
+    assert ps[0].grad.data_ptr() == f.flat_grad.data_ptr()

@@ -139,6 +139,22 @@ def gen_seq():
         recs["dtw%d_pred" % n] = pred.numpy(); recs["dtw%d_label" % n] = label.numpy(); recs["dtw%d_out" % n] = out.numpy()
         dec = [su.naive_decode(pred[:, b].numpy()) for b in range(B)]
         recs["dec%d" % n] = np.array(json.dumps([[int(x) for x in d[0]] for d in dec]))
+    # insert_spaces of the reference's HWWithStyle (numpy noise + Python round), seeded
+    import json as _json
+    from model import HWWithStyle
+    cfgm = _json.load(open(os.path.join(GOLD, "model_config_iam.json")))
+    hm = HWWithStyle(cfgm)
+    gi = torch.Generator().manual_seed(77)
+    ilabel = torch.randint(1, 80, (11, 3), generator=gi)
+    icounts = torch.rand(11, 3, 2, generator=gi) * 3
+    ilens = [11, 8, 5]
+    np.random.seed(123)
+    ispaced, ipadded = hm.insert_spaces(ilabel, ilens, icounts)
+    recs.update(ins_seed=np.array(123), ins_label=ilabel.numpy(), ins_counts=icounts.numpy(), ins_lens=np.array(ilens), ins_spaced=ispaced.numpy(),
+                ins_padded=np.array(ipadded))
+    np.random.seed(123)
+    osp, opad = seq_oracle.insert_spaces(ilabel, ilens, icounts, 80, hm.count_std, hm.dup_std)
+    assert torch.equal(osp, ispaced) and opad == ipadded
     # gt counts via the trainer's loop, restated through the reference trainer code path is heavy; the scan is pinned in gen_trainer()
     np.savez_compressed(os.path.join(GOLD, "seq_kat.npz"), **recs)
     # oracle must reproduce them exactly

@@ -1,0 +1,100 @@
+#!/usr/bin/env python
+"""python train.py -c configs/<cfg>.json [-r checkpoint] [-s soft_checkpoint] [-g gpu]
+Drop-in for the reference's train.py: classes are resolved by the names in the config (arch / loss / trainer.class), the
+config's `name` must match its file name, SIGINT saves a checkpoint. Under torchrun (WORLD_SIZE>1) every rank trains on its
+own author shard and gradients are all-reduced over RCCL. Real datasets (IAM/RIMES images) are outside the accelerated path;
+`--synthetic` drives the trainer with synthetic author batches of the configured shape."""
+import argparse
+import json
+import logging
+import os
+import signal
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+logging.basicConfig(level=logging.INFO, format="")
+
+
+def main():
+    ap = argparse.ArgumentParser(description="MI355X-native handwriting GAN trainer")
+    ap.add_argument("-c", "--config", type=str)
+    ap.add_argument("-r", "--resume", type=str, default=None)
+    ap.add_argument("-s", "--soft_resume", type=str, default=None)
+    ap.add_argument("-g", "--gpu", type=int, default=None)
+    ap.add_argument("--synthetic", action="store_true", help="synthetic author batches instead of a dataset on disk")
+    ap.add_argument("--iterations", type=int, default=None)
+    args = ap.parse_args()
+
+    resume = args.resume
+    if resume is None and args.soft_resume is not None and os.path.exists(args.soft_resume):
+        resume = args.soft_resume
+    if args.config is not None:
+        config = json.load(open(args.config))
+        if config["name"] != os.path.basename(args.config)[3:-5]:
+            raise SystemExit("config name %r does not match its file name" % config["name"])
+    elif resume is not None:
+        config = torch.load(resume, map_location="cpu", weights_only=False)["config"]
+    else:
+        raise SystemExit("need -c or -r")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        config["gpu"] = local
+    elif args.gpu is not None:
+        config["gpu"] = args.gpu
+    if args.iterations is not None:
+        config["trainer"]["iterations"] = args.iterations
+
+    import handwriting_line_generation_amd.model as models
+    import handwriting_line_generation_amd.model.loss as losses
+    import handwriting_line_generation_amd.trainer as trainers
+    from handwriting_line_generation_amd.data.synthetic import SyntheticAuthorDataset, SyntheticLoader, write_synthetic_corpus
+
+    if not args.synthetic:
+        raise SystemExit("the IAM/RIMES image pipeline is outside the accelerated path (SURVEY section 8f); run with --synthetic")
+    dl = config["data_loader"]
+    pkg_data = os.path.join(ROOT, "handwriting_line_generation_amd", "data")
+    dl["char_file"] = os.path.join(pkg_data, os.path.basename(dl["char_file"]))
+    ds = SyntheticAuthorDataset(dl["char_file"], dl["batch_size"], dl.get("a_batch_size", 1), width=512, label_len=30, num_batches=10 ** 9)
+    loader = SyntheticLoader(ds, rank, world)
+    tr = config["trainer"]
+    if "text_data" in tr and not os.path.exists(tr["text_data"]):
+        os.makedirs(tr["save_dir"], exist_ok=True)
+        tr["text_data"] = os.path.join(tr["save_dir"], "synthetic_corpus.txt")
+        if rank == 0 and not os.path.exists(tr["text_data"]):
+            write_synthetic_corpus(tr["text_data"], dl["char_file"])
+    if "encoder_weights" in tr and not os.path.exists(tr["encoder_weights"]):
+        os.makedirs(os.path.dirname(tr["encoder_weights"]) or ".", exist_ok=True)
+        if rank == 0:
+            torch.save({"state_dict": models.Autoencoder({"type": tr.get("encoder_type", "2tight"), "hwr": config["model"]["num_class"]}).state_dict()},
+                       tr["encoder_weights"])
+    if config["model"].get("pretrained_hwr") and not os.path.exists(config["model"]["pretrained_hwr"]):
+        config["model"]["pretrained_hwr"] = None
+    if world > 1:
+        torch.distributed.barrier()
+
+    model = getattr(models, config["arch"])(config["model"])
+    loss = {k: getattr(losses, v) for k, v in config["loss"].items()} if isinstance(config["loss"], dict) else getattr(losses, config["loss"])
+    trainer = getattr(trainers, config["trainer"]["class"])(model, loss, [], resume, config, loader, None, None)
+    if world > 1:
+        for p in list(trainer.model.parameters()) + list(trainer.model.buffers()):
+            torch.distributed.broadcast(p.data, 0)
+
+    def on_sigint(sig, frame):
+        if rank == 0:
+            trainer.save()
+        sys.exit(0)
+    signal.signal(signal.SIGINT, on_sigint)
+    trainer.train()
+
+
+if __name__ == "__main__":
+    main()
