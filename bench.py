@@ -97,9 +97,18 @@ def main():
 
     if rank == 0:
         fam = {}
-        for kind, flops, e0, e1 in prof:
+        by_shape = {}
+        for kind, flops, e0, e1, shape in prof:
             f = fam.setdefault(kind, [0.0, 0.0, 0])
-            f[0] += flops; f[1] += e0.elapsed_time(e1) * 1e-3; f[2] += 1
+            dt = e0.elapsed_time(e1) * 1e-3
+            f[0] += flops; f[1] += dt; f[2] += 1
+            g = by_shape.setdefault((kind, shape), [0.0, 0.0, 0])
+            g[0] += flops; g[1] += dt; g[2] += 1
+        if os.environ.get("HWG_CONV_DUMP"):
+            with open(os.environ["HWG_CONV_DUMP"], "w") as fh:
+                fh.write("# per-shape MFMA conv launches inside the timed region (%d steps): time_ms  launches  avg_us  TFLOP/s  kind  shape(N,H,W,C,K,R,S,stride,pad,dil,mode)\n" % args.steps)
+                for (kind, shape), (fl, sec, n) in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
+                    fh.write("%9.3f %6d %9.1f %7.1f  %s %s\n" % (sec * 1e3, n, sec / n * 1e6, fl / sec / 1e12 if sec > 0 else 0, kind, shape))
         dom = max(fam, key=lambda k: fam[k][1]) if fam else None
         roofline = None
         if dom:

@@ -104,10 +104,12 @@ def _conv(a):
     return a
 
 
+_FN = {name: getattr(_dll, name) for name in DECLS}
+
+
 def call(name, *args):
     """Call a status-returning entry point; raises HwgError with the library's message on failure."""
-    fn = getattr(_dll, name)
-    rc = fn(*[_conv(a) for a in args])
+    rc = _FN[name](*[a.data_ptr() if hasattr(a, "data_ptr") else a for a in args])
     if rc != 0:
         raise HwgError("%s failed (%d): %s" % (name, rc, last_error()))
 

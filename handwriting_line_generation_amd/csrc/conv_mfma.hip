@@ -442,7 +442,8 @@ __global__ void pack_weight_kernel(const float* src, float* dst, int A, int B, i
 }
 
 // column sums: x[rows][C] -> part[chunks][C]
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, long long rows, int C, float* part, long long rows_per_chunk) {
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, long long rows, int C, float* part, long long rows_per_chunk,
+                                                             float* direct_out, int accumulate) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + cl;
@@ -453,7 +454,11 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, lon
     for (long long rr = rb + rl; rr < re; rr += 4) s += x[rr * C + c];
   red[rl][cl] = s;
   __syncthreads();
-  if (rl == 0 && c < C) part[(long long)blockIdx.x * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+  if (rl == 0 && c < C) {
+    const float v = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    if (direct_out) direct_out[c] = accumulate ? direct_out[c] + v : v;   // single chunk: no second stage
+    else part[(long long)blockIdx.x * C + c] = v;
+  }
 }
 __global__ void colsum_final_kernel(const float* part, int chunks, int C, float* out, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -627,8 +632,9 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
 }
 
 static long long colsum_chunks(long long rows) {
-  long long chunks = (rows + 255) / 256;
-  if (chunks > 512) chunks = 512;
+  // each chunk is summed by 4 row lanes; keep the second stage short (<= 64 partials per column)
+  long long chunks = (rows + 63) / 64;
+  if (chunks > 64) chunks = 64;
   if (chunks < 1) chunks = 1;
   return chunks;
 }
@@ -645,8 +651,10 @@ extern "C" int hwg_colsum(const float* x, long long rows, int C, float* out, int
   hipStream_t st = (hipStream_t)stream;
   const long long chunks = colsum_chunks(rows);
   const long long rpc = (rows + chunks - 1) / chunks;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)chunks, hwg_cdiv(C, 64)), dim3(256), 0, st, x, rows, C, (float*)workspace, rpc);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)chunks, hwg_cdiv(C, 64)), dim3(256), 0, st, x, rows, C, (float*)workspace, rpc,
+                     chunks == 1 ? out : (float*)nullptr, accumulate);
   HWG_LAUNCH_CHECK("colsum_partial");
+  if (chunks == 1) return HWG_OK;
   hipLaunchKernelGGL(colsum_final_kernel, dim3(hwg_cdiv(C, 256)), dim3(256), 0, st, (const float*)workspace, (int)chunks, C, out, accumulate);
   HWG_LAUNCH_CHECK("colsum_final");
   return HWG_OK;

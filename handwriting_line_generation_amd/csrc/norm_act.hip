@@ -86,49 +86,50 @@ __global__ __launch_bounds__(256) void moments_fwd_kernel(const float* x, Geo g,
 }
 
 // ---------------- forward stage 2: statistics per group -> mean[N][C], rstd[N][C] ---------------------------------------
-__global__ void finalize_fwd_kernel(const double* part, Geo g, int mode, int groups, float eps, float* mean, float* rstd,
-                                    float* running_mean, float* running_var, float momentum) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per statistic group (IN: (n,c); GN: (n,group); BN: c), lanes sweep the partial sums, wave reduction in fp64
+__global__ __launch_bounds__(256) void finalize_fwd_kernel(const double* part, Geo g, int mode, int groups, float eps, float* mean, float* rstd,
+                                                           float* running_mean, float* running_var, float momentum) {
+  const int lane = threadIdx.x & 63;
+  const int w = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  double s1 = 0.0, s2 = 0.0;
   if (mode == MODE_BN) {
-    if (idx >= g.C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int n = 0; n < g.N; ++n)
-      for (int k = 0; k < g.chunks; ++k) {
-        const double* p = part + (((size_t)n * g.chunks + k) * g.C + idx) * 2;
-        s1 += p[0]; s2 += p[1];
-      }
+    if (w >= g.C) return;
+    const int items = g.N * g.chunks;
+    for (int it = lane; it < items; it += 64) {
+      const double* p = part + ((size_t)it * g.C + w) * 2;   // it == n*chunks + k
+      s1 += p[0]; s2 += p[1];
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
     const double cnt = (double)g.N * g.HW;
     const double m = s1 / cnt;
     double var = s2 / cnt - m * m;
     if (var < 0.0) var = 0.0;
     const float r = (float)(1.0 / sqrt(var + (double)eps));
-    for (int n = 0; n < g.N; ++n) { mean[n * g.C + idx] = (float)m; rstd[n * g.C + idx] = r; }
-    if (running_mean) {
+    for (int n = lane; n < g.N; n += 64) { mean[n * g.C + w] = (float)m; rstd[n * g.C + w] = r; }
+    if (running_mean && lane == 0) {
       const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
-      running_mean[idx] = (1.f - momentum) * running_mean[idx] + momentum * (float)m;
-      running_var[idx] = (1.f - momentum) * running_var[idx] + momentum * (float)unb;
+      running_mean[w] = (1.f - momentum) * running_mean[w] + momentum * (float)m;
+      running_var[w] = (1.f - momentum) * running_var[w] + momentum * (float)unb;
     }
     return;
   }
-  if (idx >= g.N * g.C) return;
-  const int n = idx / g.C, c = idx % g.C;
-  int cb = c, ce = c + 1;
-  if (mode == MODE_GN) {
-    const int cpg = g.C / groups;
-    cb = (c / cpg) * cpg; ce = cb + cpg;
+  const int cpg = (mode == MODE_GN) ? g.C / groups : 1;
+  const int ngrp = g.C / cpg;
+  if (w >= g.N * ngrp) return;
+  const int n = w / ngrp, cb = (w % ngrp) * cpg;
+  const int items = g.chunks * cpg;
+  for (int it = lane; it < items; it += 64) {
+    const int k = it / cpg, cc = cb + it % cpg;
+    const double* p = part + (((size_t)n * g.chunks + k) * g.C + cc) * 2;
+    s1 += p[0]; s2 += p[1];
   }
-  double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < g.chunks; ++k)
-    for (int cc = cb; cc < ce; ++cc) {
-      const double* p = part + (((size_t)n * g.chunks + k) * g.C + cc) * 2;
-      s1 += p[0]; s2 += p[1];
-    }
-  const double cnt = (double)g.HW * (ce - cb);
+  s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+  const double cnt = (double)g.HW * cpg;
   const double m = s1 / cnt;
   double var = s2 / cnt - m * m;
   if (var < 0.0) var = 0.0;
-  mean[idx] = (float)m;
-  rstd[idx] = (float)(1.0 / sqrt(var + (double)eps));
+  const float r = (float)(1.0 / sqrt(var + (double)eps));
+  for (int cc = lane; cc < cpg; cc += 64) { mean[n * g.C + cb + cc] = (float)m; rstd[n * g.C + cb + cc] = r; }
 }
 
 // ---------------- forward stage 3: y = act(mask * (gamma * xhat + beta)) -----------------------------------------------
@@ -205,62 +206,77 @@ __global__ __launch_bounds__(256) void moments_bwd_kernel(const float* dy, const
 }
 
 // ---------------- backward stage 2: per group coefficients c1,c2 [N][C] and parameter gradients ---------------------------
-// dx = rstd * (g*gamma - c1 - xhat*c2),  c1 = mean_grp(g*gamma), c2 = mean_grp(g*gamma*xhat)
-__global__ void finalize_bwd_kernel(const double* part, Geo g, int mode, int groups, const float* gamma, int per_sample,
-                                    float* c1, float* c2, float* dgamma, float* dbeta, int accumulate) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// dx = rstd * (g*gamma - c1 - xhat*c2),  c1 = mean_grp(g*gamma), c2 = mean_grp(g*gamma*xhat); one wavefront per statistic group
+__global__ __launch_bounds__(256) void finalize_bwd_kernel(const double* part, Geo g, int mode, int groups, const float* gamma, int per_sample,
+                                                           float* c1, float* c2, float* dgamma, float* dbeta, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int w = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (mode == MODE_BN) {
-    if (idx >= g.C) return;
+    if (w >= g.C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int n = 0; n < g.N; ++n)
-      for (int k = 0; k < g.chunks; ++k) {
-        const double* p = part + (((size_t)n * g.chunks + k) * g.C + idx) * 2;
-        s1 += p[0]; s2 += p[1];
-      }
+    const int items = g.N * g.chunks;
+    for (int it = lane; it < items; it += 64) {
+      const double* p = part + ((size_t)it * g.C + w) * 2;
+      s1 += p[0]; s2 += p[1];
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
     const double cnt = (double)g.N * g.HW;
-    const double gm = gamma ? (double)gamma[idx] : 1.0;
-    for (int n = 0; n < g.N; ++n) { c1[n * g.C + idx] = (float)(gm * s1 / cnt); c2[n * g.C + idx] = (float)(gm * s2 / cnt); }
-    if (dgamma) dgamma[idx] = (accumulate ? dgamma[idx] : 0.f) + (float)s2;
-    if (dbeta) dbeta[idx] = (accumulate ? dbeta[idx] : 0.f) + (float)s1;
+    const double gm = gamma ? (double)gamma[w] : 1.0;
+    for (int n = lane; n < g.N; n += 64) { c1[n * g.C + w] = (float)(gm * s1 / cnt); c2[n * g.C + w] = (float)(gm * s2 / cnt); }
+    if (lane == 0) {
+      if (dgamma) dgamma[w] = (accumulate ? dgamma[w] : 0.f) + (float)s2;
+      if (dbeta) dbeta[w] = (accumulate ? dbeta[w] : 0.f) + (float)s1;
+    }
     return;
   }
-  if (idx >= g.N * g.C) return;
-  const int n = idx / g.C, c = idx % g.C;
-  int cb = c, ce = c + 1;
-  if (mode == MODE_GN) {
-    const int cpg = g.C / groups;
-    cb = (c / cpg) * cpg; ce = cb + cpg;
-  }
+  const int cpg = (mode == MODE_GN) ? g.C / groups : 1;
+  const int ngrp = g.C / cpg;
+  if (w >= g.N * ngrp) return;
+  const int n = w / ngrp, cb = (w % ngrp) * cpg;
+  const int items = g.chunks * cpg;
   double a1 = 0.0, a2 = 0.0;
-  for (int cc = cb; cc < ce; ++cc) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < g.chunks; ++k) {
-      const double* p = part + (((size_t)n * g.chunks + k) * g.C + cc) * 2;
-      s1 += p[0]; s2 += p[1];
-    }
+  for (int it = lane; it < items; it += 64) {
+    const int k = it / cpg, cc = cb + it % cpg;
+    const double* p = part + (((size_t)n * g.chunks + k) * g.C + cc) * 2;
     const double gm = gamma ? (double)gamma[per_sample ? n * g.C + cc : cc] : 1.0;
-    a1 += gm * s1; a2 += gm * s2;
-    if (cc == c && per_sample) {
-      if (dgamma) dgamma[idx] = (accumulate ? dgamma[idx] : 0.f) + (float)s2;
-      if (dbeta) dbeta[idx] = (accumulate ? dbeta[idx] : 0.f) + (float)s1;
+    a1 += gm * p[0]; a2 += gm * p[1];
+  }
+  // per-sample affine (AdaIN / expert GroupNorm): dgamma[n,c], dbeta[n,c] are the un-weighted sums of this (n,c)
+  if (per_sample && (dgamma || dbeta)) {
+    for (int cc = 0; cc < cpg; ++cc) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = lane; k < g.chunks; k += 64) {
+        const double* p = part + (((size_t)n * g.chunks + k) * g.C + cb + cc) * 2;
+        s1 += p[0]; s2 += p[1];
+      }
+      s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+      if (lane == 0) {
+        const int idx = n * g.C + cb + cc;
+        if (dgamma) dgamma[idx] = (accumulate ? dgamma[idx] : 0.f) + (float)s2;
+        if (dbeta) dbeta[idx] = (accumulate ? dbeta[idx] : 0.f) + (float)s1;
+      }
     }
   }
-  const double cnt = (double)g.HW * (ce - cb);
-  c1[idx] = (float)(a1 / cnt);
-  c2[idx] = (float)(a2 / cnt);
+  a1 = wave_sum_d(a1); a2 = wave_sum_d(a2);
+  const double cnt = (double)g.HW * cpg;
+  for (int cc = lane; cc < cpg; cc += 64) { c1[n * g.C + cb + cc] = (float)(a1 / cnt); c2[n * g.C + cb + cc] = (float)(a2 / cnt); }
 }
-// per-channel parameter gradients for IN/GN with shared (per-channel) affine: sum over n and chunks
-__global__ void param_grad_kernel(const double* part, Geo g, float* dgamma, float* dbeta, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// per-channel parameter gradients for IN/GN with shared (per-channel) affine: sum over n and chunks, one wavefront per channel
+__global__ __launch_bounds__(256) void param_grad_kernel(const double* part, Geo g, float* dgamma, float* dbeta, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int c = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (c >= g.C) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int n = 0; n < g.N; ++n)
-    for (int k = 0; k < g.chunks; ++k) {
-      const double* p = part + (((size_t)n * g.chunks + k) * g.C + c) * 2;
-      s1 += p[0]; s2 += p[1];
-    }
-  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
-  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+  const int items = g.N * g.chunks;
+  for (int it = lane; it < items; it += 64) {
+    const double* p = part + ((size_t)it * g.C + c) * 2;
+    s1 += p[0]; s2 += p[1];
+  }
+  s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+  if (lane == 0) {
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+  }
 }
 
 // ---------------- backward stage 3 -----------------------------------------------------------------------------------------
@@ -317,18 +333,22 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* dy, const f
   if (PRE) block_reduce_store<2>(acc, g, part2, sm);
 }
 
-// dbias[c] = sum part2[...][c][0];  dnoise_w[c] = nscale * sum part2[...][c][1]
-__global__ void adain_param_grad_kernel(const double* part2, Geo g, float nscale, float* dbias, float* dnw, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// dbias[c] = sum part2[...][c][0];  dnoise_w[c] = nscale * sum part2[...][c][1]; one wavefront per channel
+__global__ __launch_bounds__(256) void adain_param_grad_kernel(const double* part2, Geo g, float nscale, float* dbias, float* dnw, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int c = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (c >= g.C) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int n = 0; n < g.N; ++n)
-    for (int k = 0; k < g.chunks; ++k) {
-      const double* p = part2 + (((size_t)n * g.chunks + k) * g.C + c) * 2;
-      s1 += p[0]; s2 += p[1];
-    }
-  if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)s1;
-  if (dnw) dnw[c] = (accumulate ? dnw[c] : 0.f) + (float)(s2 * (double)nscale);
+  const int items = g.N * g.chunks;
+  for (int it = lane; it < items; it += 64) {
+    const double* p = part2 + ((size_t)it * g.C + c) * 2;
+    s1 += p[0]; s2 += p[1];
+  }
+  s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+  if (lane == 0) {
+    if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)s1;
+    if (dnw) dnw[c] = (accumulate ? dnw[c] : 0.f) + (float)(s2 * (double)nscale);
+  }
 }
 
 // ---------------- plain elementwise: y = act(mask * (x + bias)) and its backward ----------------------------------------------
@@ -438,8 +458,8 @@ extern "C" int hwg_norm_fwd(const float* x, float* y, int N, int HW, int C, int 
   dim3 grid(g.chunks, N);
   hipLaunchKernelGGL(moments_fwd_kernel<false>, grid, dim3(256), red_smem(g), st, x, g, part, nullptr, nullptr, 0.f, 0.f, nullptr);
   HWG_LAUNCH_CHECK("norm_fwd.moments");
-  const int nfin = (mode == MODE_BN) ? C : N * C;
-  hipLaunchKernelGGL(finalize_fwd_kernel, dim3(hwg_cdiv(nfin, 128)), dim3(128), 0, st, (const double*)part, g, mode, groups, eps, mean, rstd,
+  const int nfin = (mode == MODE_BN) ? C : (mode == MODE_GN ? N * groups : N * C);
+  hipLaunchKernelGGL(finalize_fwd_kernel, dim3(hwg_cdiv(nfin, 4)), dim3(256), 0, st, (const double*)part, g, mode, groups, eps, mean, rstd,
                      running_mean, running_var, momentum);
   HWG_LAUNCH_CHECK("norm_fwd.finalize");
   hipLaunchKernelGGL(apply_fwd_kernel, grid, dim3(256), 0, st, x, y, g, (const float*)mean, (const float*)rstd, gamma, beta,
@@ -465,12 +485,12 @@ extern "C" int hwg_norm_bwd(const float* dy, const float* x, const float* y, flo
   dim3 grid(g.chunks, N);
   hipLaunchKernelGGL(moments_bwd_kernel, grid, dim3(256), red_smem(g), st, dy, x, y, g, part, mean, rstd, chan_mask, act, slope);
   HWG_LAUNCH_CHECK("norm_bwd.moments");
-  const int nfin = (mode == MODE_BN) ? C : N * C;
-  hipLaunchKernelGGL(finalize_bwd_kernel, dim3(hwg_cdiv(nfin, 128)), dim3(128), 0, st, (const double*)part, g, mode, groups, gamma,
+  const int nfin = (mode == MODE_BN) ? C : (mode == MODE_GN ? N * groups : N * C);
+  hipLaunchKernelGGL(finalize_bwd_kernel, dim3(hwg_cdiv(nfin, 4)), dim3(256), 0, st, (const double*)part, g, mode, groups, gamma,
                      affine_per_sample, c1, c2, dgamma, dbeta, accumulate);
   HWG_LAUNCH_CHECK("norm_bwd.finalize");
   if (mode != MODE_BN && !affine_per_sample && (dgamma || dbeta)) {
-    hipLaunchKernelGGL(param_grad_kernel, dim3(hwg_cdiv(C, 128)), dim3(128), 0, st, (const double*)part, g, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(param_grad_kernel, dim3(hwg_cdiv(C, 4)), dim3(256), 0, st, (const double*)part, g, dgamma, dbeta, accumulate);
     HWG_LAUNCH_CHECK("norm_bwd.param_grad");
   }
   hipLaunchKernelGGL(apply_bwd_kernel<false>, grid, dim3(256), 0, st, dy, x, y, dx, g, mean, rstd, gamma, affine_per_sample,
@@ -492,7 +512,7 @@ extern "C" int hwg_adain_fwd(const float* x, const float* noise, const float* no
   dim3 grid(g.chunks, N);
   hipLaunchKernelGGL(moments_fwd_kernel<true>, grid, dim3(256), red_smem(g), st, x, g, part, noise, noise_w, noise_scale, slope, u);
   HWG_LAUNCH_CHECK("adain_fwd.moments");
-  hipLaunchKernelGGL(finalize_fwd_kernel, dim3(hwg_cdiv(N * C, 128)), dim3(128), 0, st, (const double*)part, g, (int)MODE_IN, 1, eps, mean, rstd,
+  hipLaunchKernelGGL(finalize_fwd_kernel, dim3(hwg_cdiv(N * C, 4)), dim3(256), 0, st, (const double*)part, g, (int)MODE_IN, 1, eps, mean, rstd,
                      (float*)nullptr, (float*)nullptr, 0.f);
   HWG_LAUNCH_CHECK("adain_fwd.finalize");
   hipLaunchKernelGGL(apply_fwd_kernel, grid, dim3(256), 0, st, (const float*)u, y, g, (const float*)mean, (const float*)rstd, gamma, beta, 1,
@@ -520,14 +540,14 @@ extern "C" int hwg_adain_bwd(const float* dy, const float* u, const float* noise
                      (const float*)nullptr, 0, 0.f);
   HWG_LAUNCH_CHECK("adain_bwd.moments");
   // dgamma/dbeta are per (n,c) and are NOT accumulated (they feed the style Linear's backward)
-  hipLaunchKernelGGL(finalize_bwd_kernel, dim3(hwg_cdiv(N * C, 128)), dim3(128), 0, st, (const double*)part, g, (int)MODE_IN, 1, gamma, 1,
+  hipLaunchKernelGGL(finalize_bwd_kernel, dim3(hwg_cdiv(N * C, 4)), dim3(256), 0, st, (const double*)part, g, (int)MODE_IN, 1, gamma, 1,
                      c1, c2, dgamma, dbeta, 0);
   HWG_LAUNCH_CHECK("adain_bwd.finalize");
   hipLaunchKernelGGL(apply_bwd_kernel<true>, grid, dim3(256), red_smem(g), st, dy, u, (const float*)nullptr, dx, g, mean, rstd, gamma, 1,
                      (const float*)c1, (const float*)c2, (const float*)nullptr, 0, 0.f, noise, slope, part2);
   HWG_LAUNCH_CHECK("adain_bwd.apply");
   if (dnoise_w || dbias) {
-    hipLaunchKernelGGL(adain_param_grad_kernel, dim3(hwg_cdiv(C, 128)), dim3(128), 0, st, (const double*)part2, g, noise_scale, dbias, dnoise_w,
+    hipLaunchKernelGGL(adain_param_grad_kernel, dim3(hwg_cdiv(C, 4)), dim3(256), 0, st, (const double*)part2, g, noise_scale, dbias, dnoise_w,
                        accumulate_params);
     HWG_LAUNCH_CHECK("adain_bwd.param_grad");
   }

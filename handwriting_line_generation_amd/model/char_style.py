@@ -137,7 +137,7 @@ class CharStyleEncoder(nn.Module):
             cls_all = pred[bb, pp]
             order = np.argsort(cls_all, kind="stable")   # class-major, then (author, column): the reference's loop order
             cls_np = cls_all[order].astype(np.int32); b_np = bb[order].astype(np.int32); pos_np = pp[order].astype(np.int32)
-            idx = torch.from_numpy(np.stack([b_np, pos_np, cls_np])).to(dev)
+            idx = ops.h2d(np.stack([b_np, pos_np, cls_np]), dev)
             idx_b, idx_pos, idx_cls = idx[0].contiguous(), idx[1].contiguous(), idx[2].contiguous()
             patches = ops.gather_windows(feat_rows, idx_b, idx_pos, self.window)        # [n,1,2w+1,C]
             scores = ops.gather_scores(recog.reshape(B, Wf, self.n_class), idx_b, idx_pos, idx_cls)

@@ -22,7 +22,7 @@ KINDS = {
 
 
 def _st():
-    return torch.cuda.current_stream().cuda_stream
+    return ops._stream()
 
 
 class ExpertBank:
@@ -41,7 +41,7 @@ class ExpertBank:
         key = (self.params["w1"][1].data_ptr(), str(device))
         if self._pkey != key:
             host = np.array([[p.data_ptr() for p in self.params[k]] for k in KINDS], dtype=np.int64)
-            dev = torch.from_numpy(host).to(device)
+            dev = ops.h2d(host, device)
             self._pptr = {k: dev[i] for i, k in enumerate(KINDS)}
             self._pkey = key
         return self._pptr
@@ -59,7 +59,7 @@ class ExpertBank:
                     hp[e] = a
                     changed = True
         if changed or not self._gptr_dev:
-            dev = torch.from_numpy(np.stack([self._gptr_host[k] for k in KINDS])).to(device)
+            dev = ops.h2d(np.stack([self._gptr_host[k] for k in KINDS]), device)
             self._gptr_dev = {k: dev[i] for i, k in enumerate(KINDS)}
         return self._gptr_dev
 
@@ -138,7 +138,7 @@ def make_plan(cls_sorted_np, device):
     change = np.nonzero(np.diff(cls_sorted_np))[0] + 1
     starts = np.concatenate([[0], change, [n]]).astype(np.int32)
     seg_eid = cls_sorted_np[starts[:-1]].astype(np.int32)
-    packed = torch.from_numpy(np.concatenate([cls_sorted_np.astype(np.int32), starts, seg_eid])).to(device)
+    packed = ops.h2d(np.concatenate([cls_sorted_np.astype(np.int32), starts, seg_eid]), device)
     return {"eid": packed[:n], "seg_start": packed[n:n + starts.size], "seg_eid": packed[n + starts.size:], "G": int(seg_eid.size),
             "present": [int(e) for e in seg_eid], "n": n}
 

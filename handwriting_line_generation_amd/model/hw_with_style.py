@@ -114,7 +114,7 @@ class HWWithStyle(BaseModel):
             label_onehot = self.onehot(label)
             self.counts = self.spacer(label_onehot, style)
             spaced, padded = self.insert_spaces(label, label_lengths, self.counts)
-            spaced = spaced.to(label.device)
+            spaced = ops.h2d(spaced, label.device)
             self.gen_padded = padded
             spaced = self._clip_spaced(spaced)
             self.gen_spaced = spaced

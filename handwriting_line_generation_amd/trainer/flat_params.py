@@ -41,6 +41,9 @@ class FlatParams:
         start = len(order)
         order += [i for i in range(len(self.params)) if i not in seen]
         self.group_range["rest"] = (start, len(order))
+        for name, (a, b) in self.group_range.items():
+            for k in range(a, b):
+                self.params[order[k]]._hwg_group = (id(self), name)   # packed-weight cache epoch (ops.WEIGHT_EPOCH)
         self.order = order                      # flat position -> index in self.params
         self.pos = {pi: k for k, pi in enumerate(order)}   # param index -> flat position
         self.nt = len(order)
@@ -88,7 +91,7 @@ class FlatParams:
         return flat.data_ptr() + self.offsets * 4
 
     def masked_ptrs(self, flat, mask):
-        return torch.from_numpy(self.base_ptrs(flat) * mask.astype(np.int64)).to(self.device)
+        return ops.h2d(self.base_ptrs(flat) * mask.astype(np.int64), self.device)
 
     def group_mask(self, name):
         m = np.zeros(self.nt, dtype=bool)
@@ -104,7 +107,7 @@ class FlatParams:
         return flat[self.offsets[a]: end]
 
     def _st(self):
-        return torch.cuda.current_stream().cuda_stream
+        return ops._stream()
 
     # -- the reference's gradient bookkeeping, vectorised ------------------------------------------------
     def zero_grad(self, group):
@@ -141,9 +144,9 @@ class FlatParams:
             ptrR[k] = self.base_ptrs(buf) * tm.astype(np.int64)
             if (tm & ~self.touched).any():
                 raise RuntimeError("a stashed gradient exists for a parameter whose current gradient is None (the reference would raise here too)")
-        d_ptrR = torch.from_numpy(ptrR).to(self.device)
+        d_ptrR = ops.h2d(ptrR, self.device)
         d_ptrG = self.masked_ptrs(self.flat_grad, self.touched)
-        xs = torch.tensor([float(multipliers[k]) for k in range(ns)], dtype=torch.float32, device=self.device)
+        xs = ops.h2d(np.array([float(multipliers[k]) for k in range(ns)], dtype=np.float32), self.device)
         coef = torch.empty((ns, self.nt), dtype=torch.float32, device=self.device)
         L.call("hwg_mt_balance_coef", sumD, sumR, self.d_numel, d_ptrG, d_ptrR, xs, ns, self.nt, coef, self._st())
         for k in range(ns):
@@ -210,13 +213,14 @@ class HipAdam:
         t = np.maximum(self.steps, 1).astype(np.float64)
         step_size = (lr / (1.0 - b1 ** t)).astype(np.float32)
         bc2 = np.sqrt(1.0 - b2 ** t).astype(np.float32)
-        d_ss = torch.from_numpy(step_size).to(f.device)
-        d_bc = torch.from_numpy(bc2).to(f.device)
+        d_ss = ops.h2d(step_size, f.device)
+        d_bc = ops.h2d(bc2, f.device)
         am = active.astype(np.int64)
         tab = np.stack([f._param_ptrs * am, f.base_ptrs(f.flat_grad) * am, f.base_ptrs(self.exp_avg) * am, f.base_ptrs(self.exp_avg_sq) * am])
-        d_tab = torch.from_numpy(tab).to(f.device)
+        d_tab = ops.h2d(tab, f.device)
         L.call("hwg_mt_adam", d_tab[0], d_tab[1], d_tab[2], d_tab[3], d_ss, d_bc, float(b1), float(b2), float(self.eps), 0.0, f.d_numel,
                f.d_chunk_tensor, f.d_chunk_off, f.nchunks, CHUNK, f._st())
+        ops.bump_weight_epoch((id(f), self.group))   # parameters changed behind torch's version counters
 
     # checkpoint format of torch.optim.Adam (state keyed by parameter index within the group)
     def state_dict(self):

@@ -109,9 +109,9 @@ class HWWithStyleTrainer(BaseTrainer):
     def _to_tensor(self, instance):
         image, label = instance["image"], instance["label"]
         if image is not None:
-            image = image.to(self.gpu)
+            image = ops.h2d(image, self.gpu)
         if label is not None:
-            label = label.to(self.gpu)
+            label = ops.h2d(label, self.gpu)
         return image, label
 
     def _next_instance(self, lesson):
@@ -127,7 +127,8 @@ class HWWithStyleTrainer(BaseTrainer):
         allreduce_gradient_sets(self.flat, stashes, self.world, self.gpu)
 
     def _train_iteration(self, iteration):
-        self.model.train()
+        if not self.model.training:   # nn.Module.train() walks all ~3000 sub-modules; only do it when the mode actually changes
+            self.model.train()
         lesson = self.curriculum.getLesson(iteration) if self.curriculum else None
         instance = self._next_instance(lesson or [])
         self.optimizer.zero_grad()
@@ -393,13 +394,13 @@ class HWWithStyleTrainer(BaseTrainer):
             indexes = np.random.randint(0, len(self.prev_styles), (batch_size, 2))
             mix = np.random.uniform(self.interpolate_gen_styles_low, self.interpolate_gen_styles_high, batch_size)
             bank = torch.stack(self.prev_styles, dim=0)
-            a = bank[torch.from_numpy(indexes[:, 0]).to(device)]
-            b = bank[torch.from_numpy(indexes[:, 1]).to(device)]
+            ij = ops.h2d(indexes.T.copy(), device)
+            a = bank[ij[0]]
+            b = bank[ij[1]]
             # the reference multiplies float32 tensors by numpy float64 scalars: the scalar is rounded to float32, the product is float32
-            m1 = torch.from_numpy(mix.astype(np.float32)).to(device)[:, None]
-            m2 = torch.from_numpy((1 - mix).astype(np.float32)).to(device)[:, None]
-            return (a * m1 + b * m2).contiguous()
-        return torch.randn(batch_size, self.model.style_dim).to(device)
+            mm = ops.h2d(np.stack([mix.astype(np.float32), (1 - mix).astype(np.float32)]), device)
+            return (a * mm[0][:, None] + b * mm[1][:, None]).contiguous()
+        return ops.h2d(torch.randn(batch_size, self.model.style_dim), device)
 
     def getCER(self, gt, pred, individual=False):
         cer = wer = 0
