@@ -51,9 +51,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("HWG_DIST_BACKEND", "nccl")   # "gloo" lets two ranks share one GPU for a functional check of the DP path
+    if backend == "nccl" and world > ndev:
+        raise SystemExit("%d ranks but only %d GPUs visible" % (world, ndev))
+    local = local % ndev
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
 
     from handwriting_line_generation_amd import ops, rng

@@ -9,6 +9,7 @@
 // barrier per K step suffices. The K order inside a step is permuted identically for A and B so one
 // ds_read_b128 feeds four MFMAs (see the comment at the fragment reads).
 #include "hwg_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -117,6 +118,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK a) {
 
   float4 ra[A_IT], rb[B_IT];
   int jr = 0, js = 0, c0 = 0;  // coordinates of the tile being LOADED
+  const float* __restrict__ xg = a.x;
+  const float* __restrict__ wg = a.w;
 
   auto load_tile = [&]() {
     const int r = r0 + tr * jr, s = s0 + ts * js;
@@ -126,20 +129,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK a) {
       const int ih = a_hb[it] + ch * jr;
       const int iw = a_wb[it] + cw * js;
       const bool v = a_ok[it] && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (v) {
-        const long long off = ((long long)(a_nb[it] + ih * a.W + iw)) * a.C + c0 + a_chk[it] * 4;
-        val = *reinterpret_cast<const float4*>(a.x + off);
-      }
+      // always issue the load (from a valid dummy address when masked) and select afterwards: no exec-mask branches between the
+      // loads of one tile, so they all go out back to back
+      const long long off = v ? ((long long)(a_nb[it] + ih * a.W + iw)) * a.C + c0 + a_chk[it] * 4 : 0;
+      float4 val = *reinterpret_cast<const float4*>(xg + off);
+      if (!v) val = make_float4(0.f, 0.f, 0.f, 0.f);
       ra[it] = val;
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b_ok[it]) {
-        const long long off = ((long long)tap * a.K + n0 + b_row[it]) * a.C + c0 + b_chk[it] * 4;
-        val = *reinterpret_cast<const float4*>(a.w + off);
-      }
+      const long long off = b_ok[it] ? ((long long)tap * a.K + n0 + b_row[it]) * a.C + c0 + b_chk[it] * 4 : 0;
+      float4 val = *reinterpret_cast<const float4*>(wg + off);
+      if (!b_ok[it]) val = make_float4(0.f, 0.f, 0.f, 0.f);
       rb[it] = val;
     }
     // advance to the next tile
@@ -207,6 +208,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK a) {
   }
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  float bv[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int col = n0 + wn0 + ni * 32 + l31;
+    bv[ni] = (a.bias && col < a.K) ? a.bias[col] : 0.f;
+  }
+  float* __restrict__ yg = a.y;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -228,10 +236,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK a) {
       for (int ni = 0; ni < NI; ++ni) {
         const int col = n0 + wn0 + ni * 32 + l31;
         if (col < a.K) {
-          float v = acc[mi][ni][e];
-          if (a.bias) v += a.bias[col];
-          if (a.accumulate) v += a.y[obase + col];
-          a.y[obase + col] = v;
+          float v = acc[mi][ni][e] + bv[ni];
+          if (a.accumulate) v += yg[obase + col];
+          yg[obase + col] = v;
         }
       }
     }
@@ -565,10 +572,20 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
   int bn = d->K >= 96 ? 128 : (d->K > 32 ? 64 : 32);
   int bm = 128;
   if (bn == 128 || bn == 64) {
+    // fp32 MFMA is slow enough (64 cycles/instruction) that LDS/global traffic does not bind; what matters is having several
+    // workgroups per CU to hide load latency. Below two full waves of 128-wide tiles the 64x64 tile (4 blocks/CU) is faster
+    // (measured: 256->512 3x3 at M=8256: 76.7 vs 57.7 TFLOP/s).
     const long long blocks = (long long)hwg_cdiv(Mc, 128) * hwg_cdiv(d->K, bn) * classes;
-    if (blocks < 256) { bm = 64; bn = 64; }
+    if (blocks < 512) { bm = 64; bn = 64; }
   }
-  const int bk = (d->C % 32 == 0) ? 32 : 16;
+  int bk = (d->C % 32 == 0) ? 32 : 16;
+  if (const char* f = getenv("HWG_CONV_FORCE")) {  // tuning aid: "bm,bn,bk" (ignored when the shape cannot use it)
+    int fm = 0, fn = 0, fk = 0;
+    if (sscanf(f, "%d,%d,%d", &fm, &fn, &fk) == 3) {
+      if ((fm == 128 && (fn == 128 || fn == 64 || fn == 32)) || (fm == 64 && fn == 64)) { bm = fm; bn = fn; }
+      if (fk == 16 || (fk == 32 && d->C % 32 == 0)) bk = fk;
+    }
+  }
   k.ntm = hwg_cdiv(Mc, bm);
   k.ntm_pad = (k.ntm + 7) / 8 * 8;
   dim3 grid(k.ntm_pad, hwg_cdiv(d->K, bn), classes);
