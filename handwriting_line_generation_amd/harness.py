@@ -69,3 +69,23 @@ def build_gan_trainer(which="iam_gan", batch_size=None, a_batch_size=None, width
     losses = {name: getattr(loss_fns, fn) for name, fn in cfg["loss"].items()}
     trainer = HWWithStyleTrainer(model, losses, [], None, cfg, loader, None, None)
     return trainer, cfg
+
+
+def build_simple_trainer(which, batch_size=None, width=512, label_len=30, workdir=None, gpu=0, rank=0, world=1, model_state=None, data_seed=100):
+    """trainers of the two pre-training configs: 'iam_hwr' (CTC recogniser, BASELINE configs[0]) and 'iam_auto' (autoencoder, configs[1])"""
+    from .trainer import AutoTrainer
+    cfg = copy.deepcopy(load_config(which))
+    workdir = workdir or tempfile.mkdtemp(prefix="hwg_")
+    cfg["cuda"], cfg["gpu"] = True, gpu
+    dl = cfg["data_loader"]
+    if batch_size is not None:
+        dl["batch_size"] = batch_size
+    dl["char_file"] = CHAR_FILES["iam"]
+    cfg["trainer"]["save_dir"] = os.path.join(workdir, "saved")
+    model = (Autoencoder if cfg["arch"] == "Autoencoder" else HWWithStyle)(cfg["model"])
+    if model_state is not None:
+        model.load_state_dict(model_state)
+    ds = SyntheticAuthorDataset(dl["char_file"], dl["batch_size"], dl.get("a_batch_size", 1), width=width, label_len=label_len, seed=data_seed)
+    losses = {name: getattr(loss_fns, fn) for name, fn in cfg["loss"].items()}
+    cls = AutoTrainer if cfg["trainer"]["class"] == "AutoTrainer" else HWWithStyleTrainer
+    return cls(model, losses, [], None, cfg, SyntheticLoader(ds, rank, world), None, None), cfg

@@ -1,0 +1,98 @@
+"""Autoencoder pre-training step on HIP kernels (reference: trainer/auto_trainer.py:79-177, 255-319).
+Batch -> pad the width to a multiple of 8 with -1 -> Autoencoder (Encoder2 -> DecoderNoSkip, E_HWR) -> L1 + CTC -> backward
+-> clip_grad_value_(2) -> Adam. The perceptual encoder of the GAN trainer is the encoder trained here."""
+import json
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..base.base_trainer import BaseTrainer
+from ..utils import string_utils
+from .flat_params import allreduce_gradient_sets
+from .hw_with_style_trainer import PADDING_CONSTANT, _pad_w
+
+
+class AutoTrainer(BaseTrainer):
+    def __init__(self, model, loss, metrics, resume, config, data_loader, valid_data_loader=None, train_logger=None):
+        super().__init__(model, loss, metrics, resume, config, train_logger)
+        tr = config["trainer"]
+        self.loss_params = dict(config.get("loss_params", {}))
+        for name in self.loss:
+            self.loss_params.setdefault(name, {})
+        self.lossWeights = config.get("loss_weights", {"auto": 1, "recog": 1})
+        if data_loader is not None:
+            self.batch_size = data_loader.batch_size
+            self.data_loader = data_loader
+            self.data_loader_iter = iter(data_loader)
+        self.valid_data_loader = valid_data_loader
+        self.valid = valid_data_loader is not None
+        with open(config["data_loader"]["char_file"]) as f:
+            self.idx_to_char = {int(k): v for k, v in json.load(f)["idx_to_char"].items()}
+        self.num_class = len(self.idx_to_char) + 1
+        self.center_pad = tr.get("center_pad", True)
+        self.no_bg_loss = tr.get("no_bg_loss", False)
+        if self.no_bg_loss:
+            raise NotImplementedError("fg-mask weighted loss is not used by the shipped autoencoder config")
+        import torch.distributed as dist
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _next_instance(self):
+        try:
+            return next(self.data_loader_iter)
+        except StopIteration:
+            self.data_loader_iter = iter(self.data_loader)
+            return next(self.data_loader_iter)
+
+    def _train_iteration(self, iteration):
+        if not self.model.training:
+            self.model.train()
+        instance = self._next_instance()
+        self.optimizer.zero_grad()
+        losses = self.run_gen(instance)
+        loss = 0
+        scaled = {}
+        for name, v in losses.items():
+            v = ops.scale(v, self.lossWeights[name[:-4]])
+            scaled[name] = v
+            loss = v if isinstance(loss, int) else ops.add(loss, v)
+        loss.backward()
+        allreduce_gradient_sets(self.flat, (), self.world, self.gpu)
+        self.flat.clip_(2)
+        self.optimizer.step()
+        names = list(scaled)
+        host = torch.cat([scaled[n].detach().reshape(1) for n in names]).cpu().tolist()
+        log = dict(zip(names, host))
+        return {"loss": sum(log.values()), **log}
+
+    def run_gen(self, instance, get=[]):
+        image = ops.h2d(instance["image"], self.gpu)
+        label = ops.h2d(instance["label"], self.gpu)
+        if image.size(3) % 8 > 0:
+            p = 8 - image.size(3) % 8
+            image = _pad_w(image, p // 2, p // 2 + p % 2, "constant", PADDING_CONSTANT)
+        if "recog" in self.loss:
+            recon, pred = self.model(image)
+        else:
+            recon, pred = self.model(image), None
+        losses = {}
+        if "auto" in self.loss:
+            d = recon.size(3) - image.size(3)
+            if d > 0:
+                image = _pad_w(image, d // 2, d // 2 + d % 2, "constant", PADDING_CONSTANT) if self.center_pad else _pad_w(image, 0, d, "constant", PADDING_CONSTANT)
+            elif d < 0:
+                recon = _pad_w(recon, (-d) // 2, (-d) // 2 + (-d) % 2, "constant", PADDING_CONSTANT) if self.center_pad else _pad_w(recon, 0, -d, "constant", PADDING_CONSTANT)
+            losses["autoLoss"] = self.loss["auto"](recon, image, **self.loss_params["auto"])
+        if pred is not None:
+            B = pred.size(1)
+            losses["recogLoss"] = self.loss["recog"](pred, label.permute(1, 0), [pred.size(0)] * B, instance["label_lengths"])
+        if get:
+            return losses, {k: v for k, v in (("recon", recon), ("pred", pred)) if k in get}
+        return losses
+
+    def getCER(self, gt, pred):
+        cer = 0
+        for i, g in enumerate(gt):
+            s, _ = string_utils.naive_decode(pred[:, i])
+            cer += string_utils.cer(g, string_utils.label2str_single(s, self.idx_to_char, False))
+        return cer / len(gt)
