@@ -249,13 +249,32 @@ class _Conv2d(Function):
                 d = _desc(N, P, Q, K, C, R, S, (sh, sw), (ph, pw), (dh, dw), H, W)
                 u, v = x, dy
                 sa, sb = K * R * S, R * S
-            need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
-            ws = workspace(need, x.device)
-            e0 = _prof_begin() if (d.K > 2 and d.C > 2) else None
-            L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 1 if direct else 0, ws, ws.numel(), st)
-            _prof_end("wgrad_mfma_kernel", 2.0 * d.N * d.P * d.Q * d.K * d.C * R * S, e0, (d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad"))
-            if direct:
-                dw_ = None
+            Kq, Cq = (d.K + 3) // 4 * 4, (d.C + 3) // 4 * 4
+            if Kq != d.K or Cq != d.C:
+                # channel counts that are not multiples of 4 (RIMES: 78 classes -> 206/334-channel inputs, 78 outputs): run the kernel
+                # on zero-padded copies and keep the valid block of the result
+                dK, dC = d.K, d.C
+                up = _pad_channels(u, Kq) if Kq != dK else u
+                vp = _pad_channels(v, Cq) if Cq != dC else v
+                d.K, d.C = Kq, Cq
+                tmp = torch.empty((Kq, Cq, R, S), dtype=torch.float32, device=x.device)
+                need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
+                ws = workspace(need, x.device)
+                L.call("hwg_conv_wgrad", ctypes.byref(d), up, vp, tmp, Cq * R * S, R * S, S, 1, 0, ws, ws.numel(), st)
+                valid = tmp[:dK, :dC]
+                if direct:
+                    dw_.add_(valid)
+                    dw_ = None
+                else:
+                    dw_ = valid.contiguous()
+            else:
+                need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
+                ws = workspace(need, x.device)
+                e0 = _prof_begin() if (d.K > 2 and d.C > 2) else None
+                L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 1 if direct else 0, ws, ws.numel(), st)
+                _prof_end("wgrad_mfma_kernel", 2.0 * d.N * d.P * d.Q * d.K * d.C * R * S, e0, (d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad"))
+                if direct:
+                    dw_ = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if _direct(bref):
                 colsum(dy.view(-1, K), out=_grad_buffer(bref), accumulate=True)

@@ -50,6 +50,10 @@ CONV_CASES = [
     ("convT_s1_3x3", 2, 6, 20, 32, 32, 3, 3, (1, 1), (1, 1), (1, 1), True),
     ("convT_6x3", 2, 1, 12, 32, 64, 6, 3, (1, 1), (0, 0), (1, 1), True),
     ("convT_to1", 2, 8, 20, 32, 1, 3, 3, (1, 1), (1, 1), (1, 1), True),
+    # RIMES (78 classes): channel counts that are not multiples of 4
+    ("rimes_convT_lift_206", 2, 1, 20, 206, 64, 4, 3, (1, 1), (0, 1), (1, 1), True),
+    ("rimes_conv1d_to78", 2, 1, 30, 64, 78, 1, 3, (1, 1), (0, 0), (1, 1), False),
+    ("rimes_conv1d_334", 2, 1, 30, 334, 32, 1, 5, (1, 1), (0, 2), (1, 1), False),
 ]
 
 
