@@ -448,23 +448,43 @@ __global__ void pack_weight_kernel(const float* src, float* dst, int A, int B, i
   }
 }
 
-// column sums: x[rows][C] -> part[chunks][C]
+// column sums: x[rows][C] -> part[chunks][C]  (single chunk: straight into out)
+// V = 4: block = 16 float4 column groups (64 columns) x 16 row lanes, 256-byte coalesced row segments; V = 1: 64 columns x 4 row lanes
+template <int V>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, long long rows, int C, float* part, long long rows_per_chunk,
                                                              float* direct_out, int accumulate) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + cl;
+  constexpr int CG = 64 / V;        // column groups per block
+  constexpr int RL = 256 / CG;      // row lanes
+  __shared__ float red[RL][64];
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+  const int c = blockIdx.y * 64 + cg * V;
   const long long rb = blockIdx.x * rows_per_chunk;
   const long long re = min(rb + rows_per_chunk, rows);
-  float s = 0.f;
-  if (c < C)
-    for (long long rr = rb + rl; rr < re; rr += 4) s += x[rr * C + c];
-  red[rl][cl] = s;
+  float s[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) s[e] = 0.f;
+  if (c < C) {
+    for (long long rr = rb + rl; rr < re; rr += RL) {
+      if (V == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(x + rr * C + c);
+        s[0] += v.x; s[1 % V] += v.y; s[2 % V] += v.z; s[3 % V] += v.w;
+      } else {
+        s[0] += x[rr * C + c];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < V; ++e) red[rl][cg * V + e] = s[e];
   __syncthreads();
-  if (rl == 0 && c < C) {
-    const float v = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
-    if (direct_out) direct_out[c] = accumulate ? direct_out[c] + v : v;   // single chunk: no second stage
-    else part[(long long)blockIdx.x * C + c] = v;
+  if (threadIdx.x < 64) {
+    const int cc = blockIdx.y * 64 + threadIdx.x;
+    if (cc < C) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < RL; ++r) v += red[r][threadIdx.x];
+      if (direct_out) direct_out[cc] = accumulate ? direct_out[cc] + v : v;
+      else part[(long long)blockIdx.x * C + cc] = v;
+    }
   }
 }
 __global__ void colsum_final_kernel(const float* part, int chunks, int C, float* out, int accumulate) {
@@ -649,9 +669,9 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
 }
 
 static long long colsum_chunks(long long rows) {
-  // each chunk is summed by 4 row lanes; keep the second stage short (<= 64 partials per column)
-  long long chunks = (rows + 63) / 64;
-  if (chunks > 64) chunks = 64;
+  // ~16 rows per thread (16 row lanes per block); keep the second stage short (<= 128 partials per column)
+  long long chunks = (rows + 255) / 256;
+  if (chunks > 128) chunks = 128;
   if (chunks < 1) chunks = 1;
   return chunks;
 }
@@ -668,8 +688,12 @@ extern "C" int hwg_colsum(const float* x, long long rows, int C, float* out, int
   hipStream_t st = (hipStream_t)stream;
   const long long chunks = colsum_chunks(rows);
   const long long rpc = (rows + chunks - 1) / chunks;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)chunks, hwg_cdiv(C, 64)), dim3(256), 0, st, x, rows, C, (float*)workspace, rpc,
-                     chunks == 1 ? out : (float*)nullptr, accumulate);
+  if (C % 4 == 0)
+    hipLaunchKernelGGL(colsum_partial_kernel<4>, dim3((unsigned)chunks, hwg_cdiv(C, 64)), dim3(256), 0, st, x, rows, C, (float*)workspace, rpc,
+                       chunks == 1 ? out : (float*)nullptr, accumulate);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3((unsigned)chunks, hwg_cdiv(C, 64)), dim3(256), 0, st, x, rows, C, (float*)workspace, rpc,
+                       chunks == 1 ? out : (float*)nullptr, accumulate);
   HWG_LAUNCH_CHECK("colsum_partial");
   if (chunks == 1) return HWG_OK;
   hipLaunchKernelGGL(colsum_final_kernel, dim3(hwg_cdiv(C, 256)), dim3(256), 0, st, (const float*)workspace, (int)chunks, C, out, accumulate);
