@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be loaded first: its bundled HIP runtime has t
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _REPO_DIR = os.path.dirname(_PKG_DIR)
-LIB_PATH = os.path.join(_PKG_DIR, "libhwg_hip.so")
+LIB_PATH = os.environ.get("HWG_LIB_OVERRIDE") or os.path.join(_PKG_DIR, "libhwg_hip.so")   # override: tuning builds only
 HEADER_PATH = os.path.join(_REPO_DIR, "include", "hwg.h")
 
 
