@@ -81,6 +81,7 @@ def main():
         for b in trainer.model.buffers():
             dist.broadcast(b.data, 0)
 
+    trainer.async_log = True   # losses of step i are read back while step i+1 runs (flushed inside the timed region)
     it = 0
     for _ in range(args.warmup):
         trainer._train_iteration(it); it += 1
@@ -95,6 +96,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer._train_iteration(it); it += 1
+    trainer.flush_log()
     barrier()
     elapsed = time.perf_counter() - t0
     prof, ops.CONV_PROF = ops.CONV_PROF, None

@@ -256,13 +256,13 @@ struct WgK {
 };
 
 template <int BMU, int BNV, int BKP, int WAVES_M, int WAVES_N, int WAVES_K>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgK a) {
-  static_assert(WAVES_M * WAVES_N * WAVES_K == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_kernel(WgK a) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
   constexpr int WM = BMU / WAVES_M, WN = BNV / WAVES_N;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int UC = BMU / 4, VC = BNV / 4;
   constexpr int U_F4 = BKP * UC, V_F4 = BKP * VC;
-  constexpr int U_IT = (U_F4 + 255) / 256, V_IT = (V_F4 + 255) / 256;
+  constexpr int U_IT = (U_F4 + NT - 1) / NT, V_IT = (V_F4 + NT - 1) / NT;
   constexpr int TILE = BKP * (BMU + BNV);
   constexpr int RED = (WAVES_K > 1) ? WAVES_K * MI * NI * 16 * 64 : 0;
   constexpr int SM = (2 * TILE > RED) ? 2 * TILE : RED;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgK a) {
   bool u_ok[U_IT];
 #pragma unroll
   for (int it = 0; it < U_IT; ++it) {
-    const int f = tid + it * 256;
+    const int f = tid + it * NT;
     u_kp[it] = f / UC;
     u_c4[it] = f % UC;
     u_ok[it] = (f < U_F4) && (k0 + u_c4[it] * 4 < a.K);
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgK a) {
   bool v_ok[V_IT];
 #pragma unroll
   for (int it = 0; it < V_IT; ++it) {
-    const int f = tid + it * 256;
+    const int f = tid + it * NT;
     v_kp[it] = f / VC;
     v_c4[it] = f % VC;
     v_ok[it] = (f < V_F4) && (c0 + v_c4[it] * 4 < a.C);
@@ -338,10 +338,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgK a) {
     float* Vb = Vs + buf * BKP * BNV;
 #pragma unroll
     for (int it = 0; it < U_IT; ++it)
-      if (tid + it * 256 < U_F4) *reinterpret_cast<float4*>(Ub + u_kp[it] * BMU + u_c4[it] * 4) = ru[it];
+      if (tid + it * NT < U_F4) *reinterpret_cast<float4*>(Ub + u_kp[it] * BMU + u_c4[it] * 4) = ru[it];
 #pragma unroll
     for (int it = 0; it < V_IT; ++it)
-      if (tid + it * 256 < V_F4) *reinterpret_cast<float4*>(Vb + v_kp[it] * BNV + v_c4[it] * 4) = rv[it];
+      if (tid + it * NT < V_F4) *reinterpret_cast<float4*>(Vb + v_kp[it] * BNV + v_c4[it] * 4) = rv[it];
   };
 
   const int T = (pe > pb) ? (pe - pb + BKP - 1) / BKP : 0;
@@ -660,7 +660,7 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
   k.chunk = p.chunk;
   k.tiles_v = p.tiles_v;
   dim3 grid(p.nsplit, p.tiles_u * p.tiles_v, d->R * d->S);
-  if (p.cfg == 0) hipLaunchKernelGGL((wgrad_mfma_kernel<128, 128, 16, 2, 2, 1>), grid, dim3(256), 0, st, k);
+  if (p.cfg == 0) hipLaunchKernelGGL((wgrad_mfma_kernel<128, 128, 16, 2, 4, 1>), grid, dim3(512), 0, st, k);   // 8 waves: +2 % over 4
   else if (p.cfg == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<64, 64, 32, 2, 2, 1>), grid, dim3(256), 0, st, k);
   else hipLaunchKernelGGL((wgrad_mfma_kernel<32, 32, 32, 1, 1, 4>), grid, dim3(256), 0, st, k);
   HWG_LAUNCH_CHECK("conv_wgrad");

@@ -117,20 +117,27 @@ class CharStyleEncoder(nn.Module):
     def forward(self, x, recog):
         """x: NCHW [B',1,64,Wc] author image; recog: [B',n_class,Tc] log-probs (channel major, as the reference passes) or NHWC [B',1,Tc,n_class]"""
         B = x.shape[0]
+        if recog.dim() == 3:
+            recog = ops.permute(recog, (0, 2, 1)).unsqueeze(1)  # [B,1,T,n_class]
+        # arg-max map of the recogniser output: computed and sent to the host (side stream) before the trunk convolutions are
+        # enqueued, so that the later wait does not drain the main stream
+        T0 = recog.shape[2]
+        pred_fetch = ops.AsyncFetch(ops.argmax_rows(recog.reshape(B * T0, self.n_class)))
         feat = ops.to_nhwc(x)
         for blk in self.down:
             feat = blk(feat)
         if feat.shape[1] != 1:
             raise ValueError("style extractor expects 64-pixel-high lines (feature height %d != 1)" % feat.shape[1])
-        if recog.dim() == 3:
-            recog = ops.permute(recog, (0, 2, 1)).unsqueeze(1)  # [B,1,T,n_class]
         feat, recog = self._align(feat, recog)
         Wf = feat.shape[2]
         C = feat.shape[3]
         dev = feat.device
 
         # which classes were recognised where (one small D2H copy)
-        pred = ops.argmax_rows(recog.reshape(B * Wf, self.n_class)).view(B, Wf).cpu().numpy()
+        pred = pred_fetch.get().numpy().reshape(B, T0)
+        if Wf > T0:   # the log-probs were replicate-padded to the feature length: the arg-max map pads the same way
+            d = Wf - T0
+            pred = np.pad(pred, ((0, 0), (d // 2, d // 2 + d % 2)), mode="edge")
         bb, pp = np.nonzero(pred > 0)                 # row-major: author, then column
         feat_rows = feat.reshape(B, Wf, C)
         if bb.size:

@@ -26,6 +26,11 @@ def correct_pred(pred, label):
     return out
 
 
+def correct_pred_async(pred, label):
+    """enqueue the alignment now, collect it later with `.result()[0]` (lets the style extractor run in between)"""
+    return ops.dtw_align_async(pred.detach().contiguous(), label)
+
+
 class HWWithStyle(BaseModel):
     def __init__(self, config):
         super().__init__(config)
@@ -102,6 +107,7 @@ class HWWithStyle(BaseModel):
         self.pred = None
         self.spaced_label = None
         self.spaced_label_index = None
+        self._dtw_pending = None
         self.spacing_pred = None
         self.mask_pred = None
         self.gen_spaced = None
@@ -148,14 +154,25 @@ class HWWithStyle(BaseModel):
         if stop_grad_extractor:
             style = style.detach()
         if self.spaced_label is None:
-            self.spaced_label_index = correct_pred(self.pred, label)
+            self.spaced_label_index = self.take_alignment(label)
             self.spaced_label = self.onehot(self.spaced_label_index)
         recon = self.forward(label, None, style, self.spaced_label)
         return recon, style
 
+    def take_alignment(self, label):
+        """DTW alignment of `label` to self.pred; uses the kernel launched ahead of time by extract_style when there is one"""
+        pend, self._dtw_pending = self._dtw_pending, None
+        if pend is not None:
+            return pend.result()[0]
+        return correct_pred(self.pred, label)
+
     def extract_style(self, image, label, a_batch_size=None):
         if self.pred is None:
             self.pred = self.hwr(image, None)
+            if label is not None and self.spaced_label is None and self.use_hwr_pred_for_style:
+                # the alignment only depends on the recogniser output: start it now, its (small) result is fetched on a side stream
+                # while the style extractor runs
+                self._dtw_pending = correct_pred_async(self.pred, label)
         batch_size, feats, h, w = image.shape
         if a_batch_size is None:
             a_batch_size = batch_size

@@ -24,6 +24,34 @@ def _stream():
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
+_copy_streams = {}
+
+
+class AsyncFetch:
+    """Device->host copy on a side stream: the producer's stream keeps running (and the host keeps enqueueing) while the bytes
+    travel; `.get()` waits only for the copy. Replaces `.cpu()` / `.item()` where the value is needed later than it is produced."""
+
+    def __init__(self, tensor):
+        dev = tensor.device
+        cs = _copy_streams.get(dev)
+        if cs is None:
+            cs = _copy_streams[dev] = torch.cuda.Stream(device=dev)
+        self.src = tensor.detach()
+        self.host = torch.empty(tensor.shape, dtype=tensor.dtype, pin_memory=True)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(cs):
+            cs.wait_event(ready)
+            self.host.copy_(self.src, non_blocking=True)
+            self.done = torch.cuda.Event()
+            self.done.record()
+        self.src.record_stream(cs)
+
+    def get(self):
+        self.done.synchronize()
+        return self.host
+
+
 def h2d(host, device, dtype=None):
     """Asynchronous host->device upload through pinned staging memory. A plain `.to(device)` of pageable memory blocks the host
     until every kernel queued before it has finished, which serialises the CPU against the GPU a dozen times per step."""
@@ -780,18 +808,33 @@ def ctc_loss(log_probs, targets, input_lengths, target_lengths):
     return _CTC.apply(log_probs.contiguous(), targets, il, tl)
 
 
-def dtw_align(pred_TBC, label_LB):
-    """correct_pred: returns (aligned int64 [maxlen,B], lens[B]); one D2H sync for the path length."""
+class DTWPending:
+    """alignment kernel already enqueued; `.result()` waits (side-stream copy) only for the path lengths"""
+
+    def __init__(self, out, lens):
+        self.out, self.lens = out, lens
+        self.fetch = AsyncFetch(lens)
+
+    def result(self):
+        maxlen = int(self.fetch.get().max())
+        return self.out[:maxlen].contiguous(), self.lens
+
+
+def dtw_align_async(pred_TBC, label_LB):
     _chk(pred_TBC, "dtw pred")
     T, B, C = pred_TBC.shape
     label = h2d(label_LB, pred_TBC.device, torch.int32).contiguous()
     Lr = label.shape[0]
     out = torch.empty((T + 2 * Lr + 1, B), dtype=torch.int64, device=pred_TBC.device)
     lens = torch.empty((B,), dtype=torch.int32, device=pred_TBC.device)
-    ws = workspace(L.query("hwg_dtw_workspace", T, B, Lr), pred_TBC.device)
+    ws = torch.empty(L.query("hwg_dtw_workspace", T, B, Lr), dtype=torch.uint8, device=pred_TBC.device)   # private: outlives this call
     L.call("hwg_dtw_align", pred_TBC, label, T, B, C, Lr, out, lens, ws, ws.numel(), _stream())
-    maxlen = int(lens.max().item())
-    return out[:maxlen].contiguous(), lens
+    return DTWPending(out, lens)
+
+
+def dtw_align(pred_TBC, label_LB):
+    """correct_pred: returns (aligned int64 [maxlen,B], lens[B]); one D2H wait for the path length."""
+    return dtw_align_async(pred_TBC, label_LB).result()
 
 
 def gt_counts(index_spaced, label_LB):

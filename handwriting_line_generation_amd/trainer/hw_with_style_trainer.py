@@ -104,6 +104,8 @@ class HWWithStyleTrainer(BaseTrainer):
         self.print_dir = None  # sample image dumps need torchvision; not part of the accelerated path
         self.casesensitive = tr.get("casesensitive", True)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.async_log = tr.get("async_log", False)
+        self._pending_log = None
 
     # ------------------------------------------------------------------------------------------
     def _to_tensor(self, instance):
@@ -201,17 +203,30 @@ class HWWithStyleTrainer(BaseTrainer):
         vals = [scaled[n].detach().reshape(1) for n in names]
         if flag is not None:
             vals.append(flag.float())
-        host = torch.cat(vals).cpu().tolist() if vals else []
-        if flag is not None:
+        cer = wer = 0
+        if pred is not None:
+            cer, wer, _ = self.getCER(instance["gt"], pred.detach().cpu().numpy())
+        pending = (names, ops.AsyncFetch(torch.cat(vals)) if vals else None, flag is not None, cer, wer)
+        if self.async_log:
+            # pipelined logging: return the PREVIOUS iteration's values so that this iteration's kernels need not be drained
+            # before the next iteration is enqueued (the reference's `.item()` per loss does exactly that drain)
+            prev, self._pending_log = self._pending_log, pending
+            return self._resolve_log(prev) if prev is not None else {}
+        return self._resolve_log(pending)
+
+    def _resolve_log(self, pending):
+        names, fetch, has_flag, cer, wer = pending
+        host = fetch.get().tolist() if fetch is not None else []
+        if has_flag:
             assert host[-1] == 0.0, "a parameter became NaN/inf"
         log_losses = dict(zip(names, host))
         total = sum(log_losses.values())
         assert not (np.isnan(total) or np.isinf(total)), log_losses
-
-        cer = wer = 0
-        if pred is not None:
-            cer, wer, _ = self.getCER(instance["gt"], pred.detach().cpu().numpy())
         return {"loss": total, **log_losses, "CER": cer, "WER": wer}
+
+    def flush_log(self):
+        prev, self._pending_log = self._pending_log, None
+        return self._resolve_log(prev) if prev is not None else {}
 
     # ------------------------------------------------------------------------------------------
     def run_hwr(self, instance):
@@ -275,7 +290,7 @@ class HWWithStyleTrainer(BaseTrainer):
                 style = model.extract_style(image, label, a_batch_size)
                 if "$UNKOWN$" in instance["gt"]:
                     raise NotImplementedError("pseudo-labelled lines ('$UNKOWN$') are a data-pipeline feature outside the accelerated path")
-                spaced_idx = correct_pred(model.pred, label)
+                spaced_idx = model.take_alignment(label)
             else:
                 spaced_idx = model.spaced_label_index
             label_onehot = model.onehot(label)
