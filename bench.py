@@ -81,6 +81,9 @@ def main():
         for b in trainer.model.buffers():
             dist.broadcast(b.data, 0)
 
+    # inputs resident in HBM before the timed region (the contract's "inputs already resident"): one batch per step, built up front
+    trainer.data_loader.make_resident(args.warmup + args.steps, trainer.gpu)
+    trainer.data_loader_iter = iter(trainer.data_loader)
     trainer.async_log = True   # losses of step i are read back while step i+1 runs (flushed inside the timed region)
     it = 0
     for _ in range(args.warmup):

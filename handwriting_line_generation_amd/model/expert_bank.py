@@ -46,8 +46,13 @@ class ExpertBank:
             self._pkey = key
         return self._pptr
 
-    def grad_ptrs(self, present, device):
-        """gradient-buffer tables; allocates / marks-as-touched the buffers of the experts present in this batch"""
+    def grad_ptrs(self, plan, device):
+        """gradient-buffer tables; allocates / marks-as-touched the buffers of the experts present in this batch.
+        The walk over (kinds x present experts) runs once per plan (= once per forward): the touched flags it sets live until the
+        trainer's next zero_grad, which is always followed by a new forward and hence a new plan."""
+        if plan.get("grads_ready") and self._gptr_dev:
+            return self._gptr_dev
+        present = plan["present"]
         changed = False
         for k in KINDS:
             plist = self.params[k]
@@ -61,6 +66,7 @@ class ExpertBank:
         if changed or not self._gptr_dev:
             dev = ops.h2d(np.stack([self._gptr_host[k] for k in KINDS]), device)
             self._gptr_dev = {k: dev[i] for i, k in enumerate(KINDS)}
+        plan["grads_ready"] = True
         return self._gptr_dev
 
 
@@ -82,7 +88,7 @@ class _GroupedConv1d(Function):
         bank, wk, bk, plan, S, pad, n, R, Cin, Cout = ctx.cfg
         dy = dy.contiguous()
         pp = bank.param_ptrs(x.device)
-        gp = bank.grad_ptrs(plan["present"], x.device)
+        gp = bank.grad_ptrs(plan, x.device)
         st = _st()
         dx = None
         if ctx.needs_input_grad[0]:
@@ -126,7 +132,7 @@ class _GroupedGN(Function):
         ws = ops.workspace(L.query("hwg_norm_workspace", n, R, C), x.device)
         L.call("hwg_norm_bwd", dy, x, y, dx, n, R, C, ops.NORM_GN, groups, gamma, 1, None, ops.ACT_RELU, 0.0, mean, rstd, dgamma, dbeta, 0,
                ws, ws.numel(), st)
-        gp = bank.grad_ptrs(plan["present"], x.device)
+        gp = bank.grad_ptrs(plan, x.device)
         L.call("hwg_segment_accumulate_ptr", dgamma, plan["seg_start"], plan["seg_eid"], plan["G"], gp[gk], C, st)
         L.call("hwg_segment_accumulate_ptr", dbeta, plan["seg_start"], plan["seg_eid"], plan["G"], gp[bk], C, st)
         return dx, None, None, None, None, None, None
