@@ -24,6 +24,8 @@ struct ConvK {
   int accumulate;
   int ntm;         // M tiles of the largest parity class
   int ntm_pad;     // ntm rounded up to a multiple of 8 (XCD remap)
+  int nsplit;      // split-K: the taps x channel-steps loop is cut into nsplit ranges, one workgroup each (blockIdx.y % nsplit)
+  float* part;     // nsplit > 1: partial outputs [nsplit][N*P*Q*K] in y's layout, summed (+bias) by conv_split_reduce_kernel
 };
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
@@ -47,10 +49,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
 
   // XCD-aware tile order: the dispatcher places block b on XCD b%8, give each XCD a contiguous run
   // of M tiles so neighbouring tiles (shared halo rows, same weights) hit the same L2.
+  // (ranges differ by at most one tile: XCD i owns tiles [i*ntm/8, (i+1)*ntm/8))
   const int bid = blockIdx.x;
-  const int tile_m = (bid & 7) * (a.ntm_pad >> 3) + (bid >> 3);
-  if (tile_m >= a.ntm) return;
-  const int n0 = blockIdx.y * BN;
+  const int xcd = bid & 7;
+  const int tile_m = (xcd * a.ntm >> 3) + (bid >> 3);
+  if (tile_m >= ((xcd + 1) * a.ntm >> 3)) return;
+  const int split = blockIdx.y % a.nsplit;
+  const int n0 = (blockIdx.y / a.nsplit) * BN;
 
   int cp = 0, cq = 0, Pc = a.P, Qc = a.Q;
   int r0 = 0, s0 = 0, tr = 1, ts = 1, nr = a.R, ns = a.S;
@@ -107,7 +112,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
   }
 
   const int csteps = a.C / BK;
-  const int T = nr * ns * csteps;
+  const int Tall = nr * ns * csteps;
+  const int t_begin = (int)((long long)Tall * split / a.nsplit);
+  const int T = (int)((long long)Tall * (split + 1) / a.nsplit) - t_begin;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -118,7 +125,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
   float4 ra[A_IT], rb[B_IT];
-  int jr = 0, js = 0, c0 = 0;  // coordinates of the tile being LOADED
+  // coordinates of the tile being LOADED (this workgroup's K range starts at step t_begin)
+  int c0 = (t_begin % csteps) * BK;
+  int js = (t_begin / csteps) % (ns > 0 ? ns : 1);
+  int jr = (t_begin / csteps) / (ns > 0 ? ns : 1);
   const float* __restrict__ xg = a.x;
   const float* __restrict__ wg = a.w;
 
@@ -213,9 +223,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int col = n0 + wn0 + ni * 32 + l31;
-    bv[ni] = (a.bias && col < a.K) ? a.bias[col] : 0.f;
+    bv[ni] = (a.bias && a.nsplit == 1 && col < a.K) ? a.bias[col] : 0.f;
   }
-  float* __restrict__ yg = a.y;
+  float* __restrict__ yg = a.nsplit == 1 ? a.y : a.part + (long long)split * ((long long)a.N * a.P * a.Q * a.K);
+  const bool accum = a.accumulate && a.nsplit == 1;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -238,10 +249,41 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
         const int col = n0 + wn0 + ni * 32 + l31;
         if (col < a.K) {
           float v = acc[mi][ni][e] + bv[ni];
-          if (a.accumulate) v += yg[obase + col];
+          if (accum) v += yg[obase + col];
           yg[obase + col] = v;
         }
       }
+    }
+  }
+}
+
+// y[i] = (accumulate ? y[i] : 0) + bias[i % K] + sum_s part[s][i]   (split-K epilogue; fixed summation order -> deterministic)
+__global__ __launch_bounds__(256) void conv_split_reduce_kernel(const float* part, const float* bias, float* y, long long total, int K, int nsplit,
+                                                                int accumulate) {
+  if ((K & 3) == 0) {
+    const long long n4 = total >> 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+      float4 s = *reinterpret_cast<const float4*>(part + 4 * i);
+      for (int sp = 1; sp < nsplit; ++sp) {
+        const float4 v = *reinterpret_cast<const float4*>(part + sp * total + 4 * i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      if (bias) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + (int)((4 * i) % K));
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+      }
+      if (accumulate) {
+        const float4 o = *reinterpret_cast<const float4*>(y + 4 * i);
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+      }
+      *reinterpret_cast<float4*>(y + 4 * i) = s;
+    }
+  } else {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+      float s = part[i];
+      for (int sp = 1; sp < nsplit; ++sp) s += part[sp * total + i];
+      if (bias) s += bias[(int)(i % K)];
+      y[i] = accumulate ? y[i] + s : s;
     }
   }
 }
@@ -556,8 +598,70 @@ static int check_desc(const hwg_conv_desc* d, const char* who) {
   return HWG_OK;
 }
 
+struct ConvPlan {
+  bool mfma;
+  int bm, bn, bk, nsplit, classes;
+  long long Mc;
+};
+static ConvPlan plan_conv(const hwg_conv_desc* d) {
+  ConvPlan p;
+  p.mfma = !((!d->transposed) && (d->K <= 2 || d->C == 1));
+  p.classes = d->transposed ? d->stride_h * d->stride_w : 1;
+  p.Mc = (long long)d->N * d->P * d->Q;
+  if (d->transposed) p.Mc = (long long)d->N * hwg_cdiv(d->P, d->stride_h) * hwg_cdiv(d->Q, d->stride_w);
+  // Schedule = (tile, split-K factor) with the smallest modelled time. The model (fitted to tools/conv_sweep.py measurements):
+  //  * a CU retires one workgroup "quantum" at a time (co-resident workgroups share its matrix cores) and every XCD (32 CUs) owns
+  //    a fixed 1/8 of the M tiles, so the makespan is ceil(blocks_per_XCD / 32) quanta (beyond 8 quanta the tail evens out);
+  //  * a workgroup costs (K steps + fill/epilogue overhead) x step time at the tile's sustained rate;
+  //  * split-K adds one pass that reads the nsplit partial images and writes the output.
+  const int bk = (d->C % 32 == 0) ? 32 : 16;
+  const int taps_total = d->R * d->S;
+  const double taps_per_class = (double)taps_total / p.classes;
+  const double T_total = taps_per_class * (d->C / bk);
+  const int min_taps = d->transposed ? (d->R / d->stride_h) * (d->S / d->stride_w) : taps_total;
+  const int min_steps = (min_taps > 0 ? min_taps : 1) * (d->C / bk);
+  const double out_bytes = 4.0 * d->N * d->P * d->Q * d->K;
+  struct Tile { int bm, bn; double tflops, overhead; };
+  static const Tile tiles[4] = {{128, 128, 104.0, 1.0}, {128, 64, 94.0, 1.75}, {64, 64, 88.0, 2.5}, {128, 32, 62.0, 2.5}};
+  static const int splits[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+  int bm = 128, bn = 32, ns = 1;
+  double best = 1e30;
+  for (int ti = 0; ti < 4; ++ti) {
+    const Tile& t = tiles[ti];
+    if (d->K <= 32 ? t.bn != 32 : (t.bn == 32 || (t.bn == 128 && d->K < 96))) continue;
+    const double step_s = 2.0 * t.bm * t.bn * bk / (t.tflops * 1e12 / 256.0);
+    const double per_xcd = (double)hwg_cdiv(hwg_cdiv(p.Mc, t.bm), 8) * hwg_cdiv(d->K, t.bn) * p.classes;
+    for (int si = 0; si < 8; ++si) {
+      const int n = splits[si];
+      if (n > 1 && (min_steps / n < 3 || out_bytes * n > 1.5e9)) break;
+      const double q = per_xcd * n / 32.0;
+      const double quanta = q <= 8.0 ? ceil(q) : q + 0.5;
+      double tm = quanta * (T_total / n + t.overhead) * step_s;
+      if (n > 1) tm += (n + 1) * out_bytes / 6.0e12 + 3e-6;
+      if (tm < best) { best = tm; bm = t.bm; bn = t.bn; ns = n; }
+    }
+  }
+  if (const char* f = getenv("HWG_CONV_FORCE")) {  // tuning aid: "bm,bn,bk[,nsplit]" (ignored when the shape cannot use it)
+    int fm = 0, fn = 0, fk = 0, fs = 1;
+    if (sscanf(f, "%d,%d,%d,%d", &fm, &fn, &fk, &fs) >= 3) {
+      if ((fm == 128 && (fn == 128 || fn == 64 || fn == 32)) || (fm == 64 && fn == 64)) { bm = fm; bn = fn; }
+      if (fs >= 1 && fs <= 32) ns = fs;
+      while (ns > 1 && min_steps / ns < 3) --ns;
+    }
+  }
+  p.bm = bm; p.bn = bn; p.bk = bk; p.nsplit = ns;
+  return p;
+}
+
+extern "C" size_t hwg_conv_fwd_workspace(const hwg_conv_desc* d) {
+  if (!d || d->C % 16 != 0) return 0;
+  const ConvPlan p = plan_conv(d);
+  if (!p.mfma || p.nsplit <= 1) return 0;
+  return (size_t)p.nsplit * d->N * d->P * d->Q * d->K * sizeof(float);
+}
+
 extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
-                            int accumulate, void* stream) {
+                            int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_desc(d, "conv_fwd");
   if (rc) return rc;
   HWG_REQUIRE(x && w && y, "conv_fwd: null pointer");
@@ -578,6 +682,12 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
   }
   HWG_REQUIRE(d->C % 16 == 0, "conv_fwd: MFMA path needs C %% 16 == 0 (got C=%d); pad the channels", d->C);
 
+  const ConvPlan p = plan_conv(d);
+  const size_t need = hwg_conv_fwd_workspace(d);
+  if (need && (!workspace || workspace_bytes < need)) {
+    hwg_set_error("conv_fwd: workspace too small (%zu < %zu), size it with hwg_conv_fwd_workspace()", workspace_bytes, need);
+    return HWG_ERR_WORKSPACE;
+  }
   ConvK k;
   k.x = x; k.w = w; k.bias = bias; k.y = y;
   k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.R = d->R; k.S = d->S;
@@ -585,31 +695,12 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
   k.P = d->P; k.Q = d->Q;
   k.mode = d->transposed ? 1 : 0;
   k.accumulate = accumulate;
-  const int classes = d->transposed ? d->stride_h * d->stride_w : 1;
-  long long Mc = (long long)d->N * d->P * d->Q;
-  if (d->transposed) Mc = (long long)d->N * hwg_cdiv(d->P, d->stride_h) * hwg_cdiv(d->Q, d->stride_w);
-
-  // tile selection
-  int bn = d->K >= 96 ? 128 : (d->K > 32 ? 64 : 32);
-  int bm = 128;
-  if (bn == 128 || bn == 64) {
-    // fp32 MFMA is slow enough (64 cycles/instruction) that LDS/global traffic does not bind; what matters is having several
-    // workgroups per CU to hide load latency. Below two full waves of 128-wide tiles the 64x64 tile (4 blocks/CU) is faster
-    // (measured: 256->512 3x3 at M=8256: 76.7 vs 57.7 TFLOP/s).
-    const long long blocks = (long long)hwg_cdiv(Mc, 128) * hwg_cdiv(d->K, bn) * classes;
-    if (blocks < 512) { bm = 64; bn = 64; }
-  }
-  int bk = (d->C % 32 == 0) ? 32 : 16;
-  if (const char* f = getenv("HWG_CONV_FORCE")) {  // tuning aid: "bm,bn,bk" (ignored when the shape cannot use it)
-    int fm = 0, fn = 0, fk = 0;
-    if (sscanf(f, "%d,%d,%d", &fm, &fn, &fk) == 3) {
-      if ((fm == 128 && (fn == 128 || fn == 64 || fn == 32)) || (fm == 64 && fn == 64)) { bm = fm; bn = fn; }
-      if (fk == 16 || (fk == 32 && d->C % 32 == 0)) bk = fk;
-    }
-  }
-  k.ntm = hwg_cdiv(Mc, bm);
+  k.nsplit = p.nsplit;
+  k.part = (float*)workspace;
+  const int bm = p.bm, bn = p.bn, bk = p.bk;
+  k.ntm = hwg_cdiv(p.Mc, bm);
   k.ntm_pad = (k.ntm + 7) / 8 * 8;
-  dim3 grid(k.ntm_pad, hwg_cdiv(d->K, bn), classes);
+  dim3 grid(k.ntm_pad, hwg_cdiv(d->K, bn) * p.nsplit, p.classes);
 #define HWG_CONV_CASE(BM_, BN_, WMW, WNW)                                   \
   if (bm == BM_ && bn == BN_) {                                             \
     if (bk == 32) launch_conv<BM_, BN_, 32, WMW, WNW>(k, grid, st);         \
@@ -624,6 +715,12 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
   { hwg_set_error("conv_fwd: no tile config for bm=%d bn=%d", bm, bn); return HWG_ERR_ARG; }
 #undef HWG_CONV_CASE
   HWG_LAUNCH_CHECK("conv_fwd");
+  if (p.nsplit > 1) {
+    const long long total = (long long)d->N * d->P * d->Q * d->K;
+    hipLaunchKernelGGL(conv_split_reduce_kernel, dim3(hwg_stream_grid(total / 4 + 1, 256)), dim3(256), 0, st, (const float*)workspace, bias, y, total,
+                       d->K, p.nsplit, accumulate);
+    HWG_LAUNCH_CHECK("conv_split_reduce");
+  }
   return HWG_OK;
 }
 

@@ -185,7 +185,9 @@ def _run_conv(x, wp, bias, N, H, W, C, K, R, S, stride, pad, dil, P, Q, transpos
     d = _desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed)
     mfma = C != 1 and K > 2
     e0 = _prof_begin() if mfma else None
-    L.call("hwg_conv_fwd", ctypes.byref(d), x, wp, bias, y, 0, _stream())
+    need = L.query("hwg_conv_fwd_workspace", ctypes.byref(d))
+    ws = workspace(need, x.device) if need else None
+    L.call("hwg_conv_fwd", ctypes.byref(d), x, wp, bias, y, 0, ws, need, _stream())
     if e0 is not None:
         # algorithmic work: every output pixel x K x C x taps (transposed: every input pixel feeds RxS outputs)
         pix = N * H * W if transposed else N * P * Q

@@ -67,9 +67,12 @@ int hwg_conv_pack_weight(const float* src, float* dst, int A, int B, int Bpad, i
 
 /* y[N,P,Q,K] = gather-conv(x[N,H,W,C], w[R*S][K][C]) (+ bias[K] if bias != NULL).
  * transposed==0: standard convolution. transposed==1: conv-transpose with stride>1.
- * accumulate!=0 adds into y instead of overwriting it. */
+ * accumulate!=0 adds into y instead of overwriting it.
+ * Layers with few output pixels but a long contraction (taps x channels) are scheduled split-K: partial outputs go to the
+ * caller's workspace (hwg_conv_fwd_workspace() bytes, 0 when the schedule does not split) and are summed in a fixed order. */
+size_t hwg_conv_fwd_workspace(const hwg_conv_desc* d);
 int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
-                 int accumulate, void* stream);
+                 int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* weight gradient: dw(k,c,r,s) = sum_{n,p,q} u[n,p,q,k] * v[n, p*stride-pad+r*dil, q*stride-pad+s*dil, c]
  * written to dw[k*sa + c*sb + r*sr + s*ss] (so it lands directly in the PyTorch parameter layout).

@@ -58,7 +58,7 @@ for (name, N, H, W, C, K, R, S, stride, pad, tr) in SHAPES:
     x = torch.randn(N, H, W, C, device=dev); wp = torch.randn(R * S, K, C, device=dev) * 0.05
     y = torch.empty(N, P, Q, K, device=dev)
     d = ops._desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q, tr)
-    t = bench(lambda: L.call("hwg_conv_fwd", ctypes.byref(d), x, wp, None, y, 0, st))
+    t = bench(lambda: L.call("hwg_conv_fwd", ctypes.byref(d), x, wp, None, y, 0, None, 0, st))
     # weight gradient of the same layer: anchor = output side
     if tr:
         dw_desc = ops._desc(N, P, Q, K, C, R, S, stride, pad, dil, H, W); u, v = x, y
