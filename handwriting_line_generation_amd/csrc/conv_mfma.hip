@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
   constexpr int U_F4 = BKP * UC, V_F4 = BKP * VC;
   constexpr int U_IT = (U_F4 + NT - 1) / NT, V_IT = (V_F4 + NT - 1) / NT;
   constexpr int TILE = BKP * (BMU + BNV);
-  constexpr int RED = (WAVES_K > 1) ? WAVES_K * MI * NI * 16 * 64 : 0;
+  constexpr int RED = (WAVES_K > 1) ? WAVES_K * WAVES_M * WAVES_N * MI * NI * 16 * 64 : 0;
   constexpr int SM = (2 * TILE > RED) ? 2 * TILE : RED;
   __shared__ __attribute__((aligned(16))) float smem[SM];
   float* Us = smem;              // [2][BKP][BMU]
@@ -349,6 +349,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
 
   float4 ru[U_IT], rv[V_IT];
   int pbase = pb;  // first pixel of the tile being loaded
+  // (n, p, q) of the pixel each V load slot reads, advanced incrementally (BKP pixels per step) instead of two integer divisions per load
+  int v_q[V_IT], v_p[V_IT], v_n[V_IT];
+#pragma unroll
+  for (int it = 0; it < V_IT; ++it) {
+    const int m = pb + v_kp[it];
+    v_q[it] = m % a.Q;
+    const int t = m / a.Q;
+    v_p[it] = t % a.P;
+    v_n[it] = t / a.P;
+  }
+  const bool one_wrap = a.Q >= BKP;
   auto load_tile = [&]() {
 #pragma unroll
     for (int it = 0; it < U_IT; ++it) {
@@ -362,16 +373,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
       const int m = pbase + v_kp[it];
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
       if (v_ok[it] && m < pe) {
-        const int q = m % a.Q;
-        const int t = m / a.Q;
-        const int p = t % a.P;
-        const int n = t / a.P;
-        const int ih = p * a.sh - a.ph + r * a.dh;
-        const int iw = q * a.sw - a.pw + s * a.dw;
+        const int ih = v_p[it] * a.sh - a.ph + r * a.dh;
+        const int iw = v_q[it] * a.sw - a.pw + s * a.dw;
         if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
-          val = *reinterpret_cast<const float4*>(a.v + (((long long)n * a.H + ih) * a.W + iw) * a.C + c0 + v_c4[it] * 4);
+          val = *reinterpret_cast<const float4*>(a.v + (((long long)v_n[it] * a.H + ih) * a.W + iw) * a.C + c0 + v_c4[it] * 4);
       }
       rv[it] = val;
+      if (one_wrap) {
+        v_q[it] += BKP;
+        if (v_q[it] >= a.Q) {
+          v_q[it] -= a.Q;
+          if (++v_p[it] >= a.P) { v_p[it] = 0; ++v_n[it]; }
+        }
+      } else {
+        const int m2 = m + BKP;
+        v_q[it] = m2 % a.Q;
+        const int t2 = m2 / a.Q;
+        v_p[it] = t2 % a.P;
+        v_n[it] = t2 / a.P;
+      }
     }
     pbase += BKP;
   };
@@ -387,16 +407,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
   };
 
   const int T = (pe > pb) ? (pe - pb + BKP - 1) / BKP : 0;
-  int wm0, wn0, kbeg, kend;
-  if (WAVES_K == 1) {
-    wm0 = (wid / WAVES_N) * WM;
-    wn0 = (wid % WAVES_N) * WN;
-    kbeg = 0; kend = BKP;
-  } else {
-    wm0 = 0; wn0 = 0;
-    kbeg = wid * (BKP / WAVES_K);
-    kend = kbeg + BKP / WAVES_K;
-  }
+  // wave -> (K slice, M sub-tile, N sub-tile)
+  constexpr int WMN = WAVES_M * WAVES_N;
+  const int wk = wid / WMN, wmn = wid % WMN;
+  const int wm0 = (wmn / WAVES_N) * WM;
+  const int wn0 = (wmn % WAVES_N) * WN;
+  const int kbeg = wk * (BKP / WAVES_K);
+  const int kend = kbeg + BKP / WAVES_K;
   const int l31 = lane & 31, lhi = lane >> 5;
 
   if (T > 0) { load_tile(); store_tile(0); }
@@ -434,7 +451,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
 #pragma unroll
         for (int e = 0; e < 16; ++e) red[((wid * MI * NI + mi * NI + ni) * 16 + e) * 64 + lane] = acc[mi][ni][e];
     __syncthreads();
-    if (wid != 0) return;
+    if (wk != 0) return;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -442,7 +459,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           float sacc = 0.f;
-          for (int w = 0; w < WAVES_K; ++w) sacc += red[((w * MI * NI + mi * NI + ni) * 16 + e) * 64 + lane];
+          for (int w = 0; w < WAVES_K; ++w) sacc += red[(((w * WMN + wmn) * MI * NI + mi * NI + ni) * 16 + e) * 64 + lane];
           acc[mi][ni][e] = sacc;
         }
   }
@@ -548,17 +565,7 @@ struct WgPlan {
   int bmu, bnv, bkp;
   int tiles_u, tiles_v, nsplit, chunk;
 };
-WgPlan plan_wgrad(const hwg_conv_desc* d) {
-  WgPlan p;
-  const int K = d->K, C = d->C;
-  if (K >= 128 && C >= 128) { p.cfg = 0; p.bmu = 128; p.bnv = 128; p.bkp = 16; }
-  else if (K > 32 || C > 32) { p.cfg = 1; p.bmu = 64; p.bnv = 64; p.bkp = 32; }
-  else { p.cfg = 2; p.bmu = 32; p.bnv = 32; p.bkp = 32; }
-  p.tiles_u = hwg_cdiv(K, p.bmu);
-  p.tiles_v = hwg_cdiv(C, p.bnv);
-  const long long Mtot = (long long)d->N * d->P * d->Q;
-  const long long base = (long long)d->R * d->S * p.tiles_u * p.tiles_v;
-  long long ns = (1024 + base - 1) / base;
+static void wg_split(WgPlan& p, long long Mtot, long long ns) {
   const long long max_ns = (Mtot + 4LL * p.bkp - 1) / (4LL * p.bkp);  // at least 4 k-steps per split
   if (ns > max_ns) ns = max_ns;
   if (ns < 1) ns = 1;
@@ -568,7 +575,60 @@ WgPlan plan_wgrad(const hwg_conv_desc* d) {
   if (ns < 1) ns = 1;
   p.nsplit = (int)ns;
   p.chunk = (int)chunk;
-  return p;
+}
+static void wg_tile(WgPlan& p, int cfg, int K, int C) {
+  p.cfg = cfg;
+  if (cfg == 0) { p.bmu = 128; p.bnv = 128; p.bkp = 32; }
+  else if (cfg == 1) { p.bmu = 64; p.bnv = 64; p.bkp = 32; }
+  else { p.bmu = 32; p.bnv = 32; p.bkp = 32; }
+  p.tiles_u = hwg_cdiv(K, p.bmu);
+  p.tiles_v = hwg_cdiv(C, p.bnv);
+}
+// Schedule = (tile, number of pixel chunks) with the smallest modelled time; same quantum model as plan_conv (parameters fitted with
+// tools/wgrad_model_fit.py): ceil(blocks/256) workgroup quanta of (K steps + overhead) steps each, plus the pass that sums the per-chunk
+// partial weight images.
+WgPlan plan_wgrad(const hwg_conv_desc* d) {
+  WgPlan p;
+  const int K = d->K, C = d->C;
+  const long long Mtot = (long long)d->N * d->P * d->Q;
+  if (K <= 32 && C <= 32) {
+    wg_tile(p, 2, K, C);
+    const long long base = (long long)d->R * d->S * p.tiles_u * p.tiles_v;
+    wg_split(p, Mtot, (1024 + base - 1) / base);
+    return p;
+  }
+  if (const char* f = getenv("HWG_WGRAD_FORCE")) {  // tuning aid: "cfg,target_blocks"
+    int fc = -1, ft = 0;
+    if (sscanf(f, "%d,%d", &fc, &ft) == 2 && ft > 0 && (fc == 1 || (fc == 0 && K >= 128 && C >= 128))) {
+      wg_tile(p, fc, K, C);
+      const long long base = (long long)d->R * d->S * p.tiles_u * p.tiles_v;
+      wg_split(p, Mtot, (ft + base - 1) / base);
+      return p;
+    }
+  }
+  static const int splits[14] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
+  static const double tflops[2] = {100.0, 90.0}, overhead[2] = {1.0, 2.0};
+  const double wbytes = 4.0 * d->R * d->S * K * C;
+  double best = 1e30;
+  WgPlan bp = p;
+  for (int cfg = (K >= 128 && C >= 128) ? 0 : 1; cfg <= 1; ++cfg) {
+    WgPlan c;
+    wg_tile(c, cfg, K, C);
+    const double base = (double)d->R * d->S * c.tiles_u * c.tiles_v;
+    const double step_s = 2.0 * c.bmu * c.bnv * c.bkp / (tflops[cfg] * 1e12 / 256.0);
+    int last_ns = 0;
+    for (int si = 0; si < 14; ++si) {
+      wg_split(c, Mtot, splits[si]);
+      if (c.nsplit == last_ns) continue;
+      last_ns = c.nsplit;
+      if (wbytes * c.nsplit > 2.0e9) break;
+      const double q = base * c.nsplit / 256.0;
+      const double quanta = q <= 8.0 ? ceil(q) : q + 0.5;
+      const double tm = quanta * ((double)c.chunk / c.bkp + overhead[cfg]) * step_s + (c.nsplit + 1) * wbytes / 3.0e12 + 3e-6;
+      if (tm < best) { best = tm; bp = c; }
+    }
+  }
+  return bp;
 }
 
 }  // namespace
@@ -701,6 +761,9 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
   k.ntm = hwg_cdiv(p.Mc, bm);
   k.ntm_pad = (k.ntm + 7) / 8 * 8;
   dim3 grid(k.ntm_pad, hwg_cdiv(d->K, bn) * p.nsplit, p.classes);
+  // algorithmic work: every output pixel x K x C x taps (transposed: every input pixel feeds RxS outputs)
+  const double pix = d->transposed ? (double)d->N * d->H * d->W : (double)d->N * d->P * d->Q;
+  const int prof = hwg_prof_open(HWG_PROF_CONV, 2.0 * pix * d->K * d->C * d->R * d->S, st);
 #define HWG_CONV_CASE(BM_, BN_, WMW, WNW)                                   \
   if (bm == BM_ && bn == BN_) {                                             \
     if (bk == 32) launch_conv<BM_, BN_, 32, WMW, WNW>(k, grid, st);         \
@@ -714,11 +777,14 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
   HWG_CONV_CASE(64, 64, 2, 2)
   { hwg_set_error("conv_fwd: no tile config for bm=%d bn=%d", bm, bn); return HWG_ERR_ARG; }
 #undef HWG_CONV_CASE
+  hwg_prof_close(prof, st);
   HWG_LAUNCH_CHECK("conv_fwd");
   if (p.nsplit > 1) {
     const long long total = (long long)d->N * d->P * d->Q * d->K;
+    const int prof2 = hwg_prof_open(HWG_PROF_CONV_REDUCE, 4.0 * total * (p.nsplit + 1), st);
     hipLaunchKernelGGL(conv_split_reduce_kernel, dim3(hwg_stream_grid(total / 4 + 1, 256)), dim3(256), 0, st, (const float*)workspace, bias, y, total,
                        d->K, p.nsplit, accumulate);
+    hwg_prof_close(prof2, st);
     HWG_LAUNCH_CHECK("conv_split_reduce");
   }
   return HWG_OK;
@@ -757,13 +823,19 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
   k.chunk = p.chunk;
   k.tiles_v = p.tiles_v;
   dim3 grid(p.nsplit, p.tiles_u * p.tiles_v, d->R * d->S);
-  if (p.cfg == 0) hipLaunchKernelGGL((wgrad_mfma_kernel<128, 128, 16, 2, 4, 1>), grid, dim3(512), 0, st, k);   // 8 waves: +2 % over 4
-  else if (p.cfg == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<64, 64, 32, 2, 2, 1>), grid, dim3(256), 0, st, k);
+  const int prof = hwg_prof_open(HWG_PROF_WGRAD, 2.0 * k.Mtot * d->K * d->C * d->R * d->S, st);
+  // 16 waves and 32-pixel K steps on the big tile: +10 % over 8 waves x 16 pixels (331 -> 299 us on 512x512x3x3 at 6096 pixels)
+  if (p.cfg == 0) hipLaunchKernelGGL((wgrad_mfma_kernel<128, 128, 32, 4, 4, 1>), grid, dim3(1024), 0, st, k);
+  // 64x64: two wave groups split every 32-pixel K step between them (8 waves; 5..10 % over 4 waves on every measured shape)
+  else if (p.cfg == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<64, 64, 32, 2, 2, 2>), grid, dim3(512), 0, st, k);
   else hipLaunchKernelGGL((wgrad_mfma_kernel<32, 32, 32, 1, 1, 4>), grid, dim3(256), 0, st, k);
+  hwg_prof_close(prof, st);
   HWG_LAUNCH_CHECK("conv_wgrad");
   const long long total = (long long)d->R * d->S * d->K * d->C;
+  const int prof2 = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, 4.0 * total * (p.nsplit + 1), st);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
                      p.nsplit, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate);
+  hwg_prof_close(prof2, st);
   HWG_LAUNCH_CHECK("conv_wgrad_reduce");
   return HWG_OK;
 }

@@ -12,9 +12,71 @@ void hwg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* hwg_last_error(void) { return g_err; }
-extern "C" int hwg_abi_version(void) { return 1; }
+extern "C" int hwg_abi_version(void) { return 2; }
 extern "C" int hwg_device_ok(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n > 0 ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Launch profiler: HIP event pairs recorded immediately around the matrix-core kernel launches, on the stream they are launched
+// on (bench.py's roofline measurement). Recording them here instead of from Python keeps host time between "event" and "launch"
+// out of the measured duration. Off by default; never synchronises except in hwg_prof_stop().
+#include <atomic>
+namespace {
+struct ProfRec { hipEvent_t e0, e1; int kind, tag; double work; };
+ProfRec* g_prof = nullptr;
+int g_prof_cap = 0;
+std::atomic<int> g_prof_n{0};
+std::atomic<int> g_prof_on{0};
+thread_local int g_prof_tag = -1;
+}  // namespace
+
+int hwg_prof_open(int kind, double work, hipStream_t st) {
+  if (!g_prof_on.load(std::memory_order_relaxed)) return -1;
+  const int i = g_prof_n.fetch_add(1);
+  if (i >= g_prof_cap) return -1;
+  g_prof[i].kind = kind; g_prof[i].tag = g_prof_tag; g_prof[i].work = work;
+  (void)hipEventRecord(g_prof[i].e0, st);
+  return i;
+}
+void hwg_prof_close(int i, hipStream_t st) {
+  if (i >= 0) (void)hipEventRecord(g_prof[i].e1, st);
+}
+
+extern "C" int hwg_prof_start(int max_records) {
+  HWG_REQUIRE(max_records > 0 && !g_prof_on.load(), "prof_start: bad capacity or already running");
+  g_prof = new ProfRec[max_records];
+  for (int i = 0; i < max_records; ++i) {
+    if (hipEventCreate(&g_prof[i].e0) != hipSuccess || hipEventCreate(&g_prof[i].e1) != hipSuccess) {
+      hwg_set_error("prof_start: hipEventCreate failed");
+      return HWG_ERR_LAUNCH;
+    }
+  }
+  g_prof_cap = max_records;
+  g_prof_n.store(0);
+  g_prof_on.store(1);
+  return HWG_OK;
+}
+extern "C" int hwg_prof_tag(int tag) { g_prof_tag = tag; return HWG_OK; }
+extern "C" int hwg_prof_stop(int* kinds, int* tags, double* work, float* ms, int capacity) {
+  if (!g_prof) return 0;
+  g_prof_on.store(0);
+  int n = g_prof_n.load();
+  if (n > g_prof_cap) n = g_prof_cap;
+  int out = 0;
+  for (int i = 0; i < n; ++i) {
+    float t = 0.f;
+    (void)hipEventSynchronize(g_prof[i].e1);
+    if (hipEventElapsedTime(&t, g_prof[i].e0, g_prof[i].e1) != hipSuccess) continue;
+    if (out < capacity && kinds && tags && work && ms) {
+      kinds[out] = g_prof[i].kind; tags[out] = g_prof[i].tag; work[out] = g_prof[i].work; ms[out] = t;
+    }
+    ++out;
+  }
+  for (int i = 0; i < g_prof_cap; ++i) { (void)hipEventDestroy(g_prof[i].e0); (void)hipEventDestroy(g_prof[i].e1); }
+  delete[] g_prof;
+  g_prof = nullptr; g_prof_cap = 0; g_prof_n.store(0);
+  return out < capacity ? out : capacity;
 }

@@ -160,38 +160,46 @@ def _pad_channels(x, Cpad):
     return out
 
 
-# Optional per-launch timing of the MFMA conv kernels (bench.py's roofline measurement): when CONV_PROF is a list every MFMA
-# launch appends (kind, flops, start_event, end_event); events are recorded on the launch stream.
-CONV_PROF = None
+# Per-launch timing of the MFMA conv kernels (bench.py's roofline measurement) is done inside the library (hwg_prof_*: HIP events
+# recorded right around the launches). Here we only label the launches with their layer shape when a profile is running.
+PROF_SHAPES = None     # None, or {shape tuple: tag}
 
 
-def _prof_begin():
-    if CONV_PROF is None:
-        return None
-    e = torch.cuda.Event(enable_timing=True)
-    e.record()
-    return e
+def prof_start(max_records=200000):
+    global PROF_SHAPES
+    PROF_SHAPES = {}
+    L.call("hwg_prof_start", max_records)
 
 
-def _prof_end(kind, flops, e0, shape=None):
-    if e0 is not None:
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
-        CONV_PROF.append((kind, flops, e0, e1, shape))
+def prof_stop():
+    """-> list of (kind, shape, work, seconds); kind in conv_mfma_kernel / wgrad_mfma_kernel / conv_split_reduce / wgrad_reduce"""
+    global PROF_SHAPES
+    import numpy as np
+    cap = 200000
+    kinds = np.zeros(cap, dtype=np.int32); tags = np.zeros(cap, dtype=np.int32)
+    work = np.zeros(cap, dtype=np.float64); ms = np.zeros(cap, dtype=np.float32)
+    n = L.query("hwg_prof_stop", kinds.ctypes.data, tags.ctypes.data, work.ctypes.data, ms.ctypes.data, cap)
+    by_tag = {v: k for k, v in (PROF_SHAPES or {}).items()}
+    PROF_SHAPES = None
+    names = ("conv_mfma_kernel", "wgrad_mfma_kernel", "conv_split_reduce_kernel", "wgrad_reduce_kernel")
+    return [(names[kinds[i]], by_tag.get(int(tags[i])), float(work[i]), float(ms[i]) * 1e-3) for i in range(n)]
+
+
+def _prof_tag(shape):
+    tag = PROF_SHAPES.get(shape)
+    if tag is None:
+        tag = PROF_SHAPES[shape] = len(PROF_SHAPES)
+    L.call("hwg_prof_tag", tag)
 
 
 def _run_conv(x, wp, bias, N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed):
     y = torch.empty((N, P, Q, K), dtype=torch.float32, device=x.device)
     d = _desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed)
-    mfma = C != 1 and K > 2
-    e0 = _prof_begin() if mfma else None
+    if PROF_SHAPES is not None:
+        _prof_tag((N, H, W, C, K, R, S, stride, pad, dil, transposed))
     need = L.query("hwg_conv_fwd_workspace", ctypes.byref(d))
     ws = workspace(need, x.device) if need else None
     L.call("hwg_conv_fwd", ctypes.byref(d), x, wp, bias, y, 0, ws, need, _stream())
-    if e0 is not None:
-        # algorithmic work: every output pixel x K x C x taps (transposed: every input pixel feeds RxS outputs)
-        pix = N * H * W if transposed else N * P * Q
-        _prof_end("conv_mfma_kernel", 2.0 * pix * K * C * R * S, e0, (N, H, W, C, K, R, S, stride, pad, dil, transposed))
     return y
 
 
@@ -293,6 +301,8 @@ class _Conv2d(Function):
                 tmp = torch.empty((Kq, Cq, R, S), dtype=torch.float32, device=x.device)
                 need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
                 ws = workspace(need, x.device)
+                if PROF_SHAPES is not None:
+                    _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad"))
                 L.call("hwg_conv_wgrad", ctypes.byref(d), up, vp, tmp, Cq * R * S, R * S, S, 1, 0, ws, ws.numel(), st)
                 valid = tmp[:dK, :dC]
                 if direct:
@@ -303,9 +313,9 @@ class _Conv2d(Function):
             else:
                 need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
                 ws = workspace(need, x.device)
-                e0 = _prof_begin() if (d.K > 2 and d.C > 2) else None
+                if PROF_SHAPES is not None:
+                    _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad"))
                 L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 1 if direct else 0, ws, ws.numel(), st)
-                _prof_end("wgrad_mfma_kernel", 2.0 * d.N * d.P * d.Q * d.K * d.C * R * S, e0, (d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad"))
                 if direct:
                     dw_ = None
         if ctx.has_bias and ctx.needs_input_grad[2]:

@@ -38,6 +38,15 @@ int hwg_abi_version(void);
 /* 1 when a HIP device is present and usable */
 int hwg_device_ok(void);
 
+/* Launch profiler for the matrix-core kernels (bench.py's roofline measurement): between hwg_prof_start() and hwg_prof_stop() every
+ * MFMA convolution / weight-gradient launch (and their reduce passes) is bracketed by a HIP event pair on its stream. hwg_prof_tag()
+ * labels the launches of the calling thread's next calls. hwg_prof_stop() waits for the recorded events and returns, per launch,
+ * kind (0 conv, 1 wgrad, 2 conv split reduce, 3 wgrad reduce), tag, algorithmic work (flops; bytes for the reduce passes) and ms.
+ * Returns the number of records written. */
+int hwg_prof_start(int max_records);
+int hwg_prof_tag(int tag);
+int hwg_prof_stop(int* kinds, int* tags, double* work, float* ms, int capacity);
+
 /* activation codes used by fused epilogues */
 enum { HWG_ACT_NONE = 0, HWG_ACT_RELU = 1, HWG_ACT_LRELU = 2, HWG_ACT_TANH = 3 };
 
