@@ -297,7 +297,9 @@ struct WgK {
   int Mtot, chunk, tiles_v;
 };
 
-template <int BMU, int BNV, int BKP, int WAVES_M, int WAVES_N, int WAVES_K>
+// TAPN: single-channel gathered tensor (C == 1, first layers): the GEMM's N dimension is the taps (<= BNV) instead of C, so one
+// workgroup produces dw[k][all taps] for its pixel chunk from an im2col tile built on the fly (v loads are scalar, L1/L2 resident).
+template <int BMU, int BNV, int BKP, int WAVES_M, int WAVES_N, int WAVES_K, bool TAPN = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_kernel(WgK a) {
   constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
   constexpr int WM = BMU / WAVES_M, WN = BNV / WAVES_N;
@@ -313,8 +315,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
   float* Vs = smem + 2 * BKP * BMU;  // [2][BKP][BNV]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int tap = blockIdx.z;
+  const int tap = TAPN ? 0 : blockIdx.z;
   const int r = tap / a.S, s = tap % a.S;
+  const int RS = a.R * a.S;
   const int tu = blockIdx.y / a.tiles_v, tv = blockIdx.y % a.tiles_v;
   const int k0 = tu * BMU, c0 = tv * BNV;
   const int pb = blockIdx.x * a.chunk;
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
     const int f = tid + it * NT;
     v_kp[it] = f / VC;
     v_c4[it] = f % VC;
-    v_ok[it] = (f < V_F4) && (c0 + v_c4[it] * 4 < a.C);
+    v_ok[it] = (f < V_F4) && (c0 + v_c4[it] * 4 < (TAPN ? RS : a.C));
   }
 
   f32x16 acc[MI][NI];
@@ -373,10 +376,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
       const int m = pbase + v_kp[it];
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
       if (v_ok[it] && m < pe) {
-        const int ih = v_p[it] * a.sh - a.ph + r * a.dh;
-        const int iw = v_q[it] * a.sw - a.pw + s * a.dw;
-        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
-          val = *reinterpret_cast<const float4*>(a.v + (((long long)v_n[it] * a.H + ih) * a.W + iw) * a.C + c0 + v_c4[it] * 4);
+        if (TAPN) {
+          float e[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int tp = c0 + v_c4[it] * 4 + j;
+            const int rr = tp / a.S, ss = tp - rr * a.S;
+            const int ih = v_p[it] * a.sh - a.ph + rr * a.dh;
+            const int iw = v_q[it] * a.sw - a.pw + ss * a.dw;
+            const bool ok = tp < RS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+            e[j] = ok ? a.v[((long long)v_n[it] * a.H + ih) * a.W + iw] : 0.f;
+          }
+          val = make_float4(e[0], e[1], e[2], e[3]);
+        } else {
+          const int ih = v_p[it] * a.sh - a.ph + r * a.dh;
+          const int iw = v_q[it] * a.sw - a.pw + s * a.dw;
+          if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+            val = *reinterpret_cast<const float4*>(a.v + (((long long)v_n[it] * a.H + ih) * a.W + iw) * a.C + c0 + v_c4[it] * 4);
+        }
       }
       rv[it] = val;
       if (one_wrap) {
@@ -474,7 +491,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int c = c0 + wn0 + ni * 32 + l31;
-        if (c < a.C) pout[(long long)k * a.C + c] = acc[mi][ni][e];
+        if (TAPN) {
+          if (c < RS) pout[(long long)c * a.K + k] = acc[mi][ni][e];   // part layout [tap][K][C=1]
+        } else {
+          if (c < a.C) pout[(long long)k * a.C + c] = acc[mi][ni][e];
+        }
       }
     }
 }
@@ -491,6 +512,34 @@ __global__ void wgrad_reduce_kernel(const float* part, float* dw, int nsplit, in
     for (int sp = 0; sp < nsplit; ++sp) sum += part[(long long)sp * total + i];
     const long long o = k * sa + c * sb + (tap / S) * sr + (tap % S) * ss;
     dw[o] = accumulate ? dw[o] + sum : sum;
+  }
+}
+
+// same sum with SL "split lanes" per output: used when there are few outputs and many partial images (thread t of a workgroup owns
+// output t % OUT and partials t / OUT, t / OUT + SL, ...; the lanes are combined through LDS in lane order, so still deterministic)
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_lanes_kernel(const float* part, float* dw, int nsplit, int RS, int S, int K, int C,
+                                                                 long long sa, long long sb, long long sr, long long ss, int accumulate) {
+  constexpr int OUT = 256 / SL;
+  __shared__ float red[SL][OUT];
+  const long long total = (long long)RS * K * C;
+  const int ol = threadIdx.x % OUT, lane = threadIdx.x / OUT;
+  const long long i = (long long)blockIdx.x * OUT + ol;
+  float sum = 0.f;
+  if (i < total)
+    for (int sp = lane; sp < nsplit; sp += SL) sum += part[(long long)sp * total + i];
+  red[lane][ol] = sum;
+  __syncthreads();
+  if (lane == 0 && i < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < SL; ++l) t += red[l][ol];
+    const int c = (int)(i % C);
+    const long long q = i / C;
+    const int k = (int)(q % K);
+    const int tap = (int)(q / K);
+    const long long o = k * sa + c * sb + (tap / S) * sr + (tap % S) * ss;
+    dw[o] = accumulate ? dw[o] + t : t;
   }
 }
 
@@ -790,12 +839,21 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
   return HWG_OK;
 }
 
-static bool wgrad_is_direct(const hwg_conv_desc* d) { return d->K <= 2 || d->C <= 2; }
+// C == 1 with at most 64 taps: taps-as-N MFMA kernel; other single/double channel ends: direct kernels (conv_direct.hip)
+static bool wgrad_is_tapn(const hwg_conv_desc* d) { return d->C == 1 && d->K > 2 && d->K % 4 == 0 && d->R * d->S <= 64; }
+static bool wgrad_is_direct(const hwg_conv_desc* d) { return (d->K <= 2 || d->C <= 2) && !wgrad_is_tapn(d); }
+static WgPlan plan_wgrad_tapn(const hwg_conv_desc* d) {
+  WgPlan p;
+  p.cfg = 3; p.bmu = 64; p.bnv = 64; p.bkp = 32;
+  p.tiles_u = hwg_cdiv(d->K, 64); p.tiles_v = 1;
+  wg_split(p, (long long)d->N * d->P * d->Q, hwg_cdiv(1024, p.tiles_u));
+  return p;
+}
 
 extern "C" size_t hwg_conv_wgrad_workspace(const hwg_conv_desc* d) {
   if (!d) return 0;
   if (wgrad_is_direct(d)) return hwg_conv_wgrad_direct_workspace(d);
-  WgPlan p = plan_wgrad(d);
+  WgPlan p = wgrad_is_tapn(d) ? plan_wgrad_tapn(d) : plan_wgrad(d);
   return (size_t)p.nsplit * d->R * d->S * d->K * d->C * sizeof(float);
 }
 
@@ -807,13 +865,14 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
   HWG_REQUIRE(u && v && dw, "conv_wgrad: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (wgrad_is_direct(d)) return hwg_conv_wgrad_direct_impl(d, u, v, dw, sa, sb, sr, ss, accumulate, workspace, workspace_bytes, st);
-  HWG_REQUIRE(d->K % 4 == 0 && d->C % 4 == 0, "conv_wgrad: channels must be multiples of 4 (K=%d C=%d)", d->K, d->C);
+  const bool tapn = wgrad_is_tapn(d);
+  HWG_REQUIRE(d->K % 4 == 0 && (tapn || d->C % 4 == 0), "conv_wgrad: channels must be multiples of 4 (K=%d C=%d)", d->K, d->C);
   const size_t need = hwg_conv_wgrad_workspace(d);
   if (!workspace || workspace_bytes < need) {
     hwg_set_error("conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     return HWG_ERR_WORKSPACE;
   }
-  WgPlan p = plan_wgrad(d);
+  WgPlan p = tapn ? plan_wgrad_tapn(d) : plan_wgrad(d);
   WgK k;
   k.u = u; k.v = v; k.part = (float*)workspace;
   k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.R = d->R; k.S = d->S;
@@ -822,19 +881,27 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
   k.Mtot = d->N * d->P * d->Q;
   k.chunk = p.chunk;
   k.tiles_v = p.tiles_v;
-  dim3 grid(p.nsplit, p.tiles_u * p.tiles_v, d->R * d->S);
+  dim3 grid(p.nsplit, p.tiles_u * p.tiles_v, tapn ? 1 : d->R * d->S);
   const int prof = hwg_prof_open(HWG_PROF_WGRAD, 2.0 * k.Mtot * d->K * d->C * d->R * d->S, st);
   // 16 waves and 32-pixel K steps on the big tile: +10 % over 8 waves x 16 pixels (331 -> 299 us on 512x512x3x3 at 6096 pixels)
   if (p.cfg == 0) hipLaunchKernelGGL((wgrad_mfma_kernel<128, 128, 32, 4, 4, 1>), grid, dim3(1024), 0, st, k);
   // 64x64: two wave groups split every 32-pixel K step between them (8 waves; 5..10 % over 4 waves on every measured shape)
   else if (p.cfg == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<64, 64, 32, 2, 2, 2>), grid, dim3(512), 0, st, k);
+  else if (p.cfg == 3) hipLaunchKernelGGL((wgrad_mfma_kernel<64, 64, 32, 2, 2, 2, true>), grid, dim3(512), 0, st, k);
   else hipLaunchKernelGGL((wgrad_mfma_kernel<32, 32, 32, 1, 1, 4>), grid, dim3(256), 0, st, k);
   hwg_prof_close(prof, st);
   HWG_LAUNCH_CHECK("conv_wgrad");
   const long long total = (long long)d->R * d->S * d->K * d->C;
   const int prof2 = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, 4.0 * total * (p.nsplit + 1), st);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
-                     p.nsplit, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate);
+  if (p.nsplit >= 64 && total <= 65536)
+    hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<32>, dim3(hwg_cdiv(total, 8)), dim3(256), 0, st, (const float*)workspace, dw, p.nsplit, d->R * d->S, d->S,
+                       d->K, d->C, sa, sb, sr, ss, accumulate);
+  else if (p.nsplit >= 8 && total <= 262144)
+    hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<4>, dim3(hwg_cdiv(total, 64)), dim3(256), 0, st, (const float*)workspace, dw, p.nsplit, d->R * d->S, d->S,
+                       d->K, d->C, sa, sb, sr, ss, accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
+                       p.nsplit, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate);
   hwg_prof_close(prof2, st);
   HWG_LAUNCH_CHECK("conv_wgrad_reduce");
   return HWG_OK;

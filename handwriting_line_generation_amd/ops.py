@@ -291,7 +291,9 @@ class _Conv2d(Function):
             # single-channel ends (C == 1 first layers, K <= 2 heads) have a direct kernel; on large images the MFMA kernel on a
             # 4-channel zero-padded copy is faster (measured 164 vs 390 us for the 7x7 first layer of D), so only small ones stay direct
             tiny_end = (d.K <= 2 or d.C <= 2) and d.N * d.P * d.Q < 8192
-            if (Kq != d.K or Cq != d.C) and not tiny_end:
+            # single gathered channel (first layers): the library runs the taps as the GEMM's N dimension, no padding needed
+            tap_gemm = d.C == 1 and d.K > 2 and d.K % 4 == 0 and R * S <= 64
+            if (Kq != d.K or Cq != d.C) and not tiny_end and not tap_gemm:
                 # channel counts that are not multiples of 4 (RIMES: 78 classes -> 206/334-channel inputs, 78 outputs): run the kernel
                 # on zero-padded copies and keep the valid block of the result
                 dK, dC = d.K, d.C

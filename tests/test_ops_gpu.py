@@ -40,6 +40,8 @@ CONV_CASES = [
     ("k63_5x5", 1, 9, 20, 16, 48, 5, 5, (1, 1), (2, 2), (1, 1), False),
     ("c1_7x7", 2, 20, 50, 1, 64, 7, 7, (1, 1), (0, 3), (1, 1), False),
     ("c1_5x5", 2, 16, 40, 1, 32, 5, 5, (1, 1), (2, 2), (1, 1), False),
+    ("c1_7x7_many_chunks", 4, 64, 256, 1, 64, 7, 7, (1, 1), (0, 3), (1, 1), False),
+    ("c1_4x4_s2_k80", 2, 33, 70, 1, 80, 4, 4, (2, 2), (1, 1), (1, 1), False),
     ("c1_3x3", 2, 16, 41, 1, 64, 3, 3, (1, 1), (1, 1), (1, 1), False),
     ("to1_3x3", 3, 3, 20, 256, 1, 3, 3, (1, 1), (0, 1), (1, 1), False),
     ("to1_1x1", 3, 1, 20, 256, 1, 1, 1, (1, 1), (0, 0), (1, 1), False),
