@@ -1,167 +1,211 @@
-// Grouped ("one expert per sample") 1-D convolutions / linears for the 79 character-style experts
+// Grouped ("one expert per window") 1-D convolutions / linears for the 79 character-style experts
 // (model/char_style.py:84-124, 210-235). The reference runs one tiny network per recognised character in a Python loop;
-// here all windows of all characters go through each layer in ONE launch, every window reading the weights of its own
-// expert through a device pointer table. These layers are bound by streaming the experts' weights (1.45 MB per expert) from
-// L2/HBM, not by FLOPs (1.4 MMAC per window), so they are written as coalesced weight-streaming kernels, not GEMMs.
+// here all windows of all characters go through each layer in ONE launch. Windows are sorted by expert, so every run of windows
+// is a small GEMM against that expert's weights (read through a device pointer table):
+//   forward        Y[rows, Cout]   = Xunf[rows, Cin*S] * W^T      rows = windows of the run x R positions
+//   data gradient  dX[rows, Cin]   = dYunf[rows, Cout*S] * W
+//   weight grad    dW[Cout, Cin*S] += dY^T[Cout, rows] * Xunf
+// on the fp32 matrix cores (v_mfma_f32_32x32x2_f32). The layers are bound by streaming the present experts' weights once
+// (1.45 MB per expert), not by FLOPs; the work list is (run, 64-row tile) so that one frequent character does not serialise a launch.
 //
 // Layouts: x [n][R][Cin], y [n][R][Cout] (R positions, channels fastest); weights in the PyTorch Conv1d layout [Cout][Cin][S]
-// (nn.Linear [Cout][Cin] is S = 1, R = 1). Windows are sorted by expert; seg_start/seg_eid describe the runs.
+// (nn.Linear [Cout][Cin] is S = 1, R = 1). seg_start[G+1]/seg_eid[G] describe the runs, tile_seg/tile_row0 the row tiles.
 #include "hwg_common.h"
 
 namespace {
 
-constexpr int MAXR = 8;  // positions per window (5 for window=2)
+constexpr int MAXR = 8;      // positions per window (5 for window=2)
+constexpr int GT_ROWS = 64;  // rows per work tile (two 32-row MFMA tiles)
+constexpr int GT_CK = 64;    // channels of the LDS-staged operand per step
 
-// y[i][p][co] = b[co] + sum_{ci,s} x[i][p+s-pad][ci] * W[co][ci][s]; one wave per (window, output channel), lanes sweep (ci,s)
-__global__ __launch_bounds__(256) void gconv_fwd_kernel(const float* x, const int* eid, const long long* wptr, const long long* bptr, float* y,
-                                                        int n, int R, int Cin, int Cout, int S, int pad, int co_per_block) {
-  extern __shared__ float xs[];  // [R][Cin]
-  const int i = blockIdx.x;
-  const int e = eid[i];
-  const float* W = reinterpret_cast<const float*>(wptr[e]);
+// ---- forward: D[m = row][n = co]; A = shifted x rows from LDS, B = W rows straight from global (16-byte loads along (ci,s)) ----
+// block = 4 waves, wave w owns output channels [co_blk + 32 w, +32) and both 32-row tiles of the work tile.
+template <int S>
+__global__ __launch_bounds__(256) void gmm_fwd_kernel(const float* __restrict__ x, const int* seg_start, const int* seg_eid, const int* tile_seg,
+                                                      const int* tile_row0, const long long* wptr, const long long* bptr, float* __restrict__ y,
+                                                      int R, int Cin, int Cout, int pad) {
+  constexpr int LD = GT_CK + 1;
+  __shared__ float xs[(GT_ROWS + 2 * (S / 2)) * LD];
+  const int g = tile_seg[blockIdx.x], rc0 = tile_row0[blockIdx.x];
+  const int i0 = seg_start[g];
+  const int nrows = (seg_start[g + 1] - i0) * R;
+  const int e = seg_eid[g];
+  const float* __restrict__ W = reinterpret_cast<const float*>(wptr[e]);
   const float* bias = bptr ? reinterpret_cast<const float*>(bptr[e]) : nullptr;
-  for (int t = threadIdx.x; t < R * Cin; t += 256) xs[t] = x[(long long)i * R * Cin + t];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int co = blockIdx.y * 128 + wid * 32 + l31;
+  const bool co_ok = co < Cout;
+  const long long xbase = (long long)i0 * R * Cin;
   const int KS = Cin * S;
-  const int co0 = blockIdx.y * co_per_block;
-  for (int co = co0 + wid; co < min(co0 + co_per_block, Cout); co += 4) {
-    const float* wr = W + (long long)co * KS;
-    float acc[MAXR];
+  int pm[2];  // position inside its window of the row this lane feeds as A operand (per row tile)
 #pragma unroll
-    for (int p = 0; p < MAXR; ++p) acc[p] = 0.f;
-    for (int j = lane; j < KS; j += 64) {
-      const float w = wr[j];
-      const int ci = j / S, s = j - ci * S;
+  for (int mt = 0; mt < 2; ++mt) pm[mt] = (rc0 + mt * 32 + l31) % R;
+  f32x16 acc[2];
 #pragma unroll
-      for (int p = 0; p < MAXR; ++p) {
-        if (p >= R) break;
-        const int q = p + s - pad;
-        if (q >= 0 && q < R) acc[p] += w * xs[q * Cin + ci];
-      }
-    }
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int p = 0; p < MAXR; ++p) {
-      if (p >= R) break;
-      const float v = wave_sum(acc[p]);
-      if (lane == 0) y[((long long)i * R + p) * Cout + co] = v + (bias ? bias[co] : 0.f);
-    }
-  }
-}
+    for (int t = 0; t < 16; ++t) acc[mt][t] = 0.f;
 
-// dx[i][q][ci] = sum_{co,s} dy[i][q-s+pad][co] * W[co][ci][s]; one thread per input channel, weights read as contiguous [ci][s] runs
-__global__ __launch_bounds__(256) void gconv_dgrad_kernel(const float* dy, const int* eid, const long long* wptr, float* dx, int n, int R, int Cin,
-                                                          int Cout, int S, int pad) {
-  extern __shared__ float dys[];  // [R][Cout]
-  const int i = blockIdx.x;
-  const float* W = reinterpret_cast<const float*>(wptr[eid[i]]);
-  for (int t = threadIdx.x; t < R * Cout; t += 256) dys[t] = dy[(long long)i * R * Cout + t];
-  __syncthreads();
-  for (int ci = blockIdx.y * 256 + threadIdx.x; ci < Cin; ci += gridDim.y * 256) {
-    float acc[MAXR];
+  for (int ci0 = 0; ci0 < Cin; ci0 += GT_CK) {
+    __syncthreads();
+    // stage rows [rc0 - pad, rc0 + 64 + pad) x channels [ci0, ci0 + 64)
+    for (int t = threadIdx.x; t < (GT_ROWS + 2 * pad) * (GT_CK / 4); t += 256) {
+      const int rl = t / (GT_CK / 4), c4 = t % (GT_CK / 4);
+      const int row = rc0 - pad + rl;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row >= 0 && row < nrows && ci0 + c4 * 4 < Cin) v = *reinterpret_cast<const float4*>(x + xbase + (long long)row * Cin + ci0 + c4 * 4);
+      float* d = xs + rl * LD + c4 * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int kchunk = min(GT_CK, Cin - ci0) * S;   // contiguous (ci,s) entries of this chunk in a weight row
+    const float* wr = W + (long long)(co_ok ? co : 0) * KS + ci0 * S;
+    for (int kg = 0; kg < kchunk; kg += 8) {
+      // lane (col, half) takes 4 consecutive (ci,s) entries starting at kg + 4*half; entry j feeds MFMA j (same K permutation for A)
+      float4 wv = *reinterpret_cast<const float4*>(wr + kg + 4 * lhi);
+      if (!co_ok) wv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int q = 0; q < MAXR; ++q) acc[q] = 0.f;
-    for (int co = 0; co < Cout; ++co) {
-      const float* wr = W + ((long long)co * Cin + ci) * S;
-      for (int s = 0; s < S; ++s) {
-        const float w = wr[s];
+      for (int j = 0; j < 4; ++j) {
+        const int kk = kg + 4 * lhi + j;
+        const int cl = kk / S, sft = kk - cl * S;
+        const float b = j == 0 ? wv.x : j == 1 ? wv.y : j == 2 ? wv.z : wv.w;
 #pragma unroll
-        for (int q = 0; q < MAXR; ++q) {
-          if (q >= R) break;
-          const int p = q - s + pad;
-          if (p >= 0 && p < R) acc[q] += w * dys[p * Cout + co];
+        for (int mt = 0; mt < 2; ++mt) {
+          const int q = pm[mt] + sft - pad;
+          const float av = (q >= 0 && q < R) ? xs[(mt * 32 + l31 + sft) * LD + cl] : 0.f;
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[mt], 0, 0, 0);
         }
       }
     }
-#pragma unroll
-    for (int q = 0; q < MAXR; ++q) {
-      if (q >= R) break;
-      dx[((long long)i * R + q) * Cin + ci] = acc[q];
-    }
   }
+  if (!co_ok) return;
+  const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int row = rc0 + mt * 32 + (t & 3) + 8 * (t >> 2) + 4 * lhi;
+      if (row < nrows) y[((long long)i0 * R + row) * Cout + co] = acc[mt][t] + bv;
+    }
 }
 
-// dW[e][co][ci][s] += sum_{i in run} sum_p dy[i][p][co] * x[i][p+s-pad][ci];  db[e][co] += sum dy
-// block = (run of one expert, tile of CPB output channels). A lane owns up to WG_MAXJ (ci,s) entries; for every window it
-// first pulls the R shifted x values of its entries into registers, then reuses them for all channels of the tile, so the
-// inner loop is one LDS broadcast read (dy) per R*WG_MAXJ FMAs.
-constexpr int WG_MAXJ = 12;  // (Cin*S)/64 <= 12  (256*3/64)
-constexpr int WG_CPB = 16;   // output channels per block
-template <int R>
-__global__ __launch_bounds__(256) void gconv_wgrad_kernel(const float* dy, const float* x, const int* seg_start, const int* seg_eid,
-                                                          const long long* gwptr, const long long* gbptr, int Cin, int Cout, int S, int pad) {
-  extern __shared__ float sm[];  // xs [R][Cin] | dys [R][WG_CPB]
-  float* xs = sm;
-  float* dys = sm + R * Cin;
+// ---- data gradient: D[m = row][n = ci]; A = shifted dy rows from LDS, B = W[co][ci][0..S) (one S-float load per lane) ----
+template <int S>
+__global__ __launch_bounds__(256) void gmm_dgrad_kernel(const float* __restrict__ dy, const int* seg_start, const int* seg_eid, const int* tile_seg,
+                                                        const int* tile_row0, const long long* wptr, float* __restrict__ dx, int R, int Cin,
+                                                        int Cout, int pad) {
+  constexpr int LD = GT_CK + 1;
+  __shared__ float dys[(GT_ROWS + 2 * (S / 2)) * LD];
+  const int g = tile_seg[blockIdx.x], rc0 = tile_row0[blockIdx.x];
+  const int i0 = seg_start[g];
+  const int nrows = (seg_start[g + 1] - i0) * R;
+  const float* __restrict__ W = reinterpret_cast<const float*>(wptr[seg_eid[g]]);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int ci = blockIdx.y * 128 + wid * 32 + l31;
+  const bool ci_ok = ci < Cin;
+  const long long ybase = (long long)i0 * R * Cout;
+  int pm[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) pm[mt] = (rc0 + mt * 32 + l31) % R;
+  f32x16 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[mt][t] = 0.f;
+
+  for (int co0 = 0; co0 < Cout; co0 += GT_CK) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < (GT_ROWS + 2 * pad) * (GT_CK / 4); t += 256) {
+      const int rl = t / (GT_CK / 4), c4 = t % (GT_CK / 4);
+      const int row = rc0 - pad + rl;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row >= 0 && row < nrows && co0 + c4 * 4 < Cout) v = *reinterpret_cast<const float4*>(dy + ybase + (long long)row * Cout + co0 + c4 * 4);
+      float* d = dys + rl * LD + c4 * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int cn = min(GT_CK, Cout - co0);
+    for (int cp = 0; cp < cn; cp += 2) {
+      const int col = cp + lhi;  // this half's output channel of the k pair
+      float wv[S];
+      const float* wr = W + ((long long)(co0 + col) * Cin + (ci_ok ? ci : 0)) * S;
+#pragma unroll
+      for (int sft = 0; sft < S; ++sft) wv[sft] = (ci_ok && col < cn) ? wr[sft] : 0.f;
+#pragma unroll
+      for (int sft = 0; sft < S; ++sft) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int q = pm[mt] - sft + pad;   // position of the output row this tap came from
+          const float av = (q >= 0 && q < R) ? dys[(mt * 32 + l31 - sft + 2 * pad) * LD + col] : 0.f;
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv[sft], acc[mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!ci_ok) return;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int row = rc0 + mt * 32 + (t & 3) + 8 * (t >> 2) + 4 * lhi;
+      if (row < nrows) dx[((long long)i0 * R + row) * Cin + ci] = acc[mt][t];
+    }
+}
+
+// ---- weight gradient: D[m = co][n = ci] per tap, contraction over the rows of the run; both operands coalesced from global ----
+// block = (run, 32 output channels, 256 input channels); wave w owns input channels [ci_blk + 32 w, +32) for all S taps.
+// dW[e] and db[e] are ADDED to (the trainer's flat gradient buffer); one block per (run, tile) so the sum order is fixed.
+template <int S>
+__global__ __launch_bounds__(512) void gmm_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, const int* seg_start,
+                                                        const int* seg_eid, const long long* gwptr, const long long* gbptr, int R, int Cin,
+                                                        int Cout, int pad) {
   const int g = blockIdx.x;
+  const int i0 = seg_start[g];
+  const int nrows = (seg_start[g + 1] - i0) * R;
   const int e = seg_eid[g];
-  const int i0 = seg_start[g], i1 = seg_start[g + 1];
   float* dW = reinterpret_cast<float*>(gwptr[e]);
   float* db = gbptr ? reinterpret_cast<float*>(gbptr[e]) : nullptr;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int KS = Cin * S;
-  const int co0 = blockIdx.y * WG_CPB;
-  const int nco = min(WG_CPB, Cout - co0);
-  constexpr int MAXC = WG_CPB / 4;
-  float acc[MAXC][WG_MAXJ];
-  float bacc[MAXC];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int co = blockIdx.y * 32 + l31;         // A operand column of this lane
+  const int ci = blockIdx.z * 256 + wid * 32 + l31;
+  const bool ci_ok = ci < Cin;
+  if (blockIdx.z * 256 + wid * 32 >= Cin) return;   // whole wave outside (no barriers in this kernel)
+  const float* dyb = dy + (long long)i0 * R * Cout + co;
+  const float* xb = x + (long long)i0 * R * Cin + (ci_ok ? ci : 0);
+  f32x16 acc[S];
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    bacc[c] = 0.f;
+  for (int sft = 0; sft < S; ++sft)
 #pragma unroll
-    for (int j = 0; j < WG_MAXJ; ++j) acc[c][j] = 0.f;
-  }
-  // the (ci, s) entries this lane owns
-  int ent_ci[WG_MAXJ], ent_s[WG_MAXJ];
+    for (int t = 0; t < 16; ++t) acc[sft][t] = 0.f;
+  float bsum = 0.f;
+  int row = lhi, p = lhi % R;   // this half's row of the current k pair and its position inside the window
+  for (int r2 = 0; r2 < nrows; r2 += 2) {
+    const bool rok = row < nrows;
+    const float a = rok ? dyb[(long long)row * Cout] : 0.f;
+    bsum += a;
 #pragma unroll
-  for (int jj = 0; jj < WG_MAXJ; ++jj) {
-    const int j = lane + 64 * jj;
-    ent_ci[jj] = (j < KS) ? j / S : 0;
-    ent_s[jj] = (j < KS) ? j % S : 0;
-  }
-  for (int i = i0; i < i1; ++i) {
-    __syncthreads();
-    for (int t = threadIdx.x; t < R * Cin; t += 256) xs[t] = x[(long long)i * R * Cin + t];
-    for (int t = threadIdx.x; t < R * nco; t += 256) {
-      const int p = t / nco, c = t - p * nco;
-      dys[p * WG_CPB + c] = dy[((long long)i * R + p) * Cout + co0 + c];
+    for (int sft = 0; sft < S; ++sft) {
+      const int q = p + sft - pad;
+      const float b = (rok && ci_ok && q >= 0 && q < R) ? xb[(long long)(row + sft - pad) * Cin] : 0.f;
+      acc[sft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[sft], 0, 0, 0);
     }
-    __syncthreads();
-    float xv[WG_MAXJ][R];
+    row += 2;
+    p += 2;
+    while (p >= R) p -= R;
+  }
+  if (ci_ok) {
 #pragma unroll
-    for (int jj = 0; jj < WG_MAXJ; ++jj)
+    for (int sft = 0; sft < S; ++sft)
 #pragma unroll
-      for (int p = 0; p < R; ++p) {
-        const int q = p + ent_s[jj] - pad;
-        xv[jj][p] = (lane + 64 * jj < KS && q >= 0 && q < R) ? xs[q * Cin + ent_ci[jj]] : 0.f;
+      for (int t = 0; t < 16; ++t) {
+        const int cr = blockIdx.y * 32 + (t & 3) + 8 * (t >> 2) + 4 * lhi;
+        float* d = dW + ((long long)cr * Cin + ci) * S + sft;
+        *d += acc[sft][t];
       }
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-      const int cl = wid + 4 * c;
-      if (cl < nco) {
-        float d[R];
-        float b = 0.f;
-#pragma unroll
-        for (int p = 0; p < R; ++p) { d[p] = dys[p * WG_CPB + cl]; b += d[p]; }
-        bacc[c] += b;
-#pragma unroll
-        for (int jj = 0; jj < WG_MAXJ; ++jj)
-#pragma unroll
-          for (int p = 0; p < R; ++p) acc[c][jj] += d[p] * xv[jj][p];
-      }
-    }
   }
-#pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    const int cl = wid + 4 * c;
-    if (cl >= nco) continue;
-    float* wr = dW + (long long)(co0 + cl) * KS;
-#pragma unroll
-    for (int jj = 0; jj < WG_MAXJ; ++jj) {
-      const int j = lane + 64 * jj;
-      if (j < KS) wr[j] += acc[c][jj];
-    }
-    if (lane == 0 && db) db[co0 + cl] += bacc[c];
+  if (db && blockIdx.z == 0 && wid == 0) {
+    const float tot = bsum + __shfl_xor(bsum, 32, 64);
+    if (lhi == 0) db[co] += tot;
   }
 }
 
@@ -186,44 +230,49 @@ __global__ void segment_accumulate_ptr_kernel(const float* rows, const int* seg_
 
 }  // namespace
 
-extern "C" int hwg_grouped_conv1d_fwd(const float* x, const int* eid, const void* wptr, const void* bptr, float* y, int n, int R, int Cin, int Cout,
-                                      int S, int pad, void* stream) {
-  HWG_REQUIRE(x && eid && wptr && y && n > 0 && R > 0 && R <= MAXR && Cin > 0 && Cout > 0 && S > 0, "grouped_conv1d_fwd: bad arguments");
-  const int cpb = 32;
-  const size_t smem = (size_t)R * Cin * sizeof(float);
-  HWG_REQUIRE(smem <= 64 * 1024, "grouped_conv1d_fwd: window does not fit LDS");
-  hipLaunchKernelGGL(gconv_fwd_kernel, dim3(n, hwg_cdiv(Cout, cpb)), dim3(256), smem, (hipStream_t)stream, x, eid, (const long long*)wptr,
-                     (const long long*)bptr, y, n, R, Cin, Cout, S, pad, cpb);
+extern "C" int hwg_grouped_conv1d_fwd(const float* x, const int* seg_start, const int* seg_eid, const int* tile_seg, const int* tile_row0, int ntiles,
+                                      const void* wptr, const void* bptr, float* y, int R, int Cin, int Cout, int S, int pad, void* stream) {
+  HWG_REQUIRE(x && seg_start && seg_eid && tile_seg && tile_row0 && wptr && y && ntiles > 0 && R > 0 && R <= MAXR && Cin > 0 && Cout > 0,
+              "grouped_conv1d_fwd: bad arguments");
+  HWG_REQUIRE((S == 1 && pad == 0) || (S == 3 && pad == 1), "grouped_conv1d_fwd: only S=1/pad=0 and S=3/pad=1 are built (got S=%d pad=%d)", S, pad);
+  HWG_REQUIRE(Cin % 8 == 0, "grouped_conv1d_fwd: Cin must be a multiple of 8 (got %d)", Cin);
+  dim3 grid(ntiles, hwg_cdiv(Cout, 128));
+  hipStream_t st = (hipStream_t)stream;
+  if (S == 1)
+    hipLaunchKernelGGL(gmm_fwd_kernel<1>, grid, dim3(256), 0, st, x, seg_start, seg_eid, tile_seg, tile_row0, (const long long*)wptr, (const long long*)bptr, y,
+                       R, Cin, Cout, pad);
+  else
+    hipLaunchKernelGGL(gmm_fwd_kernel<3>, grid, dim3(256), 0, st, x, seg_start, seg_eid, tile_seg, tile_row0, (const long long*)wptr, (const long long*)bptr, y,
+                       R, Cin, Cout, pad);
   HWG_LAUNCH_CHECK("grouped_conv1d_fwd");
   return HWG_OK;
 }
-extern "C" int hwg_grouped_conv1d_dgrad(const float* dy, const int* eid, const void* wptr, float* dx, int n, int R, int Cin, int Cout, int S, int pad,
-                                        void* stream) {
-  HWG_REQUIRE(dy && eid && wptr && dx && n > 0 && R > 0 && R <= MAXR && Cin > 0 && Cout > 0 && S > 0, "grouped_conv1d_dgrad: bad arguments");
-  const size_t smem = (size_t)R * Cout * sizeof(float);
-  HWG_REQUIRE(smem <= 64 * 1024, "grouped_conv1d_dgrad: window does not fit LDS");
-  hipLaunchKernelGGL(gconv_dgrad_kernel, dim3(n, hwg_cdiv(Cin, 256)), dim3(256), smem, (hipStream_t)stream, dy, eid, (const long long*)wptr, dx, n, R,
-                     Cin, Cout, S, pad);
+extern "C" int hwg_grouped_conv1d_dgrad(const float* dy, const int* seg_start, const int* seg_eid, const int* tile_seg, const int* tile_row0, int ntiles,
+                                        const void* wptr, float* dx, int R, int Cin, int Cout, int S, int pad, void* stream) {
+  HWG_REQUIRE(dy && seg_start && seg_eid && tile_seg && tile_row0 && wptr && dx && ntiles > 0 && R > 0 && R <= MAXR && Cin > 0 && Cout > 0,
+              "grouped_conv1d_dgrad: bad arguments");
+  HWG_REQUIRE((S == 1 && pad == 0) || (S == 3 && pad == 1), "grouped_conv1d_dgrad: only S=1/pad=0 and S=3/pad=1 are built (got S=%d pad=%d)", S, pad);
+  HWG_REQUIRE(Cout % 4 == 0, "grouped_conv1d_dgrad: Cout must be a multiple of 4 (got %d)", Cout);
+  dim3 grid(ntiles, hwg_cdiv(Cin, 128));
+  hipStream_t st = (hipStream_t)stream;
+  if (S == 1)
+    hipLaunchKernelGGL(gmm_dgrad_kernel<1>, grid, dim3(256), 0, st, dy, seg_start, seg_eid, tile_seg, tile_row0, (const long long*)wptr, dx, R, Cin, Cout, pad);
+  else
+    hipLaunchKernelGGL(gmm_dgrad_kernel<3>, grid, dim3(256), 0, st, dy, seg_start, seg_eid, tile_seg, tile_row0, (const long long*)wptr, dx, R, Cin, Cout, pad);
   HWG_LAUNCH_CHECK("grouped_conv1d_dgrad");
   return HWG_OK;
 }
 extern "C" int hwg_grouped_conv1d_wgrad(const float* dy, const float* x, const int* seg_start, const int* seg_eid, int G, const void* gwptr,
                                         const void* gbptr, int R, int Cin, int Cout, int S, int pad, void* stream) {
-  HWG_REQUIRE(dy && x && seg_start && seg_eid && gwptr && G > 0 && R > 0 && R <= MAXR && Cin > 0 && Cout > 0 && S > 0, "grouped_conv1d_wgrad: bad arguments");
-  HWG_REQUIRE(Cin * S <= 64 * WG_MAXJ, "grouped_conv1d_wgrad: Cin*S=%d too large", Cin * S);
-  const size_t smem = ((size_t)R * Cin + (size_t)R * WG_CPB) * sizeof(float);
-  dim3 grid(G, hwg_cdiv(Cout, WG_CPB));
+  HWG_REQUIRE(dy && x && seg_start && seg_eid && gwptr && G > 0 && R > 0 && R <= MAXR && Cin > 0 && Cout > 0, "grouped_conv1d_wgrad: bad arguments");
+  HWG_REQUIRE((S == 1 && pad == 0) || (S == 3 && pad == 1), "grouped_conv1d_wgrad: only S=1/pad=0 and S=3/pad=1 are built (got S=%d pad=%d)", S, pad);
+  HWG_REQUIRE(Cout % 32 == 0, "grouped_conv1d_wgrad: Cout must be a multiple of 32 (got %d)", Cout);
+  dim3 grid(G, Cout / 32, hwg_cdiv(Cin, 256));
   hipStream_t st = (hipStream_t)stream;
-#define HWG_WG_CASE(RR)                                                                                                              \
-  case RR:                                                                                                                           \
-    hipLaunchKernelGGL(gconv_wgrad_kernel<RR>, grid, dim3(256), smem, st, dy, x, seg_start, seg_eid, (const long long*)gwptr,        \
-                       (const long long*)gbptr, Cin, Cout, S, pad);                                                                  \
-    break;
-  switch (R) {
-    HWG_WG_CASE(1) HWG_WG_CASE(2) HWG_WG_CASE(3) HWG_WG_CASE(4) HWG_WG_CASE(5) HWG_WG_CASE(6) HWG_WG_CASE(7) HWG_WG_CASE(8)
-    default: break;
-  }
-#undef HWG_WG_CASE
+  if (S == 1)
+    hipLaunchKernelGGL(gmm_wgrad_kernel<1>, grid, dim3(512), 0, st, dy, x, seg_start, seg_eid, (const long long*)gwptr, (const long long*)gbptr, R, Cin, Cout, pad);
+  else
+    hipLaunchKernelGGL(gmm_wgrad_kernel<3>, grid, dim3(512), 0, st, dy, x, seg_start, seg_eid, (const long long*)gwptr, (const long long*)gbptr, R, Cin, Cout, pad);
   HWG_LAUNCH_CHECK("grouped_conv1d_wgrad");
   return HWG_OK;
 }

@@ -77,7 +77,8 @@ class _GroupedConv1d(Function):
         Cout = bank.params[wk][1].shape[0]
         pp = bank.param_ptrs(x.device)
         y = torch.empty((n, 1, R, Cout), dtype=torch.float32, device=x.device)
-        L.call("hwg_grouped_conv1d_fwd", x, plan["eid"], pp[wk], pp[bk], y, n, R, Cin, Cout, S, pad, _st())
+        tseg, trow, nt = plan_tiles(plan, R, x.device)
+        L.call("hwg_grouped_conv1d_fwd", x, plan["seg_start"], plan["seg_eid"], tseg, trow, nt, pp[wk], pp[bk], y, R, Cin, Cout, S, pad, _st())
         ctx.save_for_backward(x)
         ctx.cfg = (bank, wk, bk, plan, S, pad, n, R, Cin, Cout)
         return y
@@ -93,7 +94,8 @@ class _GroupedConv1d(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            L.call("hwg_grouped_conv1d_dgrad", dy, plan["eid"], pp[wk], dx, n, R, Cin, Cout, S, pad, st)
+            tseg, trow, nt = plan_tiles(plan, R, x.device)
+            L.call("hwg_grouped_conv1d_dgrad", dy, plan["seg_start"], plan["seg_eid"], tseg, trow, nt, pp[wk], dx, R, Cin, Cout, S, pad, st)
         L.call("hwg_grouped_conv1d_wgrad", dy, x, plan["seg_start"], plan["seg_eid"], plan["G"], gp[wk], gp[bk], R, Cin, Cout, S, pad, st)
         return dx, None, None, None, None, None, None
 
@@ -146,7 +148,24 @@ def make_plan(cls_sorted_np, device):
     seg_eid = cls_sorted_np[starts[:-1]].astype(np.int32)
     packed = ops.h2d(np.concatenate([cls_sorted_np.astype(np.int32), starts, seg_eid]), device)
     return {"eid": packed[:n], "seg_start": packed[n:n + starts.size], "seg_eid": packed[n + starts.size:], "G": int(seg_eid.size),
-            "present": [int(e) for e in seg_eid], "n": n}
+            "present": [int(e) for e in seg_eid], "n": n, "starts_host": starts, "tiles": {}}
+
+
+TILE_ROWS = 64   # GT_ROWS of csrc/expert_bank.hip
+
+
+def plan_tiles(plan, R, device):
+    """work list of the grouped GEMMs for windows of R positions: (run, first row) of every tile of at most TILE_ROWS rows"""
+    hit = plan["tiles"].get(R)
+    if hit is None:
+        rows = np.diff(plan["starts_host"]).astype(np.int64) * R
+        per_run = (rows + TILE_ROWS - 1) // TILE_ROWS
+        tile_seg = np.repeat(np.arange(rows.size, dtype=np.int32), per_run)
+        first = np.concatenate([[0], np.cumsum(per_run)[:-1]])
+        tile_row0 = ((np.arange(tile_seg.size) - np.repeat(first, per_run)) * TILE_ROWS).astype(np.int32)
+        packed = ops.h2d(np.concatenate([tile_seg, tile_row0]), device)
+        hit = plan["tiles"][R] = (packed[:tile_seg.size], packed[tile_seg.size:], int(tile_seg.size))
+    return hit
 
 
 def run_experts(bank, patches, plan, groups1, groups2, eps=1e-5):

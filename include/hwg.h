@@ -225,13 +225,15 @@ int hwg_segment_weighted_mean_bwd(const float* dout, const float* wgt, const int
 int hwg_gather_scores(const float* x, int B, int Wx, int C, const int* idx_b, const int* idx_pos, const int* idx_cls, int n, float* out, void* stream);
 
 /* Grouped "one expert per window" layers for the 79 character-style experts (model/char_style.py:84-124, 210-235).
- * x [n][R][Cin] -> y [n][R][Cout]; eid[n] selects the expert of each window; wptr/bptr are device tables (int64 addresses, one per
- * expert) of weights in the Conv1d layout [Cout][Cin][S] and biases; R <= 8. Windows are sorted by expert: seg_start[G+1] / seg_eid[G]
- * describe the runs. wgrad and segment_accumulate ADD into the buffers addressed by the grad-pointer tables. */
-int hwg_grouped_conv1d_fwd(const float* x, const int* eid, const void* wptr, const void* bptr, float* y, int n, int R, int Cin, int Cout,
-                           int S, int pad, void* stream);
-int hwg_grouped_conv1d_dgrad(const float* dy, const int* eid, const void* wptr, float* dx, int n, int R, int Cin, int Cout, int S, int pad,
-                             void* stream);
+ * x [n][R][Cin] -> y [n][R][Cout]; wptr/bptr are device tables (int64 addresses, one per expert) of weights in the Conv1d layout
+ * [Cout][Cin][S] and biases; R <= 8; (S, pad) is (1, 0) or (3, 1). Windows are sorted by expert: seg_start[G+1] / seg_eid[G] describe
+ * the runs; the rows of a run (windows x R positions) are cut into work tiles of at most 64 rows, tile_seg[t] = run and
+ * tile_row0[t] = first row of tile t. Every run is one small GEMM on the matrix cores against its expert's weights.
+ * wgrad and segment_accumulate ADD into the buffers addressed by the grad-pointer tables. */
+int hwg_grouped_conv1d_fwd(const float* x, const int* seg_start, const int* seg_eid, const int* tile_seg, const int* tile_row0, int ntiles,
+                           const void* wptr, const void* bptr, float* y, int R, int Cin, int Cout, int S, int pad, void* stream);
+int hwg_grouped_conv1d_dgrad(const float* dy, const int* seg_start, const int* seg_eid, const int* tile_seg, const int* tile_row0, int ntiles,
+                             const void* wptr, float* dx, int R, int Cin, int Cout, int S, int pad, void* stream);
 int hwg_grouped_conv1d_wgrad(const float* dy, const float* x, const int* seg_start, const int* seg_eid, int G, const void* gwptr,
                              const void* gbptr, int R, int Cin, int Cout, int S, int pad, void* stream);
 int hwg_gather_rows_ptr(const void* ptrs, const int* eid, float* out, int n, int C, void* stream);

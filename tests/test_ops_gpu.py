@@ -379,3 +379,48 @@ def test_style_helpers_rng(cuda):
     assert abs((m == 0).float().mean().item() - 0.1) < 5e-3 and abs(m.max().item() - 1 / 0.9) < 1e-6
     am = ops.argmax_rows(x.view(60, 16).to(cuda))
     assert torch.equal(am.cpu().long(), x.view(60, 16).argmax(1))
+
+
+@pytest.mark.parametrize("R,Cin,Cout,S", [(5, 256, 128, 3), (5, 128, 256, 3), (5, 256, 256, 1), (1, 256, 128, 1), (3, 64, 96, 3)])
+def test_grouped_expert_layers(cuda, R, Cin, Cout, S):
+    """grouped per-expert Conv1d (hwg_grouped_conv1d_*) against torch conv1d run expert by expert; one long run spans several row tiles"""
+    import numpy as np
+    from handwriting_line_generation_amd import _lib as L, ops
+    from handwriting_line_generation_amd.model import expert_bank
+    pad = S // 2
+    g = torch.Generator().manual_seed(5)
+    E = 6
+    Ws = [torch.randn(Cout, Cin, S, generator=g) * 0.05 for _ in range(E)]
+    Bs = [torch.randn(Cout, generator=g) * 0.1 for _ in range(E)]
+    cls = np.array([0] * 3 + [2] * 41 + [3] * 1 + [5] * 14, dtype=np.int64)   # expert 1 and 4 absent; run of 41 windows -> 4 tiles at R=5
+    n = cls.size
+    x = torch.randn(n, R, Cin, generator=g)
+    dy = torch.randn(n, R, Cout, generator=g)
+    # reference
+    xr = x.clone().requires_grad_(True)
+    Wr = [w.clone().requires_grad_(True) for w in Ws]
+    Br = [b.clone().requires_grad_(True) for b in Bs]
+    yr = torch.stack([F.conv1d(xr[i].t().unsqueeze(0), Wr[cls[i]], Br[cls[i]], padding=pad)[0].t() for i in range(n)])
+    (yr * dy).sum().backward()
+    # device
+    dev = cuda
+    Wd = [w.to(dev) for w in Ws]; Bd = [b.to(dev) for b in Bs]
+    gW = [torch.full_like(w, 0.5) for w in Wd]; gB = [torch.full_like(b, 0.25) for b in Bd]   # kernels must ADD to these
+    tab = lambda ts: ops.h2d(np.array([t.data_ptr() for t in ts], dtype=np.int64), dev)
+    wptr, bptr, gwptr, gbptr = tab(Wd), tab(Bd), tab(gW), tab(gB)
+    plan = expert_bank.make_plan(cls, dev)
+    tseg, trow, nt = expert_bank.plan_tiles(plan, R, dev)
+    xd = x.to(dev); dyd = dy.to(dev)
+    y = torch.empty(n, R, Cout, device=dev); dx = torch.empty(n, R, Cin, device=dev)
+    st = ops._stream()
+    L.call("hwg_grouped_conv1d_fwd", xd, plan["seg_start"], plan["seg_eid"], tseg, trow, nt, wptr, bptr, y, R, Cin, Cout, S, pad, st)
+    L.call("hwg_grouped_conv1d_dgrad", dyd, plan["seg_start"], plan["seg_eid"], tseg, trow, nt, wptr, dx, R, Cin, Cout, S, pad, st)
+    L.call("hwg_grouped_conv1d_wgrad", dyd, xd, plan["seg_start"], plan["seg_eid"], plan["G"], gwptr, gbptr, R, Cin, Cout, S, pad, st)
+    _close(y, yr, "grouped fwd")
+    _close(dx, xr.grad, "grouped dgrad")
+    for e in range(E):
+        if Wr[e].grad is None:
+            assert torch.all(gW[e] == 0.5) and torch.all(gB[e] == 0.25), "absent expert %d was touched" % e
+        else:
+            _close(gW[e] - 0.5, Wr[e].grad, "grouped wgrad e%d" % e)
+            _close(gB[e] - 0.25, Br[e].grad, "grouped bias grad e%d" % e)
