@@ -295,6 +295,8 @@ struct WgK {
   float* part;     // [nsplit][R*S][K][C]
   int N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, P, Q;
   int Mtot, chunk, tiles_v;
+  int bias_on;          // also produce the column sums of u (the layer's bias gradient) from the tiles that pass through LDS anyway
+  long long pstride;    // floats per partial image: R*S*K*C (+K bias partials)
 };
 
 // TAPN: single-channel gathered tensor (C == 1, first layers): the GEMM's N dimension is the taps (<= BNV) instead of C, so one
@@ -433,6 +435,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
   const int kend = kbeg + BKP / WAVES_K;
   const int l31 = lane & 31, lhi = lane >> 5;
 
+  // bias gradient = column sums of u: taken by the workgroups of the first tap / first v tile from their LDS copy of the u tile
+  const bool do_bias = a.bias_on && tap == 0 && tv == 0 && tid < BMU;
+  float bsum = 0.f;
+
   if (T > 0) { load_tile(); store_tile(0); }
   __syncthreads();
   for (int t = 0; t < T; ++t) {
@@ -440,6 +446,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
     if (t + 1 < T) load_tile();
     const float* Ub = Us + buf * BKP * BMU;
     const float* Vb = Vs + buf * BKP * BNV;
+    if (do_bias) {
+#pragma unroll
+      for (int kp = 0; kp < BKP; ++kp) bsum += Ub[kp * BMU + tid];
+    }
 #pragma unroll
     for (int ks = kbeg; ks < kend; ks += 2) {
       const int kk = ks + lhi;
@@ -457,6 +467,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
     if (t + 1 < T) store_tile(buf ^ 1);
     __syncthreads();
   }
+
+  if (do_bias && k0 + tid < a.K) a.part[(long long)blockIdx.x * a.pstride + (long long)RS * a.K * a.C + k0 + tid] = bsum;
 
   if (WAVES_K > 1) {
     // cross-wave reduction of the per-wave K slices (tile buffers are free now)
@@ -481,7 +493,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
         }
   }
 
-  float* pout = a.part + ((long long)blockIdx.x * (a.R * a.S) + tap) * a.K * a.C;
+  float* pout = a.part + (long long)blockIdx.x * a.pstride + (long long)tap * a.K * a.C;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -500,16 +512,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
     }
 }
 
+// dw = (accumulate ? dw : 0) + sum over the partial images; entries past R*S*K*C of a partial image are the K bias partials
 __global__ void wgrad_reduce_kernel(const float* part, float* dw, int nsplit, int RS, int S, int K, int C,
-                                    long long sa, long long sb, long long sr, long long ss, int accumulate) {
+                                    long long sa, long long sb, long long sr, long long ss, int accumulate,
+                                    long long pstride, float* dbias, int bias_accumulate) {
   const long long total = (long long)RS * K * C;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  const long long all = total + (dbias ? K : 0);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < all; i += (long long)gridDim.x * blockDim.x) {
+    float sum = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) sum += part[(long long)sp * pstride + i];
+    if (i >= total) {
+      const int k = (int)(i - total);
+      dbias[k] = bias_accumulate ? dbias[k] + sum : sum;
+      continue;
+    }
     const int c = (int)(i % C);
     const long long t = i / C;
     const int k = (int)(t % K);
     const int tap = (int)(t / K);
-    float sum = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) sum += part[(long long)sp * total + i];
     const long long o = k * sa + c * sb + (tap / S) * sr + (tap % S) * ss;
     dw[o] = accumulate ? dw[o] + sum : sum;
   }
@@ -519,21 +539,28 @@ __global__ void wgrad_reduce_kernel(const float* part, float* dw, int nsplit, in
 // output t % OUT and partials t / OUT, t / OUT + SL, ...; the lanes are combined through LDS in lane order, so still deterministic)
 template <int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_lanes_kernel(const float* part, float* dw, int nsplit, int RS, int S, int K, int C,
-                                                                 long long sa, long long sb, long long sr, long long ss, int accumulate) {
+                                                                 long long sa, long long sb, long long sr, long long ss, int accumulate,
+                                                                 long long pstride, float* dbias, int bias_accumulate) {
   constexpr int OUT = 256 / SL;
   __shared__ float red[SL][OUT];
   const long long total = (long long)RS * K * C;
+  const long long all = total + (dbias ? K : 0);
   const int ol = threadIdx.x % OUT, lane = threadIdx.x / OUT;
   const long long i = (long long)blockIdx.x * OUT + ol;
   float sum = 0.f;
-  if (i < total)
-    for (int sp = lane; sp < nsplit; sp += SL) sum += part[(long long)sp * total + i];
+  if (i < all)
+    for (int sp = lane; sp < nsplit; sp += SL) sum += part[(long long)sp * pstride + i];
   red[lane][ol] = sum;
   __syncthreads();
-  if (lane == 0 && i < total) {
+  if (lane == 0 && i < all) {
     float t = 0.f;
 #pragma unroll
     for (int l = 0; l < SL; ++l) t += red[l][ol];
+    if (i >= total) {
+      const int kb = (int)(i - total);
+      dbias[kb] = bias_accumulate ? dbias[kb] + t : t;
+      return;
+    }
     const int c = (int)(i % C);
     const long long q = i / C;
     const int k = (int)(q % K);
@@ -854,17 +881,20 @@ extern "C" size_t hwg_conv_wgrad_workspace(const hwg_conv_desc* d) {
   if (!d) return 0;
   if (wgrad_is_direct(d)) return hwg_conv_wgrad_direct_workspace(d);
   WgPlan p = wgrad_is_tapn(d) ? plan_wgrad_tapn(d) : plan_wgrad(d);
-  return (size_t)p.nsplit * d->R * d->S * d->K * d->C * sizeof(float);
+  return (size_t)p.nsplit * ((size_t)d->R * d->S * d->K * d->C + d->K) * sizeof(float);
 }
 
 extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const float* v, float* dw,
                               long long sa, long long sb, long long sr, long long ss, int accumulate,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+                              float* dbias, int bias_accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_desc(d, "conv_wgrad");
   if (rc) return rc;
   HWG_REQUIRE(u && v && dw, "conv_wgrad: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (wgrad_is_direct(d)) return hwg_conv_wgrad_direct_impl(d, u, v, dw, sa, sb, sr, ss, accumulate, workspace, workspace_bytes, st);
+  if (wgrad_is_direct(d)) {
+    HWG_REQUIRE(!dbias, "conv_wgrad: the fused bias gradient is not available on the direct (K<=2 / C<=2) path, use hwg_colsum");
+    return hwg_conv_wgrad_direct_impl(d, u, v, dw, sa, sb, sr, ss, accumulate, workspace, workspace_bytes, st);
+  }
   const bool tapn = wgrad_is_tapn(d);
   HWG_REQUIRE(d->K % 4 == 0 && (tapn || d->C % 4 == 0), "conv_wgrad: channels must be multiples of 4 (K=%d C=%d)", d->K, d->C);
   const size_t need = hwg_conv_wgrad_workspace(d);
@@ -881,6 +911,8 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
   k.Mtot = d->N * d->P * d->Q;
   k.chunk = p.chunk;
   k.tiles_v = p.tiles_v;
+  k.bias_on = dbias ? 1 : 0;
+  k.pstride = (long long)d->R * d->S * d->K * d->C + d->K;
   dim3 grid(p.nsplit, p.tiles_u * p.tiles_v, tapn ? 1 : d->R * d->S);
   const int prof = hwg_prof_open(HWG_PROF_WGRAD, 2.0 * k.Mtot * d->K * d->C * d->R * d->S, st);
   // 16 waves and 32-pixel K steps on the big tile: +10 % over 8 waves x 16 pixels (331 -> 299 us on 512x512x3x3 at 6096 pixels)
@@ -891,17 +923,17 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
   else hipLaunchKernelGGL((wgrad_mfma_kernel<32, 32, 32, 1, 1, 4>), grid, dim3(256), 0, st, k);
   hwg_prof_close(prof, st);
   HWG_LAUNCH_CHECK("conv_wgrad");
-  const long long total = (long long)d->R * d->S * d->K * d->C;
+  const long long total = (long long)d->R * d->S * d->K * d->C + (dbias ? d->K : 0);
   const int prof2 = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, 4.0 * total * (p.nsplit + 1), st);
   if (p.nsplit >= 64 && total <= 65536)
     hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<32>, dim3(hwg_cdiv(total, 8)), dim3(256), 0, st, (const float*)workspace, dw, p.nsplit, d->R * d->S, d->S,
-                       d->K, d->C, sa, sb, sr, ss, accumulate);
+                       d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias, bias_accumulate);
   else if (p.nsplit >= 8 && total <= 262144)
     hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<4>, dim3(hwg_cdiv(total, 64)), dim3(256), 0, st, (const float*)workspace, dw, p.nsplit, d->R * d->S, d->S,
-                       d->K, d->C, sa, sb, sr, ss, accumulate);
+                       d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias, bias_accumulate);
   else
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
-                       p.nsplit, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate);
+                       p.nsplit, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias, bias_accumulate);
   hwg_prof_close(prof2, st);
   HWG_LAUNCH_CHECK("conv_wgrad_reduce");
   return HWG_OK;

@@ -258,6 +258,7 @@ class _Conv2d(Function):
         sh, sw = stride; ph, pw = padding; dh, dw = dilation
         K = dy.shape[3]
         dx = dw_ = db = None
+        bias_done = False
         st = _stream()
         if ctx.needs_input_grad[0]:
             # data gradient: contraction over K (dy's channels) producing C channels
@@ -305,7 +306,7 @@ class _Conv2d(Function):
                 ws = workspace(need, x.device)
                 if PROF_SHAPES is not None:
                     _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad"))
-                L.call("hwg_conv_wgrad", ctypes.byref(d), up, vp, tmp, Cq * R * S, R * S, S, 1, 0, ws, ws.numel(), st)
+                L.call("hwg_conv_wgrad", ctypes.byref(d), up, vp, tmp, Cq * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)
                 valid = tmp[:dK, :dC]
                 if direct:
                     dw_.add_(valid)
@@ -317,10 +318,20 @@ class _Conv2d(Function):
                 ws = workspace(need, x.device)
                 if PROF_SHAPES is not None:
                     _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad"))
-                L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 1 if direct else 0, ws, ws.numel(), st)
+                # the bias gradient (column sums of dy) rides along when dy is the kernel's anchor operand and the MFMA path runs
+                fuse_bias = (ctx.has_bias and ctx.needs_input_grad[2] and not transposed and not (d.K <= 2 or (d.C <= 2 and not tap_gemm)))
+                dbias = bacc = None
+                if fuse_bias:
+                    bdirect = _direct(bref)
+                    dbias = _grad_buffer(bref) if bdirect else torch.empty((K,), dtype=torch.float32, device=x.device)
+                    bacc = 1 if bdirect else 0
+                    bias_done = True
+                    if not bdirect:
+                        db = dbias
+                L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 1 if direct else 0, dbias, bacc or 0, ws, ws.numel(), st)
                 if direct:
                     dw_ = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and not bias_done:
             if _direct(bref):
                 colsum(dy.view(-1, K), out=_grad_buffer(bref), accumulate=True)
             else:

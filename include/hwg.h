@@ -86,11 +86,13 @@ int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float* w, const f
 /* weight gradient: dw(k,c,r,s) = sum_{n,p,q} u[n,p,q,k] * v[n, p*stride-pad+r*dil, q*stride-pad+s*dil, c]
  * written to dw[k*sa + c*sb + r*sr + s*ss] (so it lands directly in the PyTorch parameter layout).
  * u is the tensor living on the anchor grid [N,P,Q,K], v the gathered one [N,H,W,C]; d->transposed is ignored.
- * accumulate!=0 adds into dw. */
+ * accumulate!=0 adds into dw. dbias (may be NULL) additionally receives the column sums of u, dbias[k] = sum_{n,p,q} u[n,p,q,k]
+ * (the bias gradient when u is the output gradient), taken from the u tiles the kernel stages anyway; bias_accumulate!=0 adds.
+ * Not available on the direct path (K <= 2 or C <= 2 without the taps-as-N kernel): use hwg_colsum there. */
 size_t hwg_conv_wgrad_workspace(const hwg_conv_desc* d);
 int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const float* v, float* dw,
                    long long sa, long long sb, long long sr, long long ss, int accumulate,
-                   void* workspace, size_t workspace_bytes, void* stream);
+                   float* dbias, int bias_accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[C] (+)= sum over rows of x[rows][C]  (bias gradients, channel sums) */
 size_t hwg_colsum_workspace(long long rows, int C);

@@ -67,7 +67,7 @@ for (name, N, H, W, C, K, R, S, stride, pad, tr) in SHAPES:
         dw_desc = ops._desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q); u, v = y, x
         dwt = torch.empty(K, C, R, S, device=dev); sa, sb = C * R * S, R * S
     need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(dw_desc)); ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
-    tw = bench(lambda: L.call("hwg_conv_wgrad", ctypes.byref(dw_desc), u, v, dwt, sa, sb, S, 1, 0, ws, ws.numel(), st))
+    tw = bench(lambda: L.call("hwg_conv_wgrad", ctypes.byref(dw_desc), u, v, dwt, sa, sb, S, 1, 0, None, 0, ws, ws.numel(), st))
     tot["fwd"][0] += fl; tot["fwd"][1] += t; tot["wgrad"][0] += fl; tot["wgrad"][1] += tw
     print("%-26s %9d %8.2f | %7.1f %5.1f | %7.1f %5.1f" % (name, pix, fl / 1e9, t * 1e6, fl / t / 1e12, tw * 1e6, fl / tw / 1e12))
 for k, (f, t) in tot.items():

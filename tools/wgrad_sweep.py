@@ -39,7 +39,7 @@ for (N, H, W, C, K, R, S, stride, pad, dil, _), n, avg in shapes:
     def run():
         need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
         ws = ops.workspace(need, dev)
-        L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw, C * R * S, R * S, S, 1, 0, ws, ws.numel(), st)
+        L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw, C * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)
 
     os.environ.pop("HWG_WGRAD_FORCE", None)
     t_def = bench(run)
