@@ -152,19 +152,20 @@ __global__ __launch_bounds__(256) void gmm_dgrad_kernel(const float* __restrict_
     }
 }
 
-// ---- weight gradient: D[m = co][n = ci] per tap, contraction over the rows of the run; both operands coalesced from global ----
-// block = (run, 32 output channels, 256 input channels); wave w owns input channels [ci_blk + 32 w, +32) for all S taps.
-// dW[e] and db[e] are ADDED to (the trainer's flat gradient buffer); one block per (run, tile) so the sum order is fixed.
+// ---- weight gradient: D[m = co][n = ci] per tap, contraction over rows; both operands coalesced from global ----
+// Work item = (row tile of at most tile_rows rows of one run, 32 output channels, 256 input channels); wave w owns input channels
+// [ci_blk + 32 w, +32) for all S taps. Every tile writes its partial dW (and db) image to the workspace; gmm_wgrad_reduce_kernel
+// then adds the tiles of each run, in tile order, to the expert's gradient buffer, so a very frequent character is spread over
+// many workgroups and the result is still deterministic.
 template <int S>
 __global__ __launch_bounds__(512) void gmm_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, const int* seg_start,
-                                                        const int* seg_eid, const long long* gwptr, const long long* gbptr, int R, int Cin,
-                                                        int Cout, int pad) {
-  const int g = blockIdx.x;
+                                                        const int* tile_seg, const int* tile_row0, int tile_rows, float* __restrict__ part,
+                                                        int R, int Cin, int Cout, int pad) {
+  const int tile = blockIdx.x;
+  const int g = tile_seg[tile], rc0 = tile_row0[tile];
   const int i0 = seg_start[g];
   const int nrows = (seg_start[g + 1] - i0) * R;
-  const int e = seg_eid[g];
-  float* dW = reinterpret_cast<float*>(gwptr[e]);
-  float* db = gbptr ? reinterpret_cast<float*>(gbptr[e]) : nullptr;
+  const int rend = min(rc0 + tile_rows, nrows);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int co = blockIdx.y * 32 + l31;         // A operand column of this lane
   const int ci = blockIdx.z * 256 + wid * 32 + l31;
@@ -178,34 +179,62 @@ __global__ __launch_bounds__(512) void gmm_wgrad_kernel(const float* __restrict_
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[sft][t] = 0.f;
   float bsum = 0.f;
-  int row = lhi, p = lhi % R;   // this half's row of the current k pair and its position inside the window
-  for (int r2 = 0; r2 < nrows; r2 += 2) {
-    const bool rok = row < nrows;
-    const float a = rok ? dyb[(long long)row * Cout] : 0.f;
-    bsum += a;
+  constexpr int U = 4;   // k pairs in flight: all loads of U pairs are issued before their MFMAs
+  int row = rc0 + lhi, p = (rc0 + lhi) % R;   // this half's row of the current k pair and its position inside the window
+  for (int r2 = rc0; r2 < rend; r2 += 2 * U) {
+    float av[U], bv[U][S];
 #pragma unroll
-    for (int sft = 0; sft < S; ++sft) {
-      const int q = p + sft - pad;
-      const float b = (rok && ci_ok && q >= 0 && q < R) ? xb[(long long)(row + sft - pad) * Cin] : 0.f;
-      acc[sft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[sft], 0, 0, 0);
+    for (int u = 0; u < U; ++u) {
+      const int rw = row + 2 * u;
+      int pu = p + 2 * u;
+      pu %= R;
+      const bool rok = rw < rend;
+      av[u] = rok ? dyb[(long long)rw * Cout] : 0.f;
+#pragma unroll
+      for (int sft = 0; sft < S; ++sft) {
+        const int q = pu + sft - pad;
+        bv[u][sft] = (rok && ci_ok && q >= 0 && q < R) ? xb[(long long)(rw + sft - pad) * Cin] : 0.f;
+      }
     }
-    row += 2;
-    p += 2;
-    while (p >= R) p -= R;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bsum += av[u];
+#pragma unroll
+      for (int sft = 0; sft < S; ++sft) acc[sft] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][sft], acc[sft], 0, 0, 0);
+    }
+    row += 2 * U;
+    p = (p + 2 * U) % R;
   }
+  const long long img = (long long)Cout * Cin * S + Cout;   // partial image: dW then db
+  float* pw = part + (long long)tile * img;
   if (ci_ok) {
 #pragma unroll
     for (int sft = 0; sft < S; ++sft)
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int cr = blockIdx.y * 32 + (t & 3) + 8 * (t >> 2) + 4 * lhi;
-        float* d = dW + ((long long)cr * Cin + ci) * S + sft;
-        *d += acc[sft][t];
+        pw[((long long)cr * Cin + ci) * S + sft] = acc[sft][t];
       }
   }
-  if (db && blockIdx.z == 0 && wid == 0) {
+  if (blockIdx.z == 0 && wid == 0) {
     const float tot = bsum + __shfl_xor(bsum, 32, 64);
-    if (lhi == 0) db[co] += tot;
+    if (lhi == 0) pw[(long long)Cout * Cin * S + co] = tot;
+  }
+}
+// dW[e(g)] += sum_{tiles of run g} part[tile]   (and db)
+__global__ __launch_bounds__(256) void gmm_wgrad_reduce_kernel(const float* __restrict__ part, const int* run_tile0, const int* seg_eid,
+                                                               const long long* gwptr, const long long* gbptr, long long wsize, int Cout) {
+  const int g = blockIdx.y;
+  const int t0 = run_tile0[g], t1 = run_tile0[g + 1];
+  const int e = seg_eid[g];
+  float* dW = reinterpret_cast<float*>(gwptr[e]);
+  float* db = gbptr ? reinterpret_cast<float*>(gbptr[e]) : nullptr;
+  const long long img = wsize + Cout;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < img; i += (long long)gridDim.x * 256) {
+    float sacc = 0.f;
+    for (int t = t0; t < t1; ++t) sacc += part[(long long)t * img + i];
+    if (i < wsize) dW[i] += sacc;
+    else if (db) db[i - wsize] += sacc;
   }
 }
 
@@ -262,18 +291,34 @@ extern "C" int hwg_grouped_conv1d_dgrad(const float* dy, const int* seg_start, c
   HWG_LAUNCH_CHECK("grouped_conv1d_dgrad");
   return HWG_OK;
 }
-extern "C" int hwg_grouped_conv1d_wgrad(const float* dy, const float* x, const int* seg_start, const int* seg_eid, int G, const void* gwptr,
-                                        const void* gbptr, int R, int Cin, int Cout, int S, int pad, void* stream) {
-  HWG_REQUIRE(dy && x && seg_start && seg_eid && gwptr && G > 0 && R > 0 && R <= MAXR && Cin > 0 && Cout > 0, "grouped_conv1d_wgrad: bad arguments");
+extern "C" size_t hwg_grouped_conv1d_wgrad_workspace(int ntiles, int Cin, int Cout, int S) {
+  return (size_t)(ntiles > 0 ? ntiles : 0) * ((size_t)Cout * Cin * S + Cout) * sizeof(float);
+}
+extern "C" int hwg_grouped_conv1d_wgrad(const float* dy, const float* x, const int* seg_start, const int* seg_eid, int G, const int* tile_seg,
+                                        const int* tile_row0, const int* run_tile0, int ntiles, int tile_rows, const void* gwptr, const void* gbptr, int R,
+                                        int Cin, int Cout, int S, int pad, void* workspace, size_t workspace_bytes, void* stream) {
+  HWG_REQUIRE(dy && x && seg_start && seg_eid && tile_seg && tile_row0 && run_tile0 && gwptr && G > 0 && ntiles >= G && tile_rows > 0 && R > 0 && R <= MAXR && Cin > 0 &&
+                  Cout > 0, "grouped_conv1d_wgrad: bad arguments");
   HWG_REQUIRE((S == 1 && pad == 0) || (S == 3 && pad == 1), "grouped_conv1d_wgrad: only S=1/pad=0 and S=3/pad=1 are built (got S=%d pad=%d)", S, pad);
   HWG_REQUIRE(Cout % 32 == 0, "grouped_conv1d_wgrad: Cout must be a multiple of 32 (got %d)", Cout);
-  dim3 grid(G, Cout / 32, hwg_cdiv(Cin, 256));
+  const size_t need = hwg_grouped_conv1d_wgrad_workspace(ntiles, Cin, Cout, S);
+  if (!workspace || workspace_bytes < need) {
+    hwg_set_error("grouped_conv1d_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return HWG_ERR_WORKSPACE;
+  }
+  dim3 grid(ntiles, Cout / 32, hwg_cdiv(Cin, 256));
   hipStream_t st = (hipStream_t)stream;
   if (S == 1)
-    hipLaunchKernelGGL(gmm_wgrad_kernel<1>, grid, dim3(512), 0, st, dy, x, seg_start, seg_eid, (const long long*)gwptr, (const long long*)gbptr, R, Cin, Cout, pad);
+    hipLaunchKernelGGL(gmm_wgrad_kernel<1>, grid, dim3(512), 0, st, dy, x, seg_start, tile_seg, tile_row0, tile_rows, (float*)workspace, R, Cin, Cout,
+                       pad);
   else
-    hipLaunchKernelGGL(gmm_wgrad_kernel<3>, grid, dim3(512), 0, st, dy, x, seg_start, seg_eid, (const long long*)gwptr, (const long long*)gbptr, R, Cin, Cout, pad);
+    hipLaunchKernelGGL(gmm_wgrad_kernel<3>, grid, dim3(512), 0, st, dy, x, seg_start, tile_seg, tile_row0, tile_rows, (float*)workspace, R, Cin, Cout,
+                       pad);
   HWG_LAUNCH_CHECK("grouped_conv1d_wgrad");
+  const long long wsize = (long long)Cout * Cin * S;
+  hipLaunchKernelGGL(gmm_wgrad_reduce_kernel, dim3(hwg_cdiv(wsize + Cout, 256 * 4), G), dim3(256), 0, st, (const float*)workspace, run_tile0, seg_eid,
+                     (const long long*)gwptr, (const long long*)gbptr, wsize, Cout);
+  HWG_LAUNCH_CHECK("grouped_conv1d_wgrad_reduce");
   return HWG_OK;
 }
 extern "C" int hwg_gather_rows_ptr(const void* ptrs, const int* eid, float* out, int n, int C, void* stream) {

@@ -77,7 +77,7 @@ class _GroupedConv1d(Function):
         Cout = bank.params[wk][1].shape[0]
         pp = bank.param_ptrs(x.device)
         y = torch.empty((n, 1, R, Cout), dtype=torch.float32, device=x.device)
-        tseg, trow, nt = plan_tiles(plan, R, x.device)
+        tseg, trow, nt, _ = plan_tiles(plan, R, x.device)
         L.call("hwg_grouped_conv1d_fwd", x, plan["seg_start"], plan["seg_eid"], tseg, trow, nt, pp[wk], pp[bk], y, R, Cin, Cout, S, pad, _st())
         ctx.save_for_backward(x)
         ctx.cfg = (bank, wk, bk, plan, S, pad, n, R, Cin, Cout)
@@ -94,9 +94,13 @@ class _GroupedConv1d(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            tseg, trow, nt = plan_tiles(plan, R, x.device)
+            tseg, trow, nt, _ = plan_tiles(plan, R, x.device)
             L.call("hwg_grouped_conv1d_dgrad", dy, plan["seg_start"], plan["seg_eid"], tseg, trow, nt, pp[wk], dx, R, Cin, Cout, S, pad, st)
-        L.call("hwg_grouped_conv1d_wgrad", dy, x, plan["seg_start"], plan["seg_eid"], plan["G"], gp[wk], gp[bk], R, Cin, Cout, S, pad, st)
+        wseg, wrow, wnt, wrun = plan_tiles(plan, R, x.device, WGRAD_TILE_ROWS)
+        need = L.query("hwg_grouped_conv1d_wgrad_workspace", wnt, Cin, Cout, S)
+        ws = ops.workspace(need, x.device)
+        L.call("hwg_grouped_conv1d_wgrad", dy, x, plan["seg_start"], plan["seg_eid"], plan["G"], wseg, wrow, wrun, wnt, WGRAD_TILE_ROWS, gp[wk], gp[bk], R, Cin, Cout, S, pad,
+               ws, ws.numel(), st)
         return dx, None, None, None, None, None, None
 
 
@@ -151,20 +155,24 @@ def make_plan(cls_sorted_np, device):
             "present": [int(e) for e in seg_eid], "n": n, "starts_host": starts, "tiles": {}}
 
 
-TILE_ROWS = 64   # GT_ROWS of csrc/expert_bank.hip
+TILE_ROWS = 64          # GT_ROWS of csrc/expert_bank.hip (forward / data gradient)
+WGRAD_TILE_ROWS = 256   # GW_ROWS (weight gradient)
 
 
-def plan_tiles(plan, R, device):
-    """work list of the grouped GEMMs for windows of R positions: (run, first row) of every tile of at most TILE_ROWS rows"""
-    hit = plan["tiles"].get(R)
+def plan_tiles(plan, R, device, tile_rows=TILE_ROWS):
+    """work list of the grouped GEMMs for windows of R positions: (run, first row) of every tile of at most `tile_rows` rows, and the
+    first tile of every run"""
+    key = (R, tile_rows)
+    hit = plan["tiles"].get(key)
     if hit is None:
         rows = np.diff(plan["starts_host"]).astype(np.int64) * R
-        per_run = (rows + TILE_ROWS - 1) // TILE_ROWS
+        per_run = (rows + tile_rows - 1) // tile_rows
         tile_seg = np.repeat(np.arange(rows.size, dtype=np.int32), per_run)
-        first = np.concatenate([[0], np.cumsum(per_run)[:-1]])
-        tile_row0 = ((np.arange(tile_seg.size) - np.repeat(first, per_run)) * TILE_ROWS).astype(np.int32)
-        packed = ops.h2d(np.concatenate([tile_seg, tile_row0]), device)
-        hit = plan["tiles"][R] = (packed[:tile_seg.size], packed[tile_seg.size:], int(tile_seg.size))
+        first = np.concatenate([[0], np.cumsum(per_run)])
+        tile_row0 = ((np.arange(tile_seg.size) - np.repeat(first[:-1], per_run)) * tile_rows).astype(np.int32)
+        nt = int(tile_seg.size)
+        packed = ops.h2d(np.concatenate([tile_seg, tile_row0, first.astype(np.int32)]), device)
+        hit = plan["tiles"][key] = (packed[:nt], packed[nt:2 * nt], nt, packed[2 * nt:])
     return hit
 
 

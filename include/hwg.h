@@ -236,8 +236,12 @@ int hwg_grouped_conv1d_fwd(const float* x, const int* seg_start, const int* seg_
                            const void* wptr, const void* bptr, float* y, int R, int Cin, int Cout, int S, int pad, void* stream);
 int hwg_grouped_conv1d_dgrad(const float* dy, const int* seg_start, const int* seg_eid, const int* tile_seg, const int* tile_row0, int ntiles,
                              const void* wptr, float* dx, int R, int Cin, int Cout, int S, int pad, void* stream);
-int hwg_grouped_conv1d_wgrad(const float* dy, const float* x, const int* seg_start, const int* seg_eid, int G, const void* gwptr,
-                             const void* gbptr, int R, int Cin, int Cout, int S, int pad, void* stream);
+size_t hwg_grouped_conv1d_wgrad_workspace(int ntiles, int Cin, int Cout, int S);
+/* the weight gradient uses its own tiling of at most tile_rows rows per tile; run_tile0[G+1] = first tile of every run. The tiles'
+ * partial images go to the workspace and are added to the experts' buffers in tile order (deterministic). */
+int hwg_grouped_conv1d_wgrad(const float* dy, const float* x, const int* seg_start, const int* seg_eid, int G, const int* tile_seg,
+                             const int* tile_row0, const int* run_tile0, int ntiles, int tile_rows, const void* gwptr, const void* gbptr, int R,
+                             int Cin, int Cout, int S, int pad, void* workspace, size_t workspace_bytes, void* stream);
 int hwg_gather_rows_ptr(const void* ptrs, const int* eid, float* out, int n, int C, void* stream);
 int hwg_segment_accumulate_ptr(const float* rows, const int* seg_start, const int* seg_eid, int G, const void* gptrs, int C, void* stream);
 

@@ -409,13 +409,17 @@ def test_grouped_expert_layers(cuda, R, Cin, Cout, S):
     tab = lambda ts: ops.h2d(np.array([t.data_ptr() for t in ts], dtype=np.int64), dev)
     wptr, bptr, gwptr, gbptr = tab(Wd), tab(Bd), tab(gW), tab(gB)
     plan = expert_bank.make_plan(cls, dev)
-    tseg, trow, nt = expert_bank.plan_tiles(plan, R, dev)
+    tseg, trow, nt, _ = expert_bank.plan_tiles(plan, R, dev)
+    wrows = expert_bank.WGRAD_TILE_ROWS if R == 5 else 16   # small tiles too: several partial images per run
+    wseg, wrow, wnt, wrun = expert_bank.plan_tiles(plan, R, dev, wrows)
     xd = x.to(dev); dyd = dy.to(dev)
     y = torch.empty(n, R, Cout, device=dev); dx = torch.empty(n, R, Cin, device=dev)
     st = ops._stream()
     L.call("hwg_grouped_conv1d_fwd", xd, plan["seg_start"], plan["seg_eid"], tseg, trow, nt, wptr, bptr, y, R, Cin, Cout, S, pad, st)
     L.call("hwg_grouped_conv1d_dgrad", dyd, plan["seg_start"], plan["seg_eid"], tseg, trow, nt, wptr, dx, R, Cin, Cout, S, pad, st)
-    L.call("hwg_grouped_conv1d_wgrad", dyd, xd, plan["seg_start"], plan["seg_eid"], plan["G"], gwptr, gbptr, R, Cin, Cout, S, pad, st)
+    ws = ops.workspace(L.query("hwg_grouped_conv1d_wgrad_workspace", wnt, Cin, Cout, S), dev)
+    L.call("hwg_grouped_conv1d_wgrad", dyd, xd, plan["seg_start"], plan["seg_eid"], plan["G"], wseg, wrow, wrun, wnt, wrows, gwptr, gbptr, R, Cin, Cout, S, pad,
+           ws, ws.numel(), st)
     _close(y, yr, "grouped fwd")
     _close(dx, xr.grad, "grouped dgrad")
     for e in range(E):
