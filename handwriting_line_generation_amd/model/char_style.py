@@ -133,6 +133,16 @@ class CharStyleEncoder(nn.Module):
         C = feat.shape[3]
         dev = feat.device
 
+        # the branch that does not depend on the found characters goes first: the GPU works on it while the host waits for the
+        # arg-max map and builds the window lists
+        xr = ops.cat_channels([ops.relu(feat), recog], (B, 1, Wf))
+        p = self.prep
+        xr = ops.bias_act(ops.conv1d(xr, p[0].weight, None, 1, 2, 1), p[0].bias, None, ops.ACT_RELU)
+        xr = ops.max_pool2d(xr, (1, 2), (1, 2))
+        xr = p[4](p[3](xr), "relu")
+        xr = ops.bias_act(ops.conv1d(xr, p[6].weight, None, 1, 1, 1), p[6].bias, None, ops.ACT_RELU)
+        xr = ops.avg_pool2d(xr, (1, xr.shape[2])).reshape(B, -1)
+
         # which classes were recognised where (one small D2H copy)
         pred = pred_fetch.get().numpy().reshape(B, T0)
         if Wf > T0:   # the log-probs were replicate-padded to the feature length: the arg-max map pads the same way
@@ -144,26 +154,20 @@ class CharStyleEncoder(nn.Module):
             cls_all = pred[bb, pp]
             order = np.argsort(cls_all, kind="stable")   # class-major, then (author, column): the reference's loop order
             cls_np = cls_all[order].astype(np.int32); b_np = bb[order].astype(np.int32); pos_np = pp[order].astype(np.int32)
-            idx = ops.h2d(np.stack([b_np, pos_np, cls_np]), dev)
-            idx_b, idx_pos, idx_cls = idx[0].contiguous(), idx[1].contiguous(), idx[2].contiguous()
+            # one upload: window coordinates, run tables and the work-tile lists of both window lengths the experts use
+            plan = expert_bank.make_plan(cls_np, dev, window_rows=(2 * self.window + 1, 1), extra=(b_np, pos_np))
+            idx_b, idx_pos = plan["extra"]
+            idx_cls = plan["eid"]
             patches = ops.gather_windows(feat_rows, idx_b, idx_pos, self.window)        # [n,1,2w+1,C]
             scores = ops.gather_scores(recog.reshape(B, Wf, self.n_class), idx_b, idx_pos, idx_cls)
             if self._bank is None:
                 self._bank = expert_bank.ExpertBank(list(self.char_extractor))
-            plan = expert_bank.make_plan(cls_np, dev)
             ex0 = self.char_extractor[0]
             char_styles = expert_bank.run_experts(self._bank, patches, plan, ex0.conv1[2].num_groups, ex0.conv2[2].num_groups)
             avg_char_style = ops.segment_weighted_mean(char_styles, scores, idx_b, B)
         else:
             avg_char_style = torch.zeros((B, self.char_style_dim), dtype=torch.float32, device=dev)
 
-        xr = ops.cat_channels([ops.relu(feat), recog], (B, 1, Wf))
-        p = self.prep
-        xr = ops.bias_act(ops.conv1d(xr, p[0].weight, None, 1, 2, 1), p[0].bias, None, ops.ACT_RELU)
-        xr = ops.max_pool2d(xr, (1, 2), (1, 2))
-        xr = p[4](p[3](xr), "relu")
-        xr = ops.bias_act(ops.conv1d(xr, p[6].weight, None, 1, 1, 1), p[6].bias, None, ops.ACT_RELU)
-        xr = ops.avg_pool2d(xr, (1, xr.shape[2])).reshape(B, -1)
         comb = ops.cat_channels([xr.view(B, 1, 1, -1), avg_char_style.view(B, 1, 1, -1)], (B, 1, 1)).reshape(B, -1)
         f = self.final_g_spacing_style
         comb = ops.bias_act(ops.linear(comb, f[0].weight, None), f[0].bias, None, ops.ACT_RELU)

@@ -144,34 +144,54 @@ class _GroupedGN(Function):
         return dx, None, None, None, None, None, None
 
 
-def make_plan(cls_sorted_np, device):
-    """cls_sorted_np: int array of the expert id of every window, sorted ascending"""
+TILE_ROWS = 64          # GT_ROWS of csrc/expert_bank.hip (forward / data gradient)
+WGRAD_TILE_ROWS = 256   # rows per weight-gradient work tile
+
+
+def _tiles_host(starts, R, tile_rows):
+    rows = np.diff(starts).astype(np.int64) * R
+    per_run = (rows + tile_rows - 1) // tile_rows
+    tile_seg = np.repeat(np.arange(rows.size, dtype=np.int32), per_run)
+    first = np.concatenate([[0], np.cumsum(per_run)])
+    tile_row0 = ((np.arange(tile_seg.size) - np.repeat(first[:-1], per_run)) * tile_rows).astype(np.int32)
+    return tile_seg, tile_row0, first.astype(np.int32)
+
+
+def make_plan(cls_sorted_np, device, window_rows=(), extra=()):
+    """cls_sorted_np: int array of the expert id of every window, sorted ascending. `window_rows`: the R values (positions per window)
+    the plan will be used with - their work-tile lists (forward/dgrad and weight-gradient tilings) are built here and travel to the
+    device in the SAME single upload as the run tables and the caller's `extra` int32 arrays (returned as plan["extra"])."""
     n = cls_sorted_np.size
     change = np.nonzero(np.diff(cls_sorted_np))[0] + 1
     starts = np.concatenate([[0], change, [n]]).astype(np.int32)
     seg_eid = cls_sorted_np[starts[:-1]].astype(np.int32)
-    packed = ops.h2d(np.concatenate([cls_sorted_np.astype(np.int32), starts, seg_eid]), device)
-    return {"eid": packed[:n], "seg_start": packed[n:n + starts.size], "seg_eid": packed[n + starts.size:], "G": int(seg_eid.size),
+    pieces = [np.ascontiguousarray(a, dtype=np.int32).ravel() for a in extra] + [cls_sorted_np.astype(np.int32), starts, seg_eid]
+    tile_keys = []
+    for R in window_rows:
+        for tr in (TILE_ROWS, WGRAD_TILE_ROWS):
+            tile_keys.append((R, tr))
+            pieces.extend(_tiles_host(starts, R, tr))
+    packed = ops.h2d(np.concatenate(pieces), device)
+    cuts = np.cumsum([0] + [p.size for p in pieces])
+    part = [packed[cuts[i]:cuts[i + 1]] for i in range(len(pieces))]
+    ne = len(extra)
+    plan = {"extra": part[:ne], "eid": part[ne], "seg_start": part[ne + 1], "seg_eid": part[ne + 2], "G": int(seg_eid.size),
             "present": [int(e) for e in seg_eid], "n": n, "starts_host": starts, "tiles": {}}
-
-
-TILE_ROWS = 64          # GT_ROWS of csrc/expert_bank.hip (forward / data gradient)
-WGRAD_TILE_ROWS = 256   # GW_ROWS (weight gradient)
+    for j, key in enumerate(tile_keys):
+        tseg, trow, first = part[ne + 3 + 3 * j: ne + 6 + 3 * j]
+        plan["tiles"][key] = (tseg, trow, int(tseg.numel()), first)
+    return plan
 
 
 def plan_tiles(plan, R, device, tile_rows=TILE_ROWS):
     """work list of the grouped GEMMs for windows of R positions: (run, first row) of every tile of at most `tile_rows` rows, and the
-    first tile of every run"""
+    first tile of every run (built by make_plan for the announced R values, lazily otherwise)"""
     key = (R, tile_rows)
     hit = plan["tiles"].get(key)
     if hit is None:
-        rows = np.diff(plan["starts_host"]).astype(np.int64) * R
-        per_run = (rows + tile_rows - 1) // tile_rows
-        tile_seg = np.repeat(np.arange(rows.size, dtype=np.int32), per_run)
-        first = np.concatenate([[0], np.cumsum(per_run)])
-        tile_row0 = ((np.arange(tile_seg.size) - np.repeat(first[:-1], per_run)) * tile_rows).astype(np.int32)
+        tile_seg, tile_row0, first = _tiles_host(plan["starts_host"], R, tile_rows)
         nt = int(tile_seg.size)
-        packed = ops.h2d(np.concatenate([tile_seg, tile_row0, first.astype(np.int32)]), device)
+        packed = ops.h2d(np.concatenate([tile_seg, tile_row0, first]), device)
         hit = plan["tiles"][key] = (packed[:nt], packed[nt:2 * nt], nt, packed[2 * nt:])
     return hit
 
