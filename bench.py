@@ -135,6 +135,16 @@ def main():
                                               "launches": v[2], "time_frac_of_step": round(v[1] / elapsed, 3)}
                                           for k, v in fam.items() if k != dom},
                         "time_frac_of_step": round(sec / elapsed, 3)}
+        if roofline:
+            # HBM bytes per launch of the dominant kernel: PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately with rocprofv3 on this
+            # same command and corrected per MI355X_MICROARCH.md) are committed under profiles/; they cannot be collected from inside bench.py
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                if pm.get("workload") == args.workload:
+                    roofline["traffic"] = pm["kernels"][dom]["hbm_bytes_per_launch_corrected"]
+                    roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 PMC, bytes per launch)"
+            except (OSError, KeyError, ValueError):
+                pass
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             # the oracle's CPU cycle runs in a child process (it never touches the GPU) under a hard timeout
