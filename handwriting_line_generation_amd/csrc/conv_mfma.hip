@@ -584,6 +584,36 @@ __global__ void pack_weight_kernel(const float* src, float* dst, int A, int B, i
   }
 }
 
+// all cached weight images of one optimizer group re-packed in ONE launch after the Adam step (table built by the host once)
+struct PackEntry {
+  const float* src;
+  float* dst;
+  int A, B, Bpad, R, S, flip;
+  long long sa, sb, sr, ss, total, first_block;
+};
+constexpr int PACK_PER_BLOCK = 1024;
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry* table, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {   // last entry whose first_block <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].first_block <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackEntry e = table[lo];
+  const long long base = ((long long)blockIdx.x - e.first_block) * PACK_PER_BLOCK;
+#pragma unroll
+  for (int j = 0; j < PACK_PER_BLOCK / 256; ++j) {
+    const long long i = base + j * 256 + threadIdx.x;
+    if (i >= e.total) break;
+    const int b = (int)(i % e.Bpad);
+    const long long t = i / e.Bpad;
+    const int aa = (int)(t % e.A);
+    const int tap = (int)(t / e.A);
+    int r = tap / e.S, s2 = tap % e.S;
+    if (e.flip) { r = e.R - 1 - r; s2 = e.S - 1 - s2; }
+    e.dst[i] = (b < e.B) ? e.src[aa * e.sa + b * e.sb + r * e.sr + s2 * e.ss] : 0.f;
+  }
+}
+
 // column sums: x[rows][C] -> part[chunks][C]  (single chunk: straight into out)
 // V = 4: block = 16 float4 column groups (64 columns) x 16 row lanes, 256-byte coalesced row segments; V = 1: 64 columns x 4 row lanes
 template <int V>
@@ -623,12 +653,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, lon
     }
   }
 }
-__global__ void colsum_final_kernel(const float* part, int chunks, int C, float* out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// second stage: 16 columns x 16 chunk lanes per workgroup (fixed combination order -> deterministic)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, int chunks, int C, float* out, int accumulate) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float s = 0.f;
-  for (int i = 0; i < chunks; ++i) s += part[(long long)i * C + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < C)
+    for (int i = lane; i < chunks; i += 16) s += part[(long long)i * C + c];
+  red[lane][cl] = s;
+  __syncthreads();
+  if (lane == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += red[l][cl];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 template <int BM, int BN, int BK, int WM_, int WN_>
@@ -716,6 +756,13 @@ extern "C" int hwg_conv_pack_weight(const float* src, float* dst, int A, int B, 
   hipLaunchKernelGGL(pack_weight_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      src, dst, A, B, Bpad, R, S, sa, sb, sr, ss, flip);
   HWG_LAUNCH_CHECK("conv_pack_weight");
+  return HWG_OK;
+}
+
+extern "C" int hwg_conv_pack_weight_multi(const void* table, int n_entries, long long total_blocks, void* stream) {
+  HWG_REQUIRE(table && n_entries > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "conv_pack_weight_multi: bad arguments");
+  hipLaunchKernelGGL(pack_weight_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table, n_entries);
+  HWG_LAUNCH_CHECK("conv_pack_weight_multi");
   return HWG_OK;
 }
 
@@ -967,7 +1014,7 @@ extern "C" int hwg_colsum(const float* x, long long rows, int C, float* out, int
                        chunks == 1 ? out : (float*)nullptr, accumulate);
   HWG_LAUNCH_CHECK("colsum_partial");
   if (chunks == 1) return HWG_OK;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(hwg_cdiv(C, 256)), dim3(256), 0, st, (const float*)workspace, (int)chunks, C, out, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(hwg_cdiv(C, 16)), dim3(256), 0, st, (const float*)workspace, (int)chunks, C, out, accumulate);
   HWG_LAUNCH_CHECK("colsum_final");
   return HWG_OK;
 }

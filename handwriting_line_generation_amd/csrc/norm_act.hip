@@ -18,9 +18,11 @@ Geo make_geo(int N, int HW, int C) {
   g.N = N; g.HW = HW; g.C = C; g.C4 = C / 4;
   g.L = g.C4;                 // float4 lanes per pixel (<= 256)
   g.PP = 256 / g.L;           // pixels per pass
-  int chunks = (HW + 255) / 256;
+  // a workgroup sweeps PP pixels per pass; aim at ~8 passes per workgroup so that narrow-and-deep tensors (HWR tail: 126 pixels x 512
+  // channels) still spread over the chip instead of 8 workgroups running 63 dependent passes each (37 us -> latency bound)
+  int chunks = (HW + g.PP * 8 - 1) / (g.PP * 8);
   if (chunks > 64) chunks = 64;
-  while (chunks > 1 && (long long)chunks * N > 2048) chunks >>= 1;
+  while (chunks > 1 && (long long)chunks * N > 4096) chunks >>= 1;
   if (chunks < 1) chunks = 1;
   g.cs = (HW + chunks - 1) / chunks;
   g.chunks = (HW + g.cs - 1) / g.cs;

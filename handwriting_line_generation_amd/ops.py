@@ -129,8 +129,13 @@ def _desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed=0):
 
 # Packed ([tap][K][C]) images of leaf parameters are cached until the parameter changes: `_version` catches torch-side writes
 # (load_state_dict, copy_), WEIGHT_EPOCH[...] is bumped by the multi-tensor Adam kernel, which writes through raw pointers.
+# After an optimizer step `repack_group` refreshes every cached image of that optimizer's parameters in ONE launch
+# (hwg_conv_pack_weight_multi) instead of ~100 single-weight launches spread over the next step.
 WEIGHT_EPOCH = {}
-_pack_cache = {}
+_pack_cache = {}          # key -> [version, epoch, packed tensor, weight, (A, B, Bpad, R, S, sa, sb, flip)]
+_pack_tables = {}         # group -> (number of cache entries it was built for, device table, total blocks, entries)
+PACK_PER_BLOCK = 1024
+_PACK_DTYPE = None
 
 
 def bump_weight_epoch(group):
@@ -139,18 +144,47 @@ def bump_weight_epoch(group):
 
 def _pack(weight, A, B, R, S, sa, sb, flip, Bpad=None):
     Bpad = B if Bpad is None else Bpad
-    key = None
+    key = hit = group = None
     if weight.is_leaf:
-        epoch = WEIGHT_EPOCH.get(getattr(weight, "_hwg_group", None), 0)
+        group = getattr(weight, "_hwg_group", None)
+        epoch = WEIGHT_EPOCH.get(group, 0)
         key = (id(weight), weight.data_ptr(), A, B, Bpad, sa, sb, int(flip))
         hit = _pack_cache.get(key)
         if hit is not None and hit[0] == weight._version and hit[1] == epoch:
             return hit[2]
-    out = torch.empty((R * S, A, Bpad), dtype=torch.float32, device=weight.device)
+    out = hit[2] if (key is not None and hit is not None) else torch.empty((R * S, A, Bpad), dtype=torch.float32, device=weight.device)
     L.call("hwg_conv_pack_weight", weight, out, A, B, Bpad, R, S, sa, sb, S, 1, int(flip), _stream())
     if key is not None:
-        _pack_cache[key] = (weight._version, epoch, out)
+        _pack_cache[key] = [weight._version, epoch, out, weight, (A, B, Bpad, R, S, sa, sb, int(flip)), group]
     return out
+
+
+def repack_group(group):
+    """refresh all cached packed images of the parameters of `group` (call right after bump_weight_epoch(group))"""
+    global _PACK_DTYPE
+    import numpy as np
+    entries = [e for e in _pack_cache.values() if e[5] == group]
+    if not entries:
+        return
+    tab = _pack_tables.get(group)
+    if tab is None or tab[0] != len(entries):
+        if _PACK_DTYPE is None:
+            _PACK_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("A", "<i4"), ("B", "<i4"), ("Bpad", "<i4"), ("R", "<i4"), ("S", "<i4"), ("flip", "<i4"),
+                                    ("sa", "<i8"), ("sb", "<i8"), ("sr", "<i8"), ("ss", "<i8"), ("total", "<i8"), ("first_block", "<i8")])
+        host = np.zeros(len(entries), dtype=_PACK_DTYPE)
+        blocks = 0
+        for i, e in enumerate(entries):
+            A, B, Bpad, R, S, sa, sb, flip = e[4]
+            total = R * S * A * Bpad
+            host[i] = (e[3].data_ptr(), e[2].data_ptr(), A, B, Bpad, R, S, flip, sa, sb, S, 1, total, blocks)
+            blocks += (total + PACK_PER_BLOCK - 1) // PACK_PER_BLOCK
+        dev = h2d(torch.from_numpy(host.view(np.uint8)), entries[0][2].device)
+        tab = _pack_tables[group] = (len(entries), dev, blocks, entries)
+    L.call("hwg_conv_pack_weight_multi", tab[1], tab[0], tab[2], _stream())
+    epoch = WEIGHT_EPOCH.get(group, 0)
+    for e in tab[3]:
+        if e[0] == e[3]._version:    # torch-side writes still force a private re-pack on next use
+            e[1] = epoch
 
 
 def _pad_channels(x, Cpad):
@@ -291,7 +325,9 @@ class _Conv2d(Function):
             Kq, Cq = (d.K + 3) // 4 * 4, (d.C + 3) // 4 * 4
             # single-channel ends (C == 1 first layers, K <= 2 heads) have a direct kernel; on large images the MFMA kernel on a
             # 4-channel zero-padded copy is faster (measured 164 vs 390 us for the 7x7 first layer of D), so only small ones stay direct
-            tiny_end = (d.K <= 2 or d.C <= 2) and d.N * d.P * d.Q < 8192
+            # (the direct kernel runs a K<=2 head as ONE workgroup: 166 us for the discriminator's 256->1 3x3 head at 304 pixels, so heads
+            # with a wide gathered side go through the padded MFMA path as well; only narrow-and-small cases stay direct)
+            tiny_end = (d.C <= 2 or (d.K <= 2 and d.C < 16)) and d.N * d.P * d.Q < 8192
             # single gathered channel (first layers): the library runs the taps as the GEMM's N dimension, no padding needed
             tap_gemm = d.C == 1 and d.K > 2 and d.K % 4 == 0 and R * S <= 64
             if (Kq != d.K or Cq != d.C) and not tiny_end and not tap_gemm:

@@ -221,6 +221,7 @@ class HipAdam:
         L.call("hwg_mt_adam", d_tab[0], d_tab[1], d_tab[2], d_tab[3], d_ss, d_bc, float(b1), float(b2), float(self.eps), 0.0, f.d_numel,
                f.d_chunk_tensor, f.d_chunk_off, f.nchunks, CHUNK, f._st())
         ops.bump_weight_epoch((id(f), self.group))   # parameters changed behind torch's version counters
+        ops.repack_group((id(f), self.group))        # ... and their cached packed images are refreshed in one launch
 
     # checkpoint format of torch.optim.Adam (state keyed by parameter index within the group)
     def state_dict(self):

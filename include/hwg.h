@@ -74,6 +74,11 @@ typedef struct hwg_conv_desc {
 int hwg_conv_pack_weight(const float* src, float* dst, int A, int B, int Bpad, int R, int S,
                          long long sa, long long sb, long long sr, long long ss, int flip, void* stream);
 
+/* The same re-layout for many weights in one launch (after an optimizer step). table: device array of n_entries records
+ * { const float* src; float* dst; int A, B, Bpad, R, S, flip; long long sa, sb, sr, ss, total, first_block; } (88 bytes) where
+ * total = R*S*A*Bpad and first_block = running sum of ceil(total/1024); total_blocks = that sum over all entries. */
+int hwg_conv_pack_weight_multi(const void* table, int n_entries, long long total_blocks, void* stream);
+
 /* y[N,P,Q,K] = gather-conv(x[N,H,W,C], w[R*S][K][C]) (+ bias[K] if bias != NULL).
  * transposed==0: standard convolution. transposed==1: conv-transpose with stride>1.
  * accumulate!=0 adds into y instead of overwriting it.
