@@ -64,6 +64,9 @@ def main():
             dist.init_process_group(backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
 
+    # The step's host side is thousands of tiny torch-CPU / numpy ops; torch's default intra-op pool (one thread per visible core, 256 on
+    # the GPU box against a 16-CPU quota) only adds wake-up latency to them: 40.5 -> 42.8 steps/s with a single thread.
+    torch.set_num_threads(1)
     from handwriting_line_generation_amd import ops, rng
     from handwriting_line_generation_amd.harness import build_gan_trainer
 

@@ -242,6 +242,17 @@ def _needs_cpad(C, K):
     return C != 1 and K > 2 and C % 16 != 0
 
 
+def _taps(weight):
+    d = weight.dim()
+    if d == 4:
+        return weight.shape[2], weight.shape[3]
+    if d == 3:
+        return 1, weight.shape[2]
+    if d == 2:
+        return 1, 1
+    raise L.HwgError("conv weight must have 2, 3 or 4 dimensions")
+
+
 class _Conv2d(Function):
     """y = conv2d(x, w) (+b) or conv_transpose2d(x, w) (+b); x NHWC."""
 
@@ -249,7 +260,9 @@ class _Conv2d(Function):
     def forward(ctx, x, weight, bias, stride, padding, dilation, transposed, output_padding):
         _chk(x, "conv input"); _chk(weight, "conv weight"); _chk(bias, "conv bias")
         N, H, W, C = x.shape
-        R, S = weight.shape[2], weight.shape[3]
+        # Linear [O,I] and Conv1d [O,I,S] parameters are used as they are (same memory as [O,I,1,S]); a .view() of the parameter would be a
+        # non-leaf tensor, lose the packed-weight cache and the direct gradient accumulation and cost three extra ATen ops per backward
+        R, S = _taps(weight)
         sh, sw = stride; ph, pw = padding; dh, dw = dilation
         if not transposed:
             K = weight.shape[0]
@@ -288,7 +301,7 @@ class _Conv2d(Function):
         stride, padding, dilation, transposed, P, Q = ctx.geom
         dy = dy.contiguous()
         N, H, W, C = x.shape
-        R, S = weight.shape[2], weight.shape[3]
+        R, S = _taps(weight)
         sh, sw = stride; ph, pw = padding; dh, dw = dilation
         K = dy.shape[3]
         dx = dw_ = db = None
@@ -345,10 +358,10 @@ class _Conv2d(Function):
                 L.call("hwg_conv_wgrad", ctypes.byref(d), up, vp, tmp, Cq * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)
                 valid = tmp[:dK, :dC]
                 if direct:
-                    dw_.add_(valid)
+                    dw_.add_(valid.reshape(dw_.shape))
                     dw_ = None
                 else:
-                    dw_ = valid.contiguous()
+                    dw_ = valid.reshape(weight.shape).contiguous()
             else:
                 need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
                 ws = workspace(need, x.device)
@@ -385,13 +398,13 @@ def conv_transpose2d(x, weight, bias=None, stride=1, padding=0, output_padding=0
 
 def conv1d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     """x [N,1,L,C]; weight in Conv1d layout [O,I,S]"""
-    return conv2d(x, weight.unsqueeze(2), bias, (1, stride), (0, padding), (1, dilation))
+    return conv2d(x, weight, bias, (1, stride), (0, padding), (1, dilation))
 
 
 def linear(x, weight, bias=None):
     """x [rows, I] -> [rows, O]; weight [O, I]"""
     rows, I = x.shape
-    y = conv2d(x.view(rows, 1, 1, I), weight.view(weight.shape[0], I, 1, 1), bias)
+    y = conv2d(x.view(rows, 1, 1, I), weight, bias)
     return y.view(rows, weight.shape[0])
 
 

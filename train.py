@@ -13,6 +13,8 @@ import sys
 
 import torch
 
+torch.set_num_threads(1)   # host side = many tiny CPU ops; the intra-op pool only adds latency (see bench.py)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 logging.basicConfig(level=logging.INFO, format="")
