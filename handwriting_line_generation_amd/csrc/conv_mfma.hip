@@ -125,6 +125,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
   float4 ra[A_IT], rb[B_IT];
+  bool ma[A_IT];   // validity of the A loads in flight (applied when the tile is stored, so the wait for the loads sits after the MFMAs)
   // coordinates of the tile being LOADED (this workgroup's K range starts at step t_begin)
   int c0 = (t_begin % csteps) * BK;
   int js = (t_begin / csteps) % (ns > 0 ? ns : 1);
@@ -140,19 +141,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
       const int ih = a_hb[it] + ch * jr;
       const int iw = a_wb[it] + cw * js;
       const bool v = a_ok[it] && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-      // always issue the load (from a valid dummy address when masked) and select afterwards: no exec-mask branches between the
-      // loads of one tile, so they all go out back to back
+      // always issue the load (from a valid dummy address when masked): no exec-mask branches between the loads of one tile, so they
+      // all go out back to back; the zero fill happens in store_tile
       const long long off = v ? ((long long)(a_nb[it] + ih * a.W + iw)) * a.C + c0 + a_chk[it] * 4 : 0;
-      float4 val = *reinterpret_cast<const float4*>(xg + off);
-      if (!v) val = make_float4(0.f, 0.f, 0.f, 0.f);
-      ra[it] = val;
+      ra[it] = *reinterpret_cast<const float4*>(xg + off);
+      ma[it] = v;
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const long long off = b_ok[it] ? ((long long)tap * a.K + n0 + b_row[it]) * a.C + c0 + b_chk[it] * 4 : 0;
-      float4 val = *reinterpret_cast<const float4*>(wg + off);
-      if (!b_ok[it]) val = make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[it] = val;
+      rb[it] = *reinterpret_cast<const float4*>(wg + off);
     }
     // advance to the next tile
     c0 += BK;
@@ -165,11 +163,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
     float* Ab = As + buf * BM * LD;
     float* Bb = Bs + buf * BN * LD;
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it)
-      if (tid + it * NT < A_F4) *reinterpret_cast<float4*>(Ab + a_row[it] * LD + a_chk[it] * 4) = ra[it];
+    for (int it = 0; it < A_IT; ++it) {
+      float4 v = ra[it];
+      if (!ma[it]) { v.x = 0.f; v.y = 0.f; v.z = 0.f; v.w = 0.f; }
+      if (tid + it * NT < A_F4) *reinterpret_cast<float4*>(Ab + a_row[it] * LD + a_chk[it] * 4) = v;
+    }
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it)
-      if (tid + it * NT < B_F4) *reinterpret_cast<float4*>(Bb + b_row[it] * LD + b_chk[it] * 4) = rb[it];
+    for (int it = 0; it < B_IT; ++it) {
+      float4 v = rb[it];
+      if (!b_ok[it]) { v.x = 0.f; v.y = 0.f; v.z = 0.f; v.w = 0.f; }
+      if (tid + it * NT < B_F4) *reinterpret_cast<float4*>(Bb + b_row[it] * LD + b_chk[it] * 4) = v;
+    }
   };
 
   const int wm0 = (wid / WAVES_N) * WM;
@@ -805,7 +809,7 @@ static ConvPlan plan_conv(const hwg_conv_desc* d) {
   const int min_steps = (min_taps > 0 ? min_taps : 1) * (d->C / bk);
   const double out_bytes = 4.0 * d->N * d->P * d->Q * d->K;
   struct Tile { int bm, bn; double tflops, overhead; };
-  static const Tile tiles[4] = {{128, 128, 104.0, 1.0}, {128, 64, 94.0, 1.75}, {64, 64, 88.0, 2.5}, {128, 32, 62.0, 2.5}};
+  static const Tile tiles[4] = {{128, 128, 108.0, 1.0}, {128, 64, 94.0, 1.25}, {64, 64, 88.0, 1.5}, {128, 32, 62.0, 1.5}};
   static const int splits[8] = {1, 2, 3, 4, 6, 8, 12, 16};
   int bm = 128, bn = 32, ns = 1;
   double best = 1e30;
@@ -820,7 +824,7 @@ static ConvPlan plan_conv(const hwg_conv_desc* d) {
       const double q = per_xcd * n / 32.0;
       const double quanta = q <= 8.0 ? ceil(q) : q + 0.5;
       double tm = quanta * (T_total / n + t.overhead) * step_s;
-      if (n > 1) tm += (n + 1) * out_bytes / 6.0e12 + 3e-6;
+      if (n > 1) tm += (n + 1) * out_bytes / 8.0e12 + 6e-6;
       if (tm < best) { best = tm; bm = t.bm; bn = t.bn; ns = n; }
     }
   }
