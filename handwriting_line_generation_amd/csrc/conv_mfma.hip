@@ -192,31 +192,39 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
     if (t + 1 < T) load_tile();  // global loads in flight during the MFMAs below
     const float* Ab = As + buf * BM * LD;
     const float* Bb = Bs + buf * BN * LD;
-#pragma unroll
-    for (int sg = 0; sg < BK / 8; ++sg) {
-      // lane (i = lane&31, half = lane>>5) reads 4 consecutive k values starting at 4*(2*sg+half); the j-th of them
-      // is the operand of the j-th MFMA of this group. A and B use the same mapping, so MFMA j contracts
-      // k = {8sg+j, 8sg+4+j}: a permutation of the K order, which the sum does not care about.
+    // lane (i = lane&31, half = lane>>5) reads 4 consecutive k values starting at 4*(2*sg+half); the j-th of them
+    // is the operand of the j-th MFMA of this group. A and B use the same mapping, so MFMA j contracts
+    // k = {8sg+j, 8sg+4+j}: a permutation of the K order, which the sum does not care about.
+    // Software pipeline: the fragment reads of group sg+1 are issued before the MFMAs of group sg.
+    constexpr int NSG = BK / 8;
+    float4 af[2][MI], bf[2][NI];
+    auto frag = [&](int sg, int slot) {
       const int koff = 4 * (2 * sg + lhi);
-      float4 af[MI], bf[NI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        af[mi] = *reinterpret_cast<const float4*>(Ab + (wm0 + mi * 32 + l31) * LD + koff);
+      for (int mi = 0; mi < MI; ++mi) af[slot][mi] = *reinterpret_cast<const float4*>(Ab + (wm0 + mi * 32 + l31) * LD + koff);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-        bf[ni] = *reinterpret_cast<const float4*>(Bb + (wn0 + ni * 32 + l31) * LD + koff);
+      for (int ni = 0; ni < NI; ++ni) bf[slot][ni] = *reinterpret_cast<const float4*>(Bb + (wn0 + ni * 32 + l31) * LD + koff);
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int sg = 0; sg < NSG; ++sg) {
+      if (sg + 1 < NSG) frag(sg + 1, (sg + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-          const float av = j == 0 ? af[mi].x : j == 1 ? af[mi].y : j == 2 ? af[mi].z : af[mi].w;
+          const float4 a4 = af[sg & 1][mi];
+          const float av = j == 0 ? a4.x : j == 1 ? a4.y : j == 2 ? a4.z : a4.w;
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
-            const float bv = j == 0 ? bf[ni].x : j == 1 ? bf[ni].y : j == 2 ? bf[ni].z : bf[ni].w;
+            const float4 b4 = bf[sg & 1][ni];
+            const float bv = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (t + 1 < T) store_tile(buf ^ 1);
     __syncthreads();
@@ -454,19 +462,35 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
 #pragma unroll
       for (int kp = 0; kp < BKP; ++kp) bsum += Ub[kp * BMU + tid];
     }
+    // software pipeline over groups of PF k pairs: the LDS reads of group g+1 are issued before the MFMAs of group g
+    // (sched_barrier keeps the compiler from re-serialising them into read-wait-MFMA triples)
+    constexpr int KPAIRS = BKP / WAVES_K / 2;
+    constexpr int PF = KPAIRS >= 4 ? 4 : KPAIRS;
+    constexpr int NG = KPAIRS / PF;
+    float af[2][PF][MI], bf[2][PF][NI];
+    auto lds_group = [&](int g, int slot) {
 #pragma unroll
-    for (int ks = kbeg; ks < kend; ks += 2) {
-      const int kk = ks + lhi;
-      float af[MI], bf[NI];
+      for (int u = 0; u < PF; ++u) {
+        const int kk = kbeg + 2 * (g * PF + u) + lhi;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[mi] = Ub[kk * BMU + wm0 + mi * 32 + l31];
+        for (int mi = 0; mi < MI; ++mi) af[slot][u][mi] = Ub[kk * BMU + wm0 + mi * 32 + l31];
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[ni] = Vb[kk * BNV + wn0 + ni * 32 + l31];
+        for (int ni = 0; ni < NI; ++ni) bf[slot][u][ni] = Vb[kk * BNV + wn0 + ni * 32 + l31];
+      }
+    };
+    lds_group(0, 0);
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) lds_group(g + 1, (g + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+      for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][u][mi], bf[g & 1][u][ni], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (t + 1 < T) store_tile(buf ^ 1);
     __syncthreads();
@@ -727,7 +751,8 @@ WgPlan plan_wgrad(const hwg_conv_desc* d) {
     }
   }
   static const int splits[14] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
-  static const double tflops[2] = {100.0, 90.0}, overhead[2] = {1.0, 2.0};
+  static const double tflops[2] = {106.0, 90.0}, overhead[2] = {1.0, 1.0};
+  static const int waves_per_block[2] = {16, 8};
   const double wbytes = 4.0 * d->R * d->S * K * C;
   double best = 1e30;
   WgPlan bp = p;
@@ -735,7 +760,6 @@ WgPlan plan_wgrad(const hwg_conv_desc* d) {
     WgPlan c;
     wg_tile(c, cfg, K, C);
     const double base = (double)d->R * d->S * c.tiles_u * c.tiles_v;
-    const double step_s = 2.0 * c.bmu * c.bnv * c.bkp / (tflops[cfg] * 1e12 / 256.0);
     int last_ns = 0;
     for (int si = 0; si < 14; ++si) {
       wg_split(c, Mtot, splits[si]);
@@ -743,8 +767,15 @@ WgPlan plan_wgrad(const hwg_conv_desc* d) {
       last_ns = c.nsplit;
       if (wbytes * c.nsplit > 2.0e9) break;
       const double q = base * c.nsplit / 256.0;
-      const double quanta = q <= 8.0 ? ceil(q) : q + 0.5;
-      const double tm = quanta * ((double)c.chunk / c.bkp + overhead[cfg]) * step_s + (c.nsplit + 1) * wbytes / 3.0e12 + 3e-6;
+      const double quanta = q <= 2.0 ? ceil(q) : q + 0.5;
+      // sustained rate grows with the wavefronts resident per CU (latency hiding): 65 % with one 8-wave workgroup, full at >= 24 waves
+      double resident = (q > 1.0 ? q : 1.0);
+      const double max_blocks = 32.0 / waves_per_block[cfg];
+      if (resident > max_blocks) resident = max_blocks;
+      resident *= waves_per_block[cfg];
+      const double rate = tflops[cfg] * (0.65 + 0.35 * (resident >= 24.0 ? 1.0 : resident / 24.0));
+      const double step_s = 2.0 * c.bmu * c.bnv * c.bkp / (rate * 1e12 / 256.0);
+      const double tm = quanta * ((double)c.chunk / c.bkp + overhead[cfg]) * step_s + (c.nsplit + 1) * wbytes / 8.0e12 + 3e-6;
       if (tm < best) { best = tm; bp = c; }
     }
   }

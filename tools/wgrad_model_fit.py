@@ -18,9 +18,12 @@ def predict(rec, cfg, ns, chunk, base, prm):
     N, H, W, C, K, R, S = rec["shape"][:7]
     bmu, bnv, bkp = CFG[cfg]
     tf, ov = prm["cfg"][cfg]
-    step = 2.0 * bmu * bnv * bkp / (tf * 1e12 / 256)
     blocks = base * ns
     q = blocks / 256.0
+    wpb = 16 if cfg == 0 else 8
+    resident = min(max(q, 1.0), 32.0 / wpb) * wpb          # waves resident per CU
+    tf = tf * (prm["occ_floor"] + (1 - prm["occ_floor"]) * min(1.0, resident / prm["occ_w"]))
+    step = 2.0 * bmu * bnv * bkp / (tf * 1e12 / 256)
     quanta = math.ceil(q) if q <= prm["ceil_upto"] else q + 0.5
     t = quanta * (chunk / bkp + ov) * step
     t += (ns + 1) * 4.0 * R * S * K * C / prm["bw"] + prm["lat"]
@@ -46,8 +49,8 @@ def evaluate(prm, verbose=False):
     return tot, tb
 
 best = (1e30, None)
-for cu, r0, r3, ov0, ov3, bw, lat in itertools.product([2, 4, 8], [88, 94, 100], [84, 90, 96], [1, 2, 4], [1, 2, 4], [3e12, 5e12, 8e12], [3e-6, 6e-6]):
-    prm = {"cfg": {0: (r0, ov0), 1: (r3, ov3)}, "ceil_upto": cu, "bw": bw, "lat": lat}
+for cu, r0, r3, ov0, ov3, bw, lat, ofl, ow in itertools.product([2, 8], [94, 100, 106], [90, 100, 110], [1, 2], [1, 2], [5e12, 8e12], [3e-6], [0.5, 0.65, 0.8, 1.0], [16, 24, 32]):
+    prm = {"cfg": {0: (r0, ov0), 1: (r3, ov3)}, "ceil_upto": cu, "bw": bw, "lat": lat, "occ_floor": ofl, "occ_w": ow}
     r = evaluate(prm)[0]
     if r < best[0]: best = (r, prm)
 print(best, evaluate(best[1]))
