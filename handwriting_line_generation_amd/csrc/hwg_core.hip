@@ -59,6 +59,11 @@ extern "C" int hwg_prof_start(int max_records) {
   g_prof_on.store(1);
   return HWG_OK;
 }
+extern "C" int hwg_prof_enable(int on) {
+  if (!g_prof) return HWG_OK;   // no profile open: nothing to switch
+  g_prof_on.store(on ? 1 : 0);
+  return HWG_OK;
+}
 extern "C" int hwg_prof_tag(int tag) { g_prof_tag = tag; return HWG_OK; }
 extern "C" int hwg_prof_stop(int* kinds, int* tags, double* work, float* ms, int capacity) {
   if (!g_prof) return 0;

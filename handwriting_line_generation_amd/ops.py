@@ -205,6 +205,11 @@ def prof_start(max_records=200000):
     L.call("hwg_prof_start", max_records)
 
 
+def prof_enable(on):
+    """pause / resume an open profile"""
+    L.call("hwg_prof_enable", int(bool(on)))
+
+
 def prof_stop():
     """-> list of (kind, shape, work, seconds); kind in conv_mfma_kernel / wgrad_mfma_kernel / conv_split_reduce / wgrad_reduce"""
     global PROF_SHAPES

@@ -44,6 +44,7 @@ int hwg_device_ok(void);
  * kind (0 conv, 1 wgrad, 2 conv split reduce, 3 wgrad reduce), tag, algorithmic work (flops; bytes for the reduce passes) and ms.
  * Returns the number of records written. */
 int hwg_prof_start(int max_records);
+int hwg_prof_enable(int on);   /* pause / resume recording inside an open profile (sampled profiling: the event pairs cost ~7 % of a step) */
 int hwg_prof_tag(int tag);
 int hwg_prof_stop(int* kinds, int* tags, double* work, float* ms, int capacity);
 
