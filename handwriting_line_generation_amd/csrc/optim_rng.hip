@@ -28,7 +28,16 @@ __global__ __launch_bounds__(256) void mt_abs_sum_kernel(MtArgs a, double* out) 
   const long long off = a.chunk_off[blockIdx.x];
   const long long end = min(off + (long long)a.chunk, a.numel[t]);
   double s = 0.0;
-  for (long long i = off + threadIdx.x; i < end; i += 256) s += (double)fabsf(g[i]);
+  // 16-byte loads over the aligned body (every table entry is 16-byte aligned and chunks are multiples of 4 elements), scalar tail
+  const bool al = ((reinterpret_cast<uintptr_t>(g + off)) & 15) == 0;
+  const long long n4 = al ? (end - off) >> 2 : 0;
+  const float4* g4 = reinterpret_cast<const float4*>(g + off);
+#pragma unroll 4
+  for (long long j = threadIdx.x; j < n4; j += 256) {
+    const float4 v = g4[j];
+    s += (double)(fabsf(v.x) + fabsf(v.y)) + (double)(fabsf(v.z) + fabsf(v.w));
+  }
+  for (long long i = off + 4 * n4 + threadIdx.x; i < end; i += 256) s += (double)fabsf(g[i]);
   s = block_sum_d(s, sm);
   if (threadIdx.x == 0) atomicAdd(out + t, s);
 }
@@ -73,7 +82,18 @@ __global__ __launch_bounds__(256) void mt_axpy_kernel(MtArgs a, const float* coe
   if (c == 0.f) return;
   const long long off = a.chunk_off[blockIdx.x];
   const long long end = min(off + (long long)a.chunk, a.numel[t]);
-  for (long long i = off + threadIdx.x; i < end; i += 256) dst[i] += c * src[i];
+  const bool al = ((reinterpret_cast<uintptr_t>(dst + off) | reinterpret_cast<uintptr_t>(src + off)) & 15) == 0;
+  const long long n4 = al ? (end - off) >> 2 : 0;
+  float4* d4 = reinterpret_cast<float4*>(dst + off);
+  const float4* s4 = reinterpret_cast<const float4*>(src + off);
+#pragma unroll 4
+  for (long long j = threadIdx.x; j < n4; j += 256) {
+    float4 d = d4[j];
+    const float4 v = s4[j];
+    d.x += c * v.x; d.y += c * v.y; d.z += c * v.z; d.w += c * v.w;
+    d4[j] = d;
+  }
+  for (long long i = off + 4 * n4 + threadIdx.x; i < end; i += 256) dst[i] += c * src[i];
 }
 
 // op 0: a = 0 ; 1: a = clamp(a, -c, c) ; 2: flag |= any(!finite(a)) ; 3: b = a (copy) ; 4: b = a, a = 0 (stash)
@@ -85,7 +105,21 @@ __global__ __launch_bounds__(256) void mt_unary_kernel(MtArgs a, int op, float c
   const long long off = a.chunk_off[blockIdx.x];
   const long long end = min(off + (long long)a.chunk, a.numel[t]);
   bool bad = false;
-  for (long long i = off + threadIdx.x; i < end; i += 256) {
+  const bool al = ((reinterpret_cast<uintptr_t>(x + off) | (y ? reinterpret_cast<uintptr_t>(y + off) : 0)) & 15) == 0;
+  const long long n4 = al ? (end - off) >> 2 : 0;
+  float4* x4 = reinterpret_cast<float4*>(x + off);
+  float4* y4 = y ? reinterpret_cast<float4*>(y + off) : nullptr;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (long long j = threadIdx.x; j < n4; j += 256) {
+    const float4 v = x4[j];
+    if (op == 0) x4[j] = zero4;
+    else if (op == 1) x4[j] = make_float4(fminf(fmaxf(v.x, -c), c), fminf(fmaxf(v.y, -c), c), fminf(fmaxf(v.z, -c), c), fminf(fmaxf(v.w, -c), c));
+    else if (op == 2) bad |= !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+    else if (op == 3) { if (y4) y4[j] = v; }
+    else { if (y4) y4[j] = v; x4[j] = zero4; }
+  }
+  for (long long i = off + 4 * n4 + threadIdx.x; i < end; i += 256) {
     const float v = x[i];
     if (op == 0) x[i] = 0.f;
     else if (op == 1) x[i] = fminf(fmaxf(v, -c), c);
@@ -108,7 +142,33 @@ __global__ __launch_bounds__(256) void mt_adam_kernel(MtArgs a, const float* ste
   const float ss = step_size[t], b2 = bc2_sqrt[t];
   const long long off = a.chunk_off[blockIdx.x];
   const long long end = min(off + (long long)a.chunk, a.numel[t]);
-  for (long long i = off + threadIdx.x; i < end; i += 256) {
+  const bool al = ((reinterpret_cast<uintptr_t>(p + off) | reinterpret_cast<uintptr_t>(g + off) | reinterpret_cast<uintptr_t>(m + off) |
+                    reinterpret_cast<uintptr_t>(v + off)) & 15) == 0;
+  const long long n4 = al ? (end - off) >> 2 : 0;
+  float4* p4 = reinterpret_cast<float4*>(p + off);
+  float4* g4 = reinterpret_cast<float4*>(g + off);
+  float4* m4 = reinterpret_cast<float4*>(m + off);
+  float4* v4 = reinterpret_cast<float4*>(v + off);
+#pragma unroll 2
+  for (long long j = threadIdx.x; j < n4; j += 256) {
+    float4 gq = g4[j], mq = m4[j], vq = v4[j], pq = p4[j];
+    float* gp = reinterpret_cast<float*>(&gq); float* mp = reinterpret_cast<float*>(&mq);
+    float* vp = reinterpret_cast<float*>(&vq); float* pp = reinterpret_cast<float*>(&pq);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gi = gp[e];
+      if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+      gp[e] = gi;
+      const float mi = mp[e] + (gi - mp[e]) * (1.f - beta1);
+      const float vi = vp[e] * beta2 + (1.f - beta2) * gi * gi;
+      mp[e] = mi; vp[e] = vi;
+      const float denom = sqrtf(vi) / b2 + eps;
+      pp[e] = pp[e] - ss * (mi / denom);
+    }
+    if (clip > 0.f) g4[j] = gq;
+    m4[j] = mq; v4[j] = vq; p4[j] = pq;
+  }
+  for (long long i = off + 4 * n4 + threadIdx.x; i < end; i += 256) {
     float gi = g[i];
     if (clip > 0.f) { gi = fminf(fmaxf(gi, -clip), clip); g[i] = gi; }
     // exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
