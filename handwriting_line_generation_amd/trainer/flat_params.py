@@ -166,22 +166,44 @@ class FlatParams:
         return self._flag
 
 
+def start_stash_allreduce(stash, world):
+    """Data parallel: begin the SUM all-reduce of a freshly stashed gradient set without waiting for it. The collective runs on the
+    communicator's stream behind the stash copy, so it overlaps the backward passes that follow (an `auto` lesson stashes four sets
+    before it balances them). `allreduce_gradient_sets` collects it. Returns the stash as a list [buffer, mask, pending work]."""
+    import torch.distributed as dist
+    st = [stash[0], stash[1], None]
+    if world > 1:
+        st[2] = dist.all_reduce(st[0], op=dist.ReduceOp.SUM, async_op=True)
+    return st
+
+
 def allreduce_gradient_sets(flat, stashes, world, device):
     """Data-parallel averaging of the current gradient set and of every stashed set.
-    The None-masks are OR-ed first (int32 MAX): a tensor that received a gradient on any rank exists, possibly as zeros, on all."""
+    The None-masks are OR-ed first (int32 MAX): a tensor that received a gradient on any rank exists, possibly as zeros, on all.
+    Stashes whose reduction was started early (start_stash_allreduce) are only waited for."""
     import torch.distributed as dist
     if world == 1:
         return
     masks = [flat.touched] + [s[1] for s in stashes]
     m = torch.from_numpy(np.stack(masks).astype(np.int32)).to(device)
     dist.all_reduce(m, op=dist.ReduceOp.MAX)
-    m = m.cpu().numpy().astype(bool)
+    pending = []
+    for s in stashes:
+        work = s[2] if len(s) > 2 else None
+        if work is None:
+            work = dist.all_reduce(s[0], op=dist.ReduceOp.SUM, async_op=True)
+        pending.append((work, s[0]))
+    pending.append((dist.all_reduce(flat.flat_grad, op=dist.ReduceOp.SUM, async_op=True), flat.flat_grad))
+    m = m.cpu().numpy().astype(bool)     # the only host wait; the sums are in flight meanwhile
     flat.touched[:] = m[0]
     for k, s in enumerate(stashes):
         s[1][:] = m[1 + k]
-    for buf in [flat.flat_grad] + [s[0] for s in stashes]:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    for work, buf in pending:
+        work.wait()
         buf.div_(world)
+    for s in stashes:
+        if len(s) > 2:
+            s[2] = None
 
 
 class HipAdam:

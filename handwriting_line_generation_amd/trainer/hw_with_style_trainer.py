@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 from .. import ops
 from ..base.base_trainer import BaseTrainer
-from .flat_params import allreduce_gradient_sets
+from .flat_params import allreduce_gradient_sets, start_stash_allreduce
 from ..data.text_data import TextData
 from ..model.autoencoder import Encoder2
 from ..model.hw_with_style import correct_pred
@@ -128,6 +128,10 @@ class HWWithStyleTrainer(BaseTrainer):
     def _allreduce_grads(self, stashes=()):
         allreduce_gradient_sets(self.flat, stashes, self.world, self.gpu)
 
+    def _stash(self):
+        """clone-and-zero the current gradients (trainer :305-338); data parallel: their all-reduce starts right away"""
+        return start_stash_allreduce(self.flat.stash(), self.world)
+
     def _train_iteration(self, iteration):
         if not self.model.training:   # nn.Module.train() walks all ~3000 sub-modules; only do it when the mode actually changes
             self.model.train()
@@ -164,7 +168,7 @@ class HWWithStyleTrainer(BaseTrainer):
             for part in (autoGenLoss, recogLoss):
                 if not isinstance(part, int):
                     part.backward(retain_graph=True)
-                    self.saved_grads.append(f.stash())
+                    self.saved_grads.append(self._stash())
         else:
             for part in (recogLoss, autoGenLoss):
                 if not isinstance(part, int):
@@ -173,7 +177,7 @@ class HWWithStyleTrainer(BaseTrainer):
             loss.backward()
 
         if self.balance_loss and "no-step" in lesson:
-            self.saved_grads.append(f.stash())
+            self.saved_grads.append(self._stash())
         elif self.balance_loss and len(self.saved_grads) > 0:
             self._allreduce_grads(self.saved_grads)
             multipliers = None

@@ -29,13 +29,18 @@ def _worker(rank, world, port, out):
         flat.touched[k] = True
     stash_buf = torch.randn(flat.total, generator=g)
     stash_mask = np.zeros(flat.nt, dtype=bool); stash_mask[[3, 4][rank]] = True
-    stashes = [(stash_buf.clone(), stash_mask.copy())]
+    from handwriting_line_generation_amd.trainer.flat_params import start_stash_allreduce
+    early_buf = torch.randn(flat.total, generator=g)
+    early = start_stash_allreduce((early_buf.clone(), stash_mask.copy()), world)    # reduction started before the others (overlap path)
+    stashes = [(stash_buf.clone(), stash_mask.copy()), early]
     mine = flat.flat_grad.clone()
     allreduce_gradient_sets(flat, stashes, world, torch.device("cpu"))
     # gather every rank's original sets to rank-independent expectation
     gl = [torch.zeros_like(mine) for _ in range(world)]; dist.all_gather(gl, mine)
     sl = [torch.zeros_like(stash_buf) for _ in range(world)]; dist.all_gather(sl, stash_buf)
+    el = [torch.zeros_like(early_buf) for _ in range(world)]; dist.all_gather(el, early_buf)
     ok = torch.allclose(flat.flat_grad, sum(gl) / world) and torch.allclose(stashes[0][0], sum(sl) / world)
+    ok = ok and torch.allclose(early[0], sum(el) / world) and early[2] is None
     ok = ok and flat.touched.tolist() == [True, True, True, False, False, True] and stashes[0][1].tolist() == [False, False, False, True, True, False]
     # parameter .grad views still alias the flat buffer
     ok = ok and params[flat.order[1]].grad.data_ptr() == flat.flat_grad[flat.offsets[1]:].data_ptr()
