@@ -139,7 +139,8 @@ class FlatParams:
         ns = len(stashes)
         sumR = torch.empty((ns, self.nt), dtype=torch.float64, device=self.device)
         ptrR = np.zeros((ns, self.nt), dtype=np.int64)
-        for k, (buf, tm) in enumerate(stashes):
+        for k, st in enumerate(stashes):
+            buf, tm = st[0], st[1]
             sumR[k] = self.abs_sums(buf, tm)
             ptrR[k] = self.base_ptrs(buf) * tm.astype(np.int64)
             if (tm & ~self.touched).any():
