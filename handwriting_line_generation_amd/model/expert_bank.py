@@ -37,6 +37,33 @@ class ExpertBank:
         self._gptr_host = {k: np.zeros(self.E, dtype=np.int64) for k in KINDS}
         self._gptr_dev = {}
 
+    def _static_grads(self, device):
+        """True when all expert parameters own a gradient view registered with one FlatParams (then the tables are built once)"""
+        st = getattr(self, "_static_state", None)
+        if st is None:
+            ok, owner, idx = True, None, [[] for _ in range(self.E)]
+            for k in KINDS:
+                for e, p in enumerate(self.params[k]):
+                    fk = getattr(p, "_hwg_flat", None)
+                    if fk is None or p.grad is None or (owner is not None and fk[0] is not owner):
+                        ok = False
+                        break
+                    owner = fk[0]
+                    idx[e].append(fk[1])
+                if not ok:
+                    break
+            if ok:
+                host = np.array([[p.grad.data_ptr() for p in self.params[k]] for k in KINDS], dtype=np.int64)
+                dev = ops.h2d(host, device)
+                self._gptr_dev = {k: dev[i] for i, k in enumerate(KINDS)}
+                self._flat_idx = (owner, [np.array(v, dtype=np.int64) for v in idx])
+                self._grad_key = self.params["w1"][0].grad.data_ptr()
+            st = self._static_state = bool(ok)
+        if st and self.params["w1"][0].grad is not None and self.params["w1"][0].grad.data_ptr() != self._grad_key:
+            self._static_state = None      # gradients were re-created (a new FlatParams / zero_grad(set_to_none)): rebuild
+            return self._static_grads(device)
+        return st
+
     def param_ptrs(self, device):
         key = (self.params["w1"][1].data_ptr(), str(device))
         if self._pkey != key:
@@ -53,6 +80,13 @@ class ExpertBank:
         if plan.get("grads_ready") and self._gptr_dev:
             return self._gptr_dev
         present = plan["present"]
+        if self._static_grads(device):
+            # trainer case: every expert gradient is a persistent view of the flat buffer -> one static pointer table for all experts,
+            # and "touched" is one vectorised assignment over the flat indices of the present experts' tensors
+            flat, idx = self._flat_idx
+            flat.touched[np.concatenate([idx[e] for e in present])] = True
+            plan["grads_ready"] = True
+            return self._gptr_dev
         changed = False
         for k in KINDS:
             plist = self.params[k]

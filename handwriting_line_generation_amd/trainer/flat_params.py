@@ -62,6 +62,7 @@ class FlatParams:
             p.grad = self.flat_grad[self.offsets[k]: self.offsets[k] + numel[k]].view_as(p)
             p.register_post_accumulate_grad_hook(self._make_hook(k))   # gradients that still arrive through autograd
             p._hwg_touch = self._make_touch(k)                            # gradients the kernels accumulate in place (ops._grad_buffer)
+            p._hwg_flat = (self, k)                                       # lets banks of parameters mark many tensors touched at once
         # static tables
         ct, co = [], []
         for k in range(self.nt):
