@@ -39,8 +39,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=14)
-    ap.add_argument("--warmup", type=int, default=7)
+    ap.add_argument("--steps", type=int, default=56)
+    ap.add_argument("--warmup", type=int, default=14)
     ap.add_argument("--workload", default="iam_gan_b4a2_w512", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for the oracle baseline")
