@@ -136,7 +136,16 @@ def main():
                 fh.write("# per-shape MFMA conv launches inside the timed region (%d steps): time_ms  launches  avg_us  TFLOP/s  kind  shape(N,H,W,C,K,R,S,stride,pad,dil,mode)\n" % args.steps)
                 for (kind, shape), (fl, sec, n) in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
                     fh.write("%9.3f %6d %9.1f %7.1f  %s %s\n" % (sec * 1e3, n, sec / n * 1e6, fl / sec / 1e12 if sec > 0 else 0, kind, shape))
-        mf = {k: v for k, v in fam.items() if "reduce" not in k}
+        # the north-star target is stated on the G+D conv stack: every conv kernel (MFMA, direct, their reduce passes) launched by the
+        # generator's or the discriminator's layers, forward and backward, algorithmic FLOPs / kernel time
+        gd = {"G": [0.0, 0.0], "D": [0.0, 0.0]}
+        for kind, shape, work, dt in prof:
+            sc = shape[-1] if shape else None
+            if sc in gd:
+                gd[sc][1] += dt
+                if "reduce" not in kind:
+                    gd[sc][0] += work
+        mf = {k: v for k, v in fam.items() if "reduce" not in k and "direct" not in k}
         dom = max(mf, key=lambda k: mf[k][1]) if mf else None
         roofline = None
         if dom:
@@ -145,11 +154,17 @@ def main():
             roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "launches": n, "avg_launch_us": round(sec / n * 1e6, 2),
                         "gflop_per_launch": round(fl / n / 1e9, 4),
-                        "other_kernels": {k: {("achieved_GBps" if "reduce" in k else "achieved"): round(v[0] / v[1] / (1e9 if "reduce" in k else 1e12), 3),
+                        "other_kernels": {k: {("achieved_GBps" if k.endswith("reduce_kernel") else "achieved"): round(v[0] / v[1] / (1e9 if k.endswith("reduce_kernel") else 1e12), 3),
                                               "launches": v[2], "time_frac_of_step": round(v[1] / (elapsed * prof_steps / args.steps), 3)}
                                           for k, v in fam.items() if k != dom},
                         "time_frac_of_step": round(sec / (elapsed * prof_steps / args.steps), 3),
                         "profiled_steps": prof_steps}
+            gfl, gsec = gd["G"][0] + gd["D"][0], gd["G"][1] + gd["D"][1]
+            if gsec > 0:
+                roofline["gd_conv_stack"] = {"achieved": round(gfl / gsec / 1e12, 3), "frac": round(gfl / gsec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                             "gflop_per_step": round(gfl / 1e9 / max(prof_steps, 1), 1), "ms_per_step": round(gsec * 1e3 / max(prof_steps, 1), 3),
+                                             "generator": round(gd["G"][0] / gd["G"][1] / 1e12, 3) if gd["G"][1] > 0 else None,
+                                             "discriminator": round(gd["D"][0] / gd["D"][1] / 1e12, 3) if gd["D"][1] > 0 else None}
         if roofline:
             # HBM bytes per launch of the dominant kernel: PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately with rocprofv3 on this
             # same command and corrected per MI355X_MICROARCH.md) are committed under profiles/; they cannot be collected from inside bench.py

@@ -280,7 +280,9 @@ int hwg_conv_c1_fwd_impl(const hwg_conv_desc* d, const float* x, const float* w,
   k.P = d->P; k.Q = d->Q; k.accumulate = accumulate;
   const int qtiles = hwg_cdiv(d->Q, PG * 4);
   const long long blocks = (long long)d->N * d->P * qtiles;
+  const int prof = hwg_prof_open(HWG_PROF_CONV_DIRECT, 2.0 * d->N * d->P * d->Q * d->K * d->C * d->R * d->S, st);
   hipLaunchKernelGGL(conv_c1_kernel, dim3((unsigned)blocks), dim3(256), smem, st, k, KG, PG);
+  hwg_prof_close(prof, st);
   HWG_LAUNCH_CHECK("conv_c1");
   return HWG_OK;
 }
@@ -296,7 +298,9 @@ int hwg_conv_to1_fwd_impl(const hwg_conv_desc* d, const float* x, const float* w
   const long long M = (long long)d->N * d->P * d->Q;
   long long blocks = (M + 3) / 4;
   if (blocks > 4096) blocks = 4096;
+  const int prof = hwg_prof_open(HWG_PROF_CONV_DIRECT, 2.0 * d->N * d->P * d->Q * d->K * d->C * d->R * d->S, st);
   hipLaunchKernelGGL(conv_to1_kernel, dim3((unsigned)blocks), dim3(256), 0, st, k);
+  hwg_prof_close(prof, st);
   HWG_LAUNCH_CHECK("conv_to1");
   return HWG_OK;
 }
@@ -323,12 +327,14 @@ int hwg_conv_wgrad_direct_impl(const hwg_conv_desc* d, const float* u, const flo
   k.P = d->P; k.Q = d->Q;
   k.Mtot = d->N * d->P * d->Q;
   k.chunk = p.chunk; k.G = p.G; k.TSL = p.TSL; k.PL = p.PL; k.MAXT = p.MAXT;
+  const int prof = hwg_prof_open(HWG_PROF_WGRAD_DIRECT, 2.0 * k.Mtot * d->K * d->C * d->R * d->S, st);
   if (p.big_on_anchor) hipLaunchKernelGGL(wgrad_direct_kernel<1>, dim3(p.nblk), dim3(256), p.smem, st, k);
   else hipLaunchKernelGGL(wgrad_direct_kernel<0>, dim3(p.nblk), dim3(256), p.smem, st, k);
   HWG_LAUNCH_CHECK("conv_wgrad_direct");
   const long long total = (long long)d->R * d->S * d->K * d->C;
   hipLaunchKernelGGL(wgrad_direct_reduce_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, st, (const float*)ws, dw,
                      p.nblk, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate);
+  hwg_prof_close(prof, st);
   HWG_LAUNCH_CHECK("conv_wgrad_direct_reduce");
   return HWG_OK;
 }

@@ -309,6 +309,30 @@ __global__ void fused_up_weight_bwd_kernel(const float* dw4, float* dw3, long lo
     else hipLaunchKernelGGL(kern<1>, dim3(hwg_stream_grid((total_of_v), 256)), dim3(256), 0, st, __VA_ARGS__);           \
   } while (0)
 
+
+// Data gradient of a single-input-channel convolution (first layers), second half: dx[n,ih,iw] = sum_{r,s} t[n, ih+ph-r*dh, iw+pw-s*dw, r*S+s]
+// where t = dy x W^T is the per-pixel tap matrix produced by a 1x1 convolution on the matrix cores (stride 1). Taps are summed in
+// (r,s) order, one thread per input pixel.
+__global__ __launch_bounds__(256) void col2im_taps_kernel(const float* __restrict__ t, float* __restrict__ dx, int N, int H, int W, int P, int Q, int R,
+                                                          int S, int ph, int pw, int dh, int dw) {
+  const int iw = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int ih = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int n = blockIdx.z;
+  if (iw >= W || ih >= H) return;
+  const int RS = R * S;
+  float acc = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const int p = ih + ph - r * dh;
+    if (p < 0 || p >= P) continue;
+    const float* row = t + ((long long)n * P + p) * Q * RS + r * S;
+    for (int s2 = 0; s2 < S; ++s2) {
+      const int q = iw + pw - s2 * dw;
+      if (q >= 0 && q < Q) acc += row[(long long)q * RS + s2];
+    }
+  }
+  dx[((long long)n * H + ih) * W + iw] = acc;
+}
+
 }  // namespace
 
 extern "C" int hwg_avgpool_fwd(const float* x, float* y, int N, int H, int W, int C, int kh, int kw, void* stream) {
@@ -431,5 +455,14 @@ extern "C" int hwg_fused_upsample_weight_bwd(const float* dw4, float* dw3, long 
   HWG_REQUIRE(dw4 && dw3 && AB > 0, "fused_upsample_weight_bwd: bad arguments");
   hipLaunchKernelGGL(fused_up_weight_bwd_kernel, dim3(hwg_stream_grid(AB * 9, 256)), dim3(256), 0, (hipStream_t)stream, dw4, dw3, AB, mult);
   HWG_LAUNCH_CHECK("fused_upsample_weight_bwd");
+  return HWG_OK;
+}
+
+extern "C" int hwg_col2im_taps(const float* t, float* dx, int N, int H, int W, int P, int Q, int R, int S, int pad_h, int pad_w, int dil_h, int dil_w,
+                               void* stream) {
+  HWG_REQUIRE(t && dx && N > 0 && H > 0 && W > 0 && P > 0 && Q > 0 && R > 0 && S > 0 && dil_h > 0 && dil_w > 0, "col2im_taps: bad arguments");
+  hipLaunchKernelGGL(col2im_taps_kernel, dim3(hwg_cdiv(W, 64), hwg_cdiv(H, 4), N), dim3(256), 0, (hipStream_t)stream, t, dx, N, H, W, P, Q, R, S, pad_h,
+                     pad_w, dil_h, dil_w);
+  HWG_LAUNCH_CHECK("col2im_taps");
   return HWG_OK;
 }

@@ -60,6 +60,107 @@ __global__ void gather_scores_kernel(const float* x, int Wx, int C, const int* i
   out[k] = expf(x[((long long)idx_b[k] * Wx + idx_pos[k]) * C + idx_cls[k]]);
 }
 
+
+// ---- bank of linear layers sharing one input (the generator's 10 AdaIN style->(gamma,beta) affines, pure_gen.py:52-69) ----------
+// y_l = x W_l^T + b_l for l < L, x [B][I]; layer l has O_l outputs split in `halves` column blocks of O_l/halves, each written as
+// a contiguous [B][O_l/halves] matrix at y + off_l + h*B*(O_l/halves)  (so gamma and beta come out as separate contiguous tensors).
+// One wavefront per output neuron: lanes sweep the input features, the weight row is read once and reused for all B rows.
+constexpr int LB_MAXB = 16;
+__global__ __launch_bounds__(256) void linear_bank_fwd_kernel(const float* __restrict__ x, const long long* wptr, const long long* bptr, const int* O,
+                                                              const int* first_wave, const long long* off, int L, int B, int I, int halves,
+                                                              float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int w = (blockIdx.x * 256 + threadIdx.x) >> 6;   // global output neuron index over all layers
+  if (w >= first_wave[L]) return;
+  int l = 0;
+  while (l + 1 < L && first_wave[l + 1] <= w) ++l;
+  const int o = w - first_wave[l];
+  const float* W = reinterpret_cast<const float*>(wptr[l]) + (long long)o * I;
+  float acc[LB_MAXB];
+#pragma unroll
+  for (int b = 0; b < LB_MAXB; ++b) acc[b] = 0.f;
+  for (int i = lane; i < I; i += 64) {
+    const float wv = W[i];
+#pragma unroll
+    for (int b = 0; b < LB_MAXB; ++b)
+      if (b < B) acc[b] += wv * x[(long long)b * I + i];
+  }
+  const int C = O[l] / halves, h = o / C, c = o - h * C;
+  const float bias = bptr ? reinterpret_cast<const float*>(bptr[l])[o] : 0.f;
+#pragma unroll
+  for (int b = 0; b < LB_MAXB; ++b) {
+    if (b < B) {
+      const float v = wave_sum(acc[b]);
+      if (lane == 0) y[off[l] + ((long long)h * B + b) * C + c] = v + bias;
+    }
+  }
+}
+// parameter gradients, ADDED into the buffers of the tables: dW_l[o][i] += sum_b dy_l[b][o] x[b][i];  db_l[o] += sum_b dy_l[b][o]
+// dyptr[l*halves + h] points to the [B][O_l/halves] gradient of block h of layer l (0: that output was not used)
+__global__ __launch_bounds__(256) void linear_bank_wgrad_kernel(const float* __restrict__ x, const long long* dyptr, const long long* gwptr,
+                                                                const long long* gbptr, const int* O, const int* first_wave, int L, int B, int I,
+                                                                int halves) {
+  const int lane = threadIdx.x & 63;
+  const int w = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (w >= first_wave[L]) return;
+  int l = 0;
+  while (l + 1 < L && first_wave[l + 1] <= w) ++l;
+  const int o = w - first_wave[l];
+  const int C = O[l] / halves, h = o / C, c = o - h * C;
+  const float* dy = reinterpret_cast<const float*>(dyptr[l * halves + h]);
+  if (!dy) return;
+  float d[LB_MAXB];
+  float bs = 0.f;
+#pragma unroll
+  for (int b = 0; b < LB_MAXB; ++b) {
+    d[b] = (b < B) ? dy[(long long)b * C + c] : 0.f;
+    bs += d[b];
+  }
+  if (!gwptr[l]) return;   // layer frozen
+  float* gW = reinterpret_cast<float*>(gwptr[l]) + (long long)o * I;
+  for (int i = lane; i < I; i += 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int b = 0; b < LB_MAXB; ++b)
+      if (b < B) s += d[b] * x[(long long)b * I + i];
+    gW[i] += s;
+  }
+  if (lane == 0 && gbptr && gbptr[l]) reinterpret_cast<float*>(gbptr[l])[o] += bs;
+}
+// input gradient: dx[b][i] = sum_l sum_o dy_l[b][o] W_l[o][i]; one workgroup per row b, 8 thread groups split the neurons and are
+// combined through LDS in a fixed order
+__global__ __launch_bounds__(1024) void linear_bank_dgrad_kernel(const long long* dyptr, const long long* wptr, const int* O, const int* first_wave, int L,
+                                                                 int B, int I, int halves, float* __restrict__ dx) {
+  __shared__ float red[8][128];
+  const int b = blockIdx.x;
+  const int part = threadIdx.x >> 7, il = threadIdx.x & 127;
+  const int total = first_wave[L];
+  for (int i0 = 0; i0 < I; i0 += 128) {
+    const int i = i0 + il;
+    float s = 0.f;
+    if (i < I) {
+      int l = 0;
+      for (int w = part; w < total; w += 8) {
+        while (l + 1 < L && first_wave[l + 1] <= w) ++l;
+        const int o = w - first_wave[l];
+        const int C = O[l] / halves, h = o / C, c = o - h * C;
+        const float* dy = reinterpret_cast<const float*>(dyptr[l * halves + h]);
+        if (!dy) continue;
+        s += dy[(long long)b * C + c] * reinterpret_cast<const float*>(wptr[l])[(long long)o * I + i];
+      }
+    }
+    red[part][il] = s;
+    __syncthreads();
+    if (part == 0 && i < I) {
+      float t = 0.f;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) t += red[p][il];
+      dx[(long long)b * I + i] = t;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int hwg_gather_windows(const float* x, int B, int Wx, int C, const int* idx_b, const int* idx_pos, int n, int window, float* patches,
@@ -99,5 +200,30 @@ extern "C" int hwg_gather_scores(const float* x, int B, int Wx, int C, const int
   HWG_REQUIRE(x && idx_b && idx_pos && idx_cls && out && n > 0, "gather_scores: bad arguments");
   hipLaunchKernelGGL(gather_scores_kernel, dim3(hwg_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, x, Wx, C, idx_b, idx_pos, idx_cls, n, out);
   HWG_LAUNCH_CHECK("gather_scores");
+  return HWG_OK;
+}
+
+extern "C" int hwg_linear_bank_fwd(const float* x, const void* wptr, const void* bptr, const int* O, const int* first_wave, const void* off, int L, int B,
+                                   int I, int halves, int total_outputs, float* y, void* stream) {
+  HWG_REQUIRE(x && wptr && O && first_wave && off && y && L > 0 && B > 0 && B <= LB_MAXB && I > 0 && halves > 0 && total_outputs > 0,
+              "linear_bank_fwd: bad arguments (B <= %d)", LB_MAXB);
+  hipLaunchKernelGGL(linear_bank_fwd_kernel, dim3(hwg_cdiv(total_outputs, 4)), dim3(256), 0, (hipStream_t)stream, x, (const long long*)wptr,
+                     (const long long*)bptr, O, first_wave, (const long long*)off, L, B, I, halves, y);
+  HWG_LAUNCH_CHECK("linear_bank_fwd");
+  return HWG_OK;
+}
+extern "C" int hwg_linear_bank_bwd(const float* x, const void* dyptr, const void* wptr, const void* gwptr, const void* gbptr, const int* O,
+                                   const int* first_wave, int L, int B, int I, int halves, int total_outputs, float* dx, void* stream) {
+  HWG_REQUIRE(x && dyptr && wptr && gwptr && O && first_wave && L > 0 && B > 0 && B <= LB_MAXB && I > 0 && halves > 0 && total_outputs > 0,
+              "linear_bank_bwd: bad arguments (B <= %d)", LB_MAXB);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(linear_bank_wgrad_kernel, dim3(hwg_cdiv(total_outputs, 4)), dim3(256), 0, st, x, (const long long*)dyptr, (const long long*)gwptr,
+                     (const long long*)gbptr, O, first_wave, L, B, I, halves);
+  HWG_LAUNCH_CHECK("linear_bank_wgrad");
+  if (dx) {
+    hipLaunchKernelGGL(linear_bank_dgrad_kernel, dim3(B), dim3(1024), 0, st, (const long long*)dyptr, (const long long*)wptr, O, first_wave, L, B, I, halves,
+                       dx);
+    HWG_LAUNCH_CHECK("linear_bank_dgrad");
+  }
   return HWG_OK;
 }

@@ -79,6 +79,10 @@ class DiscriminatorAP(nn.Module):
         return c[14](h)
 
     def forward(self, x, return_features=False):
+        with ops.scope("D"):
+            return self._forward(x, return_features)
+
+    def _forward(self, x, return_features=False):
         """x: NCHW [N,1,64,W] (as the reference passes it) -> list of [N, -1] patch predictions"""
         batch = x.shape[0]
         h = ops.to_nhwc(x)

@@ -82,12 +82,13 @@ class StyledConvBlock(nn.Module):
             return self.conv1[1](self.conv1[0](x))
         return self.conv1[2](self.conv1[1](ops.upsample_nearest(x, self.up_scale)))
 
-    def forward(self, x, style):
+    def forward(self, x, style, affine=None):
+        """affine: ((gamma1, beta1), (gamma2, beta2)) when the generator evaluated all style affines in one launch"""
         h = self._first(x)
-        g, b = self.adain1(style)
+        g, b = affine[0] if affine is not None else self.adain1(style)
         h = ops.adain_epilogue(h, rng.noise_like_nhwc(h), self.noise1.weight_orig, g, b, self.noise1.scale, 0.2)
         h = self.conv2(h)
-        g, b = self.adain2(style)
+        g, b = affine[1] if affine is not None else self.adain2(style)
         return ops.adain_epilogue(h, rng.noise_like_nhwc(h), self.noise2.weight_orig, g, b, self.noise2.scale, 0.2)
 
 
@@ -125,6 +126,7 @@ class SpacedGenerator(nn.Module):
             emb += [Linear(style_size, style_size), Marker("leaky relu 0.2")]
         self.style_emb = nn.Sequential(*emb)
         self.gen = self.conv  # alias present in the reference's state-dict
+        self._affine_bank = None
 
     def embed_style(self, style):
         h = ops.pixel_norm(style.contiguous())
@@ -134,6 +136,10 @@ class SpacedGenerator(nn.Module):
         return h
 
     def forward(self, content, style, return_intermediate=False):
+        with ops.scope("G"):
+            return self._forward(content, style, return_intermediate)
+
+    def _forward(self, content, style, return_intermediate=False):
         """content [T,B,n_class] (time major, as in the reference) or NHWC [B,1,T,n_class]; style [B,style]; -> NCHW [B,1,64,4T]"""
         if content.dim() == 3:
             T, B, C = content.shape
@@ -142,7 +148,14 @@ class SpacedGenerator(nn.Module):
         B, _, T, _ = content.shape
         emb = self.embed_style(style)
         x = ops.cat_channels([content, emb], (B, 1, T)) if self.append_style else content
-        for blk in self.conv:
-            x = blk(x, emb)
+        # the ten style -> (gamma, beta) affines of the five blocks share their input: one bank launch instead of ten tiny GEMMs
+        # (and one gradient kernel instead of ten data-gradient GEMMs + nine accumulations of d(emb))
+        pairs = None
+        if B <= 16:
+            if self._affine_bank is None:
+                self._affine_bank = ops.LinearBank([m for blk in self.conv for m in (blk.adain1.style, blk.adain2.style)], halves=2)
+            pairs = self._affine_bank(emb)
+        for i, blk in enumerate(self.conv):
+            x = blk(x, emb, None if pairs is None else (pairs[2 * i], pairs[2 * i + 1]))
         y = ops.tanh(self.out[0](x))
         return ops.to_nchw(y)

@@ -197,6 +197,24 @@ def _pad_channels(x, Cpad):
 # Per-launch timing of the MFMA conv kernels (bench.py's roofline measurement) is done inside the library (hwg_prof_*: HIP events
 # recorded right around the launches). Here we only label the launches with their layer shape when a profile is running.
 PROF_SHAPES = None     # None, or {shape tuple: tag}
+SCOPE = None           # which network is running its forward ("G", "D", ...): convs remember it so that a profile can be split by network
+
+
+class scope:
+    """`with ops.scope("G"):` around a network's forward; nested scopes keep the outermost label"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global SCOPE
+        self.prev = SCOPE
+        if SCOPE is None:
+            SCOPE = self.name
+
+    def __exit__(self, *exc):
+        global SCOPE
+        SCOPE = self.prev
 
 
 def prof_start(max_records=200000):
@@ -220,7 +238,7 @@ def prof_stop():
     n = L.query("hwg_prof_stop", kinds.ctypes.data, tags.ctypes.data, work.ctypes.data, ms.ctypes.data, cap)
     by_tag = {v: k for k, v in (PROF_SHAPES or {}).items()}
     PROF_SHAPES = None
-    names = ("conv_mfma_kernel", "wgrad_mfma_kernel", "conv_split_reduce_kernel", "wgrad_reduce_kernel")
+    names = ("conv_mfma_kernel", "wgrad_mfma_kernel", "conv_split_reduce_kernel", "wgrad_reduce_kernel", "conv_direct_kernels", "wgrad_direct_kernels")
     return [(names[kinds[i]], by_tag.get(int(tags[i])), float(work[i]), float(ms[i]) * 1e-3) for i in range(n)]
 
 
@@ -231,11 +249,14 @@ def _prof_tag(shape):
     L.call("hwg_prof_tag", tag)
 
 
+_RUN_SCOPE = [None]     # scope of the conv op currently being executed (forward: SCOPE, backward: the scope saved at forward time)
+
+
 def _run_conv(x, wp, bias, N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed):
     y = torch.empty((N, P, Q, K), dtype=torch.float32, device=x.device)
     d = _desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed)
     if PROF_SHAPES is not None:
-        _prof_tag((N, H, W, C, K, R, S, stride, pad, dil, transposed))
+        _prof_tag((N, H, W, C, K, R, S, stride, pad, dil, transposed, _RUN_SCOPE[0]))
     need = L.query("hwg_conv_fwd_workspace", ctypes.byref(d))
     ws = workspace(need, x.device) if need else None
     L.call("hwg_conv_fwd", ctypes.byref(d), x, wp, bias, y, 0, ws, need, _stream())
@@ -264,6 +285,7 @@ class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, transposed, output_padding):
         _chk(x, "conv input"); _chk(weight, "conv weight"); _chk(bias, "conv bias")
+        ctx.scope = _RUN_SCOPE[0] = SCOPE
         N, H, W, C = x.shape
         # Linear [O,I] and Conv1d [O,I,S] parameters are used as they are (same memory as [O,I,1,S]); a .view() of the parameter would be a
         # non-leaf tensor, lose the packed-weight cache and the direct gradient accumulation and cost three extra ATen ops per backward
@@ -303,6 +325,7 @@ class _Conv2d(Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
+        _RUN_SCOPE[0] = ctx.scope
         stride, padding, dilation, transposed, P, Q = ctx.geom
         dy = dy.contiguous()
         N, H, W, C = x.shape
@@ -316,7 +339,15 @@ class _Conv2d(Function):
             # data gradient: contraction over K (dy's channels) producing C channels
             Kp = (K + 15) // 16 * 16 if _needs_cpad(K, C) else K
             dyin = _pad_channels(dy, Kp) if Kp != K else dy
-            if not transposed:
+            if not transposed and C == 1 and sh == 1 and sw == 1 and K % 16 == 0 and 1 < R * S <= 64:
+                # single-channel input (first layers): dx has one channel, so instead of a matrix-vector kernel the tap matrix
+                # t[pixel][tap] = dy x W^T is formed by a 1x1 convolution on the matrix cores and folded back by col2im (379 -> ~40 us for
+                # the discriminator's 7x7 in_conv at 8 x 64 x 512)
+                wt = _pack(weight, R * S, K, 1, 1, 1, R * S, flip=0)           # [1][taps][K]: element (tap, k) = w[k][0][tap]
+                t = _run_conv(dy, wt, None, N, P, Q, K, R * S, 1, 1, (1, 1), (0, 0), (1, 1), P, Q, 0)
+                dx = torch.empty((N, H, W, 1), dtype=torch.float32, device=x.device)
+                L.call("hwg_col2im_taps", t, dx, N, H, W, P, Q, R, S, ph, pw, dh, dw, st)
+            elif not transposed:
                 if sh == 1 and sw == 1:
                     wp = _pack(weight, C, K, R, S, R * S, C * R * S, flip=1, Bpad=Kp)
                     dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), H, W, 0)
@@ -359,7 +390,7 @@ class _Conv2d(Function):
                 need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
                 ws = workspace(need, x.device)
                 if PROF_SHAPES is not None:
-                    _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad"))
+                    _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad", ctx.scope))
                 L.call("hwg_conv_wgrad", ctypes.byref(d), up, vp, tmp, Cq * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)
                 valid = tmp[:dK, :dC]
                 if direct:
@@ -371,7 +402,7 @@ class _Conv2d(Function):
                 need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
                 ws = workspace(need, x.device)
                 if PROF_SHAPES is not None:
-                    _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad"))
+                    _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad", ctx.scope))
                 # the bias gradient (column sums of dy) rides along when dy is the kernel's anchor operand and the MFMA path runs
                 fuse_bias = (ctx.has_bias and ctx.needs_input_grad[2] and not transposed and not (d.K <= 2 or (d.C <= 2 and not tap_gemm)))
                 dbias = bacc = None
@@ -1354,3 +1385,91 @@ class _ZeroRowsFrom(Function):
 
 def zero_rows_from(x, pos):
     return _ZeroRowsFrom.apply(x, int(pos))
+
+
+# ----------------------------------------------------------------------------------------------
+# bank of linear layers sharing one input (generator AdaIN affines)
+# ----------------------------------------------------------------------------------------------
+class LinearBank:
+    """Evaluates L `Linear(I, O_l)` modules on the same input in one launch (forward) / two launches (backward) through device pointer
+    tables; the modules keep their own parameters. Each layer's output comes back split in `halves` contiguous [B, O_l/halves] tensors."""
+
+    def __init__(self, linears, halves=2):
+        import numpy as np
+        self.linears = list(linears)
+        self.halves = halves
+        self.L = len(self.linears)
+        self.I = self.linears[0].weight.shape[1]
+        self.O = [int(m.weight.shape[0]) for m in self.linears]
+        assert all(m.weight.shape[1] == self.I for m in self.linears) and all(o % halves == 0 for o in self.O)
+        self.first = np.concatenate([[0], np.cumsum(self.O)]).astype(np.int32)
+        self.total = int(self.first[-1])
+        self._tab = None
+        self._key = None
+        self._gtab = None
+        self._gkey = None
+
+    def tables(self, device, B):
+        import numpy as np
+        key = (self.linears[0].weight.data_ptr(), str(device), B)
+        if self._key != key:
+            off = (self.first[:-1].astype(np.int64)) * B
+            ints = h2d(np.concatenate([np.array(self.O, dtype=np.int32), self.first]), device)
+            ptrs = h2d(np.concatenate([np.array([m.weight.data_ptr() for m in self.linears], dtype=np.int64),
+                                       np.array([m.bias.data_ptr() for m in self.linears], dtype=np.int64), off]), device)
+            L_ = self.L
+            self._tab = (ints[:L_], ints[L_:], ptrs[:L_], ptrs[L_:2 * L_], ptrs[2 * L_:])
+            self._key = key
+        return self._tab
+
+    def grad_tables(self, device):
+        import numpy as np
+        # (_grad_buffer also marks the tensors touched for the trainer's None-gradient bookkeeping; frozen parameters get a null entry)
+        gw = [_grad_buffer(m.weight) if m.weight.requires_grad else None for m in self.linears]
+        gb = [_grad_buffer(m.bias) if m.bias.requires_grad else None for m in self.linears]
+        addr = [g.data_ptr() if g is not None else 0 for g in gw + gb]
+        key = tuple(addr)
+        if self._gkey != key:
+            ptrs = h2d(np.array(addr, dtype=np.int64), device)
+            self._gtab = (ptrs[:self.L], ptrs[self.L:])
+            self._gkey = key
+        return self._gtab
+
+    def __call__(self, x):
+        outs = _LinearBank.apply(x.contiguous(), self)
+        h = self.halves
+        return [outs[l * h:(l + 1) * h] for l in range(self.L)]
+
+
+class _LinearBank(Function):
+    @staticmethod
+    def forward(ctx, x, bank):
+        _chk(x, "linear bank input")
+        B, I = x.shape
+        assert I == bank.I
+        O, first, wptr, bptr, off = bank.tables(x.device, B)
+        y = torch.empty((bank.total * B,), dtype=torch.float32, device=x.device)
+        L.call("hwg_linear_bank_fwd", x, wptr, bptr, O, first, off, bank.L, B, I, bank.halves, bank.total, y, _stream())
+        outs = []
+        for l in range(bank.L):
+            C = bank.O[l] // bank.halves
+            base = int(bank.first[l]) * B
+            for h in range(bank.halves):
+                outs.append(y[base + h * B * C: base + (h + 1) * B * C].view(B, C))
+        ctx.save_for_backward(x)
+        ctx.bank = bank
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import numpy as np
+        (x,) = ctx.saved_tensors
+        bank = ctx.bank
+        B, I = x.shape
+        O, first, wptr, bptr, off = bank.tables(x.device, B)
+        keep = [g.contiguous() if g is not None else None for g in grads]
+        dyptr = h2d(np.array([g.data_ptr() if g is not None else 0 for g in keep], dtype=np.int64), x.device)
+        gw, gb = bank.grad_tables(x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        L.call("hwg_linear_bank_bwd", x, dyptr, wptr, gw, gb, O, first, bank.L, B, I, bank.halves, bank.total, dx, _stream())
+        return dx, None

@@ -41,7 +41,7 @@ int hwg_device_ok(void);
 /* Launch profiler for the matrix-core kernels (bench.py's roofline measurement): between hwg_prof_start() and hwg_prof_stop() every
  * MFMA convolution / weight-gradient launch (and their reduce passes) is bracketed by a HIP event pair on its stream. hwg_prof_tag()
  * labels the launches of the calling thread's next calls. hwg_prof_stop() waits for the recorded events and returns, per launch,
- * kind (0 conv, 1 wgrad, 2 conv split reduce, 3 wgrad reduce), tag, algorithmic work (flops; bytes for the reduce passes) and ms.
+ * kind (0 conv MFMA, 1 wgrad MFMA, 2 conv split reduce, 3 wgrad reduce, 4 direct conv, 5 direct wgrad incl. its reduce), tag, algorithmic work (flops; bytes for the reduce passes) and ms.
  * Returns the number of records written. */
 int hwg_prof_start(int max_records);
 int hwg_prof_enable(int on);   /* pause / resume recording inside an open profile (sampled profiling: the event pairs cost ~7 % of a step) */
@@ -88,6 +88,12 @@ int hwg_conv_pack_weight_multi(const void* table, int n_entries, long long total
 size_t hwg_conv_fwd_workspace(const hwg_conv_desc* d);
 int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                  int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Data gradient of a convolution whose input has ONE channel (first layers; stride 1), second half: the caller first forms the
+ * per-pixel tap matrix t[N,P,Q,R*S] = dy[N,P,Q,K] x W[K][R*S] with hwg_conv_fwd (1x1, on the matrix cores), then
+ * dx[n,ih,iw] = sum_{r,s} t[n, ih+pad_h-r*dil_h, iw+pad_w-s*dil_w, r*S+s]. */
+int hwg_col2im_taps(const float* t, float* dx, int N, int H, int W, int P, int Q, int R, int S, int pad_h, int pad_w, int dil_h, int dil_w,
+                    void* stream);
 
 /* weight gradient: dw(k,c,r,s) = sum_{n,p,q} u[n,p,q,k] * v[n, p*stride-pad+r*dil, q*stride-pad+s*dil, c]
  * written to dw[k*sa + c*sb + r*sr + s*ss] (so it lands directly in the PyTorch parameter layout).
@@ -231,6 +237,16 @@ int hwg_scatter_windows(const float* dpatches, int B, int Wx, int C, const int* 
 int hwg_segment_weighted_mean(const float* v, const float* wgt, const int* seg, int n, int C, int B, float* out, float* wsum, void* stream);
 int hwg_segment_weighted_mean_bwd(const float* dout, const float* wgt, const int* seg, const float* wsum, int n, int C, float* dv, void* stream);
 int hwg_gather_scores(const float* x, int B, int Wx, int C, const int* idx_b, const int* idx_pos, const int* idx_cls, int n, float* out, void* stream);
+
+/* Bank of L linear layers that share one input (the generator's ten AdaIN style -> (gamma, beta) affines, pure_gen.py:52-69, in one
+ * launch instead of ten): y_l = x W_l^T + b_l, x [B][I] (B <= 16), W_l [O_l][I] and b_l [O_l] through device pointer tables.
+ * Layer l's outputs are written as `halves` contiguous [B][O_l/halves] blocks starting at y + off[l]; first_wave[L+1] is the
+ * running sum of O_l (neuron -> layer map), total_outputs = first_wave[L]. The backward ADDS dW_l / db_l into the tables'
+ * buffers and writes dx [B][I] (optional); dyptr[l*halves + h] is the gradient of block h of layer l (0 = unused output). */
+int hwg_linear_bank_fwd(const float* x, const void* wptr, const void* bptr, const int* O, const int* first_wave, const void* off, int L, int B,
+                        int I, int halves, int total_outputs, float* y, void* stream);
+int hwg_linear_bank_bwd(const float* x, const void* dyptr, const void* wptr, const void* gwptr, const void* gbptr, const int* O,
+                        const int* first_wave, int L, int B, int I, int halves, int total_outputs, float* dx, void* stream);
 
 /* Grouped "one expert per window" layers for the 79 character-style experts (model/char_style.py:84-124, 210-235).
  * x [n][R][Cin] -> y [n][R][Cout]; wptr/bptr are device tables (int64 addresses, one per expert) of weights in the Conv1d layout
