@@ -161,6 +161,92 @@ __global__ __launch_bounds__(1024) void linear_bank_dgrad_kernel(const long long
   }
 }
 
+
+// ---- chain of L square linear layers with LeakyReLU (the generator's style embedding MLP, 6 x Linear(128,128), pure_gen.py:29-38) -------
+// in ONE workgroup per pass: h_{l+1} = lrelu(W_l h_l + b_l); the B x D activations live in LDS, weights stream from L2 (64 KB / layer).
+// acts [L+1][B][D] keeps every h_l for the backward pass (acts[0] = x).
+constexpr int MC_MAXB = 16, MC_MAXD = 256;
+__global__ __launch_bounds__(1024) void mlp_chain_fwd_kernel(const float* __restrict__ x, const long long* wptr, const long long* bptr, int L, int B, int D,
+                                                             float slope, float* __restrict__ acts) {
+  __shared__ float h[MC_MAXB * MC_MAXD];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int t = tid; t < B * D; t += nt) { h[t] = x[t]; acts[t] = x[t]; }
+  __syncthreads();
+  for (int l = 0; l < L; ++l) {
+    const float* W = reinterpret_cast<const float*>(wptr[l]);
+    const float* bias = reinterpret_cast<const float*>(bptr[l]);
+    float outv[(MC_MAXB * MC_MAXD + 1023) / 1024];
+    int cnt = 0;
+    for (int t = tid; t < B * D; t += nt, ++cnt) {
+      const int o = t % D, b = t / D;
+      const float* wr = W + (long long)o * D;
+      const float* hr = h + b * D;
+      float a = bias[o];
+      for (int i = 0; i < D; ++i) a += wr[i] * hr[i];
+      outv[cnt] = a > 0.f ? a : a * slope;
+    }
+    __syncthreads();
+    cnt = 0;
+    for (int t = tid; t < B * D; t += nt, ++cnt) {
+      h[t] = outv[cnt];
+      acts[(long long)(l + 1) * B * D + t] = outv[cnt];
+    }
+    __syncthreads();
+  }
+}
+// backward of the chain; parameter gradients are ADDED into the tables' buffers
+__global__ __launch_bounds__(1024) void mlp_chain_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ acts, const long long* wptr,
+                                                             const long long* gwptr, const long long* gbptr, int L, int B, int D, float slope,
+                                                             float* __restrict__ dx) {
+  __shared__ float dpre[MC_MAXB * MC_MAXD];   // d(pre-activation) of the current layer
+  __shared__ float hin[MC_MAXB * MC_MAXD];    // its input h_l
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int t = tid; t < B * D; t += nt) dpre[t] = dout[t];
+  __syncthreads();
+  for (int l = L - 1; l >= 0; --l) {
+    // dpre currently holds dL/dh_{l+1}; apply the LeakyReLU derivative (sign of h_{l+1} == sign of the pre-activation)
+    for (int t = tid; t < B * D; t += nt) {
+      const float hv = acts[(long long)(l + 1) * B * D + t];
+      dpre[t] *= hv > 0.f ? 1.f : slope;
+      hin[t] = acts[(long long)l * B * D + t];
+    }
+    __syncthreads();
+    const float* W = reinterpret_cast<const float*>(wptr[l]);
+    float* gW = gwptr[l] ? reinterpret_cast<float*>(gwptr[l]) : nullptr;
+    float* gb = (gbptr && gbptr[l]) ? reinterpret_cast<float*>(gbptr[l]) : nullptr;
+    if (gW) {
+      for (int t = tid; t < D * D; t += nt) {       // dW[o][i] += sum_b dpre[b][o] * h_l[b][i]
+        const int ii = t % D, o = t / D;
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += dpre[b * D + o] * hin[b * D + ii];
+        gW[t] += a;
+      }
+    }
+    if (gb) {
+      for (int o = tid; o < D; o += nt) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += dpre[b * D + o];
+        gb[o] += a;
+      }
+    }
+    // dh_l[b][i] = sum_o dpre[b][o] * W[o][i]
+    float outv[(MC_MAXB * MC_MAXD + 1023) / 1024];
+    int cnt = 0;
+    for (int t = tid; t < B * D; t += nt, ++cnt) {
+      const int ii = t % D, b = t / D;
+      float a = 0.f;
+      for (int o = 0; o < D; ++o) a += dpre[b * D + o] * W[(long long)o * D + ii];
+      outv[cnt] = a;
+    }
+    __syncthreads();
+    cnt = 0;
+    for (int t = tid; t < B * D; t += nt, ++cnt) dpre[t] = outv[cnt];
+    __syncthreads();
+  }
+  if (dx)
+    for (int t = tid; t < B * D; t += nt) dx[t] = dpre[t];
+}
+
 }  // namespace
 
 extern "C" int hwg_gather_windows(const float* x, int B, int Wx, int C, const int* idx_b, const int* idx_pos, int n, int window, float* patches,
@@ -225,5 +311,23 @@ extern "C" int hwg_linear_bank_bwd(const float* x, const void* dyptr, const void
                        dx);
     HWG_LAUNCH_CHECK("linear_bank_dgrad");
   }
+  return HWG_OK;
+}
+
+extern "C" int hwg_mlp_chain_fwd(const float* x, const void* wptr, const void* bptr, int L, int B, int D, float slope, float* acts, void* stream) {
+  HWG_REQUIRE(x && wptr && bptr && acts && L > 0 && B > 0 && B <= MC_MAXB && D > 0 && D <= MC_MAXD, "mlp_chain_fwd: bad arguments (B <= %d, D <= %d)",
+              MC_MAXB, MC_MAXD);
+  hipLaunchKernelGGL(mlp_chain_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (const long long*)wptr, (const long long*)bptr, L, B, D, slope,
+                     acts);
+  HWG_LAUNCH_CHECK("mlp_chain_fwd");
+  return HWG_OK;
+}
+extern "C" int hwg_mlp_chain_bwd(const float* dout, const float* acts, const void* wptr, const void* gwptr, const void* gbptr, int L, int B, int D,
+                                 float slope, float* dx, void* stream) {
+  HWG_REQUIRE(dout && acts && wptr && gwptr && L > 0 && B > 0 && B <= MC_MAXB && D > 0 && D <= MC_MAXD, "mlp_chain_bwd: bad arguments (B <= %d, D <= %d)",
+              MC_MAXB, MC_MAXD);
+  hipLaunchKernelGGL(mlp_chain_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dout, acts, (const long long*)wptr, (const long long*)gwptr,
+                     (const long long*)gbptr, L, B, D, slope, dx);
+  HWG_LAUNCH_CHECK("mlp_chain_bwd");
   return HWG_OK;
 }

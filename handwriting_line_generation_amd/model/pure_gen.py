@@ -127,12 +127,18 @@ class SpacedGenerator(nn.Module):
         self.style_emb = nn.Sequential(*emb)
         self.gen = self.conv  # alias present in the reference's state-dict
         self._affine_bank = None
+        self._style_chain = None
 
     def embed_style(self, style):
         h = ops.pixel_norm(style.contiguous())
-        for m in self.style_emb:
-            if isinstance(m, Linear):
-                h = ops.bias_act(ops.linear(h, m.weight, None), m.bias, None, ops.ACT_LRELU, 0.2)
+        lin = [m for m in self.style_emb if isinstance(m, Linear)]
+        if h.shape[0] <= 16 and h.shape[1] <= 256:
+            # the six Linear(128,128)+LeakyReLU layers run as one single-workgroup launch per direction (36 launches -> 2 per pass)
+            if self._style_chain is None:
+                self._style_chain = ops.MLPChain(lin, 0.2)
+            return self._style_chain(h)
+        for m in lin:
+            h = ops.bias_act(ops.linear(h, m.weight, None), m.bias, None, ops.ACT_LRELU, 0.2)
         return h
 
     def forward(self, content, style, return_intermediate=False):

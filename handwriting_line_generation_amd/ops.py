@@ -1473,3 +1473,64 @@ class _LinearBank(Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         L.call("hwg_linear_bank_bwd", x, dyptr, wptr, gw, gb, O, first, bank.L, B, I, bank.halves, bank.total, dx, _stream())
         return dx, None
+
+
+class MLPChain:
+    """L square Linear(D, D) modules each followed by LeakyReLU(slope), evaluated in one launch per direction (style embedding MLP)"""
+
+    def __init__(self, linears, slope):
+        self.linears = list(linears)
+        self.slope = float(slope)
+        self.L = len(self.linears)
+        self.D = int(self.linears[0].weight.shape[0])
+        assert all(tuple(m.weight.shape) == (self.D, self.D) for m in self.linears)
+        self._key = self._tab = self._gkey = self._gtab = None
+
+    def tables(self, device):
+        import numpy as np
+        key = (self.linears[0].weight.data_ptr(), str(device))
+        if self._key != key:
+            p = h2d(np.array([m.weight.data_ptr() for m in self.linears] + [m.bias.data_ptr() for m in self.linears], dtype=np.int64), device)
+            self._tab = (p[:self.L], p[self.L:])
+            self._key = key
+        return self._tab
+
+    def grad_tables(self, device):
+        import numpy as np
+        gw = [_grad_buffer(m.weight) if m.weight.requires_grad else None for m in self.linears]
+        gb = [_grad_buffer(m.bias) if m.bias.requires_grad else None for m in self.linears]
+        addr = [g.data_ptr() if g is not None else 0 for g in gw + gb]
+        key = tuple(addr)
+        if self._gkey != key:
+            p = h2d(np.array(addr, dtype=np.int64), device)
+            self._gtab = (p[:self.L], p[self.L:])
+            self._gkey = key
+        return self._gtab
+
+    def __call__(self, x):
+        return _MLPChain.apply(x.contiguous(), self)
+
+
+class _MLPChain(Function):
+    @staticmethod
+    def forward(ctx, x, chain):
+        _chk(x, "mlp chain input")
+        B, D = x.shape
+        assert D == chain.D
+        wptr, bptr = chain.tables(x.device)
+        acts = torch.empty((chain.L + 1, B, D), dtype=torch.float32, device=x.device)
+        L.call("hwg_mlp_chain_fwd", x, wptr, bptr, chain.L, B, D, chain.slope, acts, _stream())
+        ctx.save_for_backward(acts)
+        ctx.chain = chain
+        return acts[chain.L]
+
+    @staticmethod
+    def backward(ctx, dout):
+        (acts,) = ctx.saved_tensors
+        chain = ctx.chain
+        _, B, D = acts.shape
+        wptr, _ = chain.tables(acts.device)
+        gw, gb = chain.grad_tables(acts.device)
+        dx = torch.empty((B, D), dtype=torch.float32, device=acts.device) if ctx.needs_input_grad[0] else None
+        L.call("hwg_mlp_chain_bwd", dout.contiguous(), acts, wptr, gw, gb, chain.L, B, D, chain.slope, dx, _stream())
+        return dx, None

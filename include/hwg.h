@@ -248,6 +248,14 @@ int hwg_linear_bank_fwd(const float* x, const void* wptr, const void* bptr, cons
 int hwg_linear_bank_bwd(const float* x, const void* dyptr, const void* wptr, const void* gwptr, const void* gbptr, const int* O,
                         const int* first_wave, int L, int B, int I, int halves, int total_outputs, float* dx, void* stream);
 
+/* Chain of L square Linear(D,D)+LeakyReLU layers (the generator's style-embedding MLP, pure_gen.py:29-38) in one single-workgroup
+ * launch per direction: h_{l+1} = lrelu(W_l h_l + b_l, slope). acts [L+1][B][D] receives every h_l (acts[0] = x, acts[L] = output) and is
+ * what the backward consumes; the backward ADDS dW_l / db_l into the tables' buffers (null entry = frozen) and writes dx (optional).
+ * B <= 16, D <= 256. */
+int hwg_mlp_chain_fwd(const float* x, const void* wptr, const void* bptr, int L, int B, int D, float slope, float* acts, void* stream);
+int hwg_mlp_chain_bwd(const float* dout, const float* acts, const void* wptr, const void* gwptr, const void* gbptr, int L, int B, int D,
+                      float slope, float* dx, void* stream);
+
 /* Grouped "one expert per window" layers for the 79 character-style experts (model/char_style.py:84-124, 210-235).
  * x [n][R][Cin] -> y [n][R][Cout]; wptr/bptr are device tables (int64 addresses, one per expert) of weights in the Conv1d layout
  * [Cout][Cin][S] and biases; R <= 8; (S, pad) is (1, 0) or (3, 1). Windows are sorted by expert: seg_start[G+1] / seg_eid[G] describe
