@@ -540,10 +540,41 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
     }
 }
 
-// dw = (accumulate ? dw : 0) + sum over the partial images; entries past R*S*K*C of a partial image are the K bias partials
-__global__ void wgrad_reduce_kernel(const float* part, float* dw, int nsplit, int RS, int S, int K, int C,
-                                    long long sa, long long sb, long long sr, long long ss, int accumulate,
-                                    long long pstride, float* dbias, int bias_accumulate) {
+// dw = (accumulate ? dw : 0) + sum over the partial images; entries past R*S*K*C of a partial image are the K bias partials.
+// Four consecutive elements per thread (16-byte loads from every partial image); requires C % 4 == 0 (the kernel's own requirement).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int RS, int S, int K, int C,
+                                                           long long sa, long long sb, long long sr, long long ss, int accumulate,
+                                                           long long pstride, float* dbias, int bias_accumulate) {
+  const long long total = (long long)RS * K * C;
+  const long long all = total + (dbias ? K : 0);
+  const long long n4 = all >> 2;     // total, K and pstride are multiples of 4
+  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < n4; j += (long long)gridDim.x * blockDim.x) {
+    const long long i = j << 2;
+    float4 sum = *reinterpret_cast<const float4*>(part + i);
+    for (int sp = 1; sp < nsplit; ++sp) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (long long)sp * pstride + i);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    const float e[4] = {sum.x, sum.y, sum.z, sum.w};
+    if (i >= total) {
+      const int k = (int)(i - total);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dbias[k + u] = bias_accumulate ? dbias[k + u] + e[u] : e[u];
+      continue;
+    }
+    const int c = (int)(i % C);
+    const long long t = i / C;
+    const int k = (int)(t % K);
+    const int tap = (int)(t / K);
+    const long long o = k * sa + c * sb + (tap / S) * sr + (tap % S) * ss;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dw[o + u * sb] = accumulate ? dw[o + u * sb] + e[u] : e[u];
+  }
+}
+// scalar variant for the taps-as-N kernel (C == 1)
+__global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int RS, int S, int K,
+                                                                  int C, long long sa, long long sb, long long sr, long long ss, int accumulate,
+                                                                  long long pstride, float* dbias, int bias_accumulate) {
   const long long total = (long long)RS * K * C;
   const long long all = total + (dbias ? K : 0);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < all; i += (long long)gridDim.x * blockDim.x) {
@@ -1013,8 +1044,11 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
   else if (p.nsplit >= 8 && total <= 262144)
     hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<4>, dim3(hwg_cdiv(total, 64)), dim3(256), 0, st, (const float*)workspace, dw, p.nsplit, d->R * d->S, d->S,
                        d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias, bias_accumulate);
+  else if (d->C % 4 == 0)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hwg_stream_grid(total / 4, 256)), dim3(256), 0, st, (const float*)workspace, dw,
+                       p.nsplit, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias, bias_accumulate);
   else
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
+    hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
                        p.nsplit, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias, bias_accumulate);
   hwg_prof_close(prof2, st);
   HWG_LAUNCH_CHECK("conv_wgrad_reduce");
