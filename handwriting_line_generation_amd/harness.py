@@ -52,7 +52,9 @@ def synthetic_gan_config(which="iam_gan", batch_size=None, a_batch_size=None, wo
 
 
 def build_gan_trainer(which="iam_gan", batch_size=None, a_batch_size=None, width=512, label_len=30, min_width=None, workdir=None,
-                      gpu=0, rank=0, world=1, model_state=None, encoder_state=None, data_seed=100):
+                      gpu=0, rank=0, world=1, model_state=None, encoder_state=None, data_seed=100, resume=None):
+    if workdir is not None:
+        os.makedirs(workdir, exist_ok=True)
     cfg, workdir = synthetic_gan_config(which, batch_size, a_batch_size, workdir, gpu)
     tr = cfg["trainer"]
     if not os.path.exists(tr["encoder_weights"]):
@@ -67,7 +69,7 @@ def build_gan_trainer(which="iam_gan", batch_size=None, a_batch_size=None, width
                                 min_width=min_width, seed=data_seed)
     loader = SyntheticLoader(ds, rank, world)
     losses = {name: getattr(loss_fns, fn) for name, fn in cfg["loss"].items()}
-    trainer = HWWithStyleTrainer(model, losses, [], None, cfg, loader, None, None)
+    trainer = HWWithStyleTrainer(model, losses, [], resume, cfg, loader, None, None)
     return trainer, cfg
 
 

@@ -1,0 +1,39 @@
+"""GPU: checkpoint round trip of the GAN trainer in the reference's format (base/base_trainer.py:340-479: arch, iteration, optimizer,
+config, state_dict with the reference's 1411 keys): save after a few lessons, resume into a fresh trainer, same weights and Adam state."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_save_resume_round_trip(cuda, tmp_path):
+    import json
+    from handwriting_line_generation_amd import rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    rng.set_mode("device", seed=5)
+    torch.manual_seed(0)
+    a, _ = build_gan_trainer("iam_gan", 1, 2, width=256, label_len=12, workdir=str(tmp_path / "a"))
+    for it in range(4):
+        a._train_iteration(it)
+    a.iteration = 3
+    path = a._save_checkpoint(3, {})
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    schema = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "state_dict_schema_iam.json")))
+    assert set(ck["state_dict"]) == set(schema), "checkpoint keys differ from the reference's state-dict schema"
+    assert ck["arch"] == "HWWithStyle" and ck["iteration"] == 3 and "optimizer" in ck and "config" in ck
+    torch.manual_seed(1)     # different random init: everything must come from the checkpoint
+    b, _ = build_gan_trainer("iam_gan", 1, 2, width=256, label_len=12, workdir=str(tmp_path / "b"), resume=path)
+    assert b.start_iteration == 4
+    sa, sb = a.model.state_dict(), b.model.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k].cpu(), sb[k].cpu()), k
+    oa, ob = a.optimizer.state_dict(), b.optimizer.state_dict()
+    assert set(oa["state"]) == set(ob["state"]) and len(oa["state"]) > 0
+    for j in oa["state"]:
+        for f in ("step", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(oa["state"][j][f].cpu(), ob["state"][j][f].cpu()), (j, f)
+    # the resumed trainer keeps training
+    log = b._train_iteration(4)
+    assert all(v == v for v in log.values() if isinstance(v, float))
