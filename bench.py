@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=14)
     ap.add_argument("--workload", default="iam_gan_b4a2_w512", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gen", action="store_true", help="skip the secondary gen lines/sec measurement")
     ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work for the oracle baseline")
     args = ap.parse_args()
 
@@ -123,6 +124,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # secondary metric of BASELINE.json ("and gen lines/sec"): HWWithStyle.forward(label, lengths, style) -> images, inference only,
+    # measured AFTER the timed training region on the same weights (spacer -> host insert_spaces -> generator; one line = 64 x ~4T px)
+    gen = None
+    if rank == 0 and not args.no_gen:
+        model = trainer.model
+        model.eval()
+        B = 64            # a generation service batches requests; the training batch (8 lines) is launch-bound at 1.6 ms per call
+        gsteps = 24
+        g = torch.Generator().manual_seed(4321)
+        labels = [ops.h2d(torch.randint(1, cfg["model"]["num_class"], (wl["label_len"], B), generator=g, dtype=torch.int32), trainer.gpu) for _ in range(8)]
+        lengths = torch.IntTensor([wl["label_len"]] * B)
+        styles = [ops.h2d(torch.randn(B, cfg["model"]["style_dim"], generator=g), trainer.gpu) for _ in range(8)]
+        with torch.no_grad():
+            for i in range(5):
+                img = model(labels[i % 8], lengths, styles[i % 8])
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            px = 0
+            for i in range(gsteps):
+                img = model(labels[i % 8], lengths, styles[i % 8])
+                px += img.shape[3]
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg
+        model.train()
+        gen = {"value": round(B * gsteps / tg, 1), "unit": "lines/s (per GPU, inference)", "lines_per_call": B, "chars_per_line": wl["label_len"],
+               "mean_line_width_px": round(px / gsteps, 1), "ms_per_call": round(tg / gsteps * 1e3, 3)}
+
     if rank == 0:
         fam = {}
         by_shape = {}
@@ -196,7 +224,7 @@ def main():
             "config": {"workload": args.workload, "config_file": cfg["name"], "lines_per_gpu_step": wl["batch_size"] * wl["a_batch_size"],
                        "authors_per_gpu": wl["batch_size"], "a_batch_size": wl["a_batch_size"], "line_px": "64x%d" % wl["width"],
                        "curriculum": "count,gen,auto,disc,gen,auto,disc", "parallelism": "dp%d" % world},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "gen_lines_per_sec": gen, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:

@@ -119,8 +119,8 @@ class HWWithStyle(BaseModel):
         if spaced is None:
             label_onehot = self.onehot(label)
             self.counts = self.spacer(label_onehot, style)
-            spaced, padded = self.insert_spaces(label, label_lengths, self.counts)
-            spaced = ops.h2d(spaced, label.device)
+            idx, padded = self.insert_spaces_index(label, label_lengths, self.counts)
+            spaced = self.onehot(ops.h2d(idx.astype(np.int32), label.device))     # the one-hot is built on the device from [T,B] indices
             self.gen_padded = padded
             spaced = self._clip_spaced(spaced)
             self.gen_spaced = spaced
@@ -198,27 +198,44 @@ class HWWithStyle(BaseModel):
             return style
         return ops.repeat_rows(style, a_batch_size)
 
-    def insert_spaces(self, label, label_lengths, counts):
-        """expand text to per-column one-hot content using the predicted blank / duplicate counts
-        (host logic with numpy noise and Python banker's rounding, exactly as hw_with_style.py:302-328)"""
-        cn = counts.detach().cpu().numpy()
-        lab = label.cpu().numpy()
+    def insert_spaces_index(self, label, label_lengths, counts):
+        """expand text to per-column class indices using the predicted blank / duplicate counts: numpy noise and banker's rounding exactly
+        as hw_with_style.py:302-328, but vectorised. The reference draws, per character, count ~ N(c0, count_std) then duplicates ~
+        N(c1, dup_std) from numpy's global generator; one array-valued `np.random.normal` with the (mean, std) pairs interleaved in that
+        order consumes the identical stream. -> (idx int64 [T,B] numpy, padded list)"""
+        cn = counts.detach().cpu().numpy().astype(np.float64)
+        lab = np.asarray(label.cpu().numpy())
         batch_size = lab.shape[1]
         max_count = max(math.ceil(float(cn.max())), 3)
+        lens = [int(label_lengths[b]) for b in range(batch_size)]
+        per = 2 if self.count_duplicates else 1
+        locs = np.concatenate([cn[:n, b, :per].reshape(-1) for b, n in enumerate(lens)]) if sum(lens) else np.zeros(0)
+        scales = np.tile(np.array([self.count_std, self.dup_std][:per], dtype=np.float64), sum(lens))
+        draws = np.rint(np.random.normal(locs, scales)).astype(np.int64) if locs.size else np.zeros(0, dtype=np.int64)
+        draws = np.maximum(draws, 0)       # a negative repeat count is an empty list in the reference's `[x] * n`
         lines = []
-        for b in range(batch_size):
-            line = []
-            for i in range(int(label_lengths[b])):
-                count = round(np.random.normal(cn[i, b, 0].item(), self.count_std))
-                duplicates = round(np.random.normal(cn[i, b, 1].item(), self.dup_std)) if self.count_duplicates else 1
-                line += [0] * count + [int(lab[i, b])] * duplicates
-            lines.append(line)
+        pos = 0
+        for b, n in enumerate(lens):
+            d = draws[pos: pos + per * n]
+            pos += per * n
+            reps = np.empty(2 * n, dtype=np.int64)
+            reps[0::2] = d[0::per]
+            reps[1::2] = d[1::per] if self.count_duplicates else 1
+            vals = np.zeros(2 * n, dtype=np.int64)
+            vals[1::2] = lab[:n, b]
+            lines.append(np.repeat(vals, reps))
         T = max(len(l) for l in lines) + max_count
         idx = np.zeros((T, batch_size), dtype=np.int64)
         padded = []
         for b, line in enumerate(lines):
             idx[: len(line), b] = line
             padded.append((T - len(line)) / T)
+        return idx, padded
+
+    def insert_spaces(self, label, label_lengths, counts):
+        """reference signature: (one-hot content [T,B,num_class] on the host, padded fractions)"""
+        idx, padded = self.insert_spaces_index(label, label_lengths, counts)
+        T, batch_size = idx.shape
         spaced = torch.zeros(T, batch_size, self.num_class)
         spaced.view(-1, self.num_class)[torch.arange(T * batch_size), torch.from_numpy(idx).view(-1)] = 1
         return spaced, padded
