@@ -167,8 +167,13 @@ def main():
         # the north-star target is stated on the G+D conv stack: every conv kernel (MFMA, direct, their reduce passes) launched by the
         # generator's or the discriminator's layers, forward and backward, algorithmic FLOPs / kernel time
         gd = {"G": [0.0, 0.0], "D": [0.0, 0.0]}
+        by_net = {}
         for kind, shape, work, dt in prof:
             sc = shape[-1] if shape else None
+            bn = by_net.setdefault(str(sc), [0.0, 0.0])
+            bn[1] += dt
+            if "reduce" not in kind:
+                bn[0] += work
             if sc in gd:
                 gd[sc][1] += dt
                 if "reduce" not in kind:
@@ -193,6 +198,8 @@ def main():
                                              "gflop_per_step": round(gfl / 1e9 / max(prof_steps, 1), 1), "ms_per_step": round(gsec * 1e3 / max(prof_steps, 1), 3),
                                              "generator": round(gd["G"][0] / gd["G"][1] / 1e12, 3) if gd["G"][1] > 0 else None,
                                              "discriminator": round(gd["D"][0] / gd["D"][1] / 1e12, 3) if gd["D"][1] > 0 else None}
+            roofline["conv_time_by_network_ms_per_step"] = {k: [round(v[1] * 1e3 / max(prof_steps, 1), 3), round(v[0] / v[1] / 1e12, 1) if v[1] > 0 else None]
+                                                            for k, v in sorted(by_net.items(), key=lambda kv: -kv[1][1])}
         if roofline:
             # HBM bytes per launch of the dominant kernel: PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately with rocprofv3 on this
             # same command and corrected per MI355X_MICROARCH.md) are committed under profiles/; they cannot be collected from inside bench.py

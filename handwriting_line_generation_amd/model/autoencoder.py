@@ -31,6 +31,10 @@ class Encoder2(nn.Module):
                                         Conv2d(128, out_dim, (6, 3)))
 
     def forward(self, x):
+        with ops.scope("Encoder"):
+            return self._forward(x)
+
+    def _forward(self, x):
         """x NCHW [N,1,64,W] -> (code [N,out,1,W/8-4], mid [N,64,16,W/4]) both NCHW like the reference"""
         d1, c1, d2, c2, d3 = self.down_conv1, self.conv1, self.down_conv2, self.conv2, self.down_conv3
         h = ops.to_nhwc(x)

@@ -115,6 +115,10 @@ class CharStyleEncoder(nn.Module):
         return x, recog
 
     def forward(self, x, recog):
+        with ops.scope("StyleEx"):
+            return self._forward(x, recog)
+
+    def _forward(self, x, recog):
         """x: NCHW [B',1,64,Wc] author image; recog: [B',n_class,Tc] log-probs (channel major, as the reference passes) or NHWC [B',1,Tc,n_class]"""
         B = x.shape[0]
         if recog.dim() == 3:

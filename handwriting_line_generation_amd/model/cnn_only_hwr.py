@@ -61,6 +61,10 @@ class CNNOnlyHWR(nn.Module):
         return ops.bias_act(ops.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation), conv.bias, None, ops.ACT_RELU)
 
     def forward(self, input, style=None):
+        with ops.scope("HWR"):
+            return self._forward(input, style)
+
+    def _forward(self, input, style=None):
         """input NCHW [B,1,64,W] -> [T,B,n_class]"""
         x = ops.to_nhwc(input)
         if self.pad_cols:

@@ -29,6 +29,10 @@ class CountCNN(nn.Module):
             self.std = nn.Parameter(torch.full((1, n_out), 1.0))
 
     def forward(self, input, style):
+        with ops.scope("Spacer"):
+            return self._forward(input, style)
+
+    def _forward(self, input, style):
         """input [L,B,C] (time major) or NHWC [B,1,L,C]; style [B,S] -> [L,B,n_out]"""
         if input.dim() == 3:
             Lr, B, C = input.shape
