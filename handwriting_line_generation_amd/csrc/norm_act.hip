@@ -134,18 +134,80 @@ __global__ __launch_bounds__(256) void finalize_fwd_kernel(const double* part, G
   for (int cc = lane; cc < cpg; cc += 64) { mean[n * g.C + cb + cc] = (float)m; rstd[n * g.C + cb + cc] = r; }
 }
 
+// ---------------- statistics of one sample from the partial sums, computed inside the apply kernels (IN / GN) --------------------
+// For per-sample normalisations every workgroup of the apply pass needs only its own sample's statistics: chunks x C partial pairs.
+// Reading them here (L2 resident, just written) removes the separate finalize launches (latency bound, ~5-9 us each).
+constexpr int NS_MAXC = 1024;
+struct InlineStats {
+  const double* part;   // nullptr: statistics come from the mean/rstd (c1/c2) arrays in memory
+  int cpg;              // channels per statistic group (1 = instance norm)
+  float eps;
+  float* out_a;         // forward: mean [N][C], backward: dgamma [N][C] (per-sample affine) - written by chunk 0's workgroup
+  float* out_b;         // forward: rstd,        backward: dbeta
+  const float* gamma;   // backward only
+  int per_sample;
+  int accumulate;
+};
+// forward: s_a = mean, s_b = rstd.  backward: s_a = c1 = mean_grp(g*gamma), s_b = c2 = mean_grp(g*gamma*xhat)
+template <bool BWD>
+__device__ __forceinline__ void sample_stats(const InlineStats& is, const Geo& g, int n, float* s_a, float* s_b, double* s_t) {
+  const int tid = threadIdx.x;
+  for (int c = tid; c < g.C; c += 256) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < g.chunks; ++k) {
+      const double* p = is.part + (((size_t)n * g.chunks + k) * g.C + c) * 2;
+      s1 += p[0]; s2 += p[1];
+    }
+    if (BWD) {
+      if (blockIdx.x == 0 && is.per_sample) {
+        const int idx = n * g.C + c;
+        if (is.out_a) is.out_a[idx] = (is.accumulate ? is.out_a[idx] : 0.f) + (float)s2;
+        if (is.out_b) is.out_b[idx] = (is.accumulate ? is.out_b[idx] : 0.f) + (float)s1;
+      }
+      const double gm = is.gamma ? (double)is.gamma[is.per_sample ? n * g.C + c : c] : 1.0;
+      s1 *= gm; s2 *= gm;
+    }
+    s_t[2 * c] = s1; s_t[2 * c + 1] = s2;
+  }
+  __syncthreads();
+  const int ngrp = g.C / is.cpg;
+  const double cnt = (double)g.HW * is.cpg;
+  for (int gi = tid; gi < ngrp; gi += 256) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int cc = 0; cc < is.cpg; ++cc) { s1 += s_t[2 * (gi * is.cpg + cc)]; s2 += s_t[2 * (gi * is.cpg + cc) + 1]; }
+    float a, b;
+    if (BWD) {
+      a = (float)(s1 / cnt); b = (float)(s2 / cnt);
+    } else {
+      const double m = s1 / cnt;
+      double var = s2 / cnt - m * m;
+      if (var < 0.0) var = 0.0;
+      a = (float)m; b = (float)(1.0 / sqrt(var + (double)is.eps));
+    }
+    for (int cc = 0; cc < is.cpg; ++cc) { s_a[gi * is.cpg + cc] = a; s_b[gi * is.cpg + cc] = b; }
+  }
+  __syncthreads();
+  if (!BWD && blockIdx.x == 0) {
+    for (int c = tid; c < g.C; c += 256) { is.out_a[n * g.C + c] = s_a[c]; is.out_b[n * g.C + c] = s_b[c]; }
+  }
+}
+
 // ---------------- forward stage 3: y = act(mask * (gamma * xhat + beta)) -----------------------------------------------
 __global__ __launch_bounds__(256) void apply_fwd_kernel(const float* x, float* y, Geo g, const float* mean, const float* rstd,
                                                         const float* gamma, const float* beta, int per_sample,
-                                                        const float* mask, int act, float slope) {
+                                                        const float* mask, int act, float slope, InlineStats is) {
+  __shared__ __attribute__((aligned(16))) float s_a[NS_MAXC];
+  __shared__ __attribute__((aligned(16))) float s_b[NS_MAXC];
+  __shared__ double s_t[2 * NS_MAXC];
   const int tid = threadIdx.x;
   const int cl = tid % g.L, pl = tid / g.L;
-  if (pl >= g.PP) return;
   const int n = blockIdx.y;
+  if (is.part) sample_stats<false>(is, g, n, s_a, s_b, s_t);
+  if (pl >= g.PP) return;
   const int p0 = blockIdx.x * g.cs, p1 = min(p0 + g.cs, g.HW);
   const int c = cl * 4;
-  const float4 m4 = *reinterpret_cast<const float4*>(mean + n * g.C + c);
-  const float4 r4 = *reinterpret_cast<const float4*>(rstd + n * g.C + c);
+  const float4 m4 = is.part ? *reinterpret_cast<const float4*>(s_a + c) : *reinterpret_cast<const float4*>(mean + n * g.C + c);
+  const float4 r4 = is.part ? *reinterpret_cast<const float4*>(s_b + c) : *reinterpret_cast<const float4*>(rstd + n * g.C + c);
   float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const int ao = per_sample ? n * g.C + c : c;
   if (gamma) g4 = *reinterpret_cast<const float4*>(gamma + ao);
@@ -288,11 +350,15 @@ template <bool PRE>
 __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* dy, const float* x, const float* y, float* dx, Geo g,
                                                         const float* mean, const float* rstd, const float* gamma, int per_sample,
                                                         const float* c1, const float* c2, const float* mask, int act, float slope,
-                                                        const float* noise, float pre_slope, double* part2) {
+                                                        const float* noise, float pre_slope, double* part2, InlineStats is) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ __attribute__((aligned(16))) float s_a[NS_MAXC];
+  __shared__ __attribute__((aligned(16))) float s_b[NS_MAXC];
+  __shared__ double s_t[2 * NS_MAXC];
   const int tid = threadIdx.x;
   const int cl = tid % g.L, pl = tid / g.L;
   const int n = blockIdx.y;
+  if (is.part) sample_stats<true>(is, g, n, s_a, s_b, s_t);
   const int p0 = blockIdx.x * g.cs, p1 = min(p0 + g.cs, g.HW);
   float4 acc[2];
   acc[0] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -301,8 +367,8 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* dy, const f
     const int c = cl * 4;
     const float4 m4 = *reinterpret_cast<const float4*>(mean + n * g.C + c);
     const float4 r4 = *reinterpret_cast<const float4*>(rstd + n * g.C + c);
-    const float4 a4 = *reinterpret_cast<const float4*>(c1 + n * g.C + c);
-    const float4 b4 = *reinterpret_cast<const float4*>(c2 + n * g.C + c);
+    const float4 a4 = is.part ? *reinterpret_cast<const float4*>(s_a + c) : *reinterpret_cast<const float4*>(c1 + n * g.C + c);
+    const float4 b4 = is.part ? *reinterpret_cast<const float4*>(s_b + c) : *reinterpret_cast<const float4*>(c2 + n * g.C + c);
     float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f);
     if (gamma) g4 = *reinterpret_cast<const float4*>(gamma + (per_sample ? n * g.C + c : c));
     float4 k4 = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -460,12 +526,16 @@ extern "C" int hwg_norm_fwd(const float* x, float* y, int N, int HW, int C, int 
   dim3 grid(g.chunks, N);
   hipLaunchKernelGGL(moments_fwd_kernel<false>, grid, dim3(256), red_smem(g), st, x, g, part, nullptr, nullptr, 0.f, 0.f, nullptr);
   HWG_LAUNCH_CHECK("norm_fwd.moments");
-  const int nfin = (mode == MODE_BN) ? C : (mode == MODE_GN ? N * groups : N * C);
-  hipLaunchKernelGGL(finalize_fwd_kernel, dim3(hwg_cdiv(nfin, 4)), dim3(256), 0, st, (const double*)part, g, mode, groups, eps, mean, rstd,
-                     running_mean, running_var, momentum);
-  HWG_LAUNCH_CHECK("norm_fwd.finalize");
+  InlineStats is = {};
+  if (mode == MODE_BN) {   // batch statistics span the samples: separate finalize pass (also updates the running statistics)
+    hipLaunchKernelGGL(finalize_fwd_kernel, dim3(hwg_cdiv(C, 4)), dim3(256), 0, st, (const double*)part, g, mode, groups, eps, mean, rstd,
+                       running_mean, running_var, momentum);
+    HWG_LAUNCH_CHECK("norm_fwd.finalize");
+  } else {                 // per-sample statistics are formed inside the apply pass
+    is.part = part; is.cpg = (mode == MODE_GN) ? C / groups : 1; is.eps = eps; is.out_a = mean; is.out_b = rstd;
+  }
   hipLaunchKernelGGL(apply_fwd_kernel, grid, dim3(256), 0, st, x, y, g, (const float*)mean, (const float*)rstd, gamma, beta,
-                     affine_per_sample, chan_mask, act, slope);
+                     affine_per_sample, chan_mask, act, slope, is);
   HWG_LAUNCH_CHECK("norm_fwd.apply");
   return HWG_OK;
 }
@@ -487,16 +557,21 @@ extern "C" int hwg_norm_bwd(const float* dy, const float* x, const float* y, flo
   dim3 grid(g.chunks, N);
   hipLaunchKernelGGL(moments_bwd_kernel, grid, dim3(256), red_smem(g), st, dy, x, y, g, part, mean, rstd, chan_mask, act, slope);
   HWG_LAUNCH_CHECK("norm_bwd.moments");
-  const int nfin = (mode == MODE_BN) ? C : (mode == MODE_GN ? N * groups : N * C);
-  hipLaunchKernelGGL(finalize_bwd_kernel, dim3(hwg_cdiv(nfin, 4)), dim3(256), 0, st, (const double*)part, g, mode, groups, gamma,
-                     affine_per_sample, c1, c2, dgamma, dbeta, accumulate);
-  HWG_LAUNCH_CHECK("norm_bwd.finalize");
+  InlineStats is = {};
+  if (mode == MODE_BN) {
+    hipLaunchKernelGGL(finalize_bwd_kernel, dim3(hwg_cdiv(C, 4)), dim3(256), 0, st, (const double*)part, g, mode, groups, gamma,
+                       affine_per_sample, c1, c2, dgamma, dbeta, accumulate);
+    HWG_LAUNCH_CHECK("norm_bwd.finalize");
+  } else {
+    is.part = part; is.cpg = (mode == MODE_GN) ? C / groups : 1; is.gamma = gamma; is.per_sample = affine_per_sample;
+    is.out_a = affine_per_sample ? dgamma : nullptr; is.out_b = affine_per_sample ? dbeta : nullptr; is.accumulate = accumulate;
+  }
   if (mode != MODE_BN && !affine_per_sample && (dgamma || dbeta)) {
     hipLaunchKernelGGL(param_grad_kernel, dim3(hwg_cdiv(C, 4)), dim3(256), 0, st, (const double*)part, g, dgamma, dbeta, accumulate);
     HWG_LAUNCH_CHECK("norm_bwd.param_grad");
   }
   hipLaunchKernelGGL(apply_bwd_kernel<false>, grid, dim3(256), 0, st, dy, x, y, dx, g, mean, rstd, gamma, affine_per_sample,
-                     (const float*)c1, (const float*)c2, chan_mask, act, slope, nullptr, 0.f, nullptr);
+                     (const float*)c1, (const float*)c2, chan_mask, act, slope, nullptr, 0.f, nullptr, is);
   HWG_LAUNCH_CHECK("norm_bwd.apply");
   return HWG_OK;
 }
@@ -514,11 +589,10 @@ extern "C" int hwg_adain_fwd(const float* x, const float* noise, const float* no
   dim3 grid(g.chunks, N);
   hipLaunchKernelGGL(moments_fwd_kernel<true>, grid, dim3(256), red_smem(g), st, x, g, part, noise, noise_w, noise_scale, slope, u);
   HWG_LAUNCH_CHECK("adain_fwd.moments");
-  hipLaunchKernelGGL(finalize_fwd_kernel, dim3(hwg_cdiv(N * C, 4)), dim3(256), 0, st, (const double*)part, g, (int)MODE_IN, 1, eps, mean, rstd,
-                     (float*)nullptr, (float*)nullptr, 0.f);
-  HWG_LAUNCH_CHECK("adain_fwd.finalize");
+  InlineStats is = {};
+  is.part = part; is.cpg = 1; is.eps = eps; is.out_a = mean; is.out_b = rstd;
   hipLaunchKernelGGL(apply_fwd_kernel, grid, dim3(256), 0, st, (const float*)u, y, g, (const float*)mean, (const float*)rstd, gamma, beta, 1,
-                     (const float*)nullptr, 0, 0.f);
+                     (const float*)nullptr, 0, 0.f, is);
   HWG_LAUNCH_CHECK("adain_fwd.apply");
   return HWG_OK;
 }
@@ -541,12 +615,11 @@ extern "C" int hwg_adain_bwd(const float* dy, const float* u, const float* noise
   hipLaunchKernelGGL(moments_bwd_kernel, grid, dim3(256), red_smem(g), st, dy, u, (const float*)nullptr, g, part, mean, rstd,
                      (const float*)nullptr, 0, 0.f);
   HWG_LAUNCH_CHECK("adain_bwd.moments");
-  // dgamma/dbeta are per (n,c) and are NOT accumulated (they feed the style Linear's backward)
-  hipLaunchKernelGGL(finalize_bwd_kernel, dim3(hwg_cdiv(N * C, 4)), dim3(256), 0, st, (const double*)part, g, (int)MODE_IN, 1, gamma, 1,
-                     c1, c2, dgamma, dbeta, 0);
-  HWG_LAUNCH_CHECK("adain_bwd.finalize");
+  // dgamma/dbeta are per (n,c) and are NOT accumulated (they feed the style Linear's backward); c1/c2 are formed inside the apply pass
+  InlineStats is = {};
+  is.part = part; is.cpg = 1; is.gamma = gamma; is.per_sample = 1; is.out_a = dgamma; is.out_b = dbeta; is.accumulate = 0;
   hipLaunchKernelGGL(apply_bwd_kernel<true>, grid, dim3(256), red_smem(g), st, dy, u, (const float*)nullptr, dx, g, mean, rstd, gamma, 1,
-                     (const float*)c1, (const float*)c2, (const float*)nullptr, 0, 0.f, noise, slope, part2);
+                     (const float*)c1, (const float*)c2, (const float*)nullptr, 0, 0.f, noise, slope, part2, is);
   HWG_LAUNCH_CHECK("adain_bwd.apply");
   if (dnoise_w || dbias) {
     hipLaunchKernelGGL(adain_param_grad_kernel, dim3(hwg_cdiv(C, 4)), dim3(256), 0, st, (const double*)part2, g, noise_scale, dbias, dnoise_w,
@@ -594,7 +667,7 @@ extern "C" int hwg_norm_frozen_fwd(const float* x, float* y, int N, int HW, int 
   hipLaunchKernelGGL(frozen_stats_kernel, dim3(hwg_cdiv(N * C, 128)), dim3(128), 0, st, running_mean, running_var, eps, N, C, mean, rstd);
   HWG_LAUNCH_CHECK("norm_frozen.stats");
   hipLaunchKernelGGL(apply_fwd_kernel, dim3(g.chunks, N), dim3(256), 0, st, x, y, g, (const float*)mean, (const float*)rstd, gamma, beta, 0,
-                     (const float*)nullptr, act, slope);
+                     (const float*)nullptr, act, slope, InlineStats{});
   HWG_LAUNCH_CHECK("norm_frozen.apply");
   return HWG_OK;
 }
