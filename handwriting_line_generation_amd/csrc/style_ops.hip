@@ -127,124 +127,167 @@ __global__ __launch_bounds__(256) void linear_bank_wgrad_kernel(const float* __r
   }
   if (lane == 0 && gbptr && gbptr[l]) reinterpret_cast<float*>(gbptr[l])[o] += bs;
 }
-// input gradient: dx[b][i] = sum_l sum_o dy_l[b][o] W_l[o][i]; one workgroup per row b, 8 thread groups split the neurons and are
-// combined through LDS in a fixed order
+// input gradient: dx[b][i] = sum_l sum_o dy_l[b][o] W_l[o][i]. Stage 1: workgroup c sums its chunk of LB_OCHUNK neurons for all rows
+// (thread = (b, i), weight rows read coalesced along i and shared by the B rows) into part[c][b][i]; stage 2 adds the chunks in order.
+constexpr int LB_OCHUNK = 32;
 __global__ __launch_bounds__(1024) void linear_bank_dgrad_kernel(const long long* dyptr, const long long* wptr, const int* O, const int* first_wave, int L,
-                                                                 int B, int I, int halves, float* __restrict__ dx) {
-  __shared__ float red[8][128];
-  const int b = blockIdx.x;
-  const int part = threadIdx.x >> 7, il = threadIdx.x & 127;
+                                                                 int B, int I, int halves, float* __restrict__ part) {
   const int total = first_wave[L];
-  for (int i0 = 0; i0 < I; i0 += 128) {
-    const int i = i0 + il;
+  const int w0 = blockIdx.x * LB_OCHUNK, w1 = min(w0 + LB_OCHUNK, total);
+  int l0 = 0;
+  while (l0 + 1 < L && first_wave[l0 + 1] <= w0) ++l0;
+  for (int t = threadIdx.x; t < B * I; t += blockDim.x) {
+    const int b = t / I, i = t - b * I;
     float s = 0.f;
-    if (i < I) {
-      int l = 0;
-      for (int w = part; w < total; w += 8) {
-        while (l + 1 < L && first_wave[l + 1] <= w) ++l;
-        const int o = w - first_wave[l];
-        const int C = O[l] / halves, h = o / C, c = o - h * C;
-        const float* dy = reinterpret_cast<const float*>(dyptr[l * halves + h]);
-        if (!dy) continue;
-        s += dy[(long long)b * C + c] * reinterpret_cast<const float*>(wptr[l])[(long long)o * I + i];
-      }
+    int l = l0;
+    for (int w = w0; w < w1; ++w) {
+      while (l + 1 < L && first_wave[l + 1] <= w) ++l;
+      const int o = w - first_wave[l];
+      const int C = O[l] / halves, h = o / C, c = o - h * C;
+      const float* dy = reinterpret_cast<const float*>(dyptr[l * halves + h]);
+      if (!dy) continue;
+      s += dy[(long long)b * C + c] * reinterpret_cast<const float*>(wptr[l])[(long long)o * I + i];
     }
-    red[part][il] = s;
-    __syncthreads();
-    if (part == 0 && i < I) {
-      float t = 0.f;
-#pragma unroll
-      for (int p = 0; p < 8; ++p) t += red[p][il];
-      dx[(long long)b * I + i] = t;
-    }
-    __syncthreads();
+    part[((long long)blockIdx.x * B + b) * I + i] = s;
   }
 }
-
+__global__ __launch_bounds__(256) void linear_bank_dgrad_reduce_kernel(const float* __restrict__ part, int nchunks, int n, float* __restrict__ dx) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < nchunks; ++c) s += part[(long long)c * n + t];
+  dx[t] = s;
+}
 
 // ---- chain of L square linear layers with LeakyReLU (the generator's style embedding MLP, 6 x Linear(128,128), pure_gen.py:29-38) -------
 // in ONE workgroup per pass: h_{l+1} = lrelu(W_l h_l + b_l); the B x D activations live in LDS, weights stream from L2 (64 KB / layer).
 // acts [L+1][B][D] keeps every h_l for the backward pass (acts[0] = x).
-constexpr int MC_MAXB = 16, MC_MAXD = 256;
-__global__ __launch_bounds__(1024) void mlp_chain_fwd_kernel(const float* __restrict__ x, const long long* wptr, const long long* bptr, int L, int B, int D,
+constexpr int MC_MAXB = 16, MC_MAXD = 128;
+// A single workgroup is latency bound: every dependent global access costs ~2 us. So: the whole weight matrix of a layer sits in LDS
+// (row stride DD+1: threads holding different neurons hit different banks), thread (b, o) runs its own dot product (no cross-lane
+// reductions), and the NEXT layer's weights (and, backward, the old gradient values) are already in flight in registers while the
+// current layer is computed. DD = feature count (64-multiple), BM = row capacity (rows >= B are kept at zero).
+template <int DD, int BM>
+__global__ __launch_bounds__(1024) void mlp_chain_fwd_kernel(const float* __restrict__ x, const long long* wptr, const long long* bptr, int L, int B,
                                                              float slope, float* __restrict__ acts) {
-  __shared__ float h[MC_MAXB * MC_MAXD];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int t = tid; t < B * D; t += nt) { h[t] = x[t]; acts[t] = x[t]; }
-  __syncthreads();
+  constexpr int LDW = DD + 1, PER = DD * DD / 1024;
+  __shared__ float h[BM * DD];
+  __shared__ float hn[BM * DD];
+  __shared__ float ws[DD * LDW];
+  const int tid = threadIdx.x;
+  float nxt[PER];
+  {
+    const float* W0 = reinterpret_cast<const float*>(wptr[0]);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) nxt[u] = W0[tid + u * 1024];
+  }
+  for (int t = tid; t < BM * DD; t += 1024) {
+    const float v = t < B * DD ? x[t] : 0.f;
+    h[t] = v;
+    if (t < B * DD) acts[t] = v;
+  }
   for (int l = 0; l < L; ++l) {
-    const float* W = reinterpret_cast<const float*>(wptr[l]);
-    const float* bias = reinterpret_cast<const float*>(bptr[l]);
-    float outv[(MC_MAXB * MC_MAXD + 1023) / 1024];
-    int cnt = 0;
-    for (int t = tid; t < B * D; t += nt, ++cnt) {
-      const int o = t % D, b = t / D;
-      const float* wr = W + (long long)o * D;
-      const float* hr = h + b * D;
+    const float* __restrict__ bias = reinterpret_cast<const float*>(bptr[l]);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int t = tid + u * 1024;
+      ws[(t / DD) * LDW + (t % DD)] = nxt[u];
+    }
+    if (l + 1 < L) {
+      const float* Wn = reinterpret_cast<const float*>(wptr[l + 1]);
+#pragma unroll
+      for (int u = 0; u < PER; ++u) nxt[u] = Wn[tid + u * 1024];
+    }
+    __syncthreads();
+    for (int p = tid; p < BM * DD; p += 1024) {
+      const int b = p / DD, o = p % DD;
+      const float* wr = ws + o * LDW;
+      const float* hr = h + b * DD;
       float a = bias[o];
-      for (int i = 0; i < D; ++i) a += wr[i] * hr[i];
-      outv[cnt] = a > 0.f ? a : a * slope;
+#pragma unroll 8
+      for (int i = 0; i < DD; ++i) a += wr[i] * hr[i];
+      hn[p] = a > 0.f ? a : a * slope;
     }
     __syncthreads();
-    cnt = 0;
-    for (int t = tid; t < B * D; t += nt, ++cnt) {
-      h[t] = outv[cnt];
-      acts[(long long)(l + 1) * B * D + t] = outv[cnt];
+    for (int t = tid; t < BM * DD; t += 1024) {
+      const float v = t < B * DD ? hn[t] : 0.f;
+      h[t] = v;
+      if (t < B * DD) acts[(long long)(l + 1) * B * DD + t] = v;
     }
-    __syncthreads();
   }
 }
-// backward of the chain; parameter gradients are ADDED into the tables' buffers
+// backward of the chain; parameter gradients are ADDED into the tables' buffers (a null table entry = frozen layer).
+template <int DD, int BM, int LMAX>
 __global__ __launch_bounds__(1024) void mlp_chain_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ acts, const long long* wptr,
-                                                             const long long* gwptr, const long long* gbptr, int L, int B, int D, float slope,
+                                                             const long long* gwptr, const long long* gbptr, int L, int B, float slope,
                                                              float* __restrict__ dx) {
-  __shared__ float dpre[MC_MAXB * MC_MAXD];   // d(pre-activation) of the current layer
-  __shared__ float hin[MC_MAXB * MC_MAXD];    // its input h_l
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int t = tid; t < B * D; t += nt) dpre[t] = dout[t];
-  __syncthreads();
-  for (int l = L - 1; l >= 0; --l) {
-    // dpre currently holds dL/dh_{l+1}; apply the LeakyReLU derivative (sign of h_{l+1} == sign of the pre-activation)
-    for (int t = tid; t < B * D; t += nt) {
-      const float hv = acts[(long long)(l + 1) * B * D + t];
-      dpre[t] *= hv > 0.f ? 1.f : slope;
-      hin[t] = acts[(long long)l * B * D + t];
-    }
-    __syncthreads();
+  constexpr int PER = DD * DD / 1024;
+  __shared__ float dpre[BM * DD];               // d(pre-activation) of the current layer
+  __shared__ float dnew[BM * DD];
+  __shared__ float ha[(LMAX + 1) * BM * DD];    // every h_l, loaded once
+  __shared__ float ws[DD * DD];                 // W of the current layer, [o][i]
+  const int tid = threadIdx.x;
+  float wn[PER], gold[PER];
+  auto prefetch = [&](int l) {
     const float* W = reinterpret_cast<const float*>(wptr[l]);
+    const float* gW = gwptr[l] ? reinterpret_cast<const float*>(gwptr[l]) : nullptr;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      wn[u] = W[tid + u * 1024];
+      gold[u] = gW ? gW[tid + u * 1024] : 0.f;
+    }
+  };
+  prefetch(L - 1);
+  for (int t = tid; t < (L + 1) * BM * DD; t += 1024) {
+    const int l = t / (BM * DD), r = t % (BM * DD);
+    ha[t] = r < B * DD ? acts[(long long)l * B * DD + r] : 0.f;
+  }
+  for (int t = tid; t < BM * DD; t += 1024) dpre[t] = t < B * DD ? dout[t] : 0.f;
+  for (int l = L - 1; l >= 0; --l) {
+    __syncthreads();
+    // dpre holds dL/dh_{l+1}: apply the LeakyReLU derivative (sign of h_{l+1} == sign of the pre-activation); stage W_l
+    for (int t = tid; t < BM * DD; t += 1024) dpre[t] *= ha[(l + 1) * BM * DD + t] > 0.f ? 1.f : slope;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) ws[tid + u * 1024] = wn[u];
+    float gcur[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) gcur[u] = gold[u];
     float* gW = gwptr[l] ? reinterpret_cast<float*>(gwptr[l]) : nullptr;
     float* gb = (gbptr && gbptr[l]) ? reinterpret_cast<float*>(gbptr[l]) : nullptr;
+    if (l > 0) prefetch(l - 1);
+    __syncthreads();
+    const float* hin = ha + l * BM * DD;
     if (gW) {
-      for (int t = tid; t < D * D; t += nt) {       // dW[o][i] += sum_b dpre[b][o] * h_l[b][i]
-        const int ii = t % D, o = t / D;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {            // dW[o][i] += sum_b dpre[b][o] * h_l[b][i]   (coalesced along i)
+        const int t = tid + u * 1024;
+        const int ii = t % DD, o = t / DD;
         float a = 0.f;
-        for (int b = 0; b < B; ++b) a += dpre[b * D + o] * hin[b * D + ii];
-        gW[t] += a;
+#pragma unroll
+        for (int b = 0; b < BM; ++b) a += dpre[b * DD + o] * hin[b * DD + ii];
+        gW[t] = gcur[u] + a;
       }
     }
-    if (gb) {
-      for (int o = tid; o < D; o += nt) {
-        float a = 0.f;
-        for (int b = 0; b < B; ++b) a += dpre[b * D + o];
-        gb[o] += a;
-      }
-    }
-    // dh_l[b][i] = sum_o dpre[b][o] * W[o][i]
-    float outv[(MC_MAXB * MC_MAXD + 1023) / 1024];
-    int cnt = 0;
-    for (int t = tid; t < B * D; t += nt, ++cnt) {
-      const int ii = t % D, b = t / D;
+    if (gb && tid < DD) {
       float a = 0.f;
-      for (int o = 0; o < D; ++o) a += dpre[b * D + o] * W[(long long)o * D + ii];
-      outv[cnt] = a;
+#pragma unroll
+      for (int b = 0; b < BM; ++b) a += dpre[b * DD + tid];
+      gb[tid] += a;
+    }
+    for (int p = tid; p < BM * DD; p += 1024) {  // dh_l[b][i] = sum_o dpre[b][o] * W[o][i]
+      const int b = p / DD, ii = p % DD;
+      float a = 0.f;
+#pragma unroll 8
+      for (int o = 0; o < DD; ++o) a += dpre[b * DD + o] * ws[o * DD + ii];
+      dnew[p] = a;
     }
     __syncthreads();
-    cnt = 0;
-    for (int t = tid; t < B * D; t += nt, ++cnt) dpre[t] = outv[cnt];
-    __syncthreads();
+    for (int t = tid; t < BM * DD; t += 1024) dpre[t] = dnew[t];
   }
+  __syncthreads();
   if (dx)
-    for (int t = tid; t < B * D; t += nt) dx[t] = dpre[t];
+    for (int t = tid; t < B * DD; t += 1024) dx[t] = dpre[t];
 }
 
 }  // namespace
@@ -298,8 +341,12 @@ extern "C" int hwg_linear_bank_fwd(const float* x, const void* wptr, const void*
   HWG_LAUNCH_CHECK("linear_bank_fwd");
   return HWG_OK;
 }
+extern "C" size_t hwg_linear_bank_bwd_workspace(int total_outputs, int B, int I) {
+  return (size_t)hwg_cdiv(total_outputs > 0 ? total_outputs : 1, LB_OCHUNK) * (B > 0 ? B : 0) * (I > 0 ? I : 0) * sizeof(float);
+}
 extern "C" int hwg_linear_bank_bwd(const float* x, const void* dyptr, const void* wptr, const void* gwptr, const void* gbptr, const int* O,
-                                   const int* first_wave, int L, int B, int I, int halves, int total_outputs, float* dx, void* stream) {
+                                   const int* first_wave, int L, int B, int I, int halves, int total_outputs, float* dx, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
   HWG_REQUIRE(x && dyptr && wptr && gwptr && O && first_wave && L > 0 && B > 0 && B <= LB_MAXB && I > 0 && halves > 0 && total_outputs > 0,
               "linear_bank_bwd: bad arguments (B <= %d)", LB_MAXB);
   hipStream_t st = (hipStream_t)stream;
@@ -307,9 +354,17 @@ extern "C" int hwg_linear_bank_bwd(const float* x, const void* dyptr, const void
                      (const long long*)gbptr, O, first_wave, L, B, I, halves);
   HWG_LAUNCH_CHECK("linear_bank_wgrad");
   if (dx) {
-    hipLaunchKernelGGL(linear_bank_dgrad_kernel, dim3(B), dim3(1024), 0, st, (const long long*)dyptr, (const long long*)wptr, O, first_wave, L, B, I, halves,
-                       dx);
+    const size_t need = hwg_linear_bank_bwd_workspace(total_outputs, B, I);
+    if (!workspace || workspace_bytes < need) {
+      hwg_set_error("linear_bank_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+      return HWG_ERR_WORKSPACE;
+    }
+    const int nch = hwg_cdiv(total_outputs, LB_OCHUNK);
+    hipLaunchKernelGGL(linear_bank_dgrad_kernel, dim3(nch), dim3(1024), 0, st, (const long long*)dyptr, (const long long*)wptr, O, first_wave, L, B, I, halves,
+                       (float*)workspace);
     HWG_LAUNCH_CHECK("linear_bank_dgrad");
+    hipLaunchKernelGGL(linear_bank_dgrad_reduce_kernel, dim3(hwg_cdiv(B * I, 256)), dim3(256), 0, st, (const float*)workspace, nch, B * I, dx);
+    HWG_LAUNCH_CHECK("linear_bank_dgrad_reduce");
   }
   return HWG_OK;
 }
@@ -317,17 +372,28 @@ extern "C" int hwg_linear_bank_bwd(const float* x, const void* dyptr, const void
 extern "C" int hwg_mlp_chain_fwd(const float* x, const void* wptr, const void* bptr, int L, int B, int D, float slope, float* acts, void* stream) {
   HWG_REQUIRE(x && wptr && bptr && acts && L > 0 && B > 0 && B <= MC_MAXB && D > 0 && D <= MC_MAXD, "mlp_chain_fwd: bad arguments (B <= %d, D <= %d)",
               MC_MAXB, MC_MAXD);
-  hipLaunchKernelGGL(mlp_chain_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (const long long*)wptr, (const long long*)bptr, L, B, D, slope,
-                     acts);
+  hipStream_t st = (hipStream_t)stream;
+  HWG_REQUIRE(D == 64 || D == 128, "mlp_chain_fwd: D must be 64 or 128 (got %d)", D);
+#define HWG_MC_FWD(DD_, BM_) hipLaunchKernelGGL((mlp_chain_fwd_kernel<DD_, BM_>), dim3(1), dim3(1024), 0, st, x, (const long long*)wptr, (const long long*)bptr, L, B, slope, acts)
+  if (D == 128 && B <= 8) HWG_MC_FWD(128, 8);
+  else if (D == 128) HWG_MC_FWD(128, 16);
+  else HWG_MC_FWD(64, 16);
+#undef HWG_MC_FWD
   HWG_LAUNCH_CHECK("mlp_chain_fwd");
   return HWG_OK;
 }
 extern "C" int hwg_mlp_chain_bwd(const float* dout, const float* acts, const void* wptr, const void* gwptr, const void* gbptr, int L, int B, int D,
                                  float slope, float* dx, void* stream) {
-  HWG_REQUIRE(dout && acts && wptr && gwptr && L > 0 && B > 0 && B <= MC_MAXB && D > 0 && D <= MC_MAXD, "mlp_chain_bwd: bad arguments (B <= %d, D <= %d)",
-              MC_MAXB, MC_MAXD);
-  hipLaunchKernelGGL(mlp_chain_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dout, acts, (const long long*)wptr, (const long long*)gwptr,
-                     (const long long*)gbptr, L, B, D, slope, dx);
+  HWG_REQUIRE(dout && acts && wptr && gwptr && L > 0 && L <= 8 && B > 0 && B <= MC_MAXB && (D == 64 || D == 128),
+              "mlp_chain_bwd: bad arguments (L <= 8, B <= %d, D 64 or 128)", MC_MAXB);
+  hipStream_t st = (hipStream_t)stream;
+#define HWG_MC_BWD(DD_, BM_) hipLaunchKernelGGL((mlp_chain_bwd_kernel<DD_, BM_, 8>), dim3(1), dim3(1024), 0, st, dout, acts, (const long long*)wptr, \
+                                                (const long long*)gwptr, (const long long*)gbptr, L, B, slope, dx)
+  if (D == 128 && B <= 8) HWG_MC_BWD(128, 8);
+  else if (D == 128) HWG_MC_BWD(128, 16);
+  else if (B <= 8) HWG_MC_BWD(64, 8);
+  else HWG_MC_BWD(64, 16);
+#undef HWG_MC_BWD
   HWG_LAUNCH_CHECK("mlp_chain_bwd");
   return HWG_OK;
 }

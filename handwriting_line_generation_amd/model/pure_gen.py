@@ -132,7 +132,7 @@ class SpacedGenerator(nn.Module):
     def embed_style(self, style):
         h = ops.pixel_norm(style.contiguous())
         lin = [m for m in self.style_emb if isinstance(m, Linear)]
-        if h.shape[0] <= 16 and h.shape[1] <= 256:
+        if h.shape[0] <= 16 and h.shape[1] in (64, 128) and len(lin) <= 8:
             # the six Linear(128,128)+LeakyReLU layers run as one single-workgroup launch per direction (36 launches -> 2 per pass)
             if self._style_chain is None:
                 self._style_chain = ops.MLPChain(lin, 0.2)

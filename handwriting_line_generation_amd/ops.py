@@ -1471,7 +1471,9 @@ class _LinearBank(Function):
         dyptr = h2d(np.array([g.data_ptr() if g is not None else 0 for g in keep], dtype=np.int64), x.device)
         gw, gb = bank.grad_tables(x.device)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        L.call("hwg_linear_bank_bwd", x, dyptr, wptr, gw, gb, O, first, bank.L, B, I, bank.halves, bank.total, dx, _stream())
+        need = L.query("hwg_linear_bank_bwd_workspace", bank.total, B, I)
+        ws = workspace(need, x.device)
+        L.call("hwg_linear_bank_bwd", x, dyptr, wptr, gw, gb, O, first, bank.L, B, I, bank.halves, bank.total, dx, ws, ws.numel(), _stream())
         return dx, None
 
 

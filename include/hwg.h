@@ -245,13 +245,15 @@ int hwg_gather_scores(const float* x, int B, int Wx, int C, const int* idx_b, co
  * buffers and writes dx [B][I] (optional); dyptr[l*halves + h] is the gradient of block h of layer l (0 = unused output). */
 int hwg_linear_bank_fwd(const float* x, const void* wptr, const void* bptr, const int* O, const int* first_wave, const void* off, int L, int B,
                         int I, int halves, int total_outputs, float* y, void* stream);
+size_t hwg_linear_bank_bwd_workspace(int total_outputs, int B, int I);
 int hwg_linear_bank_bwd(const float* x, const void* dyptr, const void* wptr, const void* gwptr, const void* gbptr, const int* O,
-                        const int* first_wave, int L, int B, int I, int halves, int total_outputs, float* dx, void* stream);
+                        const int* first_wave, int L, int B, int I, int halves, int total_outputs, float* dx, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* Chain of L square Linear(D,D)+LeakyReLU layers (the generator's style-embedding MLP, pure_gen.py:29-38) in one single-workgroup
  * launch per direction: h_{l+1} = lrelu(W_l h_l + b_l, slope). acts [L+1][B][D] receives every h_l (acts[0] = x, acts[L] = output) and is
  * what the backward consumes; the backward ADDS dW_l / db_l into the tables' buffers (null entry = frozen) and writes dx (optional).
- * B <= 16, D <= 256. */
+ * B <= 16, D = 64 or 128, L <= 8. */
 int hwg_mlp_chain_fwd(const float* x, const void* wptr, const void* bptr, int L, int B, int D, float slope, float* acts, void* stream);
 int hwg_mlp_chain_bwd(const float* dout, const float* acts, const void* wptr, const void* gwptr, const void* gbptr, int L, int B, int D,
                       float slope, float* dx, void* stream);
