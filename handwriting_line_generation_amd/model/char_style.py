@@ -72,7 +72,7 @@ class CharExtractor(nn.Module):
         h = ops.relu(ops.add(h, x))
         h = self.conv2[2](self.conv2[1](h), "relu")
         h = ops.avg_pool2d(h, (1, wlen)).reshape(n, -1)
-        h = ops.bias_act(ops.linear(h, self.fc[0].weight, None), self.fc[0].bias, None, ops.ACT_RELU)
+        h = ops.bias_act(ops.linear(h, self.fc[0].weight, self.fc[0].bias), None, None, ops.ACT_RELU)
         return self.fc[2](h)
 
 
@@ -141,10 +141,10 @@ class CharStyleEncoder(nn.Module):
         # arg-max map and builds the window lists
         xr = ops.cat_channels([ops.relu(feat), recog], (B, 1, Wf))
         p = self.prep
-        xr = ops.bias_act(ops.conv1d(xr, p[0].weight, None, 1, 2, 1), p[0].bias, None, ops.ACT_RELU)
+        xr = ops.bias_act(ops.conv1d(xr, p[0].weight, p[0].bias, 1, 2, 1), None, None, ops.ACT_RELU)
         xr = ops.max_pool2d(xr, (1, 2), (1, 2))
         xr = p[4](p[3](xr), "relu")
-        xr = ops.bias_act(ops.conv1d(xr, p[6].weight, None, 1, 1, 1), p[6].bias, None, ops.ACT_RELU)
+        xr = ops.bias_act(ops.conv1d(xr, p[6].weight, p[6].bias, 1, 1, 1), None, None, ops.ACT_RELU)
         xr = ops.avg_pool2d(xr, (1, xr.shape[2])).reshape(B, -1)
 
         # which classes were recognised where (one small D2H copy)
@@ -174,5 +174,5 @@ class CharStyleEncoder(nn.Module):
 
         comb = ops.cat_channels([xr.view(B, 1, 1, -1), avg_char_style.view(B, 1, 1, -1)], (B, 1, 1)).reshape(B, -1)
         f = self.final_g_spacing_style
-        comb = ops.bias_act(ops.linear(comb, f[0].weight, None), f[0].bias, None, ops.ACT_RELU)
+        comb = ops.bias_act(ops.linear(comb, f[0].weight, f[0].bias), None, None, ops.ACT_RELU)
         return f[2](comb)

@@ -57,8 +57,8 @@ class CNNOnlyHWR(nn.Module):
             h = conv(x)
             norm = getattr(self.cnn, ("groupnorm%d" if self.norm_kind == "group" else "batchnorm%d") % i)
             return norm(h, "relu")
-        # bias + ReLU in one elementwise pass
-        return ops.bias_act(ops.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation), conv.bias, None, ops.ACT_RELU)
+        # the bias is added in the conv epilogue (its gradient then rides along in the weight-gradient kernel); ReLU is one elementwise pass
+        return ops.bias_act(ops.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation), None, None, ops.ACT_RELU)
 
     def forward(self, input, style=None):
         with ops.scope("HWR"):

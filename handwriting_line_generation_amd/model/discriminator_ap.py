@@ -63,10 +63,10 @@ class DiscriminatorAP(nn.Module):
                 SpectralConv2d(4 * dim, 1, 1, (0, 0)))
 
     def _sn_act(self, conv, x, drop=None):
-        """SN conv -> (+bias, Dropout2d mask, LeakyReLU) in one elementwise kernel"""
-        h = conv(x, with_bias=False)
+        """SN conv (+bias in its epilogue, so the bias gradient comes out of the weight-gradient kernel) -> Dropout2d mask, LeakyReLU"""
+        h = conv(x, with_bias=True)
         mask = drop.mask_for(h) if drop is not None else None
-        return ops.bias_act(h, conv.module.bias, mask, ops.ACT_LRELU, self.leak)
+        return ops.bias_act(h, None, mask, ops.ACT_LRELU, self.leak)
 
     def _low_head(self, mL):
         c = self.convs4

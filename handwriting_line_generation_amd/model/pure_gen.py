@@ -138,7 +138,7 @@ class SpacedGenerator(nn.Module):
                 self._style_chain = ops.MLPChain(lin, 0.2)
             return self._style_chain(h)
         for m in lin:
-            h = ops.bias_act(ops.linear(h, m.weight, None), m.bias, None, ops.ACT_LRELU, 0.2)
+            h = ops.bias_act(ops.linear(h, m.weight, m.bias), None, None, ops.ACT_LRELU, 0.2)
         return h
 
     def forward(self, content, style, return_intermediate=False):
