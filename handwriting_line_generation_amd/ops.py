@@ -263,9 +263,17 @@ def _run_conv(x, wp, bias, N, H, W, C, K, R, S, stride, pad, dil, P, Q, transpos
     return y
 
 
-def _needs_cpad(C, K):
-    # the MFMA path wants the contraction channels in multiples of 16; the direct kernels (C==1 / K<=2) do not
-    return C != 1 and K > 2 and C % 16 != 0
+def _cpad(C, K, fractional=False):
+    """channel count the contraction side must be zero-padded to: multiples of 16 for the MFMA path (always taken by the fractionally
+    strided mode: conv-transpose with stride > 1, data gradient of a strided conv), multiples of 4 for the K <= 2 direct kernel,
+    nothing for the single-channel direct kernel"""
+    if fractional:
+        return (C + 15) // 16 * 16
+    if C == 1:
+        return C
+    if K <= 2:
+        return (C + 3) // 4 * 4
+    return (C + 15) // 16 * 16
 
 
 def _taps(weight):
@@ -296,7 +304,7 @@ class _Conv2d(Function):
             assert weight.shape[1] == C, "conv: weight expects %d input channels, got %d" % (weight.shape[1], C)
             P = (H + 2 * ph - dh * (R - 1) - 1) // sh + 1
             Q = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
-            Cp = (C + 15) // 16 * 16 if _needs_cpad(C, K) else C
+            Cp = _cpad(C, K)
             xin = _pad_channels(x, Cp) if Cp != C else x
             wp = _pack(weight, K, C, R, S, C * R * S, R * S, flip=0, Bpad=Cp)
             y = _run_conv(xin, wp, bias, N, H, W, Cp, K, R, S, (sh, sw), (ph, pw), (dh, dw), P, Q, 0)
@@ -306,7 +314,7 @@ class _Conv2d(Function):
             oph, opw = output_padding
             P = (H - 1) * sh - 2 * ph + dh * (R - 1) + 1 + oph
             Q = (W - 1) * sw - 2 * pw + dw * (S - 1) + 1 + opw
-            Cp = (C + 15) // 16 * 16 if _needs_cpad(C, K) else C
+            Cp = _cpad(C, K, fractional=(sh != 1 or sw != 1))
             xin = _pad_channels(x, Cp) if Cp != C else x
             if sh == 1 and sw == 1:
                 # stride-1 transposed conv == correlation with mirrored taps and padding dil*(R-1)-pad
@@ -337,7 +345,7 @@ class _Conv2d(Function):
         st = _stream()
         if ctx.needs_input_grad[0]:
             # data gradient: contraction over K (dy's channels) producing C channels
-            Kp = (K + 15) // 16 * 16 if _needs_cpad(K, C) else K
+            Kp = _cpad(K, C, fractional=(not transposed and (sh != 1 or sw != 1)))
             dyin = _pad_channels(dy, Kp) if Kp != K else dy
             if not transposed and C == 1 and sh == 1 and sw == 1 and K % 16 == 0 and 1 < R * S <= 64:
                 # single-channel input (first layers): dx has one channel, so instead of a matrix-vector kernel the tap matrix
@@ -376,7 +384,7 @@ class _Conv2d(Function):
             # 4-channel zero-padded copy is faster (measured 164 vs 390 us for the 7x7 first layer of D), so only small ones stay direct
             # (the direct kernel runs a K<=2 head as ONE workgroup: 166 us for the discriminator's 256->1 3x3 head at 304 pixels, so heads
             # with a wide gathered side go through the padded MFMA path as well; only narrow-and-small cases stay direct)
-            tiny_end = (d.C <= 2 or (d.K <= 2 and d.C < 16)) and d.N * d.P * d.Q < 8192
+            tiny_end = ((d.C == 1 and d.K % 4 == 0 and d.K > 2) or (d.K <= 2 and d.C % 4 == 0 and d.C < 16)) and d.N * d.P * d.Q < 8192
             # single gathered channel (first layers): the library runs the taps as the GEMM's N dimension, no padding needed
             tap_gemm = d.C == 1 and d.K > 2 and d.K % 4 == 0 and R * S <= 64
             if (Kq != d.K or Cq != d.C) and not tiny_end and not tap_gemm:
@@ -404,7 +412,7 @@ class _Conv2d(Function):
                 if PROF_SHAPES is not None:
                     _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad", ctx.scope))
                 # the bias gradient (column sums of dy) rides along when dy is the kernel's anchor operand and the MFMA path runs
-                fuse_bias = (ctx.has_bias and ctx.needs_input_grad[2] and not transposed and not (d.K <= 2 or (d.C <= 2 and not tap_gemm)))
+                fuse_bias = (ctx.has_bias and ctx.needs_input_grad[2] and not transposed and not tiny_end and d.K > 2 and (d.C > 2 or tap_gemm))
                 dbias = bacc = None
                 if fuse_bias:
                     bdirect = _direct(bref)

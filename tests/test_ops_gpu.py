@@ -488,3 +488,43 @@ def test_linear_bank_and_mlp_chain(cuda):
     for k, (a, b) in enumerate(zip(dev_chain, ref_chain)):
         _close(a.weight.grad, b.weight.grad, "chain dW %d" % k)
         _close(a.bias.grad, b.bias.grad, "chain db %d" % k)
+
+
+def _random_conv_cases(n=36, seed=2026):
+    import random
+    rnd = random.Random(seed)
+    cases = []
+    while len(cases) < n:
+        transposed = rnd.random() < 0.25
+        C = rnd.choice([1, 3, 16, 16, 32, 48, 64, 80, 128, 208, 256])
+        K = rnd.choice([1, 2, 16, 32, 64, 78, 80, 128, 256])
+        R = rnd.choice([1, 1, 3, 3, 4, 5, 7]); S = rnd.choice([1, 3, 3, 4, 5, 7])
+        if transposed:
+            st = rnd.choice([(1, 1), (2, 2), (2, 1)]); dil = (1, 1)
+            R = max(R, st[0]); S = max(S, st[1])
+            pad = (rnd.randint(0, min(1, R - 1)), rnd.randint(0, min(1, S - 1)))
+        else:
+            st = rnd.choice([(1, 1), (1, 1), (2, 2), (2, 1)])
+            dil = rnd.choice([(1, 1), (1, 1), (1, 2), (2, 1)]) if st == (1, 1) else (1, 1)
+            pad = (rnd.randint(0, R // 2 + 1), rnd.randint(0, S // 2 + 1))
+        N = rnd.randint(1, 5); H = rnd.randint(1, 19); W = rnd.randint(1, 75)
+        if not transposed:
+            if H + 2 * pad[0] < dil[0] * (R - 1) + 1 or W + 2 * pad[1] < dil[1] * (S - 1) + 1:
+                continue
+        if transposed and ((H - 1) * st[0] - 2 * pad[0] + R < 1 or (W - 1) * st[1] - 2 * pad[1] + S < 1):
+            continue      # empty output
+        if (C == 1 and K <= 2) or N * H * W * max(C, K) > 3_000_000:
+            continue
+        cases.append(("rnd%d_C%dK%d_%dx%d_s%s_p%s_d%s%s" % (len(cases), C, K, R, S, st, pad, dil, "_T" if transposed else ""), N, H, W, C, K, R, S, st, pad, dil,
+                      transposed))
+    return cases
+
+
+import os as _os
+RANDOM_CONV_CASES = _random_conv_cases(int(_os.environ.get("HWG_TEST_RANDOM_CONVS", "36")), int(_os.environ.get("HWG_TEST_RANDOM_SEED", "2026")))
+
+
+@pytest.mark.parametrize("case", RANDOM_CONV_CASES, ids=[c[0] for c in RANDOM_CONV_CASES])
+def test_conv_random_geometry(cuda, case):
+    """seeded random conv / conv-transpose geometries (odd sizes, 1-pixel maps, RIMES channel counts, dilation, every schedule branch)"""
+    test_conv_fwd_bwd(cuda, case)
