@@ -179,27 +179,58 @@ def start_stash_allreduce(stash, world):
     return st
 
 
+def touched_spans(flat, mask, max_spans=8, min_gap=1 << 16):
+    """[(start, end)] float ranges of the flat buffer that cover every touched tensor: runs of touched tensors, merged across gaps
+    shorter than `min_gap` floats and then across the smallest gaps until at most `max_spans` remain. The mask is the OR over all
+    ranks, so every rank derives the same ranges; everything outside them is zero on every rank and needs no exchange (a `disc`
+    lesson touches 6 MB of the 190 MB buffer)."""
+    idx = np.nonzero(mask)[0]
+    if idx.size == 0:
+        return []
+    starts = flat.offsets[idx]
+    ends = starts + (flat.numel[idx] + 3) // 4 * 4
+    spans = [[int(starts[0]), int(ends[0])]]
+    for a, b in zip(starts[1:], ends[1:]):
+        if a - spans[-1][1] < min_gap:
+            spans[-1][1] = int(b)
+        else:
+            spans.append([int(a), int(b)])
+    while len(spans) > max_spans:
+        gaps = [spans[i + 1][0] - spans[i][1] for i in range(len(spans) - 1)]
+        i = int(np.argmin(gaps))
+        spans[i][1] = spans[i + 1][1]
+        del spans[i + 1]
+    return [(a, b) for a, b in spans]
+
+
 def allreduce_gradient_sets(flat, stashes, world, device):
     """Data-parallel averaging of the current gradient set and of every stashed set.
     The None-masks are OR-ed first (int32 MAX): a tensor that received a gradient on any rank exists, possibly as zeros, on all.
-    Stashes whose reduction was started early (start_stash_allreduce) are only waited for."""
+    Stashes whose reduction was started early (start_stash_allreduce, whole buffer, hidden under the later backward passes) are only
+    waited for; everything reduced here - the current set, which sits on the critical path - is exchanged only over the ranges that
+    hold touched tensors."""
     import torch.distributed as dist
     if world == 1:
         return
     masks = [flat.touched] + [s[1] for s in stashes]
     m = torch.from_numpy(np.stack(masks).astype(np.int32)).to(device)
     dist.all_reduce(m, op=dist.ReduceOp.MAX)
-    pending = []
-    for s in stashes:
-        work = s[2] if len(s) > 2 else None
-        if work is None:
-            work = dist.all_reduce(s[0], op=dist.ReduceOp.SUM, async_op=True)
-        pending.append((work, s[0]))
-    pending.append((dist.all_reduce(flat.flat_grad, op=dist.ReduceOp.SUM, async_op=True), flat.flat_grad))
-    m = m.cpu().numpy().astype(bool)     # the only host wait; the sums are in flight meanwhile
+    m = m.cpu().numpy().astype(bool)     # the only host wait (it also waits for the backward pass that produced the gradients)
     flat.touched[:] = m[0]
     for k, s in enumerate(stashes):
         s[1][:] = m[1 + k]
+    pending = []
+    for k, s in enumerate(stashes):
+        work = s[2] if len(s) > 2 else None
+        if work is not None:
+            pending.append((work, s[0]))
+        else:
+            for a, b in touched_spans(flat, m[1 + k]):
+                view = s[0][a:b]
+                pending.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True), view))
+    for a, b in touched_spans(flat, m[0]):
+        view = flat.flat_grad[a:b]
+        pending.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True), view))
     for work, buf in pending:
         work.wait()
         buf.div_(world)

@@ -27,10 +27,16 @@ def _worker(rank, world, port, out):
     for k in touch:
         params[flat.order[k]].grad.copy_(torch.randn(params[flat.order[k]].shape, generator=g))
         flat.touched[k] = True
-    stash_buf = torch.randn(flat.total, generator=g)
     stash_mask = np.zeros(flat.nt, dtype=bool); stash_mask[[3, 4][rank]] = True
+
+    def masked_randn():   # a gradient set holds values only inside tensors whose mask bit is set (everything else is zero on every rank)
+        buf = torch.zeros(flat.total)
+        for k in np.nonzero(stash_mask)[0]:
+            a = int(flat.offsets[k]); buf[a: a + int(flat.numel[k])] = torch.randn(int(flat.numel[k]), generator=g)
+        return buf
+    stash_buf = masked_randn()
     from handwriting_line_generation_amd.trainer.flat_params import start_stash_allreduce
-    early_buf = torch.randn(flat.total, generator=g)
+    early_buf = masked_randn()
     early = start_stash_allreduce((early_buf.clone(), stash_mask.copy()), world)    # reduction started before the others (overlap path)
     stashes = [(stash_buf.clone(), stash_mask.copy()), early]
     mine = flat.flat_grad.clone()
