@@ -131,19 +131,21 @@ def main():
         model = trainer.model
         model.eval()
         B = 64            # a generation service batches requests; the training batch (8 lines) is launch-bound at 1.6 ms per call
-        gsteps = 24
+        gsteps = 48
         g = torch.Generator().manual_seed(4321)
         labels = [ops.h2d(torch.randint(1, cfg["model"]["num_class"], (wl["label_len"], B), generator=g, dtype=torch.int32), trainer.gpu) for _ in range(8)]
         lengths = torch.IntTensor([wl["label_len"]] * B)
         styles = [ops.h2d(torch.randn(B, cfg["model"]["style_dim"], generator=g), trainer.gpu) for _ in range(8)]
+        from handwriting_line_generation_amd.generate import generate_stream
+        labels_host = [l.cpu() for l in labels]
+        reqs = lambda n: ((labels_host[i % 8], lengths, styles[i % 8]) for i in range(n))   # noqa: E731
         with torch.no_grad():
-            for i in range(5):
-                img = model(labels[i % 8], lengths, styles[i % 8])
+            for img, _ in generate_stream(model, reqs(5)):
+                pass
             torch.cuda.synchronize()
             tg = time.perf_counter()
             px = 0
-            for i in range(gsteps):
-                img = model(labels[i % 8], lengths, styles[i % 8])
+            for img, _ in generate_stream(model, reqs(gsteps)):     # spacer of request i+1 overlaps the host step of request i
                 px += img.shape[3]
             torch.cuda.synchronize()
             tg = time.perf_counter() - tg
