@@ -37,3 +37,24 @@ def test_save_resume_round_trip(cuda, tmp_path):
     # the resumed trainer keeps training
     log = b._train_iteration(4)
     assert all(v == v for v in log.values() if isinstance(v, float))
+
+
+def test_validation_epoch_runs(cuda, tmp_path):
+    """_valid_epoch (trainer :437-486): the validation lesson of the curriculum on a held-out loader under no_grad, weighted losses averaged"""
+    import math
+    from handwriting_line_generation_amd import rng
+    from handwriting_line_generation_amd.data.synthetic import SyntheticAuthorDataset, SyntheticLoader
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    rng.set_mode("device", seed=5)
+    torch.manual_seed(0)
+    tr, cfg = build_gan_trainer("iam_gan", 1, 2, width=256, label_len=12, workdir=str(tmp_path))
+    dl = cfg["data_loader"]
+    ds = SyntheticAuthorDataset(dl["char_file"], 1, 2, width=256, label_len=12, num_batches=3, seed=900)
+    tr.valid_data_loader = SyntheticLoader(ds)
+    before = {k: v.detach().clone() for k, v in list(tr.model.named_parameters())[:20]}
+    val = tr._valid_epoch()
+    assert val and all(k.startswith("val_") and math.isfinite(v) for k, v in val.items()), val
+    for k, v in list(tr.model.named_parameters())[:20]:
+        assert torch.equal(v, before[k]), "validation changed parameter %s" % k
+    log = tr._train_iteration(0)     # back to training mode afterwards
+    assert tr.model.training and all(math.isfinite(v) for v in log.values() if isinstance(v, float))
