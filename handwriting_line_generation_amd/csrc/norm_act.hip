@@ -87,51 +87,32 @@ __global__ __launch_bounds__(256) void moments_fwd_kernel(const float* x, Geo g,
   block_reduce_store<2>(acc, g, part, sm);
 }
 
-// ---------------- forward stage 2: statistics per group -> mean[N][C], rstd[N][C] ---------------------------------------
-// one wavefront per statistic group (IN: (n,c); GN: (n,group); BN: c), lanes sweep the partial sums, wave reduction in fp64
-__global__ __launch_bounds__(256) void finalize_fwd_kernel(const double* part, Geo g, int mode, int groups, float eps, float* mean, float* rstd,
+// ---------------- forward stage 2 (BatchNorm only): statistics per channel over all samples -> mean[N][C], rstd[N][C] ------------------
+// one wavefront per channel, lanes sweep the N x chunks partial sums, wave reduction in fp64; also updates the running statistics.
+// (per-sample normalisations - IN / GN / AdaIN - form their statistics inside the apply kernels, see sample_stats below)
+__global__ __launch_bounds__(256) void finalize_fwd_kernel(const double* part, Geo g, float eps, float* mean, float* rstd,
                                                            float* running_mean, float* running_var, float momentum) {
   const int lane = threadIdx.x & 63;
   const int w = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (w >= g.C) return;
   double s1 = 0.0, s2 = 0.0;
-  if (mode == MODE_BN) {
-    if (w >= g.C) return;
-    const int items = g.N * g.chunks;
-    for (int it = lane; it < items; it += 64) {
-      const double* p = part + ((size_t)it * g.C + w) * 2;   // it == n*chunks + k
-      s1 += p[0]; s2 += p[1];
-    }
-    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-    const double cnt = (double)g.N * g.HW;
-    const double m = s1 / cnt;
-    double var = s2 / cnt - m * m;
-    if (var < 0.0) var = 0.0;
-    const float r = (float)(1.0 / sqrt(var + (double)eps));
-    for (int n = lane; n < g.N; n += 64) { mean[n * g.C + w] = (float)m; rstd[n * g.C + w] = r; }
-    if (running_mean && lane == 0) {
-      const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
-      running_mean[w] = (1.f - momentum) * running_mean[w] + momentum * (float)m;
-      running_var[w] = (1.f - momentum) * running_var[w] + momentum * (float)unb;
-    }
-    return;
-  }
-  const int cpg = (mode == MODE_GN) ? g.C / groups : 1;
-  const int ngrp = g.C / cpg;
-  if (w >= g.N * ngrp) return;
-  const int n = w / ngrp, cb = (w % ngrp) * cpg;
-  const int items = g.chunks * cpg;
+  const int items = g.N * g.chunks;
   for (int it = lane; it < items; it += 64) {
-    const int k = it / cpg, cc = cb + it % cpg;
-    const double* p = part + (((size_t)n * g.chunks + k) * g.C + cc) * 2;
+    const double* p = part + ((size_t)it * g.C + w) * 2;   // it == n*chunks + k
     s1 += p[0]; s2 += p[1];
   }
   s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-  const double cnt = (double)g.HW * cpg;
+  const double cnt = (double)g.N * g.HW;
   const double m = s1 / cnt;
   double var = s2 / cnt - m * m;
   if (var < 0.0) var = 0.0;
   const float r = (float)(1.0 / sqrt(var + (double)eps));
-  for (int cc = lane; cc < cpg; cc += 64) { mean[n * g.C + cb + cc] = (float)m; rstd[n * g.C + cb + cc] = r; }
+  for (int n = lane; n < g.N; n += 64) { mean[n * g.C + w] = (float)m; rstd[n * g.C + w] = r; }
+  if (running_mean && lane == 0) {
+    const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+    running_mean[w] = (1.f - momentum) * running_mean[w] + momentum * (float)m;
+    running_var[w] = (1.f - momentum) * running_var[w] + momentum * (float)unb;
+  }
 }
 
 // ---------------- statistics of one sample from the partial sums, computed inside the apply kernels (IN / GN) --------------------
@@ -269,62 +250,29 @@ __global__ __launch_bounds__(256) void moments_bwd_kernel(const float* dy, const
   block_reduce_store<2>(acc, g, part, sm);
 }
 
-// ---------------- backward stage 2: per group coefficients c1,c2 [N][C] and parameter gradients ---------------------------
-// dx = rstd * (g*gamma - c1 - xhat*c2),  c1 = mean_grp(g*gamma), c2 = mean_grp(g*gamma*xhat); one wavefront per statistic group
-__global__ __launch_bounds__(256) void finalize_bwd_kernel(const double* part, Geo g, int mode, int groups, const float* gamma, int per_sample,
-                                                           float* c1, float* c2, float* dgamma, float* dbeta, int accumulate) {
+// ---------------- backward stage 2 (BatchNorm only): coefficients c1,c2 [N][C] and parameter gradients --------------------------------
+// dx = rstd * (g*gamma - c1 - xhat*c2),  c1 = mean(g*gamma), c2 = mean(g*gamma*xhat) over (N,H,W); one wavefront per channel
+__global__ __launch_bounds__(256) void finalize_bwd_kernel(const double* part, Geo g, const float* gamma, float* c1, float* c2, float* dgamma,
+                                                           float* dbeta, int accumulate) {
   const int lane = threadIdx.x & 63;
   const int w = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  if (mode == MODE_BN) {
-    if (w >= g.C) return;
-    double s1 = 0.0, s2 = 0.0;
-    const int items = g.N * g.chunks;
-    for (int it = lane; it < items; it += 64) {
-      const double* p = part + ((size_t)it * g.C + w) * 2;
-      s1 += p[0]; s2 += p[1];
-    }
-    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-    const double cnt = (double)g.N * g.HW;
-    const double gm = gamma ? (double)gamma[w] : 1.0;
-    for (int n = lane; n < g.N; n += 64) { c1[n * g.C + w] = (float)(gm * s1 / cnt); c2[n * g.C + w] = (float)(gm * s2 / cnt); }
-    if (lane == 0) {
-      if (dgamma) dgamma[w] = (accumulate ? dgamma[w] : 0.f) + (float)s2;
-      if (dbeta) dbeta[w] = (accumulate ? dbeta[w] : 0.f) + (float)s1;
-    }
-    return;
-  }
-  const int cpg = (mode == MODE_GN) ? g.C / groups : 1;
-  const int ngrp = g.C / cpg;
-  if (w >= g.N * ngrp) return;
-  const int n = w / ngrp, cb = (w % ngrp) * cpg;
-  const int items = g.chunks * cpg;
-  double a1 = 0.0, a2 = 0.0;
+  if (w >= g.C) return;
+  double s1 = 0.0, s2 = 0.0;
+  const int items = g.N * g.chunks;
   for (int it = lane; it < items; it += 64) {
-    const int k = it / cpg, cc = cb + it % cpg;
-    const double* p = part + (((size_t)n * g.chunks + k) * g.C + cc) * 2;
-    const double gm = gamma ? (double)gamma[per_sample ? n * g.C + cc : cc] : 1.0;
-    a1 += gm * p[0]; a2 += gm * p[1];
+    const double* p = part + ((size_t)it * g.C + w) * 2;
+    s1 += p[0]; s2 += p[1];
   }
-  // per-sample affine (AdaIN / expert GroupNorm): dgamma[n,c], dbeta[n,c] are the un-weighted sums of this (n,c)
-  if (per_sample && (dgamma || dbeta)) {
-    for (int cc = 0; cc < cpg; ++cc) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int k = lane; k < g.chunks; k += 64) {
-        const double* p = part + (((size_t)n * g.chunks + k) * g.C + cb + cc) * 2;
-        s1 += p[0]; s2 += p[1];
-      }
-      s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-      if (lane == 0) {
-        const int idx = n * g.C + cb + cc;
-        if (dgamma) dgamma[idx] = (accumulate ? dgamma[idx] : 0.f) + (float)s2;
-        if (dbeta) dbeta[idx] = (accumulate ? dbeta[idx] : 0.f) + (float)s1;
-      }
-    }
+  s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+  const double cnt = (double)g.N * g.HW;
+  const double gm = gamma ? (double)gamma[w] : 1.0;
+  for (int n = lane; n < g.N; n += 64) { c1[n * g.C + w] = (float)(gm * s1 / cnt); c2[n * g.C + w] = (float)(gm * s2 / cnt); }
+  if (lane == 0) {
+    if (dgamma) dgamma[w] = (accumulate ? dgamma[w] : 0.f) + (float)s2;
+    if (dbeta) dbeta[w] = (accumulate ? dbeta[w] : 0.f) + (float)s1;
   }
-  a1 = wave_sum_d(a1); a2 = wave_sum_d(a2);
-  const double cnt = (double)g.HW * cpg;
-  for (int cc = lane; cc < cpg; cc += 64) { c1[n * g.C + cb + cc] = (float)(a1 / cnt); c2[n * g.C + cb + cc] = (float)(a2 / cnt); }
 }
+
 // per-channel parameter gradients for IN/GN with shared (per-channel) affine: sum over n and chunks, one wavefront per channel
 __global__ __launch_bounds__(256) void param_grad_kernel(const double* part, Geo g, float* dgamma, float* dbeta, int accumulate) {
   const int lane = threadIdx.x & 63;
@@ -528,8 +476,8 @@ extern "C" int hwg_norm_fwd(const float* x, float* y, int N, int HW, int C, int 
   HWG_LAUNCH_CHECK("norm_fwd.moments");
   InlineStats is = {};
   if (mode == MODE_BN) {   // batch statistics span the samples: separate finalize pass (also updates the running statistics)
-    hipLaunchKernelGGL(finalize_fwd_kernel, dim3(hwg_cdiv(C, 4)), dim3(256), 0, st, (const double*)part, g, mode, groups, eps, mean, rstd,
-                       running_mean, running_var, momentum);
+    hipLaunchKernelGGL(finalize_fwd_kernel, dim3(hwg_cdiv(C, 4)), dim3(256), 0, st, (const double*)part, g, eps, mean, rstd, running_mean,
+                       running_var, momentum);
     HWG_LAUNCH_CHECK("norm_fwd.finalize");
   } else {                 // per-sample statistics are formed inside the apply pass
     is.part = part; is.cpg = (mode == MODE_GN) ? C / groups : 1; is.eps = eps; is.out_a = mean; is.out_b = rstd;
@@ -559,8 +507,8 @@ extern "C" int hwg_norm_bwd(const float* dy, const float* x, const float* y, flo
   HWG_LAUNCH_CHECK("norm_bwd.moments");
   InlineStats is = {};
   if (mode == MODE_BN) {
-    hipLaunchKernelGGL(finalize_bwd_kernel, dim3(hwg_cdiv(C, 4)), dim3(256), 0, st, (const double*)part, g, mode, groups, gamma,
-                       affine_per_sample, c1, c2, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(finalize_bwd_kernel, dim3(hwg_cdiv(C, 4)), dim3(256), 0, st, (const double*)part, g, gamma, c1, c2, dgamma, dbeta,
+                       accumulate);
     HWG_LAUNCH_CHECK("norm_bwd.finalize");
   } else {
     is.part = part; is.cpg = (mode == MODE_GN) ? C / groups : 1; is.gamma = gamma; is.per_sample = affine_per_sample;
