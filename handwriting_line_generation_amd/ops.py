@@ -79,6 +79,45 @@ def workspace(nbytes, device):
     return buf
 
 
+# ---- side stream for weight gradients -----------------------------------------------------------------------------------
+# Nothing in the backward pass waits for a conv's weight gradient, only the optimizer side does. With SIDE_WGRAD on (the trainers
+# switch it on and call join_side_stream() after every backward()), the MFMA weight-gradient kernels are enqueued on a second HIP
+# stream: their workgroups fill the CUs that the data-gradient chain leaves idle (kernel tails, small elementwise launches).
+# Per tensor the accumulation order is unchanged (all weight gradients run in order on the one side stream).
+SIDE_WGRAD = False
+_side_streams = {}
+_side_dirty = set()
+
+
+def _side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    hit = _side_streams.get(key)
+    if hit is None:
+        st = torch.cuda.Stream(device=device)
+        hit = _side_streams[key] = (st, st.cuda_stream, key)
+    return hit
+
+
+def _side_workspace(nbytes, device, stream):
+    key = ("side", device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        buf.record_stream(stream)
+        _ws_cache[key] = buf
+    return buf
+
+
+def join_side_stream():
+    """make torch's current stream wait for every weight gradient enqueued on the side stream so far"""
+    for key in list(_side_dirty):
+        st = _side_streams[key][0]
+        ev = torch.cuda.Event()
+        ev.record(st)
+        torch.cuda.current_stream().wait_event(ev)
+    _side_dirty.clear()
+
+
 def _chk(t, name, dtype=torch.float32):
     if t is None:
         return
@@ -421,7 +460,17 @@ class _Conv2d(Function):
                     bias_done = True
                     if not bdirect:
                         db = dbias
-                L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 1 if direct else 0, dbias, bacc or 0, ws, ws.numel(), st)
+                if SIDE_WGRAD and direct and (dbias is None or bacc):
+                    s2, raw2, skey = _side_stream(x.device)
+                    ev = torch.cuda.Event()
+                    ev.record()                      # dy (and x) are complete on the main stream at this point
+                    s2.wait_event(ev)
+                    ws2 = _side_workspace(need, x.device, s2)
+                    L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 1, dbias, bacc or 0, ws2, ws2.numel(), raw2)
+                    u.record_stream(s2); v.record_stream(s2)
+                    _side_dirty.add(skey)
+                else:
+                    L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 1 if direct else 0, dbias, bacc or 0, ws, ws.numel(), st)
                 if direct:
                     dw_ = None
         if ctx.has_bias and ctx.needs_input_grad[2] and not bias_done:

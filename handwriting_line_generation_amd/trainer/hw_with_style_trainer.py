@@ -9,6 +9,7 @@ Data parallelism (absent from the reference): with torch.distributed initialised
 its own author shard; gradient sets are averaged with one all-reduce (RCCL over xGMI) at the points where the reference
 reads them (before balancing / clipping), and the `None`-gradient masks are OR-ed so all ranks update the same tensors.
 """
+import os
 import json
 import random
 from collections import defaultdict
@@ -105,6 +106,9 @@ class HWWithStyleTrainer(BaseTrainer):
         self.casesensitive = tr.get("casesensitive", True)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.async_log = tr.get("async_log", False)
+        # optional: weight-gradient kernels on a second HIP stream (fills the CUs the data-gradient chain leaves idle: +2.7 % steps/s);
+        # off by default because co-running kernels inflate the per-kernel durations the roofline measurement relies on
+        ops.SIDE_WGRAD = bool(tr.get("side_stream_wgrad", False) or os.environ.get("HWG_SIDE_WGRAD"))
         self._pending_log = None
 
     # ------------------------------------------------------------------------------------------
@@ -168,6 +172,7 @@ class HWWithStyleTrainer(BaseTrainer):
             for part in (autoGenLoss, recogLoss):
                 if not isinstance(part, int):
                     part.backward(retain_graph=True)
+                    ops.join_side_stream()
                     self.saved_grads.append(self._stash())
         else:
             for part in (recogLoss, autoGenLoss):
@@ -175,6 +180,7 @@ class HWWithStyleTrainer(BaseTrainer):
                     loss = part if isinstance(loss, int) else ops.add(loss, part)
         if not isinstance(loss, int):
             loss.backward()
+            ops.join_side_stream()
 
         if self.balance_loss and "no-step" in lesson:
             self.saved_grads.append(self._stash())
