@@ -12,13 +12,60 @@ import os
 import timeit
 
 import torch
+import torch.distributed as dist
 
-from ..trainer.flat_params import FlatParams, HipAdam
+from ..logger import install_reference_aliases
 from ..utils.curriculum import Curriculum
 
 
 def ensure_dir(path):
     os.makedirs(path, exist_ok=True)
+
+
+def _atomic_write(path, write):
+    """write(file) into a sibling temporary file, then rename over `path`: readers never see a torn file"""
+    tmp = "%s.tmp%d" % (path, os.getpid())
+    with open(tmp, "wb") as f:
+        write(f)
+    os.replace(tmp, path)
+
+
+def lr_schedule(kind, tr, iterations):
+    """lr multiplier as a function of the scheduler step (reference: base/base_trainer.py:112-164)"""
+    warm = tr.get("warmup_steps", 1000)
+    if kind == "LR_test":
+        slope = (1 - 0.000001) / iterations
+        return lambda s: 0.000001 + slope * s
+    if kind == "rampup":
+        return lambda s: min(1, (s + 0.001) / warm)
+    if kind == "detector":
+        return lambda s: min((s + 1) ** -0.3, (s + 1) * warm ** -1.3)
+    if kind is True:
+        return lambda s: min((max(0.000001, s - (warm - 3)) / 100) ** -0.1, s * (1.485 / warm) + .01)
+    if kind == "cyclic":
+        mn, cyc = tr.get("min_lr_mul", 0.001), tr.get("cycle_size", 500)
+        return lambda s: (1 - (1 - mn) * ((s - 1) % cyc) / (cyc - 1))
+    if kind == "cyclic-full":
+        mn, cyc = tr.get("min_lr_mul", 0.25), tr.get("cycle_size", 500)
+
+        def true_cycle(s):
+            if (s // cyc) % 2 == 0:   # rising
+                return ((1 - mn) * (s % cyc) / (cyc - 1)) + mn
+            return 1 - (1 - mn) * (s % cyc) / (cyc - 1)
+        return true_cycle
+    if kind == "1cycle":
+        low, mn, cyc = tr.get("low_lr_mul", 0.25), tr.get("min_lr_mul", 0.0001), tr.get("cycle_size", 1000)
+        trail = iterations - 2 * cyc
+
+        def one_cycle(s):
+            if s < cyc:
+                return ((1 - low) * (s % cyc) / (cyc - 1)) + low
+            if s < 2 * cyc:
+                return 1 - (1 - low) * (s % cyc) / (cyc - 1)
+            t = s - 2 * cyc
+            return low * (trail - t) / trail + mn * t / trail
+        return one_cycle
+    raise NotImplementedError("learning schedule %r" % (kind,))
 
 
 class BaseTrainer:
@@ -71,6 +118,7 @@ class BaseTrainer:
                     disc.append(p)
                 else:
                     main.append(p)
+            from ..trainer.flat_params import FlatParams, HipAdam   # (imported here: trainer/ imports this module)
             groups = {"main": main}
             if disc:
                 groups["disc"] = disc
@@ -94,8 +142,11 @@ class BaseTrainer:
         self.start_iteration = 1
         self.checkpoint_dir = os.path.join(tr["save_dir"], self.name)
         ensure_dir(self.checkpoint_dir)
-        with open(os.path.join(self.checkpoint_dir, "config.json"), "w") as f:
-            json.dump(config, f, indent=4, sort_keys=False)
+        # data parallel: one writer. Every rank holds identical weights and optimizer state, so rank 0 alone writes config.json and
+        # the checkpoints (N ranks truncating one path at once can leave a torn file)
+        self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        if self.rank == 0:
+            _atomic_write(os.path.join(self.checkpoint_dir, "config.json"), lambda f: f.write(json.dumps(config, indent=4, sort_keys=False).encode()))
         self.swa = False
         if tr.get("swa") or tr.get("weight_averaging"):
             raise NotImplementedError("weight averaging is not used by any shipped config")
@@ -103,18 +154,12 @@ class BaseTrainer:
             self._resume_checkpoint(resume)
 
     def _make_schedule(self, tr):
-        kind = self.useLearningSchedule
-        warm = tr.get("warmup_steps", 1000)
-        if kind == "rampup":
-            return lambda s: min(1, (s + 0.001) / warm)
-        if kind == "detector":
-            return lambda s: min((s + 1) ** -0.3, (s + 1) * warm ** -1.3)
-        if kind is True:
-            return lambda s: min((max(0.000001, s - (warm - 3)) / 100) ** -0.1, s * (1.485 / warm) + .01)
-        if kind == "cyclic":
-            mn, cyc = tr.get("min_lr_mul", 0.001), tr.get("cycle_size", 500)
-            return lambda s: (1 - (1 - mn) * ((s - 1) % cyc) / (cyc - 1))
-        raise NotImplementedError("learning schedule %r" % (kind,))
+        return lr_schedule(self.useLearningSchedule, tr, self.iterations)
+
+    def scheduled_lr(self, iteration):
+        """The reference builds a fresh LambdaLR on every start (also on resume) and calls .step() BEFORE each iteration, so the
+        k-th iteration of a run trains with base_lr * lambda(k), k = 1, 2, ... (base/base_trainer.py:112-164, 216-217)."""
+        return self._base_lr * self.lr_lambda(iteration - self.start_iteration + 1)
 
     # ------------------------------------------------------------------------------------------
     def train(self):
@@ -122,7 +167,7 @@ class BaseTrainer:
         for self.iteration in range(self.start_iteration, self.iterations + 1):
             t0 = timeit.default_timer()
             if self.lr_lambda is not None:
-                self.optimizer.param_groups[0]["lr"] = self._base_lr * self.lr_lambda(self.iteration - self.start_iteration)
+                self.optimizer.param_groups[0]["lr"] = self.scheduled_lr(self.iteration)
             result = self._train_iteration(self.iteration)
             result["sec_per_iter"] = timeit.default_timer() - t0
             for k, v in result.items():
@@ -149,23 +194,42 @@ class BaseTrainer:
         self._save_checkpoint(getattr(self, "iteration", 0), {})
 
     def _save_checkpoint(self, iteration, log, save_best=False, minor=False):
-        state = {
-            "arch": type(self.model).__name__,
-            "iteration": iteration,
-            "logger": self.train_logger,
-            "optimizer": self.optimizer.state_dict() if self.optimizer is not None else None,
-            "monitor_best": self.monitor_best,
-            "config": self.config,
-            "state_dict": {k: v.cpu() for k, v in self.model.state_dict().items()},
-        }
-        fn = "checkpoint-latest.pth" if minor else "checkpoint-iteration{}.pth".format(iteration)
-        path = os.path.join(self.checkpoint_dir, fn)
-        torch.save(state, path)
-        self.logger.info("Saved checkpoint: %s", path)
+        """checkpoint dictionary of the reference (base/base_trainer.py:340-399): a major save writes checkpoint-iteration<N>.pth AND
+        refreshes checkpoint-latest.pth, a minor save only the latter. Written by rank 0 through a temporary file + rename; all
+        ranks leave together."""
+        path = None
+        if self.rank == 0:
+            install_reference_aliases()    # the pickled train logger must resolve as logger.logger.Logger, in the reference too
+            state = {
+                "arch": type(self.model).__name__,
+                "iteration": iteration,
+                "logger": self.train_logger,
+                "optimizer": self.optimizer.state_dict() if self.optimizer is not None else None,
+                "monitor_best": self.monitor_best,
+                "config": self.config,
+                "state_dict": {k: v.cpu() for k, v in self.model.state_dict().items()},
+            }
+            if self.optimizer_discriminator is not None:
+                # the reference's _resume_checkpoint reads this key (:456) although its own save omits it (the discriminator's Adam
+                # moments restart from zero there); writing it keeps the file loadable by both
+                state["optimizer_discriminator"] = self.optimizer_discriminator.state_dict()
+            from .. import rng
+            state["rng"] = rng.get_state()
+            latest = os.path.join(self.checkpoint_dir, "checkpoint-latest.pth")
+            path = latest if minor else os.path.join(self.checkpoint_dir, "checkpoint-iteration{}.pth".format(iteration))
+            _atomic_write(path, lambda f: torch.save(state, f))
+            if not minor:
+                _atomic_write(latest, lambda f: torch.save(state, f))
+            if save_best:
+                os.replace(path, os.path.join(self.checkpoint_dir, "model_best.pth"))
+            self.logger.info("Saved checkpoint: %s", path)
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
         return path
 
     def _resume_checkpoint(self, resume_path):
         self.logger.info("Loading checkpoint: %s ...", resume_path)
+        install_reference_aliases()   # checkpoints pickle the reference's logger.logger.Logger
         ckpt = torch.load(resume_path, map_location="cpu", weights_only=False)
         self.start_iteration = ckpt["iteration"] + 1
         self.monitor_best = ckpt.get("monitor_best", self.monitor_best)
@@ -173,5 +237,10 @@ class BaseTrainer:
         self.model.load_state_dict(sd)
         if self.optimizer is not None and ckpt.get("optimizer") is not None:
             self.optimizer.load_state_dict(ckpt["optimizer"])
+        if self.optimizer_discriminator is not None and ckpt.get("optimizer_discriminator") is not None:
+            self.optimizer_discriminator.load_state_dict(ckpt["optimizer_discriminator"])
+        if ckpt.get("rng") is not None:
+            from .. import rng
+            rng.set_state(ckpt["rng"], rank=self.rank)
         if ckpt.get("logger") is not None:
             self.train_logger = ckpt["logger"]

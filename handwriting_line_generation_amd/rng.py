@@ -25,6 +25,37 @@ def mode():
     return _state["mode"]
 
 
+def seed_process(base_seed, rank=0):
+    """Entry points call this once: device Philox stream keyed (base_seed, rank) so that data-parallel ranks draw different
+    generator noise / dropout masks, and torch / numpy / random host generators seeded per rank as well."""
+    import random
+
+    import numpy as np
+    set_mode("device", seed=(int(base_seed) * 1000003 + int(rank)) & 0x7FFFFFFFFFFFFFFF)
+    torch.manual_seed(int(base_seed) + rank)
+    np.random.seed((int(base_seed) + rank) % (1 << 32))
+    random.seed(int(base_seed) + rank)
+    _state["base_seed"] = int(base_seed)
+
+
+def get_state():
+    """what a checkpoint keeps so that a resumed run continues the Philox stream instead of replaying it"""
+    r = _state["rng"]
+    return {"mode": _state["mode"], "base_seed": _state.get("base_seed"), "seed": r.seed if r is not None else None,
+            "offset": r.offset if r is not None else 0}
+
+
+def set_state(st, rank=0):
+    """restore get_state(); rank r re-derives its own seed from the base seed (the checkpoint is written by rank 0)"""
+    if st.get("mode") != "device" or st.get("seed") is None:
+        return
+    base = st.get("base_seed")
+    seed = st["seed"] if base is None else (int(base) * 1000003 + int(rank)) & 0x7FFFFFFFFFFFFFFF
+    set_mode("device", seed=seed)
+    _state["rng"].offset = int(st["offset"])
+    _state["base_seed"] = base
+
+
 def _dev_rng():
     if _state["rng"] is None:
         _state["rng"] = ops.DeviceRNG(0)

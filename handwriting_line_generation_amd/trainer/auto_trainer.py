@@ -36,6 +36,7 @@ class AutoTrainer(BaseTrainer):
             raise NotImplementedError("fg-mask weighted loss is not used by the shipped autoencoder config")
         import torch.distributed as dist
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        ops.SIDE_WGRAD = bool(tr.get("side_stream_wgrad", False))   # process-global switch: every trainer states its own choice
 
     def _next_instance(self):
         try:
@@ -57,6 +58,7 @@ class AutoTrainer(BaseTrainer):
             scaled[name] = v
             loss = v if isinstance(loss, int) else ops.add(loss, v)
         loss.backward()
+        ops.join_side_stream()
         allreduce_gradient_sets(self.flat, (), self.world, self.gpu)
         self.flat.clip_(2)
         self.optimizer.step()

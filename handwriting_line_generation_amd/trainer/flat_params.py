@@ -119,6 +119,7 @@ class FlatParams:
 
     def stash(self):
         """clone every non-None gradient and zero it in place (trainer :305-311, :316-322, :331-338)"""
+        ops.join_side_stream()   # weight gradients enqueued on the side stream must have landed before the buffer is read
         buf = self._stash_pool.pop() if self._stash_pool else torch.empty_like(self.flat_grad)
         buf.copy_(self.flat_grad)
         self.flat_grad.zero_()
@@ -136,6 +137,7 @@ class FlatParams:
         """p.grad += x_k * R_k * mean|p.grad| / mean|R_k| for every stashed set k (trainer :340-377)"""
         if not stashes:
             return
+        ops.join_side_stream()
         sumD = self.abs_sums(self.flat_grad, self.touched)
         ns = len(stashes)
         sumR = torch.empty((ns, self.nt), dtype=torch.float64, device=self.device)
@@ -157,6 +159,7 @@ class FlatParams:
 
     def clip_(self, value):
         """torch.nn.utils.clip_grad_value_ over every parameter that has a gradient"""
+        ops.join_side_stream()
         L.call("hwg_mt_unary", self.masked_ptrs(self.flat_grad, self.touched), None, 1, float(value), None, self.d_numel, self.d_chunk_tensor,
                self.d_chunk_off, self.nchunks, CHUNK, self._st())
 
@@ -212,6 +215,7 @@ def allreduce_gradient_sets(flat, stashes, world, device):
     import torch.distributed as dist
     if world == 1:
         return
+    ops.join_side_stream()
     masks = [flat.touched] + [s[1] for s in stashes]
     m = torch.from_numpy(np.stack(masks).astype(np.int32)).to(device)
     dist.all_reduce(m, op=dist.ReduceOp.MAX)
@@ -262,6 +266,7 @@ class HipAdam:
         active = self.mask & f.touched
         if not active.any():
             return
+        ops.join_side_stream()
         self.steps[active] += 1
         lr = self.param_groups[0]["lr"]
         b1, b2 = self.betas

@@ -105,10 +105,13 @@ class HWWithStyleTrainer(BaseTrainer):
         self.print_dir = None  # sample image dumps need torchvision; not part of the accelerated path
         self.casesensitive = tr.get("casesensitive", True)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # control-plane group for host-side decisions every rank must take together (skip an iteration): CPU tensors over gloo, so
+        # the exchange never waits for the GPU stream the way a device collective + .item() would
+        self._ctl_group = dist.new_group(backend="gloo") if self.world > 1 else None
         self.async_log = tr.get("async_log", False)
         # optional: weight-gradient kernels on a second HIP stream (fills the CUs the data-gradient chain leaves idle: +2.7 % steps/s);
         # off by default because co-running kernels inflate the per-kernel durations the roofline measurement relies on
-        ops.SIDE_WGRAD = bool(tr.get("side_stream_wgrad", False) or os.environ.get("HWG_SIDE_WGRAD"))
+        ops.SIDE_WGRAD = bool(tr.get("side_stream_wgrad", False) or int(os.environ.get("HWG_SIDE_WGRAD", "0") or 0))
         self._pending_log = None
 
     # ------------------------------------------------------------------------------------------
@@ -129,6 +132,13 @@ class HWWithStyleTrainer(BaseTrainer):
             self.data_loader_iter = iter(self.data_loader)
             return next(self.data_loader_iter)
 
+    def _skip_together(self, local_skip):
+        if self._ctl_group is None:
+            return bool(local_skip)
+        flag = torch.tensor([1 if local_skip else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self._ctl_group)
+        return bool(flag.item())
+
     def _allreduce_grads(self, stashes=()):
         allreduce_gradient_sets(self.flat, stashes, self.world, self.gpu)
 
@@ -146,7 +156,9 @@ class HWWithStyleTrainer(BaseTrainer):
             self.optimizer_discriminator.zero_grad()
 
         if self.curriculum:
-            if all(l == 0 for l in instance["label_lengths"]):
+            # the reference skips a batch without any text; data parallel: if one rank has to skip, all do (a rank that returned
+            # alone would leave its peers waiting in the gradient all-reduce)
+            if self._skip_together(all(l == 0 for l in instance["label_lengths"])):
                 return {}
             losses = self.run_gen(instance, lesson)
             pred = None

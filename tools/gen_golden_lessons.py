@@ -1,0 +1,187 @@
+"""Per-lesson trainer goldens: the UNMODIFIED reference trainer (trainer/hw_with_style_trainer.py, CPU) is run on seeded weights,
+synthetic author batches and seeded RNG streams under short custom curricula, once in its native fp32 arithmetic and once with
+every tensor widened to fp64 (same weights, same noise / dropout / numpy draws). Recorded per iteration:
+
+  * the logged losses,
+  * a fingerprint of every parameter's gradient at the moment the reference clips it (= after stashing and balancing, right
+    before the optimizer step): None, or [sum, sum|.|, sum .^2, projection on a fixed cosine vector],
+  * the same fingerprint of every parameter's update (after - before the iteration).
+
+The fp64 run gives, per tensor, the error of the reference's own fp32 arithmetic; tests/test_trainer_gpu.py holds the HIP
+trainer to the fp32 reference at 1e-4 where the reference itself is that well conditioned and to a small multiple of the
+reference's own fp32-vs-fp64 error elsewhere (the CTC-through-recogniser gradients, tests/test_pipeline_gpu.py).
+
+Build container only:   python tools/gen_golden_lessons.py [case ...]      (writes tests/golden/lessons_<case>.json)
+"""
+import json
+import math
+import os
+import random
+import subprocess
+import sys
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WSEED_MODEL, WSEED_ENC = 21, 22
+
+# name -> (config, batch_size, a_batch_size, width, min_width, label_len, curriculum, iterations)
+CASES = {
+    # every lesson kind of the shipped curriculum from clean seeded weights, before any fp32 drift can accumulate
+    "disc": ("iam_gan", 2, 2, 256, None, 12, [["disc"]], 2),
+    "auto": ("iam_gan", 2, 2, 256, None, 12, [["auto", "auto-gen"]], 1),
+    "gen_gen_auto": ("iam_gan", 2, 2, 256, None, 12, [["no-step", "gen"], ["no-step", "gen"], ["auto", "auto-gen"]], 3),
+    # the shipped 7-lesson cycle at BASELINE configs[2] (a_batch_size = 1) and on the RIMES config (78 classes, ragged widths)
+    "cycle_a1": ("iam_gan", 2, 1, 256, None, 12, None, 7),
+    "cycle_rimes": ("rimes_gan", 1, 2, 1024, 256, 14, None, 7),
+}
+
+
+def proj_vector(n, k, dtype):
+    import torch
+    return torch.cos(torch.arange(n, dtype=torch.float64) * 0.37 + 1.3 * k).to(dtype)
+
+
+def fingerprint(t, k):
+    import torch
+    d = t.detach().double().flatten()
+    return [float(d.sum()), float(d.abs().sum()), float((d * d).sum()), float((d * proj_vector(d.numel(), k, torch.float64)).sum())]
+
+
+class _Loader:
+    def __init__(self, ds, cast):
+        self.dataset, self.batch_size, self.cast = ds, ds.batch_size, cast
+
+    def __iter__(self):
+        outer = self
+
+        class It:
+            def __init__(self):
+                self.i = 0
+
+            def next(self):
+                import torch
+                dt = torch.get_default_dtype()
+                torch.set_default_dtype(torch.float32)     # the synthetic lines are drawn in fp32 in both runs
+                b = outer.dataset.batch(self.i)
+                torch.set_default_dtype(dt)
+                b["image"] = outer.cast(b["image"])
+                self.i += 1
+                return b
+            __next__ = next
+        return It()
+
+
+def run_case(name, wide):
+    warnings.filterwarnings("ignore")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_bootstrap
+    ref_bootstrap.bootstrap()
+    import torch
+    torch.set_num_threads(8)
+    from handwriting_line_generation_amd.harness import synthetic_gan_config
+    from handwriting_line_generation_amd.data.synthetic import SyntheticAuthorDataset
+    from oracle import torch_ref
+    which, B, A, W, minW, L, curriculum, iters = CASES[name]
+    work = "/tmp/hwg_golden_lessons_%s_%d" % (name, int(wide))
+    os.makedirs(work, exist_ok=True)
+    cfg, _ = synthetic_gan_config(which, B, A, workdir=work)
+    cfg["cuda"] = False
+    if curriculum is not None:
+        cfg["trainer"]["curriculum"] = {"0": curriculum}
+    from model import HWWithStyle, Autoencoder
+    import model.loss as ref_loss
+    from trainer import HWWithStyleTrainer
+
+    # weights are drawn in fp32 (the values the GPU side re-creates from the same seeds) ...
+    ae = Autoencoder({"type": "2tight", "hwr": cfg["model"]["num_class"]})
+    enc_sd = torch_ref.seeded_state_dict(ae, WSEED_ENC)
+    torch.save({"state_dict": enc_sd}, cfg["trainer"]["encoder_weights"])
+    model_sd = torch_ref.seeded_state_dict(HWWithStyle(cfg["model"]), WSEED_MODEL)
+    cast = (lambda t: t)
+    if wide:
+        # ... and widened afterwards. Random draws keep their fp32 values: torch.FloatTensor(..) allocations of the reference become
+        # fp64 tensors whose normal_() draws in fp32, randn_like draws in fp32 and widens; Dropout2d's Bernoulli masks do not depend
+        # on the dtype (checked below through the losses: a different mask would move them by percents, not 1e-6).
+        torch.set_default_dtype(torch.float64)
+        cast = (lambda t: t.double())
+
+        class _Wide(torch.Tensor):
+            def normal_(self, *a, **k):
+                r = torch.empty(self.shape, dtype=torch.float32).normal_(*a, **k)
+                return self.as_subclass(torch.Tensor).copy_(r)
+
+        def float_tensor(*a):
+            return torch.DoubleTensor(*a).as_subclass(_Wide)
+        torch.FloatTensor = float_tensor
+        _rl = torch.randn_like
+        torch.randn_like = lambda t, **k: _rl(t.float(), **k).double()
+    model = HWWithStyle(cfg["model"])
+    model.load_state_dict(model_sd)
+    if wide:
+        model = model.double()    # buffers the reference creates with an explicit fp32 dtype (blur kernels)
+    names = [k for k, _ in model.named_parameters()]
+    ds = SyntheticAuthorDataset(cfg["data_loader"]["char_file"], B, A, width=W, label_len=L, min_width=minW)
+    losses = {n: getattr(ref_loss, f) for n, f in cfg["loss"].items()}
+    trainer = HWWithStyleTrainer(model, losses, [], None, cfg, _Loader(ds, cast), None, None)
+    if wide:
+        trainer.encoder = trainer.encoder.double()
+    torch.manual_seed(0); np.random.seed(0); random.seed(0)
+    import torch.nn.utils as nnu
+    orig_clip = nnu.clip_grad_value_
+    grads_at_clip = {}
+    cur = [0]
+
+    def spy_clip(params, value):
+        grads_at_clip[cur[0]] = [fingerprint(p.grad, k) if p.grad is not None else None for k, (_, p) in enumerate(model.named_parameters())]
+        return orig_clip(model.parameters(), value)
+    nnu.clip_grad_value_ = spy_clip
+    torch.nn.utils.clip_grad_value_ = spy_clip
+    its = []
+    for it in range(iters):
+        snap = [p.detach().clone() for p in model.parameters()]
+        cur[0] = it
+        log = trainer._train_iteration(it)
+        upd = [fingerprint(p.detach() - s, k) for k, (p, s) in enumerate(zip(model.parameters(), snap))]
+        moved = [u if u[1] != 0.0 else None for u in upd]
+        its.append({"lesson": trainer.curriculum.getLesson(it), "log": {k: float(v) for k, v in log.items()}, "grads": grads_at_clip.get(it), "update": moved})
+        print(name, "fp64" if wide else "fp32", it, its[-1]["log"], flush=True)
+    sn = {k: v.flatten()[:8].tolist() for k, v in model.state_dict().items() if k.endswith(("weight_u",))}
+    return {"names": names, "iterations": its, "u_after": sn}
+
+
+def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--child":
+        out = run_case(sys.argv[2], sys.argv[3] == "1")
+        with open(sys.argv[4], "w") as f:
+            json.dump(out, f)
+        return
+    todo = sys.argv[1:] or list(CASES)
+    for name in todo:
+        res = {}
+        for wide in (0, 1):
+            tmp = "/tmp/hwg_lessons_%s_%d.json" % (name, wide)
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", name, str(wide), tmp])
+            res[wide] = json.load(open(tmp))
+        r32, r64 = res[0], res[1]
+        which, B, A, W, minW, L, curriculum, iters = CASES[name]
+        out = {"case": name, "config": which, "batch_size": B, "a_batch_size": A, "W": W, "min_width": minW, "label_len": L,
+               "curriculum": curriculum, "wseed_model": WSEED_MODEL, "wseed_enc": WSEED_ENC, "names": r32["names"], "u_after": r32["u_after"],
+               "iterations": []}
+        for a, b in zip(r32["iterations"], r64["iterations"]):
+            assert a["lesson"] == b["lesson"]
+            for k in a["log"]:   # same draws in both precisions, or the comparison is meaningless
+                assert abs(a["log"][k] - b["log"][k]) <= 2e-3 * max(abs(b["log"][k]), 1e-2), (name, k, a["log"][k], b["log"][k])
+            out["iterations"].append({"lesson": a["lesson"], "log": a["log"], "log64": b["log"], "grads": a["grads"], "grads64": b["grads"],
+                                      "update": a["update"], "update64": b["update"]})
+        path = os.path.join(ROOT, "tests", "golden", "lessons_%s.json" % name)
+        with open(path, "w") as f:
+            json.dump(out, f, separators=(",", ":"))
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,19 @@ def main():
     if args.iterations is not None:
         config["trainer"]["iterations"] = args.iterations
 
+    # Random streams: one base seed per run (config["seed"] or drawn here and shared by all ranks), rank r draws from stream
+    # (base, r): generator noise and Dropout2d masks differ between data-parallel ranks and between runs. The Philox offset is
+    # stored in every checkpoint, so -r / -s continue the stream instead of replaying it.
+    from handwriting_line_generation_amd import rng
+    base_seed = config.get("seed")
+    if base_seed is None:
+        base_seed = int.from_bytes(os.urandom(4), "little")
+        if world > 1:
+            t = torch.tensor([base_seed], dtype=torch.int64, device="cuda")
+            torch.distributed.broadcast(t, 0)
+            base_seed = int(t.item())
+    rng.seed_process(base_seed, rank)
+
     import handwriting_line_generation_amd.model as models
     import handwriting_line_generation_amd.model.loss as losses
     import handwriting_line_generation_amd.trainer as trainers
