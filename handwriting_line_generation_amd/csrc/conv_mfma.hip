@@ -10,6 +10,7 @@
 // barrier per K step suffices. The K order inside a step is permuted identically for A and B so one
 // ds_read_b128 feeds four MFMAs (see the comment at the fragment reads).
 #include "hwg_common.h"
+#include "wino_pack.h"
 #include <stdlib.h>
 
 namespace {
@@ -649,7 +650,9 @@ struct PackEntry {
   float* dst;
   int A, B, Bpad, R, S, flip;
   long long sa, sb, sr, ss, total, first_block;
+  int mode, Apad;   // mode 1: Winograd filter transform (conv_wino.hip), total = Apad*Bpad threads
 };
+
 constexpr int PACK_PER_BLOCK = 1024;
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry* table, int n) {
   int lo = 0, hi = n - 1;
@@ -663,6 +666,10 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry*
   for (int j = 0; j < PACK_PER_BLOCK / 256; ++j) {
     const long long i = base + j * 256 + threadIdx.x;
     if (i >= e.total) break;
+    if (e.mode == 1) {
+      wino_pack_one(e.src, e.dst, i, e.A, e.Apad, e.B, e.Bpad, e.sa, e.sb, e.sr, e.ss, e.flip);
+      continue;
+    }
     const int b = (int)(i % e.Bpad);
     const long long t = i / e.Bpad;
     const int aa = (int)(t % e.A);
@@ -844,6 +851,13 @@ static int check_desc(const hwg_conv_desc* d, const char* who) {
   HWG_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0 && d->P > 0 && d->Q > 0,
               "%s: non-positive dimension", who);
   HWG_REQUIRE(d->stride_h > 0 && d->stride_w > 0 && d->dil_h > 0 && d->dil_w > 0, "%s: bad stride/dilation", who);
+  return HWG_OK;
+}
+
+// shared with conv_wino.hip: the fixed-order sum of split partial outputs
+int hwg_conv_split_reduce_launch(const float* part, const float* bias, float* y, long long total, int K, int nsplit, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(conv_split_reduce_kernel, dim3(hwg_stream_grid(total / 4 + 1, 256)), dim3(256), 0, st, part, bias, y, total, K, nsplit, accumulate);
+  HWG_LAUNCH_CHECK("conv_split_reduce");
   return HWG_OK;
 }
 

@@ -1,0 +1,928 @@
+// Winograd F(2x2, 3x3) convolution for gfx950, fused into one kernel per direction:
+//
+//   y = A^T [ sum_c (G g G^T)[k][c] (.) (B^T d B)[c] ] A        (3x3, stride 1, dilation 1)
+//
+// 16 independent GEMMs (one per position of the 4x4 transform domain) with M = 2x2 output tiles, N = output channels,
+// contraction = input channels: 2.25x fewer matrix-core MACs than the direct form, exact fp32 products, transform
+// coefficients 0, +-1, +-1/2 (error growth ~2x of the direct sum; parity tests hold it to the same 1e-4).
+//
+//   wino_conv_kernel   forward and data gradient (the data gradient of a 3x3 stride-1 conv is the same conv with mirrored taps and
+//                      swapped channel roles, which the weight transform absorbs)
+//   wino_wgrad_kernel  weight gradient: dU[pos][k][c] = sum_tiles (A dy A^T)[pos][tile][k] * (B^T x B)[pos][tile][c], dw = G^T dU G
+//
+// Nothing of the transform domain ever touches HBM: the input patches are transformed in registers on their way into LDS
+// (column transform per lane, row transform across the 4 lanes of a quad with DPP), the pre-transformed filters U stream
+// through LDS, the 16 accumulator sets of one (tile, k) live in ONE lane (v_mfma_f32_16x16x4_f32: 4 accumulator registers
+// per position), so the output transform is register-local as well.
+#include "hwg_common.h"
+#include "wino_pack.h"
+#include <stdlib.h>
+
+namespace {
+
+struct WinoK {
+  const float* x;      // [N,H,W,C]
+  const float* u;      // [C/16][16 pos][Kpad][16]   (hwg_wino_pack_weight)
+  const float* bias;   // [K] or null
+  float* y;            // [N,P,Q,K]
+  int N, H, W, C, K, Kpad, P, Q, ph, pw, TP, TQ;
+  int M;               // tiles = N*TP*TQ
+  int accumulate;
+  int nsplit;          // the C/16 chunk loop is cut into nsplit ranges (blockIdx.z); partial outputs go to `part`
+  float* part;         // [nsplit][N*P*Q*K]
+};
+
+__device__ __forceinline__ float quad_partner(float v) {
+  // lane b of every quad receives the value of lane {2,2,1,1}[b]  (DPP quad_perm)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x5A, 0xf, 0xf, false));
+}
+
+// LDS image of one round (4 positions of the transform domain): planes [4][rows][16 floats]; the four 16-byte chunks of a row are
+// XOR-swizzled with (row >> 1) & 3, which makes the ds_read_b128 fragment reads (lane -> row l&15, chunk l>>4) conflict free
+// without padding; the plane stride is == 8 (mod 32) dwords so that the 8-lane groups of the ds_write_b128 stores spread over
+// all banks.
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 16 + 4 * (chunk ^ ((row >> 1) & 3)); }
+
+template <int WGM, int WGN>
+__global__ __launch_bounds__(512) void wino_conv_kernel(WinoK a) {
+  constexpr int NT = 512;
+  static_assert(WGM * WGN == 8, "8 wavefronts per workgroup");
+  constexpr int TM = 16 * WGM, TN = 16 * WGN;
+  constexpr int PSV = TM * 16 + 8, PSU = TN * 16 + 8;
+  constexpr int XI = (TM * 16 + NT - 1) / NT;        // x work items per thread: (tile, 4-channel group, patch column)
+  constexpr int UI = (TN * 16 + NT - 1) / NT;        // u work items per thread per round: (position, k, 4-channel group)
+  constexpr int BUF = 4 * (PSV + PSU);
+  __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WGN, wn = wid % WGN;
+  const int m0 = blockIdx.x * TM;
+  const int n0 = blockIdx.y * TN;
+  const int split = blockIdx.z;
+  const int T_all = a.C >> 4;
+  const int t0 = (int)((long long)T_all * split / a.nsplit);
+  const int t1 = (int)((long long)T_all * (split + 1) / a.nsplit);
+
+  // ---- per-thread gather coordinates of the input patches -------------------------------------------------------------
+  int x_off[XI];        // element offset of (n, first patch row, patch column, 4-channel group); rows advance by W*C
+  int x_ok[XI];         // bit r: patch row r is inside the image (and the column / tile are valid)
+  int x_row[XI], x_c4[XI], x_b[XI];
+  bool x_item[XI];
+  const int row_stride = a.W * a.C;
+#pragma unroll
+  for (int it = 0; it < XI; ++it) {
+    const int id = tid + it * NT;
+    x_item[it] = id < TM * 16;
+    const int b = id & 3, c4 = (id >> 2) & 3, row = (id >> 4) % TM;
+    x_b[it] = b; x_c4[it] = c4; x_row[it] = row;
+    const int m = m0 + row;
+    const bool mok = x_item[it] && m < a.M;
+    const int mm = mok ? m : 0;
+    const int tj = mm % a.TQ;
+    const int t2 = mm / a.TQ;
+    const int ti = t2 % a.TP;
+    const int n = t2 / a.TP;
+    const int w = 2 * tj - a.pw + b;
+    const bool wok = mok && w >= 0 && w < a.W;
+    const int h0 = 2 * ti - a.ph;
+    x_off[it] = ((n * a.H + h0) * a.W + (wok ? w : 0)) * a.C + c4 * 4;
+    int okm = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (wok && h0 + r >= 0 && h0 + r < a.H) okm |= 1 << r;
+    x_ok[it] = okm;
+  }
+  // filters: item -> (position of the round, k row, 4-channel group); the image of one (chunk, position) is [Kpad][16] contiguous
+  int u_off[UI], u_lds[UI];
+  bool u_item[UI];
+#pragma unroll
+  for (int it = 0; it < UI; ++it) {
+    const int id = tid + it * NT;
+    u_item[it] = id < TN * 16;
+    const int c4 = id & 3, k = (id >> 2) % TN, pb = (id >> 2) / TN;
+    u_off[it] = (pb * a.Kpad + n0 + k) * 16 + c4 * 4;
+    u_lds[it] = pb * PSU + swz(k, c4);
+    if (n0 + k >= a.Kpad) u_item[it] = false;
+  }
+
+  f32x4 acc[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 raw[XI][4];     // patch column of the chunk being fetched (4 rows)
+  float4 tr[XI][4];      // its column transform (B^T along the rows), one float4 per transform row a'
+  float4 ur[UI];
+
+  auto load_x = [&](int t) {
+#pragma unroll
+    for (int it = 0; it < XI; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // masked rows read a valid dummy address (no exec-mask branches between the loads); they are zeroed in col_transform
+        const int off = (x_ok[it] >> r) & 1 ? x_off[it] + r * row_stride + t * 16 : 0;
+        raw[it][r] = *reinterpret_cast<const float4*>(a.x + off);
+      }
+  };
+  auto col_transform = [&]() {
+#pragma unroll
+    for (int it = 0; it < XI; ++it) {
+      float4 d[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d[r] = raw[it][r];
+        if (!((x_ok[it] >> r) & 1)) d[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      tr[it][0] = make_float4(d[0].x - d[2].x, d[0].y - d[2].y, d[0].z - d[2].z, d[0].w - d[2].w);
+      tr[it][1] = make_float4(d[1].x + d[2].x, d[1].y + d[2].y, d[1].z + d[2].z, d[1].w + d[2].w);
+      tr[it][2] = make_float4(d[2].x - d[1].x, d[2].y - d[1].y, d[2].z - d[1].z, d[2].w - d[1].w);
+      tr[it][3] = make_float4(d[1].x - d[3].x, d[1].y - d[3].y, d[1].z - d[3].z, d[1].w - d[3].w);
+    }
+  };
+  auto load_u = [&](int t, int r) {
+    const float* base = a.u + ((long long)t * 16 + r * 4) * a.Kpad * 16;
+#pragma unroll
+    for (int it = 0; it < UI; ++it) ur[it] = *reinterpret_cast<const float4*>(base + (u_item[it] ? u_off[it] : 0));
+  };
+  // row transform of transform row r across the quad (lane b holds patch column b, produces transform column b) + LDS stores
+  auto store_round = [&](int buf, int r) {
+    float* Vb = smem + buf * BUF;
+    float* Ub = Vb + 4 * PSV;
+#pragma unroll
+    for (int it = 0; it < XI; ++it) {
+      const float4 v = tr[it][r];
+      const float sa = (x_b[it] == 3) ? -1.f : 1.f;
+      const float sb = (x_b[it] & 1) ? 1.f : -1.f;
+      float4 o;
+      o.x = sa * v.x + sb * quad_partner(v.x);
+      o.y = sa * v.y + sb * quad_partner(v.y);
+      o.z = sa * v.z + sb * quad_partner(v.z);
+      o.w = sa * v.w + sb * quad_partner(v.w);
+      if (x_item[it]) *reinterpret_cast<float4*>(Vb + x_b[it] * PSV + swz(x_row[it], x_c4[it])) = o;
+    }
+#pragma unroll
+    for (int it = 0; it < UI; ++it) {
+      float4 v = ur[it];
+      if (!u_item[it]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tid + it * NT < TN * 16) *reinterpret_cast<float4*>(Ub + u_lds[it]) = v;
+    }
+  };
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int a_off = swz(wm * 16 + frow, fchunk);
+  const int b_off = swz(wn * 16 + frow, fchunk);
+
+  if (t1 > t0) {
+    load_x(t0);
+    load_u(t0, 0);
+    col_transform();
+    store_round(0, 0);
+  }
+  __syncthreads();
+
+  for (int t = t0; t < t1; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cur = r & 1;
+      const bool more = (r < 3) || (t + 1 < t1);
+      if (r == 1 && t + 1 < t1) load_x(t + 1);
+      if (more) load_u(r < 3 ? t : t + 1, (r + 1) & 3);
+      const float* Vb = smem + cur * BUF;
+      const float* Ub = Vb + 4 * PSV;
+      float4 af[4], bf[4];
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) {
+        af[pb] = *reinterpret_cast<const float4*>(Vb + pb * PSV + a_off);
+        bf[pb] = *reinterpret_cast<const float4*>(Ub + pb * PSU + b_off);
+      }
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) {
+        // element j of both fragments belongs to channel 4*(lane>>4)+j: MFMA j contracts channels {j, 4+j, 8+j, 12+j} of the chunk
+        acc[r * 4 + pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pb].x, bf[pb].x, acc[r * 4 + pb], 0, 0, 0);
+        acc[r * 4 + pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pb].y, bf[pb].y, acc[r * 4 + pb], 0, 0, 0);
+        acc[r * 4 + pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pb].z, bf[pb].z, acc[r * 4 + pb], 0, 0, 0);
+        acc[r * 4 + pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pb].w, bf[pb].w, acc[r * 4 + pb], 0, 0, 0);
+      }
+      if (more) {
+        if (r == 3) col_transform();
+        store_round(cur ^ 1, (r + 1) & 3);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- output transform (register local) and store ----------------------------------------------------------------------
+  // C/D layout of the 16x16 MFMA: column (k) = lane & 15, row (tile) = (lane >> 4) * 4 + e
+  const int k = n0 + wn * 16 + (lane & 15);
+  const bool direct = a.nsplit == 1;
+  float* yg = direct ? a.y : a.part + (long long)split * ((long long)a.N * a.P * a.Q * a.K);
+  const float bv = (direct && a.bias && k < a.K) ? a.bias[k] : 0.f;
+  const bool accum = direct && a.accumulate;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int m = m0 + wm * 16 + (lane >> 4) * 4 + e;
+    if (m >= a.M || k >= a.K) continue;
+    const int tj = m % a.TQ;
+    const int t2 = m / a.TQ;
+    const int ti = t2 % a.TP;
+    const int n = t2 / a.TP;
+    float mm[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) mm[p] = acc[p][e];
+    float y2[2][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {      // columns of the transform domain first: s0 = m0j+m1j+m2j, s1 = m1j-m2j-m3j
+      const float s0 = mm[0 * 4 + j] + mm[1 * 4 + j] + mm[2 * 4 + j];
+      const float s1 = mm[1 * 4 + j] - mm[2 * 4 + j] - mm[3 * 4 + j];
+      mm[0 * 4 + j] = s0;
+      mm[1 * 4 + j] = s1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      y2[i][0] = mm[i * 4 + 0] + mm[i * 4 + 1] + mm[i * 4 + 2];
+      y2[i][1] = mm[i * 4 + 1] - mm[i * 4 + 2] - mm[i * 4 + 3];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = 2 * ti + i;
+      if (p >= a.P) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int q = 2 * tj + j;
+        if (q >= a.Q) continue;
+        const long long o = (((long long)n * a.P + p) * a.Q + q) * a.K + k;
+        float v = y2[i][j] + bv;
+        if (accum) v += yg[o];
+        yg[o] = v;
+      }
+    }
+  }
+}
+
+// Wave-specialised variant for layers with >= 32 output channels: wavefronts 0-3 ("consumers", one per SIMD) issue nothing but fragment
+// reads and MFMAs on a 32 tile x 16 channel x 16 position block each (128 accumulator registers), wavefronts 4-7 ("producers", the
+// second wave of every SIMD) feed LDS ahead of them:
+//   * input patches: global -> registers -> column transform -> (DPP row transform) -> LDS, two rounds ahead (double buffer);
+//   * filters: already in the transform domain, so they go global -> LDS directly (global_load_lds_dwordx4, no registers, no VALU,
+//     no ds_write), three rounds ahead into a ring of three buffers; the XOR swizzle of the LDS image is applied on the global
+//     side (each lane picks the 16-byte piece that belongs into its linear LDS slot).
+// The consumers read the fragments of round s+1 into registers while the matrix cores work on round s, so no LDS latency is exposed
+// behind a barrier; the VALU / LDS-store / global-load work of the producers runs beside the MFMA pipe of the same SIMD.
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  // s_waitcnt vmcnt(n) only (expcnt / lgkmcnt fields left at "no wait"); n is wave-uniform, the immediate needs a constant
+  switch (n) {
+#define HWG_VM(N) case N: __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (15 << 8) | (((N) >> 4) << 14)); break;
+    HWG_VM(1) HWG_VM(2) HWG_VM(3) HWG_VM(4) HWG_VM(6) HWG_VM(8) HWG_VM(10) HWG_VM(12) HWG_VM(16) HWG_VM(20) HWG_VM(24) HWG_VM(28)
+    HWG_VM(32) HWG_VM(40) HWG_VM(48)
+#undef HWG_VM
+    default: __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8)); break;   // vmcnt(0)
+  }
+}
+
+constexpr int WINO_DA = 6;      // filter rounds in flight / resident ahead of the consumers (ring depth)
+
+template <int CM, int CN>
+__global__ __launch_bounds__(512) void wino_conv_ws_kernel(WinoK a) {
+  static_assert(CM * CN == 4, "4 consumer wavefronts");
+  constexpr int NX = 128;                             // threads of the two patch-producer waves
+  constexpr int TM = 32 * CM, TN = 16 * CN;
+  constexpr int PSV = TM * 16 + 8, PSU = TN * 16 + 8;
+  constexpr int VBUF = 4 * PSV, UBUF = 4 * PSU;
+  constexpr int DA = WINO_DA;
+  constexpr int XI = TM * 16 / NX;                    // (tile, 4-channel group, patch column) items per patch-producer thread and chunk
+  constexpr int UD = TN / 16;                         // LDS-DMA instructions per filter plane (TN rows of 64 B, 1 KiB per instruction)
+  __shared__ __attribute__((aligned(16))) float smem[2 * VBUF + DA * UBUF];
+  float* const Vs = smem;
+  float* const Us = smem + 2 * VBUF;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int m0 = blockIdx.x * TM;
+  const int n0 = blockIdx.y * TN;
+  const int split = blockIdx.z;
+  const int T_all = a.C >> 4;
+  const int t0 = (int)((long long)T_all * split / a.nsplit);
+  const int t1 = (int)((long long)T_all * (split + 1) / a.nsplit);
+  const int S = 4 * (t1 - t0);                        // rounds: (channel chunk, row of the transform domain)
+  const int R0 = 4 * t0;                              // absolute index of this workgroup's first round
+
+  if (wid >= 6) {
+    // =========================== filter movers (wavefronts 6, 7) ===========================
+    // Every round's filters (4 positions x TN channels x 16 input channels) go global -> LDS by DMA, DA rounds ahead, into a ring of DA
+    // buffers. Wave 6 moves planes 0, 1, wave 7 planes 2, 3. The only VMEM traffic of these waves are the DMAs, so "round q has
+    // landed" is exactly "at most (groups issued after q) * 2 UD operations outstanding".
+    const int pw = (wid - 6) * 2;
+    int u_src[2][UD];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int i = 0; i < UD; ++i) {
+        // lane -> (row, LDS slot); the slot holds channel group slot ^ ((row >> 1) & 3) (the swizzle, applied on the global side);
+        // rows past the padded channel count re-read the last row (their outputs are never stored)
+        const int row = 16 * i + (lane >> 2), slot = lane & 3;
+        int k = n0 + row;
+        if (k >= a.Kpad) k = a.Kpad - 1;
+        u_src[pl][i] = ((pw + pl) * a.Kpad + k) * 16 + 4 * (slot ^ ((row >> 1) & 3));
+      }
+    const long long u_round = 4LL * a.Kpad * 16;      // floats per round in the filter image
+    auto dma_u = [&](int ring, int round) {           // round absolute
+      const float* base = a.u + (long long)round * u_round;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        float* dst = Us + ring * UBUF + (pw + pl) * PSU;
+#pragma unroll
+        for (int i = 0; i < UD; ++i)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + u_src[pl][i]),
+                                           (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
+      }
+    };
+    int issued = 0;                                   // rounds whose DMA has been issued
+    for (; issued < DA && issued < S; ++issued) dma_u(issued, R0 + issued);
+    wait_vmcnt((issued - 1) * 2 * UD);                // round 0
+    __syncthreads();
+    wait_vmcnt(issued > 1 ? (issued - 2) * 2 * UD : 0);   // round 1
+    __syncthreads();
+    int ring = 0;                                     // slot of round s + DA == slot of round s (left by the consumers at step s - 1)
+    for (int s = 0; s < S; ++s) {
+      if (issued < S) { dma_u(ring, R0 + issued); ++issued; }
+      ring = ring == DA - 1 ? 0 : ring + 1;
+      if (s + 2 < S) wait_vmcnt((issued - (s + 3)) * 2 * UD);   // round s + 2 has landed before the consumers are let at it
+      __syncthreads();
+    }
+    return;
+  }
+  if (wid >= 4) {
+    // =========================== patch producers (wavefronts 4, 5) ===========================
+    const int pt = tid - 256;
+    int x_off[XI], x_ok[XI], x_lds[XI];
+    float x_sa[XI], x_sb[XI];
+    const int row_stride = a.W * a.C;
+#pragma unroll
+    for (int it = 0; it < XI; ++it) {
+      const int id = pt + it * NX;
+      const int b = id & 3, c4 = (id >> 2) & 3, row = id >> 4;
+      x_lds[it] = b * PSV + swz(row, c4);
+      x_sa[it] = (b == 3) ? -1.f : 1.f;
+      x_sb[it] = (b & 1) ? 1.f : -1.f;
+      const int m = m0 + row;
+      const bool mok = m < a.M;
+      const int mm = mok ? m : 0;
+      const int tj = mm % a.TQ;
+      const int t2 = mm / a.TQ;
+      const int ti = t2 % a.TP;
+      const int n = t2 / a.TP;
+      const int w = 2 * tj - a.pw + b;
+      const bool wok = mok && w >= 0 && w < a.W;
+      const int h0 = 2 * ti - a.ph;
+      x_off[it] = ((n * a.H + h0) * a.W + (wok ? w : 0)) * a.C + c4 * 4;
+      int okm = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (wok && h0 + r >= 0 && h0 + r < a.H) okm |= 1 << r;
+      x_ok[it] = okm;
+    }
+    float4 raw[XI][4], tr[XI][4];
+    auto load_x = [&](int t) {
+#pragma unroll
+      for (int it = 0; it < XI; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int off = (x_ok[it] >> r) & 1 ? x_off[it] + r * row_stride + t * 16 : 0;
+          raw[it][r] = *reinterpret_cast<const float4*>(a.x + off);
+        }
+    };
+    auto col_transform = [&]() {
+#pragma unroll
+      for (int it = 0; it < XI; ++it) {
+        float4 d[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          d[r] = raw[it][r];
+          if (!((x_ok[it] >> r) & 1)) d[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        tr[it][0] = make_float4(d[0].x - d[2].x, d[0].y - d[2].y, d[0].z - d[2].z, d[0].w - d[2].w);
+        tr[it][1] = make_float4(d[1].x + d[2].x, d[1].y + d[2].y, d[1].z + d[2].z, d[1].w + d[2].w);
+        tr[it][2] = make_float4(d[2].x - d[1].x, d[2].y - d[1].y, d[2].z - d[1].z, d[2].w - d[1].w);
+        tr[it][3] = make_float4(d[1].x - d[3].x, d[1].y - d[3].y, d[1].z - d[3].z, d[1].w - d[3].w);
+      }
+    };
+    auto write_v = [&](int buf, int r) {
+      float* B = Vs + buf * VBUF;
+#pragma unroll
+      for (int it = 0; it < XI; ++it) {
+        const float4 v = tr[it][r];
+        float4 o;
+        o.x = x_sa[it] * v.x + x_sb[it] * quad_partner(v.x);
+        o.y = x_sa[it] * v.y + x_sb[it] * quad_partner(v.y);
+        o.z = x_sa[it] * v.z + x_sb[it] * quad_partner(v.z);
+        o.w = x_sa[it] * v.w + x_sb[it] * quad_partner(v.w);
+        *reinterpret_cast<float4*>(B + x_lds[it]) = o;
+      }
+    };
+    // patches of chunk c are fetched a whole chunk (4 rounds) before their column transform
+    if (S > 0) {
+      load_x(t0);
+      col_transform();
+      if (t0 + 1 < t1) load_x(t0 + 1);
+      write_v(0, 0);
+    }
+    __syncthreads();
+    if (S > 0) write_v(1, 1);
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // step s = 4 (t - t0) + r: the consumers multiply round s and read the fragments of round s + 1; this side fills round s + 2
+        const int s = 4 * (t - t0) + r;
+        if (s + 2 < S) {
+          if (r == 2) {
+            col_transform();                          // chunk t + 1 (fetched during chunk t - 1 / the prologue)
+            if (t + 2 < t1) load_x(t + 2);
+          }
+          write_v(r & 1, (r + 2) & 3);
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
+
+  // =========================== consumers ===========================
+  __builtin_amdgcn_s_setprio(1);
+  const int cm = wid / CN, cn = wid % CN;
+  const int frow = lane & 15, fchunk = lane >> 4;
+  int a_off[2];
+  a_off[0] = swz(cm * 32 + frow, fchunk);
+  a_off[1] = swz(cm * 32 + 16 + frow, fchunk);
+  const int b_off = swz(cn * 16 + frow, fchunk);
+
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    acc[p][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[p][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float4 fa[2][4][2], fb[2][4];
+  auto read_frags = [&](int set, int vbuf, int uring) {
+    const float* A = Vs + vbuf * VBUF;
+    const float* B = Us + uring * UBUF + b_off;
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+      fa[set][pb][0] = *reinterpret_cast<const float4*>(A + pb * PSV + a_off[0]);
+      fa[set][pb][1] = *reinterpret_cast<const float4*>(A + pb * PSV + a_off[1]);
+      fb[set][pb] = *reinterpret_cast<const float4*>(B + pb * PSU);
+    }
+  };
+  __syncthreads();
+  if (S > 0) read_frags(0, 0, 0);
+  __syncthreads();
+  int ring = 1;                                       // ring slot of round s + 1
+  for (int t = t0; t < t1; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int s = 4 * (t - t0) + r;
+      const int cur = r & 1;
+      if (s + 1 < S) read_frags(cur ^ 1, cur ^ 1, ring);
+      ring = ring == WINO_DA - 1 ? 0 : ring + 1;
+      // element j of the fragments is channel 4*(lane>>4)+j of the chunk; j outermost: 8 independent accumulators between two
+      // MFMAs on the same one (dependent latency of v_mfma_f32_16x16x4_f32 is 40 cycles, issue interval 32)
+#define HWG_WINO_MFMA(J)                                                                                                     \
+      _Pragma("unroll") for (int pb = 0; pb < 4; ++pb) {                                                                     \
+        acc[r * 4 + pb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][pb][0].J, fb[cur][pb].J, acc[r * 4 + pb][0], 0, 0, 0); \
+        acc[r * 4 + pb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][pb][1].J, fb[cur][pb].J, acc[r * 4 + pb][1], 0, 0, 0); \
+      }
+      HWG_WINO_MFMA(x) HWG_WINO_MFMA(y) HWG_WINO_MFMA(z) HWG_WINO_MFMA(w)
+#undef HWG_WINO_MFMA
+      // keep the barrier BEHIND the MFMAs: hoisted in front of them (legal, they touch no LDS) it would stall the matrix pipe on the
+      // fragment reads of the next round and on the producers every round
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+    }
+  }
+  __builtin_amdgcn_s_setprio(0);
+
+  // output transform (register local) and store: column (k) = lane & 15, row (tile) = (lane >> 4) * 4 + e of each 16x16 block
+  const int k = n0 + cn * 16 + (lane & 15);
+  const bool direct = a.nsplit == 1;
+  float* yg = direct ? a.y : a.part + (long long)split * ((long long)a.N * a.P * a.Q * a.K);
+  const float bv = (direct && a.bias && k < a.K) ? a.bias[k] : 0.f;
+  const bool accum = direct && a.accumulate;
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = m0 + cm * 32 + blk * 16 + (lane >> 4) * 4 + e;
+      if (m >= a.M || k >= a.K) continue;
+      const int tj = m % a.TQ;
+      const int t2 = m / a.TQ;
+      const int ti = t2 % a.TP;
+      const int n = t2 / a.TP;
+      float mm[16];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) mm[p] = acc[p][blk][e];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float s0 = mm[0 * 4 + j] + mm[1 * 4 + j] + mm[2 * 4 + j];
+        const float s1 = mm[1 * 4 + j] - mm[2 * 4 + j] - mm[3 * 4 + j];
+        mm[0 * 4 + j] = s0;
+        mm[1 * 4 + j] = s1;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int p = 2 * ti + i;
+        if (p >= a.P) continue;
+        const float y0 = mm[i * 4 + 0] + mm[i * 4 + 1] + mm[i * 4 + 2];
+        const float y1 = mm[i * 4 + 1] - mm[i * 4 + 2] - mm[i * 4 + 3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int q = 2 * tj + j;
+          if (q >= a.Q) continue;
+          const long long o = (((long long)n * a.P + p) * a.Q + q) * a.K + k;
+          float v = (j == 0 ? y0 : y1) + bv;
+          if (accum) v += yg[o];
+          yg[o] = v;
+        }
+      }
+    }
+}
+
+// 64 tile x 64 channel workgroup tile on 12 wavefronts: 8 consumers (two per SIMD, 32 tiles x 16 channels x 16 positions = 128
+// accumulator registers each) and 4 producers (patch transform + filter DMA, one filter plane each). Twice the MFMA work per byte
+// that enters the CU compared with the 32 x 64 kernel above - the transform-domain operands are 16/9 larger than the direct ones and
+// a Winograd tile is only 4 pixels, so operand traffic (L2 -> LDS), not the matrix pipe, bounds the smaller tiles. The register file is
+// the limit: 12 waves x 168 registers is all of it, hence the fragments are read one position ahead (24 registers) instead of one
+// round ahead; the second consumer of each SIMD covers the LDS latency behind the barrier.
+constexpr int WINO_DB = 4;      // filter rounds in the ring of the big kernel
+
+__global__ __launch_bounds__(768) void wino_conv_big_kernel(WinoK a) {
+  constexpr int TM = 64, TN = 64, NX = 256;
+  constexpr int PSV = TM * 16 + 8, PSU = TN * 16 + 8;
+  constexpr int VBUF = 4 * PSV, UBUF = 4 * PSU;
+  constexpr int DA = WINO_DB;
+  constexpr int XI = TM * 16 / NX;                    // 4
+  constexpr int UD = TN / 16;                         // 4 DMA instructions per plane
+  __shared__ __attribute__((aligned(16))) float smem[2 * VBUF + DA * UBUF];
+  float* const Vs = smem;
+  float* const Us = smem + 2 * VBUF;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int m0 = blockIdx.x * TM;
+  const int n0 = blockIdx.y * TN;
+  const int split = blockIdx.z;
+  const int T_all = a.C >> 4;
+  const int t0 = (int)((long long)T_all * split / a.nsplit);
+  const int t1 = (int)((long long)T_all * (split + 1) / a.nsplit);
+  const int S = 4 * (t1 - t0);
+  // Every workgroup walks the channel chunks in the same cyclic order but starts at a different one: otherwise all 256 CUs stream the
+  // same 16 KB of filters at the same moment and queue up behind the few L2 channels that hold it (measured: the DMA issue alone took
+  // 1700 cycles per round). The sum over the chunks is order independent up to fp32 rounding and fixed per workgroup.
+  const int TC = t1 - t0;
+  const int rot = TC > 0 ? (int)((blockIdx.x * 7u + blockIdx.y * 3u) % (unsigned)TC) : 0;
+  auto chunk_of = [&](int tau) { int c = tau + rot; if (c >= TC) c -= TC; return t0 + c; };   // tau in [0, TC)
+
+  if (wid >= 8) {
+    // =========================== producers (wavefronts 8..11) ===========================
+    const int pt = tid - 512;
+    const int pw = wid - 8;                           // filter plane moved by this wave
+    // item it of a thread = (tile row (pt >> 4) + 16 it, 4-channel group (pt >> 2) & 3, patch column pt & 3): column, channel group, signs
+    // of the row transform and the swizzle term are the same for all four items
+    int x_off[XI], x_ok[XI];
+    const int xb = pt & 3, xc4 = (pt >> 2) & 3;
+    const int x_lds0 = xb * PSV + swz(pt >> 4, xc4);  // + 256 it
+    const float x_sa = (xb == 3) ? -1.f : 1.f, x_sb = (xb & 1) ? 1.f : -1.f;
+    const int row_stride = a.W * a.C;
+#pragma unroll
+    for (int it = 0; it < XI; ++it) {
+      const int b = xb, c4 = xc4, row = (pt >> 4) + 16 * it;
+      const int m = m0 + row;
+      const bool mok = m < a.M;
+      const int mm = mok ? m : 0;
+      const int tj = mm % a.TQ;
+      const int t2 = mm / a.TQ;
+      const int ti = t2 % a.TP;
+      const int n = t2 / a.TP;
+      const int w = 2 * tj - a.pw + b;
+      const bool wok = mok && w >= 0 && w < a.W;
+      const int h0 = 2 * ti - a.ph;
+      x_off[it] = ((n * a.H + h0) * a.W + (wok ? w : 0)) * a.C + c4 * 4;
+      int okm = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (wok && h0 + r >= 0 && h0 + r < a.H) okm |= 1 << r;
+      x_ok[it] = okm;
+    }
+    int u_src[UD];
+#pragma unroll
+    for (int i = 0; i < UD; ++i) {
+      const int row = 16 * i + (lane >> 2), slot = lane & 3;
+      int k = n0 + row;
+      if (k >= a.Kpad) k = a.Kpad - 1;
+      u_src[i] = (pw * a.Kpad + k) * 16 + 4 * (slot ^ ((row >> 1) & 3));
+    }
+    const long long u_round = 4LL * a.Kpad * 16;
+    float4 raw[XI][4], tr[XI][4];
+    auto load_x = [&](int t) {
+#pragma unroll
+      for (int it = 0; it < XI; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int off = (x_ok[it] >> r) & 1 ? x_off[it] + r * row_stride + t * 16 : 0;
+          raw[it][r] = *reinterpret_cast<const float4*>(a.x + off);
+        }
+    };
+    auto col_transform = [&]() {
+#pragma unroll
+      for (int it = 0; it < XI; ++it) {
+        float4 d[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          d[r] = raw[it][r];
+          if (!((x_ok[it] >> r) & 1)) d[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        tr[it][0] = make_float4(d[0].x - d[2].x, d[0].y - d[2].y, d[0].z - d[2].z, d[0].w - d[2].w);
+        tr[it][1] = make_float4(d[1].x + d[2].x, d[1].y + d[2].y, d[1].z + d[2].z, d[1].w + d[2].w);
+        tr[it][2] = make_float4(d[2].x - d[1].x, d[2].y - d[1].y, d[2].z - d[1].z, d[2].w - d[1].w);
+        tr[it][3] = make_float4(d[1].x - d[3].x, d[1].y - d[3].y, d[1].z - d[3].z, d[1].w - d[3].w);
+      }
+    };
+    auto dma_u = [&](int ring, int round) {
+      const float* base = a.u + (long long)round * u_round;
+      float* dst = Us + ring * UBUF + pw * PSU;
+#pragma unroll
+      for (int i = 0; i < UD; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + u_src[i]),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
+    };
+    auto write_v = [&](int buf, int r) {
+      float* B = Vs + buf * VBUF;
+#pragma unroll
+      for (int it = 0; it < XI; ++it) {
+        const float4 v = tr[it][r];
+        float4 o;
+        o.x = x_sa * v.x + x_sb * quad_partner(v.x);
+        o.y = x_sa * v.y + x_sb * quad_partner(v.y);
+        o.z = x_sa * v.z + x_sb * quad_partner(v.z);
+        o.w = x_sa * v.w + x_sb * quad_partner(v.w);
+        *reinterpret_cast<float4*>(B + x_lds0 + it * 256) = o;
+      }
+    };
+    // VMEM bookkeeping for the filter DMAs (in-order counter shared with the patch loads): hist[j] = operations issued in each of the
+    // last DA steps (oldest first); every step's DMA is the FIRST operation of its step.
+    int hist[DA], hdma[DA];
+#pragma unroll
+    for (int j = 0; j < DA; ++j) { hist[j] = 0; hdma[j] = 0; }
+    int issued = 0;
+    // prologue: patches of chunk t0 (transformed, round 0 stored), filter rounds 0 .. DA-1 in flight
+    if (S > 0) {
+      load_x(chunk_of(0));
+      col_transform();
+      write_v(0, 0);
+    }
+    for (; issued < DA && issued < S; ++issued) dma_u(issued, 4 * chunk_of(issued >> 2) + (issued & 3));
+    wait_vmcnt((issued - 1) * UD);                    // round 0 landed: (issued - 1) younger DMA groups may stay in flight
+    // history as if those had been issued in the DA steps before step 0 (round j by "step j - DA")
+#pragma unroll
+    for (int j = 0; j < DA; ++j) { hdma[j] = j < issued ? UD : 0; hist[j] = hdma[j]; }
+    __syncthreads();
+    int ring = 0;
+    for (int t = t0; t < t1; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // step s: the consumers multiply round s. This side stores the patches of round s + 1, issues the filter DMA of round s + DA
+        // (slot of round s ... free only after this step's barrier, so it is issued for the slot the consumers left LAST step: round
+        // s - 1 + DA), and makes sure the filters of round s + 1 have landed before the barrier.
+        const int s = 4 * (t - t0) + r;
+        int ops = 0, dops = 0;
+        if (s >= 1 && issued < S) { dma_u(ring, 4 * chunk_of(issued >> 2) + (issued & 3)); ++issued; ring = ring == DA - 1 ? 0 : ring + 1; ops = dops = UD; }
+        if (s + 1 < S) {
+          if (r == 3) col_transform();                // chunk t + 1 (fetched two steps ago, when half of this chunk's registers were free)
+          write_v((r + 1) & 1, (r + 1) & 3);
+          if (r == 1 && t + 1 < t1) { load_x(chunk_of(t + 1 - t0)); ops += XI * 4; }
+        }
+        // shift the history, then: round s + 1 was issued DA - 1 steps ago at the earliest ... find it: it is the DMA of history entry
+        // DA - 1 - (issued - 1 - (s + 1)) = the (issued - s - 2)-th youngest DMA group
+#pragma unroll
+        for (int j = 0; j + 1 < DA; ++j) { hist[j] = hist[j + 1]; hdma[j] = hdma[j + 1]; }
+        hist[DA - 1] = ops; hdma[DA - 1] = dops;
+        if (s + 1 < S) {
+          // newer than round s + 1's DMA: the rest of its own step + all later steps. Groups are issued one per step in round order,
+          // so round s + 1 sits (issued - 1 - (s + 1)) DMA-carrying steps back from the youngest DMA-carrying step.
+          int back = issued - 2 - s;                  // DMA groups younger than round s + 1
+          int n = 0, seen = 0;
+#pragma unroll
+          for (int j = DA - 1; j >= 0; --j) {
+            if (seen < back || (seen == back && hdma[j] == 0)) { n += hist[j]; seen += hdma[j] ? 1 : 0; }
+            else if (seen == back && hdma[j] != 0) { n += hist[j] - hdma[j]; seen = back + 1; }
+          }
+          wait_vmcnt(n);
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
+
+  // =========================== consumers (wavefronts 0..7) ===========================
+  const int cm = wid >> 2, cn = wid & 3;
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int a_off0 = swz(cm * 32 + frow, fchunk);
+  const int a_off1 = swz(cm * 32 + 16 + frow, fchunk);
+  const int b_off = swz(cn * 16 + frow, fchunk);
+
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    acc[p][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[p][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  int ring = 0;
+  for (int t = t0; t < t1; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* A = Vs + (r & 1) * VBUF;
+      const float* B = Us + ring * UBUF + b_off;
+      ring = ring == DA - 1 ? 0 : ring + 1;
+      float4 fa0[2], fa1[2], fb[2];
+      fa0[0] = *reinterpret_cast<const float4*>(A + a_off0);
+      fa1[0] = *reinterpret_cast<const float4*>(A + a_off1);
+      fb[0] = *reinterpret_cast<const float4*>(B);
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) {
+        const int c = pb & 1;
+        if (pb < 3) {
+          fa0[c ^ 1] = *reinterpret_cast<const float4*>(A + (pb + 1) * PSV + a_off0);
+          fa1[c ^ 1] = *reinterpret_cast<const float4*>(A + (pb + 1) * PSV + a_off1);
+          fb[c ^ 1] = *reinterpret_cast<const float4*>(B + (pb + 1) * PSU);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4& c0 = acc[r * 4 + pb][0];
+        f32x4& c1 = acc[r * 4 + pb][1];
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[c].x, fb[c].x, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[c].x, fb[c].x, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[c].y, fb[c].y, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[c].y, fb[c].y, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[c].z, fb[c].z, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[c].z, fb[c].z, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[c].w, fb[c].w, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[c].w, fb[c].w, c1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+  }
+
+  const int k = n0 + cn * 16 + (lane & 15);
+  const bool direct = a.nsplit == 1;
+  float* yg = direct ? a.y : a.part + (long long)split * ((long long)a.N * a.P * a.Q * a.K);
+  const float bv = (direct && a.bias && k < a.K) ? a.bias[k] : 0.f;
+  const bool accum = direct && a.accumulate;
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = m0 + cm * 32 + blk * 16 + (lane >> 4) * 4 + e;
+      if (m >= a.M || k >= a.K) continue;
+      const int tj = m % a.TQ;
+      const int t2 = m / a.TQ;
+      const int ti = t2 % a.TP;
+      const int n = t2 / a.TP;
+      float mm[16];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) mm[p] = acc[p][blk][e];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float s0 = mm[0 * 4 + j] + mm[1 * 4 + j] + mm[2 * 4 + j];
+        const float s1 = mm[1 * 4 + j] - mm[2 * 4 + j] - mm[3 * 4 + j];
+        mm[0 * 4 + j] = s0;
+        mm[1 * 4 + j] = s1;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int p = 2 * ti + i;
+        if (p >= a.P) continue;
+        const float y0 = mm[i * 4 + 0] + mm[i * 4 + 1] + mm[i * 4 + 2];
+        const float y1 = mm[i * 4 + 1] - mm[i * 4 + 2] - mm[i * 4 + 3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int q = 2 * tj + j;
+          if (q >= a.Q) continue;
+          const long long o = (((long long)n * a.P + p) * a.Q + q) * a.K + k;
+          float v = (j == 0 ? y0 : y1) + bv;
+          if (accum) v += yg[o];
+          yg[o] = v;
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino_pack_weight_kernel(const float* src, float* dst, int A, int Apad, int B, int Bpad,
+                                                               long long sa, long long sb, long long sr, long long ss, int flip) {
+  const long long total = (long long)Apad * Bpad;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    wino_pack_one(src, dst, i, A, Apad, B, Bpad, sa, sb, sr, ss, flip);
+}
+
+struct WinoPlan {
+  int cfg;      // 0: 64 tiles x 32 k, 1: 32 x 64, 2: 128 x 16 (all-purpose kernel); 4: 32 x 64 (wave-specialised kernel); 3 unused
+  int tm, tn, nsplit;
+};
+static void wino_cfg(WinoPlan& p, int cfg) {
+  static const int tms[6] = {64, 32, 128, 64, 32, 64}, tns[6] = {32, 64, 16, 32, 64, 64};
+  p.cfg = cfg; p.tm = tms[cfg]; p.tn = tns[cfg];
+}
+static WinoPlan plan_wino(const hwg_conv_desc* d) {
+  WinoPlan p;
+  const long long M = (long long)d->N * hwg_cdiv(d->P, 2) * hwg_cdiv(d->Q, 2);
+  // measured on MI355X (tools/wino_check.py, profiles/r02_wino_shapes.txt): 32 x 64 tiles of the all-purpose kernel are the best
+  // default; the 64 x 64 twelve-wave kernel wins once the channel loop is long (C >= 128) and there are enough tiles to fill the chip
+  if (d->K <= 16) wino_cfg(p, 2);
+  else if (d->K <= 48) wino_cfg(p, 0);
+  else if (d->C >= 128 && (long long)hwg_cdiv(M, 64) * hwg_cdiv(d->K, 64) >= 224) wino_cfg(p, 5);
+  else wino_cfg(p, 1);
+  if (const char* f = getenv("HWG_WINO_FORCE")) {   // tuning aid: "cfg[,nsplit]"
+    int fc = -1, fs = 0;
+    const int n = sscanf(f, "%d,%d", &fc, &fs);
+    if (n >= 1 && fc >= 0 && fc <= 5 && fc != 3 && (fc == 2 || d->K > 16)) wino_cfg(p, fc);
+    if (n >= 2 && fs >= 1) { p.nsplit = fs; if (p.nsplit > d->C / 16) p.nsplit = d->C / 16; return p; }
+  }
+  // few workgroups and a long channel loop: cut the loop so that the chip is filled (partials summed by the split reduce pass)
+  const long long blocks = (long long)hwg_cdiv(M, p.tm) * hwg_cdiv(d->K, p.tn);
+  const int chunks = d->C / 16;
+  int ns = 1;
+  while (blocks * ns < 512 && ns * 2 <= chunks / 4 && ns < 16) ns *= 2;
+  p.nsplit = ns;
+  return p;
+}
+
+}  // namespace
+
+extern "C" int hwg_wino_supported(const hwg_conv_desc* d) {
+  if (!d || d->transposed) return 0;
+  if (d->R != 3 || d->S != 3 || d->stride_h != 1 || d->stride_w != 1 || d->dil_h != 1 || d->dil_w != 1) return 0;
+  if (d->C % 16 != 0 || d->K < 16) return 0;
+  if (d->P != d->H + 2 * d->pad_h - 2 || d->Q != d->W + 2 * d->pad_w - 2) return 0;
+  if (const char* f = getenv("HWG_WINO")) if (atoi(f) == 0) return 0;
+  return 1;
+}
+
+extern "C" size_t hwg_wino_weight_floats(int A, int B) {
+  const size_t Apad = (size_t)(A + 15) / 16 * 16, Bpad = (size_t)(B + 15) / 16 * 16;
+  return 16 * Apad * Bpad;
+}
+
+extern "C" int hwg_wino_pack_weight(const float* src, float* dst, int A, int B, long long sa, long long sb, long long sr, long long ss,
+                                    int flip, void* stream) {
+  HWG_REQUIRE(src && dst && A > 0 && B > 0, "wino_pack_weight: bad arguments");
+  const int Apad = (A + 15) / 16 * 16, Bpad = (B + 15) / 16 * 16;
+  hipLaunchKernelGGL(wino_pack_weight_kernel, dim3(hwg_stream_grid((long long)Apad * Bpad, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, A, Apad,
+                     B, Bpad, sa, sb, sr, ss, flip);
+  HWG_LAUNCH_CHECK("wino_pack_weight");
+  return HWG_OK;
+}
+
+extern "C" size_t hwg_wino_conv_workspace(const hwg_conv_desc* d) {
+  if (!hwg_wino_supported(d)) return 0;
+  const WinoPlan p = plan_wino(d);
+  if (p.nsplit <= 1) return 0;
+  return (size_t)p.nsplit * d->N * d->P * d->Q * d->K * sizeof(float);
+}
+
+int hwg_conv_split_reduce_launch(const float* part, const float* bias, float* y, long long total, int K, int nsplit, int accumulate, hipStream_t st);
+
+extern "C" int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const float* u, const float* bias, float* y, int accumulate,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  HWG_REQUIRE(d && x && u && y, "wino_conv_fwd: null pointer");
+  HWG_REQUIRE(hwg_wino_supported(d), "wino_conv_fwd: needs a 3x3 stride-1 dilation-1 convolution with C %% 16 == 0 and K >= 16");
+  hipStream_t st = (hipStream_t)stream;
+  const WinoPlan p = plan_wino(d);
+  const size_t need = hwg_wino_conv_workspace(d);
+  if (need && (!workspace || workspace_bytes < need)) {
+    hwg_set_error("wino_conv_fwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return HWG_ERR_WORKSPACE;
+  }
+  WinoK k;
+  k.x = x; k.u = u; k.bias = bias; k.y = y;
+  k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.Kpad = (d->K + 15) / 16 * 16;
+  k.P = d->P; k.Q = d->Q; k.ph = d->pad_h; k.pw = d->pad_w;
+  k.TP = hwg_cdiv(d->P, 2); k.TQ = hwg_cdiv(d->Q, 2);
+  k.M = d->N * k.TP * k.TQ;
+  k.accumulate = accumulate;
+  k.nsplit = p.nsplit;
+  k.part = (float*)workspace;
+  dim3 grid(hwg_cdiv(k.M, p.tm), hwg_cdiv(d->K, p.tn), p.nsplit);
+  const int prof = hwg_prof_open(HWG_PROF_CONV, 2.0 * d->N * d->P * d->Q * (double)d->K * d->C * 9.0, st);
+  if (p.cfg == 0) hipLaunchKernelGGL((wino_conv_kernel<4, 2>), grid, dim3(512), 0, st, k);
+  else if (p.cfg == 1) hipLaunchKernelGGL((wino_conv_kernel<2, 4>), grid, dim3(512), 0, st, k);
+  else if (p.cfg == 2) hipLaunchKernelGGL((wino_conv_kernel<8, 1>), grid, dim3(512), 0, st, k);
+  else if (p.cfg == 5) hipLaunchKernelGGL(wino_conv_big_kernel, grid, dim3(768), 0, st, k);
+  else hipLaunchKernelGGL((wino_conv_ws_kernel<1, 4>), grid, dim3(512), 0, st, k);
+  hwg_prof_close(prof, st);
+  HWG_LAUNCH_CHECK("wino_conv_fwd");
+  if (p.nsplit > 1) {
+    const long long total = (long long)d->N * d->P * d->Q * d->K;
+    const int prof2 = hwg_prof_open(HWG_PROF_CONV_REDUCE, 4.0 * total * (p.nsplit + 1), st);
+    const int rc = hwg_conv_split_reduce_launch((const float*)workspace, bias, y, total, d->K, p.nsplit, accumulate, st);
+    hwg_prof_close(prof2, st);
+    if (rc) return rc;
+  }
+  return HWG_OK;
+}

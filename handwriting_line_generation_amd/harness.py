@@ -52,11 +52,13 @@ def synthetic_gan_config(which="iam_gan", batch_size=None, a_batch_size=None, wo
 
 
 def build_gan_trainer(which="iam_gan", batch_size=None, a_batch_size=None, width=512, label_len=30, min_width=None, workdir=None,
-                      gpu=0, rank=0, world=1, model_state=None, encoder_state=None, data_seed=100, resume=None):
+                      gpu=0, rank=0, world=1, model_state=None, encoder_state=None, data_seed=100, resume=None, curriculum=None):
     if workdir is not None:
         os.makedirs(workdir, exist_ok=True)
     cfg, workdir = synthetic_gan_config(which, batch_size, a_batch_size, workdir, gpu)
     tr = cfg["trainer"]
+    if curriculum is not None:
+        tr["curriculum"] = {"0": curriculum}
     if not os.path.exists(tr["encoder_weights"]):
         ae = Autoencoder({"type": tr.get("encoder_type", "2tight"), "hwr": cfg["model"]["num_class"]})
         sd = encoder_state if encoder_state is not None else ae.state_dict()   # keys 'encoder.*' are the ones the trainer reads

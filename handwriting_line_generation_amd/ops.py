@@ -181,20 +181,32 @@ def bump_weight_epoch(group):
     WEIGHT_EPOCH[group] = WEIGHT_EPOCH.get(group, 0) + 1
 
 
-def _pack(weight, A, B, R, S, sa, sb, flip, Bpad=None):
+def _pack(weight, A, B, R, S, sa, sb, flip, Bpad=None, wino=False):
+    """engine image of a weight: [tap][A][Bpad], or (wino) the Winograd-domain filters U = G g G^T as [Bpad/16][16][Apad][16]"""
     Bpad = B if Bpad is None else Bpad
+    Apad = (A + 15) // 16 * 16 if wino else A
+    if wino:
+        Bpad = (B + 15) // 16 * 16
     key = hit = group = None
     if weight.is_leaf:
         group = getattr(weight, "_hwg_group", None)
         epoch = WEIGHT_EPOCH.get(group, 0)
-        key = (id(weight), weight.data_ptr(), A, B, Bpad, sa, sb, int(flip))
+        key = (id(weight), weight.data_ptr(), A, B, Bpad, sa, sb, int(flip), bool(wino))
         hit = _pack_cache.get(key)
         if hit is not None and hit[0] == weight._version and hit[1] == epoch:
             return hit[2]
-    out = hit[2] if (key is not None and hit is not None) else torch.empty((R * S, A, Bpad), dtype=torch.float32, device=weight.device)
-    L.call("hwg_conv_pack_weight", weight, out, A, B, Bpad, R, S, sa, sb, S, 1, int(flip), _stream())
+    if key is not None and hit is not None:
+        out = hit[2]
+    elif wino:
+        out = torch.empty((Bpad // 16, 16, Apad, 16), dtype=torch.float32, device=weight.device)
+    else:
+        out = torch.empty((R * S, A, Bpad), dtype=torch.float32, device=weight.device)
+    if wino:
+        L.call("hwg_wino_pack_weight", weight, out, A, B, sa, sb, S, 1, int(flip), _stream())
+    else:
+        L.call("hwg_conv_pack_weight", weight, out, A, B, Bpad, R, S, sa, sb, S, 1, int(flip), _stream())
     if key is not None:
-        _pack_cache[key] = [weight._version, epoch, out, weight, (A, B, Bpad, R, S, sa, sb, int(flip)), group]
+        _pack_cache[key] = [weight._version, epoch, out, weight, (A, B, Bpad, R, S, sa, sb, int(flip), int(bool(wino)), Apad), group]
     return out
 
 
@@ -209,13 +221,14 @@ def repack_group(group):
     if tab is None or tab[0] != len(entries):
         if _PACK_DTYPE is None:
             _PACK_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("A", "<i4"), ("B", "<i4"), ("Bpad", "<i4"), ("R", "<i4"), ("S", "<i4"), ("flip", "<i4"),
-                                    ("sa", "<i8"), ("sb", "<i8"), ("sr", "<i8"), ("ss", "<i8"), ("total", "<i8"), ("first_block", "<i8")])
+                                    ("sa", "<i8"), ("sb", "<i8"), ("sr", "<i8"), ("ss", "<i8"), ("total", "<i8"), ("first_block", "<i8"),
+                                    ("mode", "<i4"), ("Apad", "<i4")])
         host = np.zeros(len(entries), dtype=_PACK_DTYPE)
         blocks = 0
         for i, e in enumerate(entries):
-            A, B, Bpad, R, S, sa, sb, flip = e[4]
-            total = R * S * A * Bpad
-            host[i] = (e[3].data_ptr(), e[2].data_ptr(), A, B, Bpad, R, S, flip, sa, sb, S, 1, total, blocks)
+            A, B, Bpad, R, S, sa, sb, flip, mode, Apad = e[4]
+            total = Apad * Bpad if mode else R * S * A * Bpad
+            host[i] = (e[3].data_ptr(), e[2].data_ptr(), A, B, Bpad, R, S, flip, sa, sb, S, 1, total, blocks, mode, Apad)
             blocks += (total + PACK_PER_BLOCK - 1) // PACK_PER_BLOCK
         dev = h2d(torch.from_numpy(host.view(np.uint8)), entries[0][2].device)
         tab = _pack_tables[group] = (len(entries), dev, blocks, entries)
@@ -291,15 +304,27 @@ def _prof_tag(shape):
 _RUN_SCOPE = [None]     # scope of the conv op currently being executed (forward: SCOPE, backward: the scope saved at forward time)
 
 
-def _run_conv(x, wp, bias, N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed):
+def _run_conv(x, wp, bias, N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed, wino=False):
     y = torch.empty((N, P, Q, K), dtype=torch.float32, device=x.device)
     d = _desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed)
     if PROF_SHAPES is not None:
         _prof_tag((N, H, W, C, K, R, S, stride, pad, dil, transposed, _RUN_SCOPE[0]))
+    if wino:
+        need = L.query("hwg_wino_conv_workspace", ctypes.byref(d))
+        ws = workspace(need, x.device) if need else None
+        L.call("hwg_wino_conv_fwd", ctypes.byref(d), x, wp, bias, y, 0, ws, need, _stream())
+        return y
     need = L.query("hwg_conv_fwd_workspace", ctypes.byref(d))
     ws = workspace(need, x.device) if need else None
     L.call("hwg_conv_fwd", ctypes.byref(d), x, wp, bias, y, 0, ws, need, _stream())
     return y
+
+
+WINOGRAD = True     # 3x3 / stride 1 / dilation 1 products with >= 16 output channels run as F(2x2,3x3) (csrc/conv_wino.hip)
+
+
+def _wino_ok(C, K, R, S, stride, dil):
+    return WINOGRAD and R == 3 and S == 3 and stride == (1, 1) and dil == (1, 1) and C % 16 == 0 and K >= 16
 
 
 def _cpad(C, K, fractional=False):
@@ -345,8 +370,9 @@ class _Conv2d(Function):
             Q = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
             Cp = _cpad(C, K)
             xin = _pad_channels(x, Cp) if Cp != C else x
-            wp = _pack(weight, K, C, R, S, C * R * S, R * S, flip=0, Bpad=Cp)
-            y = _run_conv(xin, wp, bias, N, H, W, Cp, K, R, S, (sh, sw), (ph, pw), (dh, dw), P, Q, 0)
+            wino = _wino_ok(Cp, K, R, S, (sh, sw), (dh, dw))
+            wp = _pack(weight, K, C, R, S, C * R * S, R * S, flip=0, Bpad=Cp, wino=wino)
+            y = _run_conv(xin, wp, bias, N, H, W, Cp, K, R, S, (sh, sw), (ph, pw), (dh, dw), P, Q, 0, wino)
         else:
             K = weight.shape[1]
             assert weight.shape[0] == C, "conv_transpose: weight expects %d input channels, got %d" % (weight.shape[0], C)
@@ -357,8 +383,9 @@ class _Conv2d(Function):
             xin = _pad_channels(x, Cp) if Cp != C else x
             if sh == 1 and sw == 1:
                 # stride-1 transposed conv == correlation with mirrored taps and padding dil*(R-1)-pad
-                wp = _pack(weight, K, C, R, S, R * S, K * R * S, flip=1, Bpad=Cp)
-                y = _run_conv(xin, wp, bias, N, H, W, Cp, K, R, S, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), P, Q, 0)
+                wino = _wino_ok(Cp, K, R, S, (1, 1), (dh, dw)) and dh * (R - 1) - ph >= 0 and dw * (S - 1) - pw >= 0
+                wp = _pack(weight, K, C, R, S, R * S, K * R * S, flip=1, Bpad=Cp, wino=wino)
+                y = _run_conv(xin, wp, bias, N, H, W, Cp, K, R, S, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), P, Q, 0, wino)
             else:
                 assert dh == 1 and dw == 1, "strided conv_transpose needs dilation 1"
                 wp = _pack(weight, K, C, R, S, R * S, K * R * S, flip=0, Bpad=Cp)
@@ -396,16 +423,18 @@ class _Conv2d(Function):
                 L.call("hwg_col2im_taps", t, dx, N, H, W, P, Q, R, S, ph, pw, dh, dw, st)
             elif not transposed:
                 if sh == 1 and sw == 1:
-                    wp = _pack(weight, C, K, R, S, R * S, C * R * S, flip=1, Bpad=Kp)
-                    dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), H, W, 0)
+                    wino = _wino_ok(Kp, C, R, S, (1, 1), (dh, dw)) and dh * (R - 1) - ph >= 0 and dw * (S - 1) - pw >= 0
+                    wp = _pack(weight, C, K, R, S, R * S, C * R * S, flip=1, Bpad=Kp, wino=wino)
+                    dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), H, W, 0, wino)
                 else:
                     assert dh == 1 and dw == 1, "strided conv backward needs dilation 1"
                     wp = _pack(weight, C, K, R, S, R * S, C * R * S, flip=0, Bpad=Kp)
                     dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (sh, sw), (ph, pw), (1, 1), H, W, 1)
             else:
                 # gradient of a transposed conv is an ordinary (strided) correlation of dy
-                wp = _pack(weight, C, K, R, S, K * R * S, R * S, flip=0, Bpad=Kp)
-                dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (sh, sw), (ph, pw), (dh, dw), H, W, 0)
+                wino = _wino_ok(Kp, C, R, S, (sh, sw), (dh, dw))
+                wp = _pack(weight, C, K, R, S, K * R * S, R * S, flip=0, Bpad=Kp, wino=wino)
+                dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (sh, sw), (ph, pw), (dh, dw), H, W, 0, wino)
         wref, bref = ctx.param_refs
         if ctx.needs_input_grad[1]:
             direct = _direct(wref)

@@ -113,6 +113,7 @@ class HWWithStyleTrainer(BaseTrainer):
         # off by default because co-running kernels inflate the per-kernel durations the roofline measurement relies on
         ops.SIDE_WGRAD = bool(tr.get("side_stream_wgrad", False) or int(os.environ.get("HWG_SIDE_WGRAD", "0") or 0))
         self._pending_log = None
+        self.pre_clip_hook = None
 
     # ------------------------------------------------------------------------------------------
     def _to_tensor(self, instance):
@@ -211,6 +212,8 @@ class HWWithStyleTrainer(BaseTrainer):
 
         flag = None
         if self.curriculum and "no-step" not in lesson:
+            if self.pre_clip_hook is not None:    # parity tests read the balanced gradients here, where the reference clips them (:381)
+                self.pre_clip_hook(iteration)
             f.clip_(2)
             flag = f.params_nonfinite_flag()
             if "disc" in lesson or "auto-disc" in lesson:

@@ -76,8 +76,9 @@ int hwg_conv_pack_weight(const float* src, float* dst, int A, int B, int Bpad, i
                          long long sa, long long sb, long long sr, long long ss, int flip, void* stream);
 
 /* The same re-layout for many weights in one launch (after an optimizer step). table: device array of n_entries records
- * { const float* src; float* dst; int A, B, Bpad, R, S, flip; long long sa, sb, sr, ss, total, first_block; } (88 bytes) where
- * total = R*S*A*Bpad and first_block = running sum of ceil(total/1024); total_blocks = that sum over all entries. */
+ * { const float* src; float* dst; int A, B, Bpad, R, S, flip; long long sa, sb, sr, ss, total, first_block; int mode, Apad; }
+ * (96 bytes) where total = R*S*A*Bpad and first_block = running sum of ceil(total/1024); total_blocks = that sum over all entries.
+ * mode 1 = the Winograd filter transform of hwg_wino_pack_weight (then Apad = ceil16(A), Bpad = ceil16(B), total = Apad*Bpad). */
 int hwg_conv_pack_weight_multi(const void* table, int n_entries, long long total_blocks, void* stream);
 
 /* y[N,P,Q,K] = gather-conv(x[N,H,W,C], w[R*S][K][C]) (+ bias[K] if bias != NULL).
@@ -105,6 +106,21 @@ size_t hwg_conv_wgrad_workspace(const hwg_conv_desc* d);
 int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const float* v, float* dw,
                    long long sa, long long sb, long long sr, long long ss, int accumulate,
                    float* dbias, int bias_accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Winograd F(2x2,3x3) path for 3x3 / stride 1 / dilation 1 convolutions with C % 16 == 0 and K >= 16 (same call sites as
+ * hwg_conv_fwd: the 3x3 layers of model/discriminator_ap.py:84-131, model/cnn_only_hwr.py:31-32, model/pure_gen.py:161-197,
+ * model/char_style.py:65-71, model/autoencoder.py:346-395 and their data gradients). Input, filter and output transforms are
+ * fused into the kernel; the 16 transform-domain GEMMs run on v_mfma_f32_16x16x4_f32 (2.25x fewer MACs than the direct form).
+ * hwg_wino_pack_weight turns a weight (element (a,b,r,s) at src[a*sa+b*sb+r*sr+s*ss], a = output channel of THIS product,
+ * b = contracted channel, flip mirrors the taps) into U = G g G^T laid out [ceil16(B)/16][16][ceil16(A)][16]
+ * (hwg_wino_weight_floats(A, B) floats). d describes the product as for hwg_conv_fwd (transposed must be 0). */
+int hwg_wino_supported(const hwg_conv_desc* d);
+size_t hwg_wino_weight_floats(int A, int B);
+int hwg_wino_pack_weight(const float* src, float* dst, int A, int B, long long sa, long long sb, long long sr, long long ss,
+                         int flip, void* stream);
+size_t hwg_wino_conv_workspace(const hwg_conv_desc* d);
+int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const float* u, const float* bias, float* y,
+                      int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[C] (+)= sum over rows of x[rows][C]  (bias gradients, channel sums) */
 size_t hwg_colsum_workspace(long long rows, int C);

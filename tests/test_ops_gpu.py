@@ -1,5 +1,7 @@
 """Per-kernel numerics: every HIP op (through the C-ABI) against a plain PyTorch fp32 CPU reference of the same op.
 Tolerance: 1e-4 of the reference's max magnitude (BASELINE.json north_star: fp32 1e-4); integer outputs exact."""
+import zlib
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -52,6 +54,16 @@ CONV_CASES = [
     ("convT_s1_3x3", 2, 6, 20, 32, 32, 3, 3, (1, 1), (1, 1), (1, 1), True),
     ("convT_6x3", 2, 1, 12, 32, 64, 6, 3, (1, 1), (0, 0), (1, 1), True),
     ("convT_to1", 2, 8, 20, 32, 1, 3, 3, (1, 1), (1, 1), (1, 1), True),
+    # Winograd F(2x2,3x3) path (3x3 / stride 1 / dilation 1, >= 16 output channels): odd sizes, every padding the networks use
+    # (0/1 forward, 2 = data gradient of pad 0), channel counts off the tile sizes, the split-channel schedule, 16-wide layers
+    ("wino_odd_pad1", 3, 9, 13, 16, 16, 3, 3, (1, 1), (1, 1), (1, 1), False),
+    ("wino_pad0_k48", 2, 7, 30, 32, 48, 3, 3, (1, 1), (0, 0), (1, 1), False),
+    ("wino_pad01_c48_k80", 2, 6, 21, 48, 80, 3, 3, (1, 1), (0, 1), (1, 1), False),
+    ("wino_split_c256", 1, 4, 30, 256, 64, 3, 3, (1, 1), (1, 1), (1, 1), False),
+    ("wino_k16_wide", 2, 32, 120, 16, 16, 3, 3, (1, 1), (1, 1), (1, 1), False),
+    ("wino_c24_padded", 2, 5, 11, 24, 32, 3, 3, (1, 1), (1, 1), (1, 1), False),
+    ("wino_big_tiles", 4, 20, 130, 64, 128, 3, 3, (1, 1), (0, 1), (1, 1), False),
+    ("wino_1row", 2, 3, 40, 128, 256, 3, 3, (1, 1), (0, 1), (1, 1), False),
     # RIMES (78 classes): channel counts that are not multiples of 4
     ("rimes_convT_lift_206", 2, 1, 20, 206, 64, 4, 3, (1, 1), (0, 1), (1, 1), True),
     ("rimes_conv1d_to78", 2, 1, 30, 64, 78, 1, 3, (1, 1), (0, 0), (1, 1), False),
@@ -63,7 +75,7 @@ CONV_CASES = [
 def test_conv_fwd_bwd(cuda, case):
     from handwriting_line_generation_amd import ops
     name, N, H, W, C, K, R, S, stride, pad, dil, transposed = case
-    g = torch.Generator().manual_seed(hash(name) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)   # (hash() changes with PYTHONHASHSEED)
     x = torch.randn(N, C, H, W, generator=g)
     if transposed:
         w = torch.randn(C, K, R, S, generator=g) * (1.0 / (C * R * S) ** 0.5)
@@ -92,6 +104,27 @@ def test_conv_fwd_bwd(cuda, case):
     _close(nchw(xg.grad), xr.grad, name + ".dx")
     _close(wg.grad, wr.grad, name + ".dw")
     _close(bg.grad, br.grad, name + ".db")
+
+
+def test_winograd_agrees_with_direct_engine(cuda):
+    """the same 3x3 layer through the F(2x2,3x3) kernels and through the direct implicit-GEMM kernels"""
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 11, 37, 64, generator=g).to(cuda)
+    w = (torch.randn(96, 64, 3, 3, generator=g) / 24).to(cuda)
+    gy = torch.randn(3, 11, 37, 96, generator=g).to(cuda)
+    outs = []
+    for flag in (True, False):
+        ops.WINOGRAD = flag
+        try:
+            xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            y = ops.conv2d(xg, wg, None, 1, 1)
+            y.backward(gy)
+            outs.append((y.detach(), xg.grad, wg.grad))
+        finally:
+            ops.WINOGRAD = True
+    for a, b, n in zip(outs[0], outs[1], ("y", "dx", "dw")):
+        _close(a, b, "winograd vs direct " + n, tol=2e-5)
 
 
 def test_linear(cuda):

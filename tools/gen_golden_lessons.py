@@ -32,7 +32,9 @@ CASES = {
     # every lesson kind of the shipped curriculum from clean seeded weights, before any fp32 drift can accumulate
     "disc": ("iam_gan", 2, 2, 256, None, 12, [["disc"]], 2),
     "auto": ("iam_gan", 2, 2, 256, None, 12, [["auto", "auto-gen"]], 1),
-    "gen_gen_auto": ("iam_gan", 2, 2, 256, None, 12, [["no-step", "gen"], ["no-step", "gen"], ["auto", "auto-gen"]], 3),
+    # (two text lessons in a row are not a valid schedule: the reference indexes its four balance multipliers by stash number and
+    #  a gen,gen,auto sequence produces six stashes; gen -> auto with its four stashes is iterations 1-2 of the cycles below)
+    "cycle": ("iam_gan", 2, 2, 256, None, 12, None, 7),
     # the shipped 7-lesson cycle at BASELINE configs[2] (a_batch_size = 1) and on the RIMES config (78 classes, ragged widths)
     "cycle_a1": ("iam_gan", 2, 1, 256, None, 12, None, 7),
     "cycle_rimes": ("rimes_gan", 1, 2, 1024, 256, 14, None, 7),
@@ -118,7 +120,8 @@ def run_case(name, wide):
             return torch.DoubleTensor(*a).as_subclass(_Wide)
         torch.FloatTensor = float_tensor
         _rl = torch.randn_like
-        torch.randn_like = lambda t, **k: _rl(t.float(), **k).double()
+        torch.randn_like = lambda t, **k: _rl(t.to(torch.float32), **k).double()
+        torch.Tensor.float = lambda self, *a, **k: self.double()    # explicit .float() casts (model/loss.py MSELoss target) widen too
     model = HWWithStyle(cfg["model"])
     model.load_state_dict(model_sd)
     if wide:
@@ -164,17 +167,21 @@ def main():
         res = {}
         for wide in (0, 1):
             tmp = "/tmp/hwg_lessons_%s_%d.json" % (name, wide)
+            if os.environ.get("HWG_GOLDEN_REUSE") and os.path.exists(tmp):
+                res[wide] = json.load(open(tmp))
+                continue
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", name, str(wide), tmp])
             res[wide] = json.load(open(tmp))
         r32, r64 = res[0], res[1]
         which, B, A, W, minW, L, curriculum, iters = CASES[name]
         out = {"case": name, "config": which, "batch_size": B, "a_batch_size": A, "W": W, "min_width": minW, "label_len": L,
-               "curriculum": curriculum, "wseed_model": WSEED_MODEL, "wseed_enc": WSEED_ENC, "names": r32["names"], "u_after": r32["u_after"],
+               "curriculum": curriculum, "wseed_model": WSEED_MODEL, "wseed_enc": WSEED_ENC, "names": r32["names"], "u_after": r32["u_after"], "u_after64": r64["u_after"],
                "iterations": []}
         for a, b in zip(r32["iterations"], r64["iterations"]):
             assert a["lesson"] == b["lesson"]
-            for k in a["log"]:   # same draws in both precisions, or the comparison is meaningless
-                assert abs(a["log"][k] - b["log"][k]) <= 2e-3 * max(abs(b["log"][k]), 1e-2), (name, k, a["log"][k], b["log"][k])
+            for k in a["log"]:   # same draws in both precisions, or the comparison is meaningless (a different noise tensor or dropout
+                # mask moves a loss by tens of percent; fp32 drift over a chained cycle stays below one percent)
+                assert abs(a["log"][k] - b["log"][k]) <= 3e-2 * max(abs(b["log"][k]), 1e-2), (name, k, a["log"][k], b["log"][k])
             out["iterations"].append({"lesson": a["lesson"], "log": a["log"], "log64": b["log"], "grads": a["grads"], "grads64": b["grads"],
                                       "update": a["update"], "update64": b["update"]})
         path = os.path.join(ROOT, "tests", "golden", "lessons_%s.json" % name)
