@@ -14,7 +14,7 @@ import timeit
 import torch
 import torch.distributed as dist
 
-from ..logger import install_reference_aliases
+from ..logger import install_reference_aliases, load_checkpoint
 from ..utils.curriculum import Curriculum
 
 
@@ -229,8 +229,7 @@ class BaseTrainer:
 
     def _resume_checkpoint(self, resume_path):
         self.logger.info("Loading checkpoint: %s ...", resume_path)
-        install_reference_aliases()   # checkpoints pickle the reference's logger.logger.Logger
-        ckpt = torch.load(resume_path, map_location="cpu", weights_only=False)
+        ckpt = load_checkpoint(resume_path)   # (checkpoints pickle the reference's logger.logger.Logger)
         self.start_iteration = ckpt["iteration"] + 1
         self.monitor_best = ckpt.get("monitor_best", self.monitor_best)
         sd = {k: v for k, v in ckpt["state_dict"].items() if not k.startswith("style_from_normal")}

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
 
   // bias gradient = column sums of u: taken by the workgroups of the first tap / first v tile from their LDS copy of the u tile
   const bool do_bias = a.bias_on && tap == 0 && tv == 0 && tid < BMU;
-  float bsum = 0.f;
+  double bsum = 0.0;   // a bias gradient is the difference of large, nearly cancelling partial sums (real vs fake lines in a `disc` lesson): fp64
 
   if (T > 0) { load_tile(); store_tile(0); }
   __syncthreads();
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
     const float* Vb = Vs + buf * BKP * BNV;
     if (do_bias) {
 #pragma unroll
-      for (int kp = 0; kp < BKP; ++kp) bsum += Ub[kp * BMU + tid];
+      for (int kp = 0; kp < BKP; ++kp) bsum += (double)Ub[kp * BMU + tid];
     }
     // software pipeline over groups of PF k pairs: the LDS reads of group g+1 are issued before the MFMAs of group g
     // (sched_barrier keeps the compiler from re-serialising them into read-wait-MFMA triples)
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
     __syncthreads();
   }
 
-  if (do_bias && k0 + tid < a.K) a.part[(long long)blockIdx.x * a.pstride + (long long)RS * a.K * a.C + k0 + tid] = bsum;
+  if (do_bias && k0 + tid < a.K) a.part[(long long)blockIdx.x * a.pstride + (long long)RS * a.K * a.C + k0 + tid] = (float)bsum;
 
   if (WAVES_K > 1) {
     // cross-wave reduction of the per-wave K slices (tile buffers are free now)
@@ -687,21 +687,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, lon
                                                              float* direct_out, int accumulate) {
   constexpr int CG = 64 / V;        // column groups per block
   constexpr int RL = 256 / CG;      // row lanes
-  __shared__ float red[RL][64];
+  __shared__ double red[RL][64];
   const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
   const int c = blockIdx.y * 64 + cg * V;
   const long long rb = blockIdx.x * rows_per_chunk;
   const long long re = min(rb + rows_per_chunk, rows);
-  float s[V];
+  double s[V];        // fp64: column sums feed bias gradients, which are small differences of large sums
 #pragma unroll
-  for (int e = 0; e < V; ++e) s[e] = 0.f;
+  for (int e = 0; e < V; ++e) s[e] = 0.0;
   if (c < C) {
     for (long long rr = rb + rl; rr < re; rr += RL) {
       if (V == 4) {
         const float4 v = *reinterpret_cast<const float4*>(x + rr * C + c);
-        s[0] += v.x; s[1 % V] += v.y; s[2 % V] += v.z; s[3 % V] += v.w;
+        s[0] += (double)v.x; s[1 % V] += (double)v.y; s[2 % V] += (double)v.z; s[3 % V] += (double)v.w;
       } else {
-        s[0] += x[rr * C + c];
+        s[0] += (double)x[rr * C + c];
       }
     }
   }
@@ -711,11 +711,11 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, lon
   if (threadIdx.x < 64) {
     const int cc = blockIdx.y * 64 + threadIdx.x;
     if (cc < C) {
-      float v = 0.f;
+      double v = 0.0;
 #pragma unroll
       for (int r = 0; r < RL; ++r) v += red[r][threadIdx.x];
-      if (direct_out) direct_out[cc] = accumulate ? direct_out[cc] + v : v;
-      else part[(long long)blockIdx.x * C + cc] = v;
+      if (direct_out) direct_out[cc] = accumulate ? direct_out[cc] + (float)v : (float)v;
+      else part[(long long)blockIdx.x * C + cc] = (float)v;
     }
   }
 }

@@ -909,7 +909,7 @@ extern "C" int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const f
   k.nsplit = p.nsplit;
   k.part = (float*)workspace;
   dim3 grid(hwg_cdiv(k.M, p.tm), hwg_cdiv(d->K, p.tn), p.nsplit);
-  const int prof = hwg_prof_open(HWG_PROF_CONV, 2.0 * d->N * d->P * d->Q * (double)d->K * d->C * 9.0, st);
+  const int prof = hwg_prof_open(HWG_PROF_CONV_WINO, 2.0 * d->N * d->P * d->Q * (double)d->K * d->C * 9.0, st);
   if (p.cfg == 0) hipLaunchKernelGGL((wino_conv_kernel<4, 2>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 1) hipLaunchKernelGGL((wino_conv_kernel<2, 4>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 2) hipLaunchKernelGGL((wino_conv_kernel<8, 1>), grid, dim3(512), 0, st, k);

@@ -30,7 +30,7 @@ void hwg_set_error(const char* fmt, ...);
 // launch profiler (hwg_core.hip): returns a record index or -1 when profiling is off
 int hwg_prof_open(int kind, double work, hipStream_t st);
 void hwg_prof_close(int rec, hipStream_t st);
-enum { HWG_PROF_CONV = 0, HWG_PROF_WGRAD = 1, HWG_PROF_CONV_REDUCE = 2, HWG_PROF_WGRAD_REDUCE = 3, HWG_PROF_CONV_DIRECT = 4, HWG_PROF_WGRAD_DIRECT = 5 };
+enum { HWG_PROF_CONV = 0, HWG_PROF_WGRAD = 1, HWG_PROF_CONV_REDUCE = 2, HWG_PROF_WGRAD_REDUCE = 3, HWG_PROF_CONV_DIRECT = 4, HWG_PROF_WGRAD_DIRECT = 5, HWG_PROF_CONV_WINO = 6, HWG_PROF_WGRAD_WINO = 7 };
 
 static inline int hwg_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

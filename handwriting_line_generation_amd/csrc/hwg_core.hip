@@ -12,7 +12,7 @@ void hwg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* hwg_last_error(void) { return g_err; }
-extern "C" int hwg_abi_version(void) { return 2; }
+extern "C" int hwg_abi_version(void) { return 3; }
 extern "C" int hwg_device_ok(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

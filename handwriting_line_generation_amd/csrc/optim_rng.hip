@@ -39,7 +39,23 @@ __global__ __launch_bounds__(256) void mt_abs_sum_kernel(MtArgs a, double* out) 
   }
   for (long long i = off + 4 * n4 + threadIdx.x; i < end; i += 256) s += (double)fabsf(g[i]);
   s = block_sum_d(s, sm);
-  if (threadIdx.x == 0) atomicAdd(out + t, s);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;      // per-chunk partial; mt_abs_sum_final_kernel adds a tensor's chunks in table order
+}
+
+// sums[t] = sum of the chunk partials of tensor t, in chunk-table order (a tensor's chunks are consecutive entries): deterministic,
+// unlike an atomicAdd per chunk
+__global__ __launch_bounds__(256) void mt_abs_sum_final_kernel(const double* part, const int* chunk_tensor, int nchunks, int nt, double* sums) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nt) return;
+  // first chunk of tensor t by binary search (chunk_tensor is non-decreasing)
+  int lo = 0, hi = nchunks;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_tensor[mid] < t) lo = mid + 1; else hi = mid;
+  }
+  double s = 0.0;
+  for (int c = lo; c < nchunks && chunk_tensor[c] == t; ++c) s += part[c];
+  sums[t] = s;
 }
 
 // coefficients of the balanced add:  coef[k][t] = x_k * D_t / R_kt   (0 when the stashed tensor is absent or all-zero)
@@ -235,10 +251,16 @@ MtArgs make_mt(const void* pa, const void* pb, const void* pc, const void* pd, c
 }  // namespace
 
 extern "C" int hwg_mt_abs_sum(const void* ptrs, const void* numel, const void* chunk_tensor, const void* chunk_off, int nchunks, int chunk,
-                              double* out_sums, void* stream) {
-  HWG_REQUIRE(ptrs && numel && chunk_tensor && chunk_off && out_sums && nchunks > 0 && chunk > 0, "mt_abs_sum: bad arguments");
+                              int nt, double* chunk_partials, double* out_sums, void* stream) {
+  HWG_REQUIRE(ptrs && numel && chunk_tensor && chunk_off && chunk_partials && out_sums && nchunks > 0 && chunk > 0 && nt > 0, "mt_abs_sum: bad arguments");
   MtArgs a = make_mt(ptrs, nullptr, nullptr, nullptr, numel, chunk_tensor, chunk_off, chunk);
-  hipLaunchKernelGGL(mt_abs_sum_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a, out_sums);
+  if (hipMemsetAsync(chunk_partials, 0, (size_t)nchunks * sizeof(double), (hipStream_t)stream) != hipSuccess) {   // absent tensors leave theirs untouched
+    hwg_set_error("mt_abs_sum: memset failed");
+    return HWG_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(mt_abs_sum_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a, chunk_partials);
+  hipLaunchKernelGGL(mt_abs_sum_final_kernel, dim3(hwg_cdiv(nt, 256)), dim3(256), 0, (hipStream_t)stream, (const double*)chunk_partials,
+                     (const int*)chunk_tensor, nchunks, nt, out_sums);
   HWG_LAUNCH_CHECK("mt_abs_sum");
   return HWG_OK;
 }

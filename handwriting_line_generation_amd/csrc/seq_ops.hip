@@ -158,15 +158,23 @@ __global__ __launch_bounds__(256) void ctc_beta_grad_kernel(const float* lp, con
     float* lsum = lcab + C;    // [C] sum of exp(alpha+beta - max)
     for (int c = threadIdx.x; c < C; c += 256) { lmax[c] = NEG; lsum[c] = 0.f; }
     __syncthreads();
-    // log-sum of alpha*beta per class, one thread per extended-target state (two LDS-atomic passes: max, then sum)
-    for (int s = threadIdx.x; s < NS; s += 256) {
-      const float v = la[(long long)t * NSmax + s] + cur[s];
-      if (v != NEG) atomicMax(&lmax[ctc_ext(tg, s)], v);
-    }
-    __syncthreads();
-    for (int s = threadIdx.x; s < NS; s += 256) {
-      const float v = la[(long long)t * NSmax + s] + cur[s];
-      if (v != NEG) { const int c = ctc_ext(tg, s); atomicAdd(&lsum[c], expf(v - lmax[c])); }
+    // log-sum of alpha*beta per class: one thread per class walks the extended target in state order (a fixed summation order: LDS atomics
+    // would make the gradient differ in its last bits from run to run, which Adam's sign-like first steps amplify)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float m = NEG;
+      for (int s = (c == 0 ? 0 : 1); s < NS; s += 2) {
+        if (ctc_ext(tg, s) != c) continue;
+        const float v = la[(long long)t * NSmax + s] + cur[s];
+        if (v > m) m = v;
+      }
+      float sum = 0.f;
+      if (m != NEG)
+        for (int s = (c == 0 ? 0 : 1); s < NS; s += 2) {
+          if (ctc_ext(tg, s) != c) continue;
+          const float v = la[(long long)t * NSmax + s] + cur[s];
+          if (v != NEG) sum += expf(v - m);
+        }
+      lmax[c] = m; lsum[c] = sum;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {

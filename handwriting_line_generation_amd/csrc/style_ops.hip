@@ -17,17 +17,29 @@ __global__ void gather_windows_kernel(const float* x, int Wx, int C, const int* 
     patches[i] = (pos >= 0 && pos < Wx) ? x[((long long)idx_b[k] * Wx + pos) * C + c] : 0.f;
   }
 }
-// dx[b_i][pos][c] += dpatches[i][j][c]   (windows overlap -> atomics)
-__global__ void scatter_windows_kernel(const float* dpatches, int Wx, int C, const int* idx_b, const int* idx_pos, int n, int w, float* dx) {
+// dx[b][pos][c] = sum over the windows that cover (b, pos) of dpatches[k][j][c]. The windows overlap, so a scatter would need floating
+// point atomics (non-deterministic summation order); instead the window list is inverted once (at most ONE window is centred on a given
+// (sample, column): the column's arg-max class) and every output element gathers its <= 2w+1 contributions in a fixed order.
+__global__ void window_index_kernel(const int* idx_b, const int* idx_pos, int n, int Wx, int* win_of) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) win_of[idx_b[k] * Wx + idx_pos[k]] = k;
+}
+__global__ void scatter_windows_kernel(const float* dpatches, int B, int Wx, int C, const int* win_of, int w, float* dx) {
   const int WW = 2 * w + 1;
-  const long long total = (long long)n * WW * C;
+  const long long total = (long long)B * Wx * C;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const long long t = i / C;
-    const int j = (int)(t % WW);
-    const int k = (int)(t / WW);
-    const int pos = idx_pos[k] - w + j;
-    if (pos >= 0 && pos < Wx) atomicAdd(dx + ((long long)idx_b[k] * Wx + pos) * C + c, dpatches[i]);
+    const int pos = (int)(t % Wx);
+    const int b = (int)(t / Wx);
+    float acc = 0.f;
+    for (int j = 0; j < WW; ++j) {
+      const int centre = pos + w - j;
+      if (centre < 0 || centre >= Wx) continue;
+      const int k = win_of[b * Wx + centre];
+      if (k >= 0) acc += dpatches[((long long)k * WW + j) * C + c];
+    }
+    dx[i] = acc;
   }
 }
 // total[b][c] = sum_{i: seg_i == b} wgt_i * v[i][c];  wsum[b] = sum wgt_i;  out = wsum != 0 ? total / wsum : total
@@ -301,11 +313,16 @@ extern "C" int hwg_gather_windows(const float* x, int B, int Wx, int C, const in
   HWG_LAUNCH_CHECK("gather_windows");
   return HWG_OK;
 }
-extern "C" int hwg_scatter_windows(const float* dpatches, int B, int Wx, int C, const int* idx_b, const int* idx_pos, int n, int window, float* dx,
-                                   void* stream) {
-  HWG_REQUIRE(dpatches && idx_b && idx_pos && dx && B > 0 && Wx > 0 && C > 0 && n > 0 && window >= 0, "scatter_windows: bad arguments");
-  const long long total = (long long)n * (2 * window + 1) * C;
-  hipLaunchKernelGGL(scatter_windows_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dpatches, Wx, C, idx_b, idx_pos, n,
+extern "C" int hwg_scatter_windows(const float* dpatches, int B, int Wx, int C, const int* idx_b, const int* idx_pos, int n, int window, int* win_of,
+                                   float* dx, void* stream) {
+  HWG_REQUIRE(dpatches && idx_b && idx_pos && win_of && dx && B > 0 && Wx > 0 && C > 0 && n > 0 && window >= 0, "scatter_windows: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(win_of, 0xFF, (size_t)B * Wx * sizeof(int), st) != hipSuccess) {
+    hwg_set_error("scatter_windows: memset failed");
+    return HWG_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(window_index_kernel, dim3(hwg_cdiv(n, 256)), dim3(256), 0, st, idx_b, idx_pos, n, Wx, win_of);
+  hipLaunchKernelGGL(scatter_windows_kernel, dim3(hwg_stream_grid((long long)B * Wx * C, 256)), dim3(256), 0, st, dpatches, B, Wx, C, (const int*)win_of,
                      window, dx);
   HWG_LAUNCH_CHECK("scatter_windows");
   return HWG_OK;

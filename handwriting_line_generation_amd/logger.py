@@ -29,3 +29,11 @@ def install_reference_aliases():
         mod = sys.modules.get(name)
         if mod is None or not hasattr(mod, "Logger"):
             sys.modules[name] = this
+
+
+def load_checkpoint(path):
+    """torch.load of a checkpoint written by this package or by the reference (whose pickled `logger.logger.Logger` needs the aliases, and
+    whose files torch >= 2.6 refuses under its weights-only default)"""
+    import torch
+    install_reference_aliases()
+    return torch.load(path, map_location="cpu", weights_only=False)

@@ -114,6 +114,9 @@ class CharStyleEncoder(nn.Module):
             x = ops.pad2d(x, d // 2, d // 2 + d % 2, 0, 0, "replicate")
         return x, recog
 
+    # workload counters (bench.py reports them: how many character windows / distinct experts a style extraction ran)
+    stats = {"calls": 0, "windows": 0, "experts": 0}
+
     def forward(self, x, recog):
         with ops.scope("StyleEx"):
             return self._forward(x, recog)
@@ -153,6 +156,10 @@ class CharStyleEncoder(nn.Module):
             d = Wf - T0
             pred = np.pad(pred, ((0, 0), (d // 2, d // 2 + d % 2)), mode="edge")
         bb, pp = np.nonzero(pred > 0)                 # row-major: author, then column
+        st = self.stats
+        st["calls"] += 1
+        st["windows"] += int(bb.size)
+        st["experts"] += int(np.unique(pred[bb, pp]).size) if bb.size else 0
         feat_rows = feat.reshape(B, Wf, C)
         if bb.size:
             cls_all = pred[bb, pp]

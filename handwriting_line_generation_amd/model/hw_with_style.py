@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from ..logger import load_checkpoint
 from ..base.base_model import BaseModel
 from .char_style import CharStyleEncoder
 from .cnn_only_hwr import CNNOnlyHWR
@@ -73,7 +74,7 @@ class HWWithStyle(BaseModel):
         pre = g("pretrained_hwr")
         if pre is not None:
             if os.path.exists(pre):
-                snap = torch.load(pre, map_location="cpu", weights_only=False)
+                snap = load_checkpoint(pre)
                 sd = {k[4:]: v for k, v in snap["state_dict"].items() if k.startswith("hwr.")} or snap["state_dict"]
                 self.hwr.load_state_dict(sd)
             elif not g("RUN"):

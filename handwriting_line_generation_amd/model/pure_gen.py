@@ -98,8 +98,10 @@ class _EqualConv1x1(nn.Module):
     def __init__(self, in_channel, out_channel):
         super().__init__()
         self.conv = nn.Module()
-        self.conv.weight_orig = nn.Parameter(torch.randn(out_channel, in_channel, 1, 1))
+        # registration order of the reference: nn.Conv2d registers (weight, bias), the equal-lr hook then deletes `weight` and registers
+        # `weight_orig` behind `bias` - parameter order matters: torch.optim.Adam's checkpointed state is keyed by parameter index
         self.conv.bias = nn.Parameter(torch.zeros(out_channel))
+        self.conv.weight_orig = nn.Parameter(torch.randn(out_channel, in_channel, 1, 1))
         self.scale = math.sqrt(2.0 / in_channel)
 
     def forward(self, x):

@@ -281,7 +281,8 @@ def prof_enable(on):
 
 
 def prof_stop():
-    """-> list of (kind, shape, work, seconds); kind in conv_mfma_kernel / wgrad_mfma_kernel / conv_split_reduce / wgrad_reduce"""
+    """-> list of (kind, shape, work, seconds); kind in conv_mfma_kernel / wgrad_mfma_kernel / conv_split_reduce / wgrad_reduce / direct kernels /
+    wino_conv_kernel (the three Winograd forward / data-gradient kernels; work = direct-form FLOPs of the layer) / wino_wgrad_kernel"""
     global PROF_SHAPES
     import numpy as np
     cap = 200000
@@ -290,7 +291,8 @@ def prof_stop():
     n = L.query("hwg_prof_stop", kinds.ctypes.data, tags.ctypes.data, work.ctypes.data, ms.ctypes.data, cap)
     by_tag = {v: k for k, v in (PROF_SHAPES or {}).items()}
     PROF_SHAPES = None
-    names = ("conv_mfma_kernel", "wgrad_mfma_kernel", "conv_split_reduce_kernel", "wgrad_reduce_kernel", "conv_direct_kernels", "wgrad_direct_kernels")
+    names = ("conv_mfma_kernel", "wgrad_mfma_kernel", "conv_split_reduce_kernel", "wgrad_reduce_kernel", "conv_direct_kernels", "wgrad_direct_kernels",
+             "wino_conv_kernel", "wino_wgrad_kernel")
     return [(names[kinds[i]], by_tag.get(int(tags[i])), float(work[i]), float(ms[i]) * 1e-3) for i in range(n)]
 
 
@@ -320,7 +322,9 @@ def _run_conv(x, wp, bias, N, H, W, C, K, R, S, stride, pad, dil, P, Q, transpos
     return y
 
 
-WINOGRAD = True     # 3x3 / stride 1 / dilation 1 products with >= 16 output channels run as F(2x2,3x3) (csrc/conv_wino.hip)
+# 3x3 / stride 1 / dilation 1 products with >= 16 output channels run as F(2x2,3x3) (csrc/conv_wino.hip); HWG_WINO=0 keeps them on the
+# direct implicit-GEMM kernels (A/B timing and numerics comparisons)
+WINOGRAD = bool(int(__import__("os").environ.get("HWG_WINO", "1") or 1))
 
 
 def _wino_ok(C, K, R, S, stride, dil):
@@ -1146,8 +1150,9 @@ class _GatherWindows(Function):
     def backward(ctx, dy):
         idx_b, idx_pos = ctx.saved_tensors
         B, Wx, C, n, window = ctx.cfg
-        dx = torch.zeros((B, Wx, C), dtype=torch.float32, device=dy.device)
-        L.call("hwg_scatter_windows", dy.contiguous(), B, Wx, C, idx_b, idx_pos, n, window, dx, _stream())
+        dx = torch.empty((B, Wx, C), dtype=torch.float32, device=dy.device)
+        win_of = torch.empty((B * Wx,), dtype=torch.int32, device=dy.device)
+        L.call("hwg_scatter_windows", dy.contiguous(), B, Wx, C, idx_b, idx_pos, n, window, win_of, dx, _stream())
         return dx, None, None, None
 
 
@@ -1521,15 +1526,21 @@ class LinearBank:
             self._gkey = key
         return self._gtab
 
+    def params(self):
+        return [m.weight for m in self.linears] + [m.bias for m in self.linears]
+
     def __call__(self, x):
-        outs = _LinearBank.apply(x.contiguous(), self)
+        # the parameters are passed to the autograd function although the kernels reach them through pointer tables: autograd must see
+        # inputs that require grad, or - when x itself does not (the sampled styles of the text-only "gen" lessons) - it would never call
+        # backward and the parameters would silently get no gradient
+        outs = _LinearBank.apply(x.contiguous(), self, *self.params())
         h = self.halves
         return [outs[l * h:(l + 1) * h] for l in range(self.L)]
 
 
 class _LinearBank(Function):
     @staticmethod
-    def forward(ctx, x, bank):
+    def forward(ctx, x, bank, *params):
         _chk(x, "linear bank input")
         B, I = x.shape
         assert I == bank.I
@@ -1560,7 +1571,7 @@ class _LinearBank(Function):
         need = L.query("hwg_linear_bank_bwd_workspace", bank.total, B, I)
         ws = workspace(need, x.device)
         L.call("hwg_linear_bank_bwd", x, dyptr, wptr, gw, gb, O, first, bank.L, B, I, bank.halves, bank.total, dx, ws, ws.numel(), _stream())
-        return dx, None
+        return (dx, None) + (None,) * (2 * bank.L)      # parameter gradients were accumulated in place (grad_tables)
 
 
 class MLPChain:
@@ -1595,13 +1606,16 @@ class MLPChain:
             self._gkey = key
         return self._gtab
 
+    def params(self):
+        return [m.weight for m in self.linears] + [m.bias for m in self.linears]
+
     def __call__(self, x):
-        return _MLPChain.apply(x.contiguous(), self)
+        return _MLPChain.apply(x.contiguous(), self, *self.params())    # (parameters passed for autograd's sake, see LinearBank.__call__)
 
 
 class _MLPChain(Function):
     @staticmethod
-    def forward(ctx, x, chain):
+    def forward(ctx, x, chain, *params):
         _chk(x, "mlp chain input")
         B, D = x.shape
         assert D == chain.D
@@ -1621,4 +1635,4 @@ class _MLPChain(Function):
         gw, gb = chain.grad_tables(acts.device)
         dx = torch.empty((B, D), dtype=torch.float32, device=acts.device) if ctx.needs_input_grad[0] else None
         L.call("hwg_mlp_chain_bwd", dout.contiguous(), acts, wptr, gw, gb, chain.L, B, D, chain.slope, dx, _stream())
-        return dx, None
+        return (dx, None) + (None,) * (2 * chain.L)

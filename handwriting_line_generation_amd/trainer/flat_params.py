@@ -129,8 +129,10 @@ class FlatParams:
         self._stash_pool.append(stash[0])
 
     def abs_sums(self, flat, mask):
-        out = torch.zeros(self.nt, dtype=torch.float64, device=self.device)
-        L.call("hwg_mt_abs_sum", self.masked_ptrs(flat, mask), self.d_numel, self.d_chunk_tensor, self.d_chunk_off, self.nchunks, CHUNK, out, self._st())
+        out = torch.empty(self.nt, dtype=torch.float64, device=self.device)
+        part = torch.empty(self.nchunks, dtype=torch.float64, device=self.device)
+        L.call("hwg_mt_abs_sum", self.masked_ptrs(flat, mask), self.d_numel, self.d_chunk_tensor, self.d_chunk_off, self.nchunks, CHUNK, self.nt, part, out,
+               self._st())
         return out
 
     def balance(self, stashes, multipliers):

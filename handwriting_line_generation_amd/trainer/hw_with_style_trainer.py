@@ -20,6 +20,7 @@ import torch.distributed as dist
 
 from .. import ops
 from ..base.base_trainer import BaseTrainer
+from ..logger import load_checkpoint
 from .flat_params import allreduce_gradient_sets, start_stash_allreduce
 from ..data.text_data import TextData
 from ..model.autoencoder import Encoder2
@@ -96,7 +97,7 @@ class HWWithStyleTrainer(BaseTrainer):
             dims = {"2": 256, "2tight": 32, "2tighter": 16}
             if etype not in dims:
                 raise NotImplementedError("perceptual encoder type %r: only the Encoder2 family is on the accelerated path" % etype)
-            snap = torch.load(tr["encoder_weights"], map_location="cpu", weights_only=False)
+            snap = load_checkpoint(tr["encoder_weights"])
             enc_sd = {k[8:]: v for k, v in snap["state_dict"].items() if k.startswith("encoder.")}
             self.encoder = Encoder2(dims[etype])
             self.encoder.load_state_dict(enc_sd)
@@ -152,6 +153,16 @@ class HWWithStyleTrainer(BaseTrainer):
             self.model.train()
         lesson = self.curriculum.getLesson(iteration) if self.curriculum else None
         instance = self._next_instance(lesson or [])
+        produced = self._forward_backward(instance, lesson)
+        if produced is None:
+            return {}
+        return self._apply_step(lesson, iteration, instance, *produced)
+
+    def _forward_backward(self, instance, lesson):
+        """Gradient production of one iteration (trainer :236-338): zero the gradients of the optimizer(s) in play, run the lesson's forward
+        graph, weight the losses and run the up-to-three backward passes of the balancing scheme; every separately balanced gradient set is
+        stashed (clone-and-zero) as it is produced, and a "no-step" lesson stashes its main set as well. Everything a rank contributes to a
+        data-parallel step is in `self.flat` and `self.saved_grads` afterwards. Returns (scaled losses, pred) or None when the batch is skipped."""
         self.optimizer.zero_grad()
         if self.curriculum and any("disc" in l for l in lesson):
             self.optimizer_discriminator.zero_grad()
@@ -160,13 +171,13 @@ class HWWithStyleTrainer(BaseTrainer):
             # the reference skips a batch without any text; data parallel: if one rank has to skip, all do (a rank that returned
             # alone would leave its peers waiting in the gradient all-reduce)
             if self._skip_together(all(l == 0 for l in instance["label_lengths"])):
-                return {}
+                return None
             losses = self.run_gen(instance, lesson)
             pred = None
         else:
             pred, losses = self.run_hwr(instance)
         if losses is None:
-            return {}
+            return None
 
         loss = recogLoss = autoGenLoss = 0
         scaled = {}
@@ -180,7 +191,6 @@ class HWWithStyleTrainer(BaseTrainer):
             else:
                 loss = v if isinstance(loss, int) else ops.add(loss, v)
 
-        f = self.flat
         if self.balance_loss:
             for part in (autoGenLoss, recogLoss):
                 if not isinstance(part, int):
@@ -194,9 +204,16 @@ class HWWithStyleTrainer(BaseTrainer):
         if not isinstance(loss, int):
             loss.backward()
             ops.join_side_stream()
-
         if self.balance_loss and "no-step" in lesson:
             self.saved_grads.append(self._stash())
+        return scaled, pred
+
+    def _apply_step(self, lesson, iteration, instance, scaled, pred):
+        """Gradient consumption (trainer :340-391): data-parallel averaging of every gradient set, balancing of the stashed sets into the
+        current one, clip to +-2, NaN scan, optimizer step; then the log."""
+        f = self.flat
+        if self.balance_loss and "no-step" in lesson:
+            pass
         elif self.balance_loss and len(self.saved_grads) > 0:
             self._allreduce_grads(self.saved_grads)
             multipliers = None

@@ -41,7 +41,7 @@ int hwg_device_ok(void);
 /* Launch profiler for the matrix-core kernels (bench.py's roofline measurement): between hwg_prof_start() and hwg_prof_stop() every
  * MFMA convolution / weight-gradient launch (and their reduce passes) is bracketed by a HIP event pair on its stream. hwg_prof_tag()
  * labels the launches of the calling thread's next calls. hwg_prof_stop() waits for the recorded events and returns, per launch,
- * kind (0 conv MFMA, 1 wgrad MFMA, 2 conv split reduce, 3 wgrad reduce, 4 direct conv, 5 direct wgrad incl. its reduce), tag, algorithmic work (flops; bytes for the reduce passes) and ms.
+ * kind (0 conv MFMA, 1 wgrad MFMA, 2 conv split reduce, 3 wgrad reduce, 4 direct conv, 5 direct wgrad incl. its reduce, 6 Winograd conv, 7 Winograd wgrad), tag, algorithmic work (flops; bytes for the reduce passes) and ms.
  * Returns the number of records written. */
 int hwg_prof_start(int max_records);
 int hwg_prof_enable(int on);   /* pause / resume recording inside an open profile (sampled profiling: the event pairs cost ~7 % of a step) */
@@ -249,7 +249,10 @@ int hwg_argmax_rows(const float* x, int* out, long long rows, int C, void* strea
  * Character-specific style extraction helpers (model/char_style.py:204-235,286).
  * ------------------------------------------------------------------------------------------ */
 int hwg_gather_windows(const float* x, int B, int Wx, int C, const int* idx_b, const int* idx_pos, int n, int window, float* patches, void* stream);
-int hwg_scatter_windows(const float* dpatches, int B, int Wx, int C, const int* idx_b, const int* idx_pos, int n, int window, float* dx, void* stream);
+/* gradient of hwg_gather_windows: dx[b][pos][c] = sum of the window entries that cover (b, pos), gathered in a fixed order (no atomics).
+ * At most one window may be centred on a given (sample, column) - true for the arg-max map the windows come from. win_of: B*Wx ints of scratch. */
+int hwg_scatter_windows(const float* dpatches, int B, int Wx, int C, const int* idx_b, const int* idx_pos, int n, int window, int* win_of,
+                        float* dx, void* stream);
 int hwg_segment_weighted_mean(const float* v, const float* wgt, const int* seg, int n, int C, int B, float* out, float* wsum, void* stream);
 int hwg_segment_weighted_mean_bwd(const float* dout, const float* wgt, const int* seg, const float* wsum, int n, int C, float* dv, void* stream);
 int hwg_gather_scores(const float* x, int B, int Wx, int C, const int* idx_b, const int* idx_pos, const int* idx_cls, int n, float* out, void* stream);
@@ -298,8 +301,10 @@ int hwg_segment_accumulate_ptr(const float* rows, const int* seg_start, const in
  * Tensor lists are device tables: ptrs (int64 addresses, 0 = absent), numel (int64), and a chunk table
  * (chunk_tensor int32, chunk_off int64) with `chunk` elements per entry.
  * ------------------------------------------------------------------------------------------ */
+/* out_sums[t] = sum |x| over tensor t (all nt tensors; absent ones give 0). Two stages, no atomics: per-chunk partials (chunk_partials,
+ * nchunks doubles of scratch), then the chunks of a tensor - consecutive entries of the chunk table - are added in table order. */
 int hwg_mt_abs_sum(const void* ptrs, const void* numel, const void* chunk_tensor, const void* chunk_off, int nchunks, int chunk,
-                   double* out_sums, void* stream);
+                   int nt, double* chunk_partials, double* out_sums, void* stream);
 int hwg_mt_balance_coef(const double* sumD, const double* sumR, const void* numel, const void* ptr_grad, const void* ptr_R,
                         const float* xs, int nsets, int nt, float* coef, void* stream);
 int hwg_mt_axpy(const void* ptrs_dst, const void* ptrs_src, const float* coef, const void* numel, const void* chunk_tensor,

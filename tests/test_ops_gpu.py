@@ -381,6 +381,38 @@ def test_dtw_matches_python_restatement(cuda):
         assert torch.equal(gt.cpu(), gt_ref) and int(meta[0].item()) == pos_ref and int(meta[1].item()) == 0
 
 
+def test_dtw_reference_known_answers_on_hip(cuda):
+    """the reference's own correct_pred outputs (tests/golden/seq_kat.npz, recorded by tools/gen_golden.py from model/hw_with_style.py:18-74:
+    exact ties resolved by first minimum, T=122 / L=30 full size, paths longer than T) straight through hwg_dtw_align: bit exact"""
+    import os
+    import numpy as np
+    from handwriting_line_generation_amd import ops
+    kat = np.load(os.path.join(os.path.dirname(__file__), "golden", "seq_kat.npz"))
+    for n in range(5):
+        pred = torch.from_numpy(kat["dtw%d_pred" % n]); label = torch.from_numpy(kat["dtw%d_label" % n])
+        got, lens = ops.dtw_align(pred.to(cuda).contiguous(), label.to(cuda))
+        ref = torch.from_numpy(kat["dtw%d_out" % n])
+        assert got.dtype == torch.int64 and torch.equal(got.cpu(), ref), "reference KAT dtw%d differs on the HIP kernel" % n
+
+
+def test_dtw_edge_shapes_exact(cuda):
+    """degenerate geometries of the alignment, recorded from the reference's correct_pred (tests/golden/seq_kat_edges.npz): one prediction
+    step, fewer steps than the blank-interleaved label (the path runs along the label axis and is longer than T), a single character,
+    all-equal costs (every minimum is a tie), one-hot predictions, a zero-padded label tail"""
+    import os
+    import numpy as np
+    from handwriting_line_generation_amd import ops
+    kat = np.load(os.path.join(os.path.dirname(__file__), "golden", "seq_kat_edges.npz"))
+    n = 0
+    while "dtw%d_pred" % n in kat:
+        pred = torch.from_numpy(kat["dtw%d_pred" % n]); label = torch.from_numpy(kat["dtw%d_label" % n]); ref = torch.from_numpy(kat["dtw%d_out" % n])
+        got, lens = ops.dtw_align(pred.to(cuda).contiguous(), label.to(cuda))
+        assert torch.equal(got.cpu(), ref), "dtw edge case %d (T=%d, L=%d)" % (n, pred.shape[0], label.shape[0])
+        assert int(lens.max()) == ref.shape[0]
+        n += 1
+    assert n >= 8
+
+
 def test_style_helpers_rng(cuda):
     from handwriting_line_generation_amd import ops
     g = torch.Generator().manual_seed(14)
@@ -461,6 +493,32 @@ def test_grouped_expert_layers(cuda, R, Cin, Cout, S):
         else:
             _close(gW[e] - 0.5, Wr[e].grad, "grouped wgrad e%d" % e)
             _close(gB[e] - 0.25, Br[e].grad, "grouped bias grad e%d" % e)
+
+
+def test_style_path_parameters_get_gradients_from_a_constant_style(cuda):
+    """text-only "gen" lessons feed the generator a sampled style that does not require grad (trainer :984): the style MLP and the AdaIN
+    affines must still receive their parameter gradients, exactly as torch's Linear modules do"""
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(12)
+    B, I = 4, 128
+    ref_lin = [torch.nn.Linear(I, o) for o in (64, 32)]
+    dev_lin = [torch.nn.Linear(I, o).to(cuda) for o in (64, 32)]
+    ref_chain = [torch.nn.Linear(I, I) for _ in range(3)]
+    dev_chain = [torch.nn.Linear(I, I).to(cuda) for _ in range(3)]
+    for a, b in zip(dev_lin + dev_chain, ref_lin + ref_chain):
+        a.load_state_dict(b.state_dict())
+    x = torch.randn(B, I, generator=g)                      # no requires_grad anywhere on the input side
+    h = x
+    for m in ref_chain:
+        h = F.leaky_relu(m(h), 0.2)
+    sum(m(h).pow(2).sum() for m in ref_lin).backward()
+    hd = ops.MLPChain(dev_chain, 0.2)(x.to(cuda))
+    assert hd.requires_grad, "the chain's output must require grad through its parameters"
+    sum(torch.cat(pr, 1).pow(2).sum() for pr in ops.LinearBank(dev_lin, halves=2)(hd)).backward()
+    for k, (a, b) in enumerate(zip(dev_lin + dev_chain, ref_lin + ref_chain)):
+        assert a.weight.grad is not None and a.bias.grad is not None, "layer %d got no gradient" % k
+        _close(a.weight.grad, b.weight.grad, "dW %d" % k)
+        _close(a.bias.grad, b.bias.grad, "db %d" % k)
 
 
 def test_linear_bank_and_mlp_chain(cuda):

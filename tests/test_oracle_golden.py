@@ -82,6 +82,19 @@ def test_state_dict_schema_matches_reference():
     assert sum(p.numel() for p in m.parameters()) == 47358027 and len(list(m.parameters())) == 1324
 
 
+def test_seq_edge_known_answers():
+    kat = np.load(os.path.join(GOLD, "seq_kat_edges.npz"))
+    n = 0
+    while "dtw%d_pred" % n in kat:
+        out = seq_oracle.correct_pred(torch.from_numpy(kat["dtw%d_pred" % n]), torch.from_numpy(kat["dtw%d_label" % n]))
+        assert np.array_equal(out.numpy(), kat["dtw%d_out" % n]), n
+        if hasattr(seq_oracle, "correct_pred_c"):
+            outc = seq_oracle.correct_pred_c(torch.from_numpy(kat["dtw%d_pred" % n]), torch.from_numpy(kat["dtw%d_label" % n]))
+            assert np.array_equal(outc.numpy(), kat["dtw%d_out" % n]), "C oracle, case %d" % n
+        n += 1
+    assert n >= 8
+
+
 def test_seq_known_answers():
     kat = np.load(os.path.join(GOLD, "seq_kat.npz"))
     for n in range(5):

@@ -27,7 +27,7 @@ def test_loss_path_gradients_vs_fp64(cuda):
     image = torch.rand(B, 1, 64, 4 * T, generator=g) * 2 - 1
     labels = torch.randint(1, 80, (B, 12), generator=g)
 
-    def run(kind, hip, dt=torch.float32):
+    def run(kind, hip, dt=torch.float32, perturb=None):
         torch.manual_seed(77)
         if hip:
             st = style.to(dev).requires_grad_(True)
@@ -39,6 +39,13 @@ def test_loss_path_gradients_vs_fp64(cuda):
             for k in ('G',):
                 for kk, vv in sd[k].items():
                     if vv.dtype.is_floating_point and 'running' not in kk and not kk.endswith(('weight_flip',)) and not ('conv1.2.weight' in kk or 'conv1.1.weight' in kk and vv.shape[1:] == (1, 3, 3)): vv.requires_grad_(True)
+            if perturb is not None:    # conditioning probe: every weight moved by 1e-6 relative
+                gp = torch.Generator().manual_seed(perturb)
+                with torch.no_grad():
+                    for net in sd.values():
+                        for vv in net.values():
+                            if vv.dtype.is_floating_point:
+                                vv.mul_(1 + 1e-6 * torch.randn(vv.shape, generator=gp, dtype=vv.dtype))
             st = style.clone().to(dt).requires_grad_(True)
             if dt == torch.float64:
                 _rl = torch.randn_like
@@ -79,14 +86,22 @@ def test_loss_path_gradients_vs_fp64(cuda):
         lh, dsh, gh = run(kind, True)
         lo, dso, go = run(kind, False)
         ld, dsd, gd = run(kind, False, torch.float64)
+        # conditioning of this loss path: how far the fp64 gradients move when every weight changes by 1e-6 relative (the L1 terms have sign()
+        # derivatives, the recogniser / encoder stacks ReLU and pooling gates); an independent fp32 implementation cannot be closer than that
+        sens, gsens = 0.0, {}
+        for trial in (1, 2, 3, 4):
+            _, dsp, gp_ = run(kind, False, torch.float64, perturb=trial)
+            sens = max(sens, rel(dsp, dsd))
+            for k in gd:
+                gsens[k] = max(gsens.get(k, 0.0), rel(gp_[k], gd[k]))
         if abs(lh - lo) > 1e-5 * max(abs(lo), 1e-3):
             bad.append('%s loss %.8g vs %.8g' % (kind, lh, lo))
         eh, eo = rel(dsh, dsd), rel(dso, dsd)
-        if eh > 4 * eo + 2e-5:
-            bad.append('%s dstyle err vs fp64: HIP %.2e, fp32 oracle %.2e' % (kind, eh, eo))
+        if eh > max(4 * eo + 2e-5, 3 * sens):
+            bad.append('%s dstyle err vs fp64: HIP %.2e, fp32 oracle %.2e, sensitivity %.2e' % (kind, eh, eo, sens))
         for k in ('conv.0.conv2.weight', 'conv.2.conv2.weight', 'conv.4.conv2.weight', 'conv.3.conv1.0.weight'):
             eh, eo = rel(gh[k], gd[k]), rel(go[k], gd[k])
-            if eh > 4 * eo + 2e-5:
-                bad.append('%s d%s err vs fp64: HIP %.2e, fp32 oracle %.2e' % (kind, k, eh, eo))
+            if eh > max(4 * eo + 2e-5, 3 * gsens[k]):
+                bad.append('%s d%s err vs fp64: HIP %.2e, fp32 oracle %.2e, sensitivity %.2e' % (kind, k, eh, eo, gsens[k]))
     rng.set_mode('device')
     assert not bad, '; '.join(bad)

@@ -164,6 +164,42 @@ def gen_seq():
     print("seq_kat: 5 DTW cases, oracle exact")
 
 
+EDGE_DTW = [(1, 2, 1, "rand"), (1, 3, 4, "rand"), (2, 2, 5, "rand"), (3, 1, 1, "rand"), (7, 2, 10, "rand"), (9, 3, 4, "flat"), (40, 2, 3, "flat"),
+            (16, 2, 8, "onehot")]
+
+
+def edge_dtw_case(n):
+    """inputs of the n-th degenerate alignment geometry (shared with tests/test_ops_gpu.py through the stored arrays)"""
+    import torch.nn.functional as F
+    T, B, Lr, kind = EDGE_DTW[n]
+    C = 12
+    g = torch.Generator().manual_seed(500 + n)
+    if kind == "rand":
+        pred = F.log_softmax(torch.randn(T, B, C, generator=g) * 3, dim=2)
+    elif kind == "flat":
+        pred = torch.full((T, B, C), -2.5)
+    else:
+        pred = F.log_softmax(20.0 * F.one_hot(torch.randint(0, C, (T, B), generator=g), C).float(), dim=2)
+    label = torch.randint(1, C, (Lr, B), generator=g)
+    if Lr > 2:
+        label[Lr - 1:, 0] = 0
+    return pred, label
+
+
+def gen_seq_edges():
+    """degenerate geometries of correct_pred (one prediction step, fewer steps than the blank-interleaved label, all-equal costs, one-hot
+    predictions, zero-padded tails) through the reference's own function; the oracle must agree exactly"""
+    from model.hw_with_style import correct_pred
+    recs = {}
+    for n in range(len(EDGE_DTW)):
+        pred, label = edge_dtw_case(n)
+        out = correct_pred(pred, label)
+        assert torch.equal(seq_oracle.correct_pred(pred, label), out), EDGE_DTW[n]
+        recs["dtw%d_pred" % n] = pred.numpy(); recs["dtw%d_label" % n] = label.numpy(); recs["dtw%d_out" % n] = out.numpy()
+    np.savez_compressed(os.path.join(GOLD, "seq_kat_edges.npz"), **recs)
+    print("seq_kat_edges: %d DTW cases, oracle exact" % len(EDGE_DTW))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     what = sys.argv[1:] or ["modules", "seq"]
@@ -171,6 +207,8 @@ if __name__ == "__main__":
         gen_modules()
     if "seq" in what:
         gen_seq()
+    if "seq_edges" in what or "seq" in what:
+        gen_seq_edges()
     if "trainer" in what:
         import gen_golden_trainer
         gen_golden_trainer.main()

@@ -76,7 +76,7 @@ class _Loader:
         return It()
 
 
-def run_case(name, wide):
+def run_case(name, wide, variant=0):
     warnings.filterwarnings("ignore")
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -122,6 +122,12 @@ def run_case(name, wide):
         _rl = torch.randn_like
         torch.randn_like = lambda t, **k: _rl(t.to(torch.float32), **k).double()
         torch.Tensor.float = lambda self, *a, **k: self.double()    # explicit .float() casts (model/loss.py MSELoss target) widen too
+    if variant:
+        # an "equally valid fp32 run": every weight moved by 1e-7 relative (below fp32 resolution of most, one ulp of some). Over a chained
+        # cycle such runs drift apart the way two correct fp32 implementations do (Adam's first steps follow the SIGN of near-zero gradient
+        # elements); the spread of several variants around the fp64 run is the yardstick for the chained cases.
+        gv = torch.Generator().manual_seed(1000 + variant)
+        model_sd = {k: (v * (1 + 1e-7 * torch.randn(v.shape, generator=gv)) if v.dtype.is_floating_point and v.dim() > 0 else v) for k, v in model_sd.items()}
     model = HWWithStyle(cfg["model"])
     model.load_state_dict(model_sd)
     if wide:
@@ -143,22 +149,103 @@ def run_case(name, wide):
         return orig_clip(model.parameters(), value)
     nnu.clip_grad_value_ = spy_clip
     torch.nn.utils.clip_grad_value_ = spy_clip
+    # what the discriminator is fed (shape + fingerprint of every call's input): separates "the discriminator's arithmetic differs"
+    # from "it was shown a different image" when a gradient comparison fails
+    d_calls, d_last = [], {}
+
+    def d_hook(mod, args):
+        d_calls.append([list(args[0].shape)] + fingerprint(args[0], 0))
+        d_last.update(x=args[0].detach().clone(), rng=torch.get_rng_state(), sd={k: v.detach().clone() for k, v in mod.state_dict().items()})
+    model.discriminator.register_forward_pre_hook(d_hook)
+
+    def disc_conditioning():
+        """How far the discriminator's hinge-step gradients move when the generated half of its input changes by fp32 rounding (relative
+        3e-7 - what separates two correct fp32 generators). With untrained weights the generated lines are narrow and replicate-padded to
+        the width of the real ones: whole rows of activations are identical, LeakyReLU gates flip for hundreds of pixels at once, and the
+        first layers' gradients move by 1e-3 for a 3e-7 change of the input. No implementation can be closer to the reference than that."""
+        import torch.nn.functional as F
+        x, n = d_last["x"].float(), d_last["x"].shape[0] // 2
+        pn = [k for k, p in model.discriminator.named_parameters() if p.requires_grad]
+
+        def grads(xx):
+            sd2 = {k: (v.clone().float() if v.dtype.is_floating_point else v.clone()) for k, v in d_last["sd"].items()}
+            for k in pn:
+                sd2[k].requires_grad_(True)
+            keep = torch.get_rng_state()
+            torch.set_rng_state(d_last["rng"])
+            outs = torch_ref.discriminator(sd2, xx)
+            torch.set_rng_state(keep)
+            (sum(F.relu(1.0 - o[:n]).mean() + F.relu(1.0 + o[n:]).mean() for o in outs) / len(outs)).backward()
+            return {k: sd2[k].grad for k in pn}
+        dt = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float32)
+        try:
+            g0 = grads(x)
+            worst = {k: 0.0 for k in pn}
+            for trial in range(8):
+                xp = x.clone()
+                xp[n:] *= 1 + 3e-7 * torch.randn(xp[n:].shape, generator=torch.Generator().manual_seed(7 + trial))
+                g1 = grads(xp)
+                for k in pn:
+                    if g0[k] is not None:
+                        worst[k] = max(worst[k], float((g1[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30)))
+        finally:
+            torch.set_default_dtype(dt)
+        return {"discriminator." + k: v for k, v in worst.items()}
     its = []
     for it in range(iters):
         snap = [p.detach().clone() for p in model.parameters()]
         cur[0] = it
+        del d_calls[:]
         log = trainer._train_iteration(it)
         upd = [fingerprint(p.detach() - s, k) for k, (p, s) in enumerate(zip(model.parameters(), snap))]
         moved = [u if u[1] != 0.0 else None for u in upd]
-        its.append({"lesson": trainer.curriculum.getLesson(it), "log": {k: float(v) for k, v in log.items()}, "grads": grads_at_clip.get(it), "update": moved})
+        # gradient sets left stashed by a "no-step" lesson (trainer :304-338), in stash order: each a per-parameter list like `grads`
+        stashes = [[fingerprint(R, k) if R is not None else None for k, R in enumerate(sg)] for sg in getattr(trainer, "saved_grads", [])]
+        its.append({"lesson": trainer.curriculum.getLesson(it), "log": {k: float(v) for k, v in log.items()}, "grads": grads_at_clip.get(it), "update": moved, "stashes": stashes, "d_inputs": [list(c) for c in d_calls],
+                    "d_cond": disc_conditioning() if ("disc" in trainer.curriculum.getLesson(it) and not wide) else None})
         print(name, "fp64" if wide else "fp32", it, its[-1]["log"], flush=True)
     sn = {k: v.flatten()[:8].tolist() for k, v in model.state_dict().items() if k.endswith(("weight_u",))}
     return {"names": names, "iterations": its, "u_after": sn}
 
 
+def tensor_error(x, y):
+    """error of fingerprint x against fingerprint y (same formula as tests/test_trainer_lessons_gpu.py)"""
+    nrm = math.sqrt(max(y[2], 1e-300))
+    return max(abs(x[3] - y[3]) / nrm, abs(x[1] - y[1]) / max(y[1], 1e-300))
+
+
+def spread(tops, runs, ref64):
+    """largest pooled error against the fp64 run over the perturbed fp32 runs, per (kind, sub-network); largest loss / discriminator-input
+    differences"""
+    out = {"groups": {}, "log": {}, "d_inputs": []}
+    for run in runs:
+        sets = [("grad", run["grads"], ref64["grads"]), ("update", run["update"], ref64["update"])]
+        sets += [("stash%d" % j, a, b) for j, (a, b) in enumerate(zip(run.get("stashes") or [], ref64.get("stashes") or []))]
+        for kind, xs, ys in sets:
+            if xs is None or ys is None:
+                continue
+            acc = {}
+            for top, x, y in zip(tops, xs, ys):
+                if x is not None and y is not None:
+                    acc.setdefault(top, []).append(tensor_error(x, y) ** 2)
+            for top, es in acc.items():
+                key = "%s|%s" % (kind, top)
+                out["groups"][key] = max(out["groups"].get(key, 0.0), math.sqrt(sum(es) / len(es)))
+        for k, v in run["log"].items():
+            out["log"][k] = max(out["log"].get(k, 0.0), abs(v - ref64["log"][k]))
+        for j, (a, b) in enumerate(zip(run.get("d_inputs") or [], ref64.get("d_inputs") or [])):
+            e = abs(a[4] - b[4]) / math.sqrt(b[3])
+            if j < len(out["d_inputs"]):
+                out["d_inputs"][j] = max(out["d_inputs"][j], e)
+            else:
+                out["d_inputs"].append(e)
+    return out
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--child":
-        out = run_case(sys.argv[2], sys.argv[3] == "1")
+        out = run_case(sys.argv[2], sys.argv[3] == "1", int(sys.argv[5]) if len(sys.argv) > 5 else 0)
         with open(sys.argv[4], "w") as f:
             json.dump(out, f)
         return
@@ -174,6 +261,14 @@ def main():
             res[wide] = json.load(open(tmp))
         r32, r64 = res[0], res[1]
         which, B, A, W, minW, L, curriculum, iters = CASES[name]
+        variants = []
+        if name.startswith("cycle"):
+            for v in (1, 2, 3):
+                tmp = "/tmp/hwg_lessons_%s_v%d.json" % (name, v)
+                if not (os.environ.get("HWG_GOLDEN_REUSE") and os.path.exists(tmp)):
+                    subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", name, "0", tmp, str(v)])
+                variants.append(json.load(open(tmp)))
+        names_top = [n.split(".")[0] for n in r32["names"]]
         out = {"case": name, "config": which, "batch_size": B, "a_batch_size": A, "W": W, "min_width": minW, "label_len": L,
                "curriculum": curriculum, "wseed_model": WSEED_MODEL, "wseed_enc": WSEED_ENC, "names": r32["names"], "u_after": r32["u_after"], "u_after64": r64["u_after"],
                "iterations": []}
@@ -183,7 +278,9 @@ def main():
                 # mask moves a loss by tens of percent; fp32 drift over a chained cycle stays below one percent)
                 assert abs(a["log"][k] - b["log"][k]) <= 3e-2 * max(abs(b["log"][k]), 1e-2), (name, k, a["log"][k], b["log"][k])
             out["iterations"].append({"lesson": a["lesson"], "log": a["log"], "log64": b["log"], "grads": a["grads"], "grads64": b["grads"],
-                                      "update": a["update"], "update64": b["update"]})
+                                      "spread": spread(names_top, [v["iterations"][len(out["iterations"])] for v in variants], b) if variants else None,
+                                      "update": a["update"], "update64": b["update"], "d_inputs": a.get("d_inputs"), "d_inputs64": b.get("d_inputs"), "d_cond": a.get("d_cond"),
+                                      "stashes": a.get("stashes"), "stashes64": b.get("stashes")})
         path = os.path.join(ROOT, "tests", "golden", "lessons_%s.json" % name)
         with open(path, "w") as f:
             json.dump(out, f, separators=(",", ":"))
