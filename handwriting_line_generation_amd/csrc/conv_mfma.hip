@@ -865,6 +865,7 @@ struct ConvPlan {
   bool mfma;
   int bm, bn, bk, nsplit, classes;
   long long Mc;
+  double model_s;   // modelled duration of the chosen schedule (seconds)
 };
 static ConvPlan plan_conv(const hwg_conv_desc* d) {
   ConvPlan p;
@@ -913,7 +914,15 @@ static ConvPlan plan_conv(const hwg_conv_desc* d) {
     }
   }
   p.bm = bm; p.bn = bn; p.bk = bk; p.nsplit = ns;
+  p.model_s = best;
   return p;
+}
+
+// modelled duration of the direct implicit-GEMM schedule (conv_wino.hip weighs its own model against it)
+double hwg_conv_direct_model_seconds(const hwg_conv_desc* d) {
+  if (!d || d->C % 16 != 0) return 1e30;
+  const ConvPlan p = plan_conv(d);
+  return p.mfma ? p.model_s : 1e30;
 }
 
 extern "C" size_t hwg_conv_fwd_workspace(const hwg_conv_desc* d) {

@@ -829,28 +829,44 @@ static void wino_cfg(WinoPlan& p, int cfg) {
   static const int tms[6] = {64, 32, 128, 64, 32, 64}, tns[6] = {32, 64, 16, 32, 64, 64};
   p.cfg = cfg; p.tm = tms[cfg]; p.tn = tns[cfg];
 }
-static WinoPlan plan_wino(const hwg_conv_desc* d) {
-  WinoPlan p;
+// Schedule = (kernel variant, channel split) with the smallest modelled time. Model (fitted to tools/wino_check.py sweeps on MI355X,
+// profiles/r02_wino_shapes.txt): one workgroup per CU at a time, so the launch takes ceil(workgroups / 256) rounds of
+// (fixed + rounds-of-the-channel-loop x step) microseconds; a channel split adds the pass that sums the partial outputs.
+struct WinoCost { int cfg; double fixed_us, step_us; };
+static const WinoCost kWinoCost[4] = {{1, 2.5, 1.17}, {5, 11.0, 2.09}, {0, 8.0, 1.2}, {2, 6.5, 1.5}};
+static WinoPlan plan_wino(const hwg_conv_desc* d, double* model_s = nullptr) {
+  WinoPlan best;
+  wino_cfg(best, d->K <= 16 ? 2 : d->K <= 48 ? 0 : 1);
+  best.nsplit = 1;
   const long long M = (long long)d->N * hwg_cdiv(d->P, 2) * hwg_cdiv(d->Q, 2);
-  // measured on MI355X (tools/wino_check.py, profiles/r02_wino_shapes.txt): 32 x 64 tiles of the all-purpose kernel are the best
-  // default; the 64 x 64 twelve-wave kernel wins once the channel loop is long (C >= 128) and there are enough tiles to fill the chip
-  if (d->K <= 16) wino_cfg(p, 2);
-  else if (d->K <= 48) wino_cfg(p, 0);
-  else if (d->C >= 128 && (long long)hwg_cdiv(M, 64) * hwg_cdiv(d->K, 64) >= 224) wino_cfg(p, 5);
-  else wino_cfg(p, 1);
+  const int chunks = d->C / 16;
+  const double out_bytes = 4.0 * d->N * d->P * d->Q * d->K;
+  double best_t = 1e30;
+  for (int ci = 0; ci < 4; ++ci) {
+    const WinoCost& wc = kWinoCost[ci];
+    if (wc.cfg == 2 && d->K > 16) continue;
+    if (wc.cfg == 0 && d->K > 48) continue;
+    if ((wc.cfg == 1 || wc.cfg == 5) && d->K <= 48) continue;
+    if (wc.cfg == 5 && d->C < 64) continue;
+    WinoPlan p;
+    wino_cfg(p, wc.cfg);
+    const long long blocks = (long long)hwg_cdiv(M, p.tm) * hwg_cdiv(d->K, p.tn);
+    for (int ns = 1; ns <= 8 && ns * 2 <= (chunks > 1 ? chunks : 2); ns *= 2) {
+      if (ns > 1 && (chunks / ns < 2 || out_bytes * ns > 1.5e9)) break;
+      const double rounds = (double)hwg_cdiv(blocks * ns, 256);
+      double t = rounds * (wc.fixed_us + 4.0 * hwg_cdiv(chunks, ns) * wc.step_us) * 1e-6;
+      if (ns > 1) t += (ns + 1) * out_bytes / 3.0e12 + 6e-6;
+      if (t < best_t) { best_t = t; best = p; best.nsplit = ns; }
+    }
+  }
   if (const char* f = getenv("HWG_WINO_FORCE")) {   // tuning aid: "cfg[,nsplit]"
     int fc = -1, fs = 0;
     const int n = sscanf(f, "%d,%d", &fc, &fs);
-    if (n >= 1 && fc >= 0 && fc <= 5 && fc != 3 && (fc == 2 || d->K > 16)) wino_cfg(p, fc);
-    if (n >= 2 && fs >= 1) { p.nsplit = fs; if (p.nsplit > d->C / 16) p.nsplit = d->C / 16; return p; }
+    if (n >= 1 && fc >= 0 && fc <= 5 && fc != 3 && fc != 4 && (fc == 2 || d->K > 16)) wino_cfg(best, fc);
+    if (n >= 2 && fs >= 1) best.nsplit = fs > chunks ? chunks : fs;
   }
-  // few workgroups and a long channel loop: cut the loop so that the chip is filled (partials summed by the split reduce pass)
-  const long long blocks = (long long)hwg_cdiv(M, p.tm) * hwg_cdiv(d->K, p.tn);
-  const int chunks = d->C / 16;
-  int ns = 1;
-  while (blocks * ns < 512 && ns * 2 <= chunks / 4 && ns < 16) ns *= 2;
-  p.nsplit = ns;
-  return p;
+  if (model_s) *model_s = best_t;
+  return best;
 }
 
 }  // namespace
@@ -862,6 +878,18 @@ extern "C" int hwg_wino_supported(const hwg_conv_desc* d) {
   if (d->P != d->H + 2 * d->pad_h - 2 || d->Q != d->W + 2 * d->pad_w - 2) return 0;
   if (const char* f = getenv("HWG_WINO")) if (atoi(f) == 0) return 0;
   return 1;
+}
+
+double hwg_conv_direct_model_seconds(const hwg_conv_desc* d);
+
+/* 1 when the Winograd schedule is modelled faster than the direct implicit-GEMM one (few tiles x many channels - the 512-channel layers
+ * of the recogniser at 8 x 129 - stream 16 MB of transform-domain filters per 2000 tiles and stay on the direct kernels) */
+extern "C" int hwg_wino_preferred(const hwg_conv_desc* d) {
+  if (!hwg_wino_supported(d)) return 0;
+  if (const char* f = getenv("HWG_WINO")) if (atoi(f) == 2) return 1;     // 2: always, 0: never (hwg_wino_supported), default: by model
+  double tw = 0.0;
+  (void)plan_wino(d, &tw);
+  return tw < 0.97 * hwg_conv_direct_model_seconds(d) ? 1 : 0;
 }
 
 extern "C" size_t hwg_wino_weight_floats(int A, int B) {

@@ -1,0 +1,261 @@
+"""Author-grouped line batches from IAM-style data on disk (reference: datasets/author_hw_dataset.py:27-591, utils/parseIAM.py:11-70,
+utils/augmentation.py:61-72), without OpenCV: decoding, cropping, height normalisation and the affine augmentation go through PIL / numpy.
+
+Directory layout (the reference's): `<data_dir>/forms/<page>.png`, `<data_dir>/xmls/<page>.xml` (IAM form XML: writer id, lines with
+word/cmp boxes), and `data/sets.json` = {"train": [pages], "valid": [...], "test": [...]} (looked up next to the char set file or in the
+working directory). One dataset item = `a_batch_size` lines of one author; `collate` pads `batch_size` such items to a common width
+(-1) and label length (0) - the instance dict `HWWithStyleTrainer.run_gen` consumes.
+
+Interpolation differs from cv2 in the last bits (PIL bicubic for the height normalisation, bilinear for the affine warp); everything
+downstream of the decoded pixels - normalisation 1 - p/128, padding, label encoding, grouping of an author's lines, the draw order of the
+augmentation parameters - follows the reference.
+"""
+import json
+import math
+import os
+import xml.etree.ElementTree as ET
+from collections import defaultdict
+from xml.sax.saxutils import unescape as _unescape
+
+import numpy as np
+import torch
+
+from ..utils import string_utils
+
+PADDING_CONSTANT = -1
+
+
+def parse_iam_xml(path):
+    """-> ([([y0, y1, x0, x1], text), ...], writer id): line boxes from the component boxes, padded to the page's mean line height
+    (parseIAM.getWordAndLineBoundaries / getLineBoundaries)"""
+    root = ET.parse(path).getroot()
+    writer = root.attrib["writer-id"]
+    lines, all_h = [], 0
+    for line in root.findall("./handwritten-part/line"):
+        text = _unescape(line.attrib["text"]).replace("&quot;", '"')
+        min_x = min_y = 99999999
+        max_x = max_y = -1
+        for word in line.findall("word"):
+            for cmp in word.findall("cmp"):
+                x, y, w, h = (int(cmp.attrib[k]) for k in ("x", "y", "width", "height"))
+                max_x, min_x = max(max_x, x + w), min(min_x, x)
+                max_y, min_y = max(max_y, y + h), min(min_y, y)
+        lines.append(([min_y, max_y + 1, min_x, max_x + 1], text))
+        all_h += 1 + max_y - min_y
+    mean_h = all_h / max(len(lines), 1)
+    out = []
+    for b, text in lines:
+        diff = mean_h - (b[1] - b[0])
+        if diff > 0:
+            b[0] -= diff / 2
+            b[1] += diff / 2
+        b[2] -= mean_h / 4
+        b[3] += mean_h / 4
+        out.append(([round(v) for v in b], text))
+    return out, writer
+
+
+def _read_gray(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("L"))
+
+
+def _resize(img, percent):
+    from PIL import Image
+    w, h = max(int(round(img.shape[1] * percent)), 1), max(int(round(img.shape[0] * percent)), 1)
+    return np.asarray(Image.fromarray(img).resize((w, h), Image.BICUBIC))
+
+
+def affine_trans(img, skew, strech):
+    """horizontal stretch + shear around the mid-line (augmentation.affine_trans): x' = strech*x + tan(skew)*(y - h/2), white border"""
+    from PIL import Image
+    m = math.tan(skew)
+    h = img.shape[0] / 2
+    size = (int(img.shape[1] * strech), img.shape[0])
+    coeffs = (1.0 / strech, -m / strech, h * m / strech, 0.0, 1.0, 0.0)      # PIL wants the destination -> source map
+    return np.asarray(Image.fromarray(img).transform(size, Image.AFFINE, coeffs, resample=Image.BILINEAR, fillcolor=255))
+
+
+class AuthorHWDataset(torch.utils.data.Dataset):
+    def __init__(self, dirPath, split, config):
+        split = config.get("split", split)
+        self.img_height = config["img_height"]
+        self.batch_size = config["a_batch_size"]          # lines per item (the reference's naming)
+        self.no_spaces = config.get("no_spaces", False)
+        self.max_width = config.get("max_width", 3000)
+        for key in ("triplet", "style_loc", "spaced_loc", "fg_masks_dir", "include_stroke_aug", "remove_bg"):
+            if key == "fg_masks_dir":
+                continue     # only read by the (unreachable) no_bg_loss branch
+            if config.get(key):
+                raise NotImplementedError("data option %r is not used by the shipped GAN configs" % key)
+        sets = None
+        for cand in (os.path.join("data", "sets.json"), os.path.join(os.path.dirname(config["char_file"]), "sets.json"), os.path.join(dirPath, "sets.json")):
+            if os.path.exists(cand):
+                sets = json.load(open(cand))
+                break
+        if sets is None:
+            raise FileNotFoundError("sets.json (train/valid/test page lists) not found in data/, next to the char set or in %s" % dirPath)
+        pages = []
+        for s in (split if isinstance(split, (list, tuple)) else [split]):
+            pages += sets[s]
+        self.authors = defaultdict(list)
+        self.max_char_len = 0
+        for name in pages:
+            lines, author = parse_iam_xml(os.path.join(dirPath, "xmls", name + ".xml"))
+            self.max_char_len = max([self.max_char_len] + [len(t) for _, t in lines])
+            self.authors[author] += [(os.path.join(dirPath, "forms", name + ".png"),) + l for l in lines]
+        self.author_list = sorted(self.authors)
+        # items: consecutive groups of a_batch_size lines of one author; the left-over lines are topped up with the author's first ones
+        self.lineIndex = []
+        short = config.get("short", False)
+        for author, lines in self.authors.items():
+            n_full = len(lines) // self.batch_size
+            stop = False
+            for i in range(n_full):
+                self.lineIndex.append((author, [self.batch_size * i + n for n in range(self.batch_size)]))
+                if short and i >= short:
+                    stop = True
+                    break
+            if stop:
+                continue
+            leftover = len(lines) % self.batch_size
+            fill = self.batch_size - leftover
+            self.lineIndex.append((author, list(range(fill)) + [len(lines) - (1 + i) for i in range(leftover)]))
+        if config.get("overfit"):
+            self.lineIndex = self.lineIndex[:10]
+        with open(config["char_file"]) as f:
+            self.char_to_idx = json.load(f)["char_to_idx"]
+        self.augmentation = config.get("augmentation")
+        self.max_strech = 0.4
+        self.max_rot_rad = 45 / 180 * math.pi
+        self._pages = {}
+
+    def __len__(self):
+        return len(self.lineIndex)
+
+    def max_len(self):
+        return self.max_char_len
+
+    def _page(self, path):
+        if path not in self._pages:
+            if len(self._pages) > 8:
+                self._pages.clear()
+            self._pages[path] = _read_gray(path)
+        return self._pages[path]
+
+    def _fit(self, img):
+        """height -> img_height (never wider than max_width; short results are centred on white), as author_hw_dataset.py:386-404"""
+        if img.shape[0] != self.img_height:
+            percent = float(self.img_height) / img.shape[0]
+            if img.shape[1] * percent > self.max_width:
+                percent = self.max_width / img.shape[1]
+            img = _resize(img, percent)
+        elif img.shape[1] > self.max_width:
+            img = _resize(img, self.max_width / img.shape[1])
+        if img.shape[0] < self.img_height:
+            diff = self.img_height - img.shape[0]
+            img = np.pad(img, ((diff // 2, diff // 2 + diff % 2), (0, 0)), "constant", constant_values=255)
+        elif img.shape[0] > self.img_height:
+            img = img[:self.img_height]
+        return img
+
+    def __getitem__(self, idx):
+        if self.augmentation == "affine":     # one draw per item, shared by the author's lines (the reference's order: strech, then skew)
+            strech = (self.max_strech * 2) * np.random.random() - self.max_strech + 1
+            skew = (self.max_rot_rad * 2) * np.random.random() - self.max_rot_rad
+        author, lines = self.lineIndex[idx]
+        images = []
+        for line in lines:
+            if line >= len(self.authors[author]):
+                line = (line + 37) % len(self.authors[author])
+            path, lb, gt = self.authors[author][line]
+            if self.no_spaces:
+                gt = gt.replace(" ", "")
+            page = self._page(path)
+            img = self._fit(page[max(lb[0], 0):lb[1], max(lb[2], 0):lb[3]])
+            if self.augmentation == "affine" and img.shape[1] * strech > self.max_width:
+                strech = self.max_width / img.shape[1]
+            images.append((line, gt, img))
+        batch = []
+        for line, gt, img in images:
+            if isinstance(self.augmentation, str) and "affine" in self.augmentation:
+                img = affine_trans(img, skew, strech)
+            if len(gt) == 0:
+                return None
+            batch.append({"image": 1.0 - img.astype(np.float32)[..., None] / 128.0, "gt": gt,
+                          "gt_label": string_utils.str2label_single(gt, self.char_to_idx), "name": "%s_%d" % (author, line)})
+        dim1 = max(b["image"].shape[1] for b in batch)
+        images_t = np.full((len(batch), self.img_height, dim1, 1), PADDING_CONSTANT, dtype=np.float32)
+        max_label = max(b["gt_label"].shape[0] for b in batch)
+        labels = np.zeros((max_label, len(batch)), dtype=np.int32)
+        for i, b in enumerate(batch):
+            images_t[i, :, :b["image"].shape[1], :] = b["image"]
+            labels[:b["gt_label"].shape[0], i] = b["gt_label"]
+        images_t = torch.from_numpy(images_t.transpose(0, 3, 1, 2))
+        return {"image": images_t, "mask": None, "top_and_bottom": None, "center_line": None, "label": torch.from_numpy(labels), "style": None,
+                "label_lengths": torch.IntTensor([b["gt_label"].shape[0] for b in batch]), "gt": [b["gt"] for b in batch], "spaced_label": None,
+                "author": [author] * len(batch), "author_idx": [self.author_list.index(author)] * len(batch), "name": [b["name"] for b in batch]}
+
+
+def collate(batch):
+    """items -> instance dict (author_hw_dataset.py:27-112): images padded with -1 to the widest item, labels with 0 to the longest"""
+    if len(batch) == 1:
+        batch[0]["a_batch_size"] = batch[0]["image"].size(0)
+        return batch[0]
+    batch = [b for b in batch if b is not None]
+    A = len(batch[0]["gt"])
+    dim1, dim2 = batch[0]["image"].shape[1], batch[0]["image"].shape[2]
+    dim3 = max(b["image"].shape[3] for b in batch)
+    max_label = max(b["label"].size(0) for b in batch)
+    images = torch.full((len(batch) * A, dim1, dim2, dim3), float(PADDING_CONSTANT))
+    labels = torch.zeros((max_label, len(batch) * A), dtype=torch.int32)
+    for i, b in enumerate(batch):
+        images[i * A:(i + 1) * A, :, :, :b["image"].shape[3]] = b["image"]
+        labels[:b["label"].size(0), i * A:(i + 1) * A] = b["label"]
+    return {"image": images, "mask": None, "top_and_bottom": None, "center_line": None, "label": labels, "style": None,
+            "label_lengths": torch.cat([b["label_lengths"] for b in batch], dim=0), "gt": [l for b in batch for l in b["gt"]], "spaced_label": None,
+            "author": [l for b in batch for l in b["author"]], "author_idx": [l for b in batch for l in b["author_idx"]],
+            "name": [l for b in batch for l in b["name"]], "a_batch_size": A}
+
+
+class ShardedLoader:
+    """DataLoader over the items of one data-parallel rank: the epoch's (seeded) item order is cut into batches of `batch_size` items and
+    rank r takes batches r, r + N, ... - every rank sees different authors, all ranks take the same number of steps per epoch. Batches are
+    prefetched by `num_workers` torch DataLoader workers; `.batch_size` / `.dataset` as the trainer expects."""
+
+    def __init__(self, dataset, batch_size, shuffle, num_workers, rank=0, world=1, seed=0):
+        self.dataset, self.batch_size, self.shuffle, self.num_workers = dataset, batch_size, shuffle, num_workers
+        self.rank, self.world, self.seed, self.epoch = rank, world, seed, 0
+
+    def _batches(self):
+        n = len(self.dataset)
+        order = np.random.RandomState(self.seed + self.epoch).permutation(n) if self.shuffle else np.arange(n)
+        full = [order[i:i + self.batch_size].tolist() for i in range(0, n - self.batch_size + 1, self.batch_size)] or [order.tolist()]
+        usable = len(full) // self.world * self.world or len(full)
+        return full[:usable][self.rank::self.world] or full[:1]
+
+    def __len__(self):
+        return len(self._batches())
+
+    def __iter__(self):
+        batches = self._batches()
+        self.epoch += 1
+        return iter(torch.utils.data.DataLoader(self.dataset, batch_sampler=batches, num_workers=self.num_workers, collate_fn=collate))
+
+
+def getDataLoader(config, split, rank=0, world=1):
+    """data_loader.getDataLoader of the reference (data_loader/data_loaders.py:11-75) for the author-grouped IAM dataset -> (train, valid)"""
+    dl = config["data_loader"]
+    if dl["data_set_name"] != "AuthorHWDataset":
+        raise NotImplementedError("dataset %r: only the author-grouped IAM line dataset has a loader here" % dl["data_set_name"])
+    val = dict(config.get("validation", {}))
+    for k, v in dl.items():
+        val.setdefault(k, v)
+    if split == "train":
+        train = AuthorHWDataset(dl["data_dir"], "train", dl)
+        valid = AuthorHWDataset(dl["data_dir"], "valid", val)
+        tl = ShardedLoader(train, dl["batch_size"], dl.get("shuffle", True), dl.get("num_workers", 1), rank, world)
+        vl = ShardedLoader(valid, val.get("batch_size", dl["batch_size"]), val.get("shuffle", False), val.get("num_workers", 1)) if len(valid) else None
+        return tl, vl
+    test = AuthorHWDataset(dl["data_dir"], split, val)
+    return ShardedLoader(test, val.get("batch_size", dl["batch_size"]), False, val.get("num_workers", 1)), None

@@ -327,8 +327,20 @@ def _run_conv(x, wp, bias, N, H, W, C, K, R, S, stride, pad, dil, P, Q, transpos
 WINOGRAD = bool(int(__import__("os").environ.get("HWG_WINO", "1") or 1))
 
 
-def _wino_ok(C, K, R, S, stride, dil):
-    return WINOGRAD and R == 3 and S == 3 and stride == (1, 1) and dil == (1, 1) and C % 16 == 0 and K >= 16
+_wino_choice = {}
+
+
+def _wino_ok(N, H, W, C, K, R, S, stride, pad, dil, P, Q):
+    """the library's cost models decide per product (cached per geometry): many tiles x few channels run as Winograd, few tiles x many
+    channels (the 512-channel recogniser layers) stay on the direct kernels"""
+    if not (WINOGRAD and R == 3 and S == 3 and stride == (1, 1) and dil == (1, 1) and C % 16 == 0 and K >= 16 and pad[0] >= 0 and pad[1] >= 0):
+        return False
+    key = (N, H, W, C, K, pad)
+    hit = _wino_choice.get(key)
+    if hit is None:
+        d = _desc(N, H, W, C, K, 3, 3, (1, 1), pad, (1, 1), P, Q, 0)
+        hit = _wino_choice[key] = bool(L.query("hwg_wino_preferred", ctypes.byref(d)))
+    return hit
 
 
 def _cpad(C, K, fractional=False):
@@ -374,7 +386,7 @@ class _Conv2d(Function):
             Q = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
             Cp = _cpad(C, K)
             xin = _pad_channels(x, Cp) if Cp != C else x
-            wino = _wino_ok(Cp, K, R, S, (sh, sw), (dh, dw))
+            wino = _wino_ok(N, H, W, Cp, K, R, S, (sh, sw), (ph, pw), (dh, dw), P, Q)
             wp = _pack(weight, K, C, R, S, C * R * S, R * S, flip=0, Bpad=Cp, wino=wino)
             y = _run_conv(xin, wp, bias, N, H, W, Cp, K, R, S, (sh, sw), (ph, pw), (dh, dw), P, Q, 0, wino)
         else:
@@ -387,7 +399,7 @@ class _Conv2d(Function):
             xin = _pad_channels(x, Cp) if Cp != C else x
             if sh == 1 and sw == 1:
                 # stride-1 transposed conv == correlation with mirrored taps and padding dil*(R-1)-pad
-                wino = _wino_ok(Cp, K, R, S, (1, 1), (dh, dw)) and dh * (R - 1) - ph >= 0 and dw * (S - 1) - pw >= 0
+                wino = _wino_ok(N, H, W, Cp, K, R, S, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), P, Q)
                 wp = _pack(weight, K, C, R, S, R * S, K * R * S, flip=1, Bpad=Cp, wino=wino)
                 y = _run_conv(xin, wp, bias, N, H, W, Cp, K, R, S, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), P, Q, 0, wino)
             else:
@@ -427,7 +439,7 @@ class _Conv2d(Function):
                 L.call("hwg_col2im_taps", t, dx, N, H, W, P, Q, R, S, ph, pw, dh, dw, st)
             elif not transposed:
                 if sh == 1 and sw == 1:
-                    wino = _wino_ok(Kp, C, R, S, (1, 1), (dh, dw)) and dh * (R - 1) - ph >= 0 and dw * (S - 1) - pw >= 0
+                    wino = _wino_ok(N, P, Q, Kp, C, R, S, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), H, W)
                     wp = _pack(weight, C, K, R, S, R * S, C * R * S, flip=1, Bpad=Kp, wino=wino)
                     dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), H, W, 0, wino)
                 else:
@@ -436,7 +448,7 @@ class _Conv2d(Function):
                     dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (sh, sw), (ph, pw), (1, 1), H, W, 1)
             else:
                 # gradient of a transposed conv is an ordinary (strided) correlation of dy
-                wino = _wino_ok(Kp, C, R, S, (sh, sw), (dh, dw))
+                wino = _wino_ok(N, P, Q, Kp, C, R, S, (sh, sw), (ph, pw), (dh, dw), H, W)
                 wp = _pack(weight, C, K, R, S, K * R * S, R * S, flip=0, Bpad=Kp, wino=wino)
                 dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (sh, sw), (ph, pw), (dh, dw), H, W, 0, wino)
         wref, bref = ctx.param_refs

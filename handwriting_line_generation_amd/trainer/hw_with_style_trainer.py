@@ -477,13 +477,26 @@ class HWWithStyleTrainer(BaseTrainer):
         return cer, wer, pred_strs
 
     def _valid_epoch(self):
+        """validation pass (trainer :437-486): the curriculum's validation lesson (or the recogniser step) on every batch of the validation
+        loader under no_grad; weighted losses, CER and WER averaged over the batches"""
         self.model.eval()
         totals = defaultdict(float)
+        total_loss = total_cer = total_wer = 0.0
         n = 0
         with torch.no_grad():
             for instance in self.valid_data_loader:
-                losses = self.run_gen(instance, self.curriculum.getValid()) if self.curriculum else self.run_hwr(instance)[1]
+                if self.curriculum:
+                    losses, pred = self.run_gen(instance, self.curriculum.getValid()), None
+                else:
+                    pred, losses = self.run_hwr(instance)
                 for name, v in losses.items():
-                    totals["val_" + name] += float(v) * self.lossWeights[name[:-4]]
+                    w = float(v) * self.lossWeights[name[:-4]]
+                    total_loss += w
+                    totals["val_" + name] += w
+                if pred is not None:
+                    cer, wer, _ = self.getCER(instance["gt"], pred.detach().cpu().numpy())
+                    total_cer += cer
+                    total_wer += wer
                 n += 1
-        return {k: v / max(n, 1) for k, v in totals.items()}
+        n = max(n, 1)
+        return {"val_loss": total_loss / n, "val_CER": total_cer / n, "val_WER": total_wer / n, **{k: v / n for k, v in totals.items()}}

@@ -115,6 +115,8 @@ int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const float* v, float
  * b = contracted channel, flip mirrors the taps) into U = G g G^T laid out [ceil16(B)/16][16][ceil16(A)][16]
  * (hwg_wino_weight_floats(A, B) floats). d describes the product as for hwg_conv_fwd (transposed must be 0). */
 int hwg_wino_supported(const hwg_conv_desc* d);
+/* 1 when the library's cost models put the Winograd schedule ahead of the direct one for this product (callers pick the weight image accordingly) */
+int hwg_wino_preferred(const hwg_conv_desc* d);
 size_t hwg_wino_weight_floats(int A, int B);
 int hwg_wino_pack_weight(const float* src, float* dst, int A, int B, long long sa, long long sb, long long sr, long long ss,
                          int flip, void* stream);

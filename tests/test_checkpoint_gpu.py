@@ -58,3 +58,47 @@ def test_validation_epoch_runs(cuda, tmp_path):
         assert torch.equal(v, before[k]), "validation changed parameter %s" % k
     log = tr._train_iteration(0)     # back to training mode afterwards
     assert tr.model.training and all(math.isfinite(v) for v in log.values() if isinstance(v, float))
+
+
+def test_eval_writer_and_style_dump(cuda, tmp_path):
+    """evaluate.eval_writer (new_eval.py / get_styles.py semantics): recogniser CER on real lines equals what getCER gives on the recogniser's
+    eval-mode output, generated lines are scored against the same texts, one style per author, deterministic under fixed host seeds"""
+    import math
+    import pickle
+    import numpy as np
+    from handwriting_line_generation_amd import rng
+    from handwriting_line_generation_amd.data.synthetic import SyntheticAuthorDataset, SyntheticLoader
+    from handwriting_line_generation_amd.evaluate import dump_styles, eval_writer
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    rng.set_mode("host")
+    try:
+        torch.manual_seed(0)
+        tr, cfg = build_gan_trainer("iam_gan", 2, 2, width=256, label_len=10, workdir=str(tmp_path))
+        ds = SyntheticAuthorDataset(cfg["data_loader"]["char_file"], 2, 2, width=256, label_len=10, num_batches=2, seed=700)
+        torch.manual_seed(1); np.random.seed(1)
+        r1 = eval_writer(tr, SyntheticLoader(ds))
+        torch.manual_seed(1); np.random.seed(1)
+        r2 = eval_writer(tr, SyntheticLoader(ds))
+        assert tr.model.training
+        for k in ("cer_real", "wer_real", "cer_gen", "wer_gen"):
+            assert math.isfinite(r1[k]) and r1[k] >= 0 and r1[k] == r2[k]
+        assert r1["styles"].shape == (4, 128) and len(r1["authors"]) == 4 and np.array_equal(r1["styles"], r2["styles"])
+        # the real-line CER is getCER of the eval-mode recogniser output
+        inst = ds.batch(0)
+        tr.model.eval()
+        with torch.no_grad():
+            pred = tr.model.hwr(inst["image"].to(cuda), None).cpu().numpy()
+        tr.model.train()
+        inst1 = ds.batch(1)
+        tr.model.eval()
+        with torch.no_grad():
+            pred1 = tr.model.hwr(inst1["image"].to(cuda), None).cpu().numpy()
+        tr.model.train()
+        want = (tr.getCER(inst["gt"], pred)[0] + tr.getCER(inst1["gt"], pred1)[0]) / 2
+        assert abs(r1["cer_real"] - want) < 1e-9
+        path = str(tmp_path / "styles.pkl")
+        dump_styles(r1, path)
+        back = pickle.load(open(path, "rb"))
+        assert set(back) == {"styles", "authors"} and back["styles"].shape == (4, 128)
+    finally:
+        rng.set_mode("device")

@@ -30,3 +30,104 @@ def test_stream_equals_sequential(cuda, tmp_path):
     assert len(seq) == len(stream) == 3
     for a, b in zip(seq, stream):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+def _oracle_style(sd, image, label, a_batch_size, use_pred, n_class=80):
+    """recogniser -> (log-probs | one-hot DTW alignment) -> lines of an author side by side -> style extractor (generate.py:58-81)"""
+    import torch.nn.functional as F
+    from oracle import seq_oracle, torch_ref
+    sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}   # noqa: E731
+    pred = torch_ref.hwr(sub("hwr."), image)
+    if use_pred:
+        spaced = pred.permute(1, 2, 0)
+    else:
+        spaced = F.one_hot(seq_oracle.correct_pred(pred, label), n_class).float().permute(1, 2, 0)
+    B, feats, h, w = image.shape
+    T = spaced.shape[2]
+    ci = image.permute(1, 2, 0, 3).contiguous().view(feats, h, B // a_batch_size, w * a_batch_size).permute(2, 0, 1, 3)
+    cl = spaced.permute(1, 0, 2).contiguous().view(n_class, B // a_batch_size, T * a_batch_size).permute(1, 0, 2)
+    return torch_ref.style_extractor(sub("style_extractor."), ci, cl, n_class=n_class)
+
+
+@pytest.mark.parametrize("use_pred", [True, False])
+def test_get_style_matches_oracle(cuda, tmp_path, use_pred):
+    """generate.get_style (reference generate.py:48-83, style_together): HIP recogniser + alignment + author collapse + style extractor vs the
+    oracle composition on the same seeded weights"""
+    from handwriting_line_generation_amd import rng
+    from handwriting_line_generation_amd.generate import get_style
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    from handwriting_line_generation_amd.model import HWWithStyle
+    from oracle import cases, torch_ref
+    import json, os
+    cfg_model = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "model_config_iam.json")))
+    sd = torch_ref.seeded_state_dict(HWWithStyle(cfg_model), 21)
+    trainer, cfg = build_gan_trainer("iam_gan", 2, 2, width=192, label_len=8, workdir=str(tmp_path), model_state=sd)
+    cfg["trainer"]["style_together"] = True
+    cfg["trainer"]["use_hwr_pred_for_style"] = use_pred
+    g = torch.Generator().manual_seed(6)
+    image = torch.rand(4, 1, 64, 192, generator=g) * 2 - 1
+    label = torch.randint(1, 80, (8, 4), generator=g, dtype=torch.int32)
+    inst = {"image": image, "label": label, "a_batch_size": 2}
+    rng.set_mode("host")
+    try:
+        trainer.model.train()          # the recogniser normalises with batch statistics in training mode, as in the reference's trainer
+        with torch.no_grad():
+            style = get_style(cfg, trainer.model, inst, trainer.gpu)
+        ref = _oracle_style(sd, image, label.long(), 2, use_pred)
+    finally:
+        rng.set_mode("device")
+    assert style.shape == ref.shape == (2, 128)
+    err = float((style.cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-4, err
+
+
+def test_forward_generate_interpolate_match_oracle(cuda, tmp_path):
+    """model(label, lengths, style) end to end under the reference's host RNG (numpy draws in insert_spaces, torch noise in the generator):
+    spacer -> insert_spaces -> one-hot -> generator vs the oracle; generate() and interpolate() (generate.py:796-828) on top of it"""
+    import json, os
+    import torch.nn.functional as F
+    from handwriting_line_generation_amd import rng
+    from handwriting_line_generation_amd.generate import generate, interpolate
+    from handwriting_line_generation_amd.harness import build_gan_trainer, CHAR_FILES
+    from handwriting_line_generation_amd.model import HWWithStyle
+    from handwriting_line_generation_amd.utils import string_utils
+    from oracle import seq_oracle, torch_ref
+    cfg_model = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "model_config_iam.json")))
+    sd = torch_ref.seeded_state_dict(HWWithStyle(cfg_model), 21)
+    # a spacer that spreads the text out (the seeded one predicts ~0 blanks, a line would be only a few columns wide)
+    sd["spacer.mean"] = torch.tensor([[3.0, 1.0]]).view_as(sd["spacer.mean"])
+    trainer, cfg = build_gan_trainer("iam_gan", 1, 1, width=128, label_len=6, workdir=str(tmp_path), model_state=sd)
+    model = trainer.model
+    char_to_idx = json.load(open(CHAR_FILES["iam"]))["char_to_idx"]
+    text = "hello world"
+    g = torch.Generator().manual_seed(2)
+    s1, s2 = torch.randn(1, 128, generator=g), torch.randn(1, 128, generator=g)
+    sub = lambda p: {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}   # noqa: E731
+
+    def oracle_line(style):
+        lab = torch.from_numpy(string_utils.str2label_single(text, char_to_idx).astype(np.int64))[:, None]
+        counts = torch_ref.spacer(sub("spacer."), F.one_hot(lab, 80).float(), style, training=False)
+        spaced, _ = seq_oracle.insert_spaces(lab, [lab.shape[0]], counts, 80, 1e-8, 1e-9)
+        return torch_ref.generator(sub("generator."), spaced, style)
+    rng.set_mode("host")
+    model.eval()
+    try:
+        with torch.no_grad():
+            torch.manual_seed(4); np.random.seed(4)
+            img = generate(model, s1.to(cuda), text, char_to_idx, cuda)
+            torch.manual_seed(4); np.random.seed(4)
+            ref = oracle_line(s1)
+            assert img.shape == ref.shape and img.shape[3] > 4 * len(text)
+            assert float((img.cpu() - ref).abs().max()) < 1e-4
+            torch.manual_seed(5); np.random.seed(5)
+            imgs, styles = interpolate(model, s1.to(cuda), s2.to(cuda), text, char_to_idx, cuda, step=0.25)
+            assert len(imgs) == len(styles) == 4
+            torch.manual_seed(5); np.random.seed(5)
+            for k, alpha in enumerate(np.arange(0, 1.0, 0.25)):
+                st = s2 * float(alpha) + float(1 - alpha) * s1
+                assert float((styles[k] - st).abs().max()) < 1e-6
+                r = oracle_line(st)
+                assert imgs[k].shape == r.shape and float((imgs[k].cpu() - r).abs().max()) < 1e-4, (k, float((imgs[k].cpu() - r).abs().max()))
+    finally:
+        rng.set_mode("device")
+        model.train()

@@ -75,6 +75,21 @@ CONV_CASES = [
 def test_conv_fwd_bwd(cuda, case):
     from handwriting_line_generation_amd import ops
     name, N, H, W, C, K, R, S, stride, pad, dil, transposed = case
+    if name.startswith("wino_"):
+        # the library picks Winograd or the direct kernels per geometry from its cost models; these cases must run the Winograd kernels
+        import os
+        os.environ["HWG_WINO"] = "2"
+        ops._wino_choice.clear()
+        try:
+            return _conv_case(cuda, ops, case)
+        finally:
+            os.environ.pop("HWG_WINO", None)
+            ops._wino_choice.clear()
+    return _conv_case(cuda, ops, case)
+
+
+def _conv_case(cuda, ops, case):
+    name, N, H, W, C, K, R, S, stride, pad, dil, transposed = case
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)   # (hash() changes with PYTHONHASHSEED)
     x = torch.randn(N, C, H, W, generator=g)
     if transposed:
@@ -114,8 +129,11 @@ def test_winograd_agrees_with_direct_engine(cuda):
     w = (torch.randn(96, 64, 3, 3, generator=g) / 24).to(cuda)
     gy = torch.randn(3, 11, 37, 96, generator=g).to(cuda)
     outs = []
+    import os
     for flag in (True, False):
         ops.WINOGRAD = flag
+        os.environ["HWG_WINO"] = "2"       # "always" when enabled (default: the library's cost models choose per geometry)
+        ops._wino_choice.clear()
         try:
             xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
             y = ops.conv2d(xg, wg, None, 1, 1)
@@ -123,6 +141,8 @@ def test_winograd_agrees_with_direct_engine(cuda):
             outs.append((y.detach(), xg.grad, wg.grad))
         finally:
             ops.WINOGRAD = True
+            os.environ.pop("HWG_WINO", None)
+            ops._wino_choice.clear()
     for a, b, n in zip(outs[0], outs[1], ("y", "dx", "dw")):
         _close(a, b, "winograd vs direct " + n, tol=2e-5)
 

@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from handwriting_line_generation_amd import ops  # noqa: E402
 
+os.environ["HWG_WINO"] = "2"
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(3)
 shapes = [(2, 32, 32, 64, 128, 1, 1), (2, 16, 16, 128, 256, 1, 1), (2, 16, 16, 256, 256, 1, 1), (2, 8, 17, 256, 512, 1, 1), (2, 8, 17, 512, 512, 0, 0),

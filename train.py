@@ -74,13 +74,21 @@ def main():
     import handwriting_line_generation_amd.trainer as trainers
     from handwriting_line_generation_amd.data.synthetic import SyntheticAuthorDataset, SyntheticLoader, write_synthetic_corpus
 
-    if not args.synthetic:
-        raise SystemExit("the IAM/RIMES image pipeline is outside the accelerated path (SURVEY section 8f); run with --synthetic")
     dl = config["data_loader"]
     pkg_data = os.path.join(ROOT, "handwriting_line_generation_amd", "data")
-    dl["char_file"] = os.path.join(pkg_data, os.path.basename(dl["char_file"]))
-    ds = SyntheticAuthorDataset(dl["char_file"], dl["batch_size"], dl.get("a_batch_size", 1), width=512, label_len=30, num_batches=10 ** 9)
-    loader = SyntheticLoader(ds, rank, world)
+    if not os.path.exists(dl["char_file"]):
+        dl["char_file"] = os.path.join(pkg_data, os.path.basename(dl["char_file"]))
+    valid_loader = None
+    if args.synthetic:
+        ds = SyntheticAuthorDataset(dl["char_file"], dl["batch_size"], dl.get("a_batch_size", 1), width=512, label_len=30, num_batches=10 ** 9)
+        loader = SyntheticLoader(ds, rank, world)
+    elif os.path.isdir(os.path.join(dl["data_dir"], "xmls")):
+        # a dataset on disk in the reference's layout: author-grouped batches, every rank its own authors (data/author_hw_dataset.py)
+        from handwriting_line_generation_amd.data.author_hw_dataset import getDataLoader
+        loader, valid_loader = getDataLoader(config, "train", rank, world)
+    else:
+        raise SystemExit("no dataset at %r (expected the reference's layout: forms/, xmls/, data/sets.json); pass --synthetic to train on "
+                         "synthetic author batches of the configured shape" % dl["data_dir"])
     tr = config["trainer"]
     if "text_data" in tr and not os.path.exists(tr["text_data"]):
         os.makedirs(tr["save_dir"], exist_ok=True)
@@ -99,7 +107,8 @@ def main():
 
     model = getattr(models, config["arch"])(config["model"])
     loss = {k: getattr(losses, v) for k, v in config["loss"].items()} if isinstance(config["loss"], dict) else getattr(losses, config["loss"])
-    trainer = getattr(trainers, config["trainer"]["class"])(model, loss, [], resume, config, loader, None, None)
+    from handwriting_line_generation_amd.logger import Logger
+    trainer = getattr(trainers, config["trainer"]["class"])(model, loss, [], resume, config, loader, valid_loader, Logger())
     if world > 1:
         for p in list(trainer.model.parameters()) + list(trainer.model.buffers()):
             torch.distributed.broadcast(p.data, 0)
