@@ -133,7 +133,9 @@ def main():
     if profiling:
         ops.prof_start()
     from handwriting_line_generation_amd.model.char_style import CharStyleEncoder
+    from handwriting_line_generation_amd.trainer import flat_params
     CharStyleEncoder.stats.update(calls=0, windows=0, experts=0)
+    flat_params.COMM.update(collectives=0, bytes=0)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-lesson GPU time: one event between steps
     first_lesson = it % cycle
     barrier()
@@ -278,6 +280,10 @@ def main():
             "roofline": roofline, "gen_lines_per_sec": gen, "cpu_baseline": cpu,
             # GPU time between the starts of consecutive steps (HIP events on the step stream), averaged per lesson of the curriculum
             "per_lesson_ms": per_lesson_ms,
+            # data parallel: ranks in the process group and this rank's all-reduce traffic (gradient sets + None-masks) per step
+            "data_parallel": {"world_size": world, "backend": (dist.get_backend() if world > 1 else None),
+                              "collectives_per_step": round(flat_params.COMM["collectives"] / args.steps, 2),
+                              "allreduce_mbytes_per_step": round(flat_params.COMM["bytes"] / args.steps / 1e6, 2)},
             "inputs_resident": True,     # one synthetic batch per step built and uploaded before the timed region (SyntheticLoader.make_resident)
             # load of the per-character expert bank (K18): style extractions in the timed region, character windows and distinct experts per call
             "style_extractor_load": {"recogniser": "peaked (70% blanks, +10 logit on one class per column)" if wl.get("peaked") else "random-init on uniform-noise lines",

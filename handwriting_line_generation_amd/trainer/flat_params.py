@@ -173,6 +173,15 @@ class FlatParams:
         return self._flag
 
 
+# data-parallel traffic counters (bench.py reports them per step so that a first multi-GPU run is self-diagnosing)
+COMM = {"collectives": 0, "bytes": 0}
+
+
+def _count(t):
+    COMM["collectives"] += 1
+    COMM["bytes"] += t.numel() * t.element_size()
+
+
 def start_stash_allreduce(stash, world):
     """Data parallel: begin the SUM all-reduce of a freshly stashed gradient set without waiting for it. The collective runs on the
     communicator's stream behind the stash copy, so it overlaps the backward passes that follow (an `auto` lesson stashes four sets
@@ -180,6 +189,7 @@ def start_stash_allreduce(stash, world):
     import torch.distributed as dist
     st = [stash[0], stash[1], None]
     if world > 1:
+        _count(st[0])
         st[2] = dist.all_reduce(st[0], op=dist.ReduceOp.SUM, async_op=True)
     return st
 
@@ -220,6 +230,7 @@ def allreduce_gradient_sets(flat, stashes, world, device):
     ops.join_side_stream()
     masks = [flat.touched] + [s[1] for s in stashes]
     m = torch.from_numpy(np.stack(masks).astype(np.int32)).to(device)
+    _count(m)
     dist.all_reduce(m, op=dist.ReduceOp.MAX)
     m = m.cpu().numpy().astype(bool)     # the only host wait (it also waits for the backward pass that produced the gradients)
     flat.touched[:] = m[0]
@@ -233,9 +244,11 @@ def allreduce_gradient_sets(flat, stashes, world, device):
         else:
             for a, b in touched_spans(flat, m[1 + k]):
                 view = s[0][a:b]
+                _count(view)
                 pending.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True), view))
     for a, b in touched_spans(flat, m[0]):
         view = flat.flat_grad[a:b]
+        _count(view)
         pending.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True), view))
     for work, buf in pending:
         work.wait()

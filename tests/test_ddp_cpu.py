@@ -22,12 +22,12 @@ def _worker(rank, world, port, out):
     params = list(net.parameters())
     flat = FlatParams(params, {"main": params[:4], "disc": params[4:]})
     g = torch.Generator().manual_seed(10 + rank)
-    # rank 0 touches tensors {0,1,2}, rank 1 touches {1,2,5}; one stash each with different masks
-    touch = [{0, 1, 2}, {1, 2, 5}][rank]
+    # rank 0 touches tensors {0,1,2}, rank 1 touches {1,2,5}, rank 2 only {2}; one stash each with different masks
+    touch = [{0, 1, 2}, {1, 2, 5}, {2}][rank]
     for k in touch:
         params[flat.order[k]].grad.copy_(torch.randn(params[flat.order[k]].shape, generator=g))
         flat.touched[k] = True
-    stash_mask = np.zeros(flat.nt, dtype=bool); stash_mask[[3, 4][rank]] = True
+    stash_mask = np.zeros(flat.nt, dtype=bool); stash_mask[[3, 4, 3][rank]] = True
 
     def masked_randn():   # a gradient set holds values only inside tensors whose mask bit is set (everything else is zero on every rank)
         buf = torch.zeros(flat.total)
@@ -47,22 +47,50 @@ def _worker(rank, world, port, out):
     el = [torch.zeros_like(early_buf) for _ in range(world)]; dist.all_gather(el, early_buf)
     ok = torch.allclose(flat.flat_grad, sum(gl) / world) and torch.allclose(stashes[0][0], sum(sl) / world)
     ok = ok and torch.allclose(early[0], sum(el) / world) and early[2] is None
-    ok = ok and flat.touched.tolist() == [True, True, True, False, False, True] and stashes[0][1].tolist() == [False, False, False, True, True, False]
+    ok = ok and flat.touched.tolist() == [True, True, True, False, False, True]
+    ok = ok and stashes[0][1].tolist() == ([False, False, False, True, True, False] if world >= 2 else stash_mask.tolist())
     # parameter .grad views still alias the flat buffer
     ok = ok and params[flat.order[1]].grad.data_ptr() == flat.flat_grad[flat.offsets[1]:].data_ptr()
     out[rank] = bool(ok)
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_exchange():
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gradient_exchange_equals_average_of_all_ranks(world):
+    """2 and 3 ranks (an odd world: the average is not a power-of-two division, ranks touch different tensor sets, one rank touches a single
+    tensor so that its span list differs from the others' before the masks are OR-ed)"""
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     out = mgr.dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    assert out.get(0) and out.get(1), dict(out)
+    assert all(out.get(r) for r in range(world)), dict(out)
+
+
+def test_touched_spans_cover_exactly_the_touched_tensors():
+    """the ranges exchanged for the current gradient set: every touched tensor inside, merged across small gaps, at most max_spans ranges"""
+    import types
+    from handwriting_line_generation_amd.trainer.flat_params import touched_spans
+    numel = np.array([10, 70000, 5, 300000, 8, 8, 100000, 4], dtype=np.int64)
+    padded = (numel + 3) // 4 * 4
+    flat = types.SimpleNamespace(offsets=np.concatenate([[0], np.cumsum(padded)[:-1]]), numel=numel)
+    mask = np.array([1, 0, 1, 0, 1, 1, 0, 1], dtype=bool)
+    spans = touched_spans(flat, mask, max_spans=8, min_gap=1 << 16)
+    covered = np.zeros(int(padded.sum()), dtype=bool)
+    for a, b in spans:
+        assert a < b and a % 4 == 0
+        covered[a:b] = True
+    for k in np.nonzero(mask)[0]:
+        assert covered[flat.offsets[k]: flat.offsets[k] + numel[k]].all()
+    # tensors 1 (70000 floats) and 3 (300000) are untouched and longer than the merge gap: they stay outside
+    assert not covered[flat.offsets[3] + 10] and not covered[flat.offsets[1] + 10]
+    assert len(touched_spans(flat, mask, max_spans=2)) == 2
+    assert touched_spans(flat, np.zeros(8, dtype=bool)) == []
