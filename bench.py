@@ -249,11 +249,29 @@ def main():
         if roofline:
             # HBM bytes per launch of the dominant kernel: PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately with rocprofv3 on this
             # same command and corrected per MI355X_MICROARCH.md) are committed under profiles/; they cannot be collected from inside bench.py
+            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    if pm.get("workload") == args.workload and dom in pm["kernels"]:
+                        roofline["traffic"] = pm["kernels"][dom]["hbm_bytes_per_launch_corrected"]
+                        roofline["traffic_source"] = "profiles/%s (rocprofv3 PMC over the whole step, bytes per launch)" % name
+                        break
+                except (OSError, KeyError, ValueError):
+                    pass
+            # ... and per layer shape (tools/pmc_shapes.py replays the step's top conv shapes under the same counters): measured HBM bytes against
+            # the one-pass operand bytes 4*(input + weights + output), weighted by this run's launch counts
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                if pm.get("workload") == args.workload:
-                    roofline["traffic"] = pm["kernels"][dom]["hbm_bytes_per_launch_corrected"]
-                    roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 PMC, bytes per launch)"
+                ps = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_shapes.json")))
+                launches = {(k, repr(sh)): v[2] for (k, sh), v in by_shape.items()}
+                tot = {}
+                for row in ps["shapes"]:
+                    n_here = launches.get((row["kind"], row["shape"]), 0)
+                    t = tot.setdefault(row["kind"], [0.0, 0.0, 0])
+                    t[0] += n_here * (row["hbm_fetch_bytes"] + row["hbm_write_bytes"]); t[1] += n_here * row["algorithmic_bytes"]; t[2] += n_here
+                roofline["traffic_by_shape"] = {"source": "profiles/r02_pmc_shapes.json",
+                                                "kernels": {k: {"launches_covered": t[2], "launches": fam[k][2], "hbm_bytes_per_launch": round(t[0] / t[2]),
+                                                                "operand_bytes_per_launch": round(t[1] / t[2]), "ratio": round(t[0] / t[1], 2)}
+                                                            for k, t in tot.items() if t[2] > 0 and k in fam}}
             except (OSError, KeyError, ValueError):
                 pass
         cpu = None

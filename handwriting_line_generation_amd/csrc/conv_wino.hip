@@ -30,7 +30,31 @@ struct WinoK {
   int accumulate;
   int nsplit;          // the C/16 chunk loop is cut into nsplit ranges (blockIdx.z); partial outputs go to `part`
   float* part;         // [nsplit][N*P*Q*K]
+  int mt, nt;          // workgroup tiles along M and K
+  int xcd_order;       // 1: every XCD owns a contiguous run of the (split, n-tile, m-tile) sequence, 0: plain launch order
 };
+
+// Work item of this workgroup. The dispatcher places block b on XCD b % 8 and every XCD has its own 4 MiB L2: with the plain order all
+// eight L2s stream the complete filter image and input (the 512-channel layers of the recogniser measured 10 x their operand bytes
+// in L2 misses); giving each XCD a contiguous run of the (split, n-tile, m-tile) sequence leaves it one slice of the filters and,
+// when the channel loop is split, only its channel range of the input.
+__device__ __forceinline__ bool wino_work_item(const WinoK& a, int& mtile, int& ntile, int& split) {
+  const int total = a.mt * a.nt * a.nsplit;
+  int w = blockIdx.x;
+  if (a.xcd_order) {
+    const int xcd = w & 7, slot = w >> 3;
+    const int lo = (int)((long long)xcd * total >> 3), hi = (int)((long long)(xcd + 1) * total >> 3);
+    w = lo + slot;
+    if (w >= hi) return false;
+  } else if (w >= total) {
+    return false;
+  }
+  mtile = w % a.mt;
+  const int r = w / a.mt;
+  ntile = r % a.nt;
+  split = r / a.nt;
+  return true;
+}
 
 __device__ __forceinline__ float quad_partner(float v) {
   // lane b of every quad receives the value of lane {2,2,1,1}[b]  (DPP quad_perm)
@@ -56,9 +80,10 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoK a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WGN, wn = wid % WGN;
-  const int m0 = blockIdx.x * TM;
-  const int n0 = blockIdx.y * TN;
-  const int split = blockIdx.z;
+  int mtile, ntile, split;
+  if (!wino_work_item(a, mtile, ntile, split)) return;
+  const int m0 = mtile * TM;
+  const int n0 = ntile * TN;
   const int T_all = a.C >> 4;
   const int t0 = (int)((long long)T_all * split / a.nsplit);
   const int t1 = (int)((long long)T_all * (split + 1) / a.nsplit);
@@ -295,9 +320,10 @@ __global__ __launch_bounds__(512) void wino_conv_ws_kernel(WinoK a) {
   float* const Us = smem + 2 * VBUF;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int m0 = blockIdx.x * TM;
-  const int n0 = blockIdx.y * TN;
-  const int split = blockIdx.z;
+  int mtile, ntile, split;
+  if (!wino_work_item(a, mtile, ntile, split)) return;
+  const int m0 = mtile * TM;
+  const int n0 = ntile * TN;
   const int T_all = a.C >> 4;
   const int t0 = (int)((long long)T_all * split / a.nsplit);
   const int t1 = (int)((long long)T_all * (split + 1) / a.nsplit);
@@ -564,9 +590,10 @@ __global__ __launch_bounds__(768) void wino_conv_big_kernel(WinoK a) {
   float* const Us = smem + 2 * VBUF;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int m0 = blockIdx.x * TM;
-  const int n0 = blockIdx.y * TN;
-  const int split = blockIdx.z;
+  int mtile, ntile, split;
+  if (!wino_work_item(a, mtile, ntile, split)) return;
+  const int m0 = mtile * TM;
+  const int n0 = ntile * TN;
   const int T_all = a.C >> 4;
   const int t0 = (int)((long long)T_all * split / a.nsplit);
   const int t1 = (int)((long long)T_all * (split + 1) / a.nsplit);
@@ -575,7 +602,7 @@ __global__ __launch_bounds__(768) void wino_conv_big_kernel(WinoK a) {
   // same 16 KB of filters at the same moment and queue up behind the few L2 channels that hold it (measured: the DMA issue alone took
   // 1700 cycles per round). The sum over the chunks is order independent up to fp32 rounding and fixed per workgroup.
   const int TC = t1 - t0;
-  const int rot = TC > 0 ? (int)((blockIdx.x * 7u + blockIdx.y * 3u) % (unsigned)TC) : 0;
+  const int rot = TC > 0 ? (int)(((unsigned)mtile * 7u + (unsigned)ntile * 3u) % (unsigned)TC) : 0;
   auto chunk_of = [&](int tau) { int c = tau + rot; if (c >= TC) c -= TC; return t0 + c; };   // tau in [0, TC)
 
   if (wid >= 8) {
@@ -936,7 +963,10 @@ extern "C" int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const f
   k.accumulate = accumulate;
   k.nsplit = p.nsplit;
   k.part = (float*)workspace;
-  dim3 grid(hwg_cdiv(k.M, p.tm), hwg_cdiv(d->K, p.tn), p.nsplit);
+  k.mt = hwg_cdiv(k.M, p.tm); k.nt = hwg_cdiv(d->K, p.tn);
+  static const int order_env = [] { const char* e = getenv("HWG_WINO_ORDER"); return e ? atoi(e) : 1; }();
+  k.xcd_order = order_env;
+  dim3 grid((k.mt * k.nt * p.nsplit + 7) / 8 * 8);
   const int prof = hwg_prof_open(HWG_PROF_CONV_WINO, 2.0 * d->N * d->P * d->Q * (double)d->K * d->C * 9.0, st);
   if (p.cfg == 0) hipLaunchKernelGGL((wino_conv_kernel<4, 2>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 1) hipLaunchKernelGGL((wino_conv_kernel<2, 4>), grid, dim3(512), 0, st, k);

@@ -25,6 +25,8 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 SLACK = 2.0          # pooled HIP error may be this multiple of the reference's own pooled fp32-vs-fp64 error (where that exceeds 1e-4)
 OUTLIER = 6.0        # a single tensor may be this far above its group's bound (one-sample estimates, see _judge)
+FLIPS = 2            # sign flips of near-zero gradient elements a single tensor's Adam update may differ by (see _judge)
+LATE = 2.0           # extra factor on SLACK after iteration 2 of a chained run (the reference's own fp32 and fp64 runs are >25 % apart by then)
 COND = 4.0           # multiple of the measured input-rounding sensitivity of the discriminator's gradients (disc lessons, see _judge)
 TOL = 1e-4
 
@@ -100,7 +102,9 @@ def _collect(kind, it, names, got, ref32, ref64, bad, rows, cond=None, spread=No
         l1 = max(b[1], 1e-300)
         e_ref = max(abs(a[3] - b[3]) / nrm, abs(a[1] - b[1]) / l1)
         e_hip = max(abs(g[3] - b[3]) / nrm, abs(g[1] - b[1]) / l1)
-        rows.append((it, kind, n.split(".")[0], n, e_hip, e_ref, (cond or {}).get(n, 0.0), ((spread or {}).get("groups") or {}).get("%s|%s" % (kind, n.split(".")[0]), 0.0)))
+        n_eff = b[1] * b[1] / max(b[2], 1e-300)      # (L1 / L2)^2: the element count when all magnitudes are equal, as in Adam's first steps
+        rows.append((it, kind, n.split(".")[0], n, e_hip, e_ref, (cond or {}).get(n, 0.0), ((spread or {}).get("groups") or {}).get("%s|%s" % (kind, n.split(".")[0]), 0.0),
+                     n_eff))
 
 
 def _judge(rows, bad, summary):
@@ -109,8 +113,8 @@ def _judge(rows, bad, summary):
     (iteration, gradient/update, sub-network): the pooled RMS error of the HIP path must stay within max(1e-4, SLACK x pooled RMS error of the
     reference's own fp32 arithmetic), and no single tensor may exceed OUTLIER x that bound."""
     groups = {}
-    for it, kind, top, n, eh, er, cd, sp in rows:
-        groups.setdefault((it, kind, top), []).append((n, eh, er, cd, sp))
+    for it, kind, top, n, eh, er, cd, sp, n_eff in rows:
+        groups.setdefault((it, kind, top), []).append((n, eh, er, cd, sp, n_eff))
     cond_seen = {}
     for key, items in sorted(groups.items()):
         rms_h = math.sqrt(sum(e[1] ** 2 for e in items) / len(items))
@@ -122,12 +126,15 @@ def _judge(rows, bad, summary):
         # replicate-padded rows), so the largest pooled value seen so far in the run is used
         rms_c = math.sqrt(sum(e[3] ** 2 for e in items) / len(items))
         cond_seen[key[1:]] = rms_c = max(rms_c, cond_seen.get(key[1:], 0.0))
-        bound = max(TOL, SLACK * rms_r, COND * rms_c)
+        bound = max(TOL, SLACK * (LATE if key[0] > 2 else 1.0) * rms_r, COND * rms_c)
         summary.append((key, len(items), rms_h, rms_r, bound))
         if rms_h > bound:
             bad.append("it%d %s %s: pooled error %.2e over %d tensors > %.2e (reference fp32-vs-fp64 %.2e)" % (key[0], key[1], key[2], rms_h, len(items), bound, rms_r))
-        for n, eh, er, cd, sp in items:
-            if eh > OUTLIER * max(bound, er):
+        for n, eh, er, cd, sp, n_eff in items:
+            # Adam's early steps are sign-like (m / sqrt(v) = +-1): an element whose gradient is within rounding of zero moves by +-lr either way,
+            # and one such flip shifts the tensor's update by 2 / sqrt(elements) of its norm - not an error of either implementation
+            flip = FLIPS * 2.0 / math.sqrt(max(n_eff, 1.0)) if key[1] == "update" else 0.0
+            if eh > max(OUTLIER * max(bound, er), flip):
                 bad.append("it%d %s %s: error %.2e vs fp64, group bound %.2e, reference's own error %.2e" % (key[0], key[1], n, eh, bound, er))
 
 
@@ -204,7 +211,8 @@ def test_lessons_match_reference_per_tensor(cuda, tmp_path, case):
         for k, rv in gold["u_after"].items():
             got = sd[k].flatten()[:8].cpu().tolist()
             r64 = gold["u_after64"][k]
-            tol = max(TOL, 4.0 * max(abs(a - b) for a, b in zip(rv, r64)))
+            # ... or as far as the golden's 1e-6-perturbed fp32 runs end up from the fp64 run after the whole chain
+            tol = max(TOL, 4.0 * max(abs(a - b) for a, b in zip(rv, r64)), OUTLIER * ((gold.get("u_after_spread") or {}).get(k, 0.0)))
             if max(abs(a - b) for a, b in zip(got, r64)) > tol:
                 bad.append("%s after the run: %s vs %s" % (k, got, rv))
         _judge(rows, bad, summary)
@@ -215,7 +223,7 @@ def test_lessons_match_reference_per_tensor(cuda, tmp_path, case):
             print("   it%d %-6s %-16s %5d  %.2e  %.2e  %.2e" % (key[0], key[1], key[2], n, rh, rr, bound))
         if os.environ.get("HWG_LESSON_VERBOSE"):
             seen_k = {}
-            for it, kind, top, n, eh, er, cd, sp in sorted([r for r in rows if r[2] != "hwr"], key=lambda r: (r[0], r[1], -r[4])):
+            for it, kind, top, n, eh, er, cd, sp, _ in sorted([r for r in rows if r[2] != "hwr"], key=lambda r: (r[0], r[1], -r[4])):
                 seen_k[(it, kind)] = seen_k.get((it, kind), 0) + 1
                 if seen_k[(it, kind)] <= 6:
                     print("      worst: it%d %-6s %-60s HIP %.2e  reference %.2e" % (it, kind, n, eh, er))

@@ -272,6 +272,8 @@ def main():
         names_top = [n.split(".")[0] for n in r32["names"]]
         out = {"case": name, "config": which, "batch_size": B, "a_batch_size": A, "W": W, "min_width": minW, "label_len": L,
                "curriculum": curriculum, "wseed_model": WSEED_MODEL, "wseed_enc": WSEED_ENC, "names": r32["names"], "u_after": r32["u_after"], "u_after64": r64["u_after"],
+               # how far the power-iteration vectors of the 1e-6-perturbed fp32 runs end up from the fp64 run's
+               "u_after_spread": {k: max(max(abs(x - y) for x, y in zip(v["u_after"][k], r64["u_after"][k])) for v in variants) for k in r32["u_after"]} if variants else None,
                "iterations": []}
         for a, b in zip(r32["iterations"], r64["iterations"]):
             assert a["lesson"] == b["lesson"]

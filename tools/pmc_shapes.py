@@ -4,6 +4,7 @@
   2. rocprofv3 --kernel-trace --pmc FETCH_SIZE -d <dir>/fetch -o out -- python3 tools/pmc_shapes.py run <shapes.txt>
      rocprofv3 --kernel-trace --pmc WRITE_SIZE -d <dir>/write -o out -- python3 tools/pmc_shapes.py run <shapes.txt>
   3. python tools/pmc_shapes.py parse <shapes.txt> <dir> <out.json>
+  (python tools/pmc_shapes.py time <shapes.txt>: the same replay timed with HIP events - A/B of a kernel change on the step's launch mix)
 
 `run` replays the top shapes one after the other (REPS launches each, a marker kernel in between) through the same C entry points the
 step uses; `parse` cuts the dispatch trace at the markers and sums the counters of everything launched for a shape (main kernel plus its
@@ -54,7 +55,7 @@ def algorithmic_bytes(kind, sh):
     return 4.0 * (N * H * W * C + N * P * Q * K + K * C * R * S)
 
 
-def run(path):
+def run(path, timing=False):
     import torch
     from handwriting_line_generation_amd import _lib as L
     from handwriting_line_generation_amd import ops
@@ -62,7 +63,11 @@ def run(path):
     st = ops._stream()
     marker = torch.empty(4, dtype=torch.float32, device=dev)
     g = torch.Generator().manual_seed(0)
+    total = 0.0
+    only = os.environ.get("PMC_SHAPES_KIND")
     for ms, n, kind, sh in read_shapes(path):
+        if only and only not in kind:
+            continue
         N, H, W, C, K, R, S, stride, pad, dil = sh[:10]
         wgrad = sh[10] == "wgrad"
         transposed = 0 if wgrad else int(sh[10])
@@ -92,26 +97,34 @@ def run(path):
             need = L.query("hwg_conv_fwd_workspace", ctypes.byref(d))
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
             call = lambda: L.call("hwg_conv_fwd", ctypes.byref(d), x, w, None, y, 0, ws, ws.numel(), st)  # noqa: E731
+        if timing:
+            for _ in range(3):
+                call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 20
+            total += us * n
+            print("%8.1f us  x%3d  (bench %8.1f)  %-18s %s" % (us, n, ms * 1e3 / n, kind, sh), flush=True)
+            continue
         L.call("hwg_randn", marker, 4, 1, 0, st)          # marker kernel: start of this shape's group
         for _ in range(REPS):
             call()
         torch.cuda.synchronize()
+    if timing:
+        print("weighted total %.3f ms (bench: %.3f ms)" % (total * 1e-3, sum(r[0] for r in read_shapes(path))))
+        return
     L.call("hwg_randn", marker, 4, 1, 0, st)
 
 
-def _dispatches(db):
+def _dispatches(db, counter):
     import sqlite3
-    con = sqlite3.connect(db)
-    cur = con.cursor()
-    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
-    T = lambda n: [t for t in tabs if t.startswith(n)][0]   # noqa: E731
-    q = ("select d.id, s.kernel_name, p.symbol, e.value from %s d join %s s on d.kernel_id = s.id join %s e on e.event_id = d.event_id "
-         "join %s p on e.pmc_id = p.id order by d.id" % (T("rocpd_kernel_dispatch"), T("rocpd_info_kernel_symbol"), T("rocpd_pmc_event"), T("rocpd_info_pmc")))
-    out = {}
-    for did, name, sym, val in cur.execute(q):
-        e = out.setdefault(did, [name, 0.0])
-        e[1] += val                                   # summed over the counter's instances
-    return [out[k] for k in sorted(out)]
+    cur = sqlite3.connect(db).cursor()
+    q = "select dispatch_id, kernel_name, sum(value) from counters_collection where counter_name = ? group by dispatch_id order by dispatch_id"
+    return [(name, val) for _, name, val in cur.execute(q, (counter,))]
 
 
 def parse(path, pmc_dir, out_json):
@@ -122,7 +135,7 @@ def parse(path, pmc_dir, out_json):
         dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(pmc_dir, which)) for f in fs if f.endswith(".db")]
         assert dbs, "no rocprofv3 database under %s/%s" % (pmc_dir, which)
         groups, cur = [], None
-        for name, val in _dispatches(dbs[0]):
+        for name, val in _dispatches(dbs[0], "FETCH_SIZE" if which == "fetch" else "WRITE_SIZE"):
             if "randn" in name:
                 cur = []
                 groups.append(cur)
@@ -135,7 +148,8 @@ def parse(path, pmc_dir, out_json):
         fetch = 2.0 * 1024.0 * sum(v for _, v in gf) / REPS        # KiB -> bytes, x2 (gfx950 half-counting of wide reads)
         write = 1024.0 * sum(v for _, v in gw) / REPS
         alg = algorithmic_bytes(kind, sh)
-        table.append({"kind": kind, "shape": repr(sh), "launches_in_bench": n, "ms_in_bench": ms, "kernels": sorted({k.split("(")[0][:60] for k, _ in gf}),
+        clean = lambda k: k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]   # noqa: E731
+        table.append({"kind": kind, "shape": repr(sh), "launches_in_bench": n, "ms_in_bench": ms, "kernels": sorted({clean(k) for k, _ in gf}),
                       "hbm_fetch_bytes": round(fetch), "hbm_write_bytes": round(write), "algorithmic_bytes": round(alg),
                       "ratio": round((fetch + write) / alg, 2)})
     with open(out_json, "w") as f:
@@ -145,7 +159,7 @@ def parse(path, pmc_dir, out_json):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "run":
-        run(sys.argv[2])
+    if sys.argv[1] in ("run", "time"):
+        run(sys.argv[2], timing=sys.argv[1] == "time")
     else:
         parse(sys.argv[2], sys.argv[3], sys.argv[4])

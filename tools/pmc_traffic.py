@@ -10,12 +10,12 @@ def per_kernel(path, counter):
 f = per_kernel(sys.argv[1], "FETCH_SIZE"); w = per_kernel(sys.argv[2], "WRITE_SIZE")
 rows = []
 for k in f:
-    if "mfma" not in k: continue
+    if "mfma" not in k and "wino_conv" not in k: continue
     n, fs = f[k]; nw, wsz = w.get(k, (0, 0.0))
     rows.append((k, n, fs / n * 1024, (wsz / nw * 1024 if nw else 0.0)))
 agg = {}
 for k, n, fb, wb in rows:
-    fam = "conv_mfma_kernel" if k.startswith("conv_mfma") else "wgrad_mfma_kernel"
+    fam = "conv_mfma_kernel" if k.startswith("conv_mfma") else "wino_conv_kernel" if k.startswith("wino_conv") else "wino_wgrad_kernel" if k.startswith("wino_wgrad") else "wgrad_mfma_kernel"
     a = agg.setdefault(fam, [0, 0.0, 0.0]); a[0] += n; a[1] += fb * n; a[2] += wb * n
 for fam, (n, fb, wb) in agg.items():
     print(json.dumps({"kernel": fam, "launches": n, "fetch_bytes_per_launch_raw": round(fb / n), "write_bytes_per_launch": round(wb / n),
