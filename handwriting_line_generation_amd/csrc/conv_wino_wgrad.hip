@@ -1,0 +1,374 @@
+// Weight gradient of 3x3 stride-1 convolutions in the Winograd domain, F(3x3, 2x2) (the transpose of conv_wino.hip's F(2x2, 3x3)):
+//   forward   Y = A^T [ (G g G^T) . (B^T d B) ] A        per 2x2 output tile, summed over input channels
+//   backward  dU[pos][k][c] = sum over tiles  Z[pos][k] * V[pos][c],   Z = A dY A^T (4x4 from the 2x2 tile of dy),  V = B^T d B
+//             dg[k][c]      = G^T dU[.][k][c] G                       (3x3 from 4x4, done by the reduce kernel)
+// 16 multiplies per tile and channel pair instead of 36: 2.25x fewer matrix-core FLOPs than the direct tap-by-tap product, and every
+// input patch / dy tile is read ONCE for all nine taps (the direct kernel streams them once per tap).
+//
+// One workgroup (8 wavefronts) owns a 64 (k) x 64 (c) block of dU for all 16 positions - 64k fp32 accumulators, 128 registers per
+// lane: wavefront w keeps positions 2w and 2w+1 as 4x4 blocks of 16x16 (v_mfma_f32_16x16x4_f32, contraction over tiles). A round
+// covers 8 tiles (4 horizontally adjacent pairs): wavefronts 0-3 fetch the 4x6 input patch of one pair for 64 channels (one channel
+// per lane: 256-byte coalesced rows), transform it in registers and store V, wavefronts 4-7 do the same for the 2x4 dy pixels (Z).
+// LDS image of a round: [Z | V][16 positions][64 channels][8 tiles], 64 KB, double buffered; a row of 8 tiles is four 2-tile slots,
+// XOR-swizzled by the channel so that both the ds_write_b64 stores (lane = channel) and the ds_read_b64 fragment reads
+// (lane = 16 channels x 4 slots) are bank-conflict free. The matrix pipe sees 64 MFMAs per wavefront per round against ~200 VALU
+// instructions of transform work, which the second wavefront of each SIMD overlaps.
+// Partial images go to [split][16][K][C]; wino_wgrad_reduce_kernel sums the splits and applies G^T . G.
+#include "hwg_common.h"
+#include <stdlib.h>
+
+namespace {
+
+struct WinoWgK {
+  const float* x;    // [N,H,W,C]
+  const float* dy;   // [N,P,Q,K]
+  float* part;       // [nsplit][16][K][C]
+  int N, H, W, C, K, P, Q, ph, pw, TP, TQ2;
+  int MP;            // tile pairs: N * TP * TQ2
+  int kt, ct, nsplit;
+};
+
+// slot of tile pair `pair` (0..3) inside the 8-float row of channel `ch`
+__device__ __forceinline__ int wg_slot(int ch, int pair) {
+  const int j = (ch >> 3) & 3;
+  return pair ^ (((j & 1) << 1) | (j >> 1));
+}
+
+constexpr int WG_PLANE = 64 * 8;           // floats of one position of one operand
+constexpr int WG_OPER = 16 * WG_PLANE;     // one operand, all positions
+constexpr int WG_BUF = 2 * WG_OPER;        // Z then V
+
+// One role's rounds. Stage r of the pipeline, all in one basic block so that the scheduler can interleave them (the matrix pipe needs 32
+// cycles per MFMA and is shared by the two wavefronts of a SIMD; the ~8 other instructions per MFMA fit in its shadow):
+//   A  fragment reads + 64 MFMAs on the LDS image of round r
+//   B  transform of the elements fetched for round r+1 (in registers since the previous stage) -> other LDS image
+//   C  global loads for round r+2 (in flight during the next stage's MFMAs)
+// Rounds past the end of the pixel range run with everything masked (B writes zeros, C reads clamped addresses) - no control flow.
+template <bool XROLE, int DBG>
+__device__ __forceinline__ void wg_rounds(const WinoWgK& a, float* smem, f32x4 (&acc)[2][4][4], int widu, int lane, int ch0, int p_lo, int p_hi, int rounds) {
+  constexpr int NR = XROLE ? 24 : 8;
+  constexpr int NQ = XROLE ? 6 : 4;       // columns of a fetched pair (x: 4x6 patch, dy: 2x4 pixels)
+  const int pairw = widu & 3;
+  // Everything about a fetch except the channel is the same for the 64 lanes of a wavefront (they share the tile pair). The (row, column)
+  // byte offsets and validity of the NR elements are computed across the lanes (lane i < NR = element i: ~15 VALU instructions for all of
+  // them), then handed to the loads as scalar offsets (v_readlane); the loads are buffer loads with the channel in the vector offset.
+  // Out-of-image elements are fetched from the clamped coordinate and multiplied by 0 in the transform, so the loads carry no control
+  // flow and stay in flight behind the next stage's MFMAs. Lanes past the last channel repeat it (their rows of dU are never stored).
+  const int voff = 4 * min(ch0 + lane, (XROLE ? a.C : a.K) - 1);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(XROLE ? a.x : a.dy), 0, 0x7fffffff, 0x00020000);
+  const int rows = XROLE ? a.H : a.P, cols = XROLE ? a.W : a.Q, chans = XROLE ? a.C : a.K;
+  const int el = lane < NR ? lane : 0;
+  const int e_r = el / NQ, e_q = el - e_r * NQ;
+  float raw[NR];
+  float e_mask = 0.f;                     // lane i: 1.0 when element i of the fetched pair lies inside the image
+
+  auto fetch = [&](int rnd) {
+    const int p = p_lo + rnd * 4 + pairw;
+    const bool pv = p < p_hi;
+    const int pp = pv ? p : p_lo;
+    const int t2 = pp / a.TQ2, tjp = pp - t2 * a.TQ2;
+    const int n = t2 / a.TP, ti = t2 - n * a.TP;
+    const int h0 = XROLE ? 2 * ti - a.ph : 2 * ti, w0 = XROLE ? 4 * tjp - a.pw : 4 * tjp;
+    const int hr = h0 + e_r, wq = w0 + e_q;                         // per lane
+    const bool ok = pv && (unsigned)hr < (unsigned)rows && (unsigned)wq < (unsigned)cols;
+    const int off = ((n * rows + min(max(hr, 0), rows - 1)) * cols + min(max(wq, 0), cols - 1)) * (4 * chans);
+    e_mask = ok ? 1.f : 0.f;
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      raw[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, __builtin_amdgcn_readlane(off, i), 0));
+  };
+  // transform the fetched pair and store its two tiles (one ds_write_b64 per position)
+  auto transform_store = [&](int buf) {
+    float* dst = smem + buf * WG_BUF + (XROLE ? WG_OPER : 0) + lane * 8 + 2 * wg_slot(lane, pairw);
+    float d[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) d[i] = raw[i] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e_mask), i));
+    if (XROLE) {
+      float t[4][6];                      // column transform (B^T over the rows) of the six patch columns
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const float d0 = d[q], d1 = d[6 + q], d2 = d[12 + q], d3 = d[18 + q];
+        t[0][q] = d0 - d2; t[1][q] = d1 + d2; t[2][q] = d2 - d1; t[3][q] = d1 - d3;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // tile 0 uses columns 0..3, tile 1 columns 2..5
+        *reinterpret_cast<float2*>(dst + (i * 4 + 0) * WG_PLANE) = make_float2(t[i][0] - t[i][2], t[i][2] - t[i][4]);
+        *reinterpret_cast<float2*>(dst + (i * 4 + 1) * WG_PLANE) = make_float2(t[i][1] + t[i][2], t[i][3] + t[i][4]);
+        *reinterpret_cast<float2*>(dst + (i * 4 + 2) * WG_PLANE) = make_float2(t[i][2] - t[i][1], t[i][4] - t[i][3]);
+        *reinterpret_cast<float2*>(dst + (i * 4 + 3) * WG_PLANE) = make_float2(t[i][1] - t[i][3], t[i][3] - t[i][5]);
+      }
+    } else {
+      // Z = A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]; d = rows (y0, y1) x columns (tile 0: 0,1; tile 1: 2,3)
+      float rr[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float y0 = d[q], y1 = d[4 + q];
+        rr[0][q] = y0; rr[1][q] = y0 + y1; rr[2][q] = y0 - y1; rr[3][q] = -y1;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<float2*>(dst + (i * 4 + 0) * WG_PLANE) = make_float2(rr[i][0], rr[i][2]);
+        *reinterpret_cast<float2*>(dst + (i * 4 + 1) * WG_PLANE) = make_float2(rr[i][0] + rr[i][1], rr[i][2] + rr[i][3]);
+        *reinterpret_cast<float2*>(dst + (i * 4 + 2) * WG_PLANE) = make_float2(rr[i][0] - rr[i][1], rr[i][2] - rr[i][3]);
+        *reinterpret_cast<float2*>(dst + (i * 4 + 3) * WG_PLANE) = make_float2(-rr[i][1], -rr[i][3]);
+      }
+    }
+  };
+
+  // fragment addressing: lane -> (row r of the 16-channel block, 2-tile slot g): MFMA e of a round contracts tiles {e, 2+e, 4+e, 6+e}
+  const int fr = lane & 15, fg = lane >> 4;
+  int f_off[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) f_off[b] = (b * 16 + fr) * 8 + 2 * wg_slot(b * 16 + fr, fg);
+
+  fetch(0);
+  transform_store(0);
+  fetch(1);
+  __syncthreads();
+  for (int rnd = 0; rnd < rounds; ++rnd) {
+    const int cur = rnd & 1;
+    const float* Zb = smem + cur * WG_BUF + (2 * widu) * WG_PLANE;
+    const float* Vb = Zb + WG_OPER;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float2 af[4], bf[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        af[b] = *reinterpret_cast<const float2*>(Zb + p * WG_PLANE + f_off[b]);
+        bf[b] = *reinterpret_cast<const float2*>(Vb + p * WG_PLANE + f_off[b]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (DBG & 1) acc[p][i][j][0] += af[i].x * bf[j].x;
+          else acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[p][i][j], 0, 0, 0);
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (DBG & 1) acc[p][i][j][1] += af[i].y * bf[j].y;
+          else acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[p][i][j], 0, 0, 0);
+        }
+    }
+    if (!(DBG & 2)) {
+      transform_store(cur ^ 1);
+      fetch(rnd + 2);
+    }
+    // interleave: one MFMA, then up to 8 of anything else (VALU / SALU / VMEM / DS) that is ready
+#pragma unroll
+    for (int g = 0; g < 64; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x096, XROLE ? 8 : 4, 0);
+    }
+    __syncthreads();
+  }
+}
+
+template <int DBG>
+__global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgK a) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * WG_BUF];      // 128 KB
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // work item: every XCD takes a contiguous run of the (split, k-tile, c-tile) sequence - the workgroups of one pixel range share
+  // their x / dy reads through that XCD's L2
+  const int total = a.kt * a.ct * a.nsplit;
+  int w = blockIdx.x;
+  {
+    const int xcd = w & 7, slot = w >> 3;
+    const int lo = (int)((long long)xcd * total >> 3), hi = (int)((long long)(xcd + 1) * total >> 3);
+    w = lo + slot;
+    if (w >= hi) return;
+  }
+  const int c0 = (w % a.ct) * 64;
+  const int k0 = ((w / a.ct) % a.kt) * 64;
+  const int split = w / (a.ct * a.kt);
+  const int p_lo = (int)((long long)a.MP * split / a.nsplit);
+  const int p_hi = (int)((long long)a.MP * (split + 1) / a.nsplit);
+  const int rounds = (p_hi - p_lo + 3) >> 2;
+  const int widu = __builtin_amdgcn_readfirstlane(wid);
+
+  f32x4 acc[2][4][4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[p][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // wavefronts 0-3 fetch and transform input patches (V), 4-7 the dy tiles (Z); all eight run the MFMAs of their two positions
+  if (widu < 4) wg_rounds<true, DBG>(a, smem, acc, widu, lane, c0, p_lo, p_hi, rounds);
+  else wg_rounds<false, DBG>(a, smem, acc, widu, lane, k0, p_lo, p_hi, rounds);
+
+  // ---- partial image: [split][pos][K][C]; C/D layout of the 16x16 block: column (c) = lane & 15, row (k) = (lane >> 4) * 4 + e
+  float* out = a.part + ((long long)split * 16 + 2 * wid) * a.K * a.C;
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = c0 + j * 16 + (lane & 15);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = k0 + i * 16 + (lane >> 4) * 4 + e;
+          if (k < a.K && c < a.C) out[((long long)p * a.K + k) * a.C + c] = acc[p][i][j][e];
+        }
+      }
+}
+
+// dw[k][c][r][s] (+)= G^T ( sum over splits of dU[.][k][c] ) G,  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+// block: 64 consecutive c (coalesced rows of the partial images) x 4 position groups; grid (ceil(C/64), K, chunks). With chunks > 1
+// (many pixel ranges, few output blocks: the 64-channel layers have 256 partial images of one block) a first pass only sums its
+// chunk of the splits into [chunk][16][K][C] (stage_out), a second pass over those finishes - fixed summation order, no atomics.
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ stage_out,
+                                                                int nsplit, int per_chunk, int K, int C,
+                                                                long long sa, long long sb, long long sr, long long ss, int accumulate) {
+  __shared__ float S[16][65];
+  const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, k = blockIdx.y;
+  const long long plane = (long long)K * C;
+  const int s_lo = blockIdx.z * per_chunk, s_hi = min(s_lo + per_chunk, nsplit);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const float* p0 = part + ((long long)s_lo * 16 + pg * 4) * plane + (long long)k * C + c;
+    int sp = s_lo;
+    for (; sp + 4 <= s_hi; sp += 4) {       // 16 independent loads in flight
+      float v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[u][q] = p0[(u * 16 + q) * plane];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] += v[u][q];
+      p0 += 64 * plane;
+    }
+    for (; sp < s_hi; ++sp) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q] += p0[q * plane];
+      p0 += 16 * plane;
+    }
+  }
+  if (stage_out) {
+    if (c < C) {
+      float* o = stage_out + ((long long)blockIdx.z * 16 + pg * 4) * plane + (long long)k * C + c;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q * plane] = s[q];
+    }
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) S[pg * 4 + q][cl] = s[q];
+  __syncthreads();
+  if (pg < 3 && c < C) {
+    // row r = pg of dg: first contract the rows (i) with column r of G, then the columns (j)
+    float t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float u0 = S[0 * 4 + j][cl], u1 = S[1 * 4 + j][cl], u2 = S[2 * 4 + j][cl], u3 = S[3 * 4 + j][cl];
+      t[j] = pg == 0 ? u0 + 0.5f * (u1 + u2) : pg == 1 ? 0.5f * (u1 - u2) : 0.5f * (u1 + u2) + u3;
+    }
+    const float g0 = t[0] + 0.5f * (t[1] + t[2]);
+    const float g1 = 0.5f * (t[1] - t[2]);
+    const float g2 = 0.5f * (t[1] + t[2]) + t[3];
+    float* o = dw + k * sa + c * sb + pg * sr;
+    if (accumulate) { o[0] += g0; o[ss] += g1; o[2 * ss] += g2; }
+    else { o[0] = g0; o[ss] = g1; o[2 * ss] = g2; }
+  }
+}
+
+struct WgPlan { int kt, ct, nsplit, MP, chunks, per_chunk; };
+
+WgPlan plan_wino_wgrad(const hwg_conv_desc* d) {
+  WgPlan p;
+  p.kt = hwg_cdiv(d->K, 64);
+  p.ct = hwg_cdiv(d->C, 64);
+  const int TP = hwg_cdiv(d->P, 2), TQ2 = hwg_cdiv(hwg_cdiv(d->Q, 2), 2);
+  p.MP = d->N * TP * TQ2;
+  const int rounds_all = hwg_cdiv(p.MP, 4);
+  // one workgroup per CU (128 KB of LDS): as many pixel ranges as fill the 256 CUs once, at least 4 rounds each
+  int ns = 256 / (p.kt * p.ct);
+  if (ns < 1) ns = 1;
+  const int cap = rounds_all / 4 > 1 ? rounds_all / 4 : 1;
+  if (ns > cap) ns = cap;
+  static const int force = [] { const char* e = getenv("HWG_WINO_WGRAD_SPLIT"); return e ? atoi(e) : 0; }();
+  if (force > 0) ns = force < rounds_all ? force : rounds_all;
+  p.nsplit = ns;
+  // two-pass reduce when the final pass alone would have few blocks with long serial sums
+  const int blocks = hwg_cdiv(d->C, 64) * d->K;
+  p.chunks = 1; p.per_chunk = ns;
+  if (ns >= 32 && blocks < 1024) {
+    p.per_chunk = 16;
+    p.chunks = hwg_cdiv(ns, 16);
+  }
+  return p;
+}
+
+}  // namespace
+
+extern "C" int hwg_wino_wgrad_supported(const hwg_conv_desc* d) {
+  if (!d) return 0;
+  return d->R == 3 && d->S == 3 && d->stride_h == 1 && d->stride_w == 1 && d->dil_h == 1 && d->dil_w == 1 && !d->transposed &&
+         d->K >= 16 && d->C >= 16 && d->P == d->H + 2 * d->pad_h - 2 && d->Q == d->W + 2 * d->pad_w - 2 && d->P >= 1 && d->Q >= 1 &&
+         (long long)d->N * d->H * d->W * d->C < (1ll << 29) && (long long)d->N * d->P * d->Q * d->K < (1ll << 29);   // 32-bit byte offsets
+}
+
+extern "C" int hwg_wino_wgrad_preferred(const hwg_conv_desc* d) {
+  const char* e = getenv("HWG_WINO_WGRAD");      // 0 never, 2 always (tests), default: the rule below
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0 || !hwg_wino_wgrad_supported(d)) return 0;
+  if (mode == 2) return 1;
+  // the 64 x 64 block wastes matrix-core work on narrower layers, and short pixel ranges cannot amortise the 16-position epilogue
+  const long long tiles = (long long)d->N * hwg_cdiv(d->P, 2) * hwg_cdiv(d->Q, 2);
+  return d->K >= 48 && d->C >= 48 && tiles * hwg_cdiv(d->K, 64) * hwg_cdiv(d->C, 64) >= 256 * 32;
+}
+
+extern "C" size_t hwg_wino_wgrad_workspace(const hwg_conv_desc* d) {
+  if (!hwg_wino_wgrad_supported(d)) return 0;
+  const WgPlan p = plan_wino_wgrad(d);
+  return (size_t)(p.nsplit + (p.chunks > 1 ? p.chunks : 0)) * 16 * d->K * d->C * sizeof(float);
+}
+
+extern "C" int hwg_wino_wgrad(const hwg_conv_desc* d, const float* dy, const float* x, float* dw, long long sa, long long sb, long long sr,
+                              long long ss, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  HWG_REQUIRE(d && dy && x && dw, "wino_wgrad: null pointer");
+  HWG_REQUIRE(hwg_wino_wgrad_supported(d), "wino_wgrad: needs a 3x3 stride-1 dilation-1 convolution with K, C >= 16");
+  const size_t need = hwg_wino_wgrad_workspace(d);
+  if (!workspace || workspace_bytes < need) {
+    hwg_set_error("wino_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return HWG_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const WgPlan p = plan_wino_wgrad(d);
+  WinoWgK k;
+  k.x = x; k.dy = dy; k.part = (float*)workspace;
+  k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.P = d->P; k.Q = d->Q; k.ph = d->pad_h; k.pw = d->pad_w;
+  k.TP = hwg_cdiv(d->P, 2); k.TQ2 = hwg_cdiv(hwg_cdiv(d->Q, 2), 2);
+  k.MP = p.MP; k.kt = p.kt; k.ct = p.ct; k.nsplit = p.nsplit;
+  const int total = p.kt * p.ct * p.nsplit;
+  int prof = hwg_prof_open(HWG_PROF_WGRAD_WINO, 2.0 * d->N * d->P * d->Q * (double)d->K * d->C * 9.0, st);
+  static const int dbg = [] { const char* e = getenv("HWG_WWG_DEBUG"); return e ? atoi(e) : 0; }();
+  if (dbg == 1) hipLaunchKernelGGL(wino_wgrad_kernel<1>, dim3((total + 7) / 8 * 8), dim3(512), 0, st, k);
+  else if (dbg == 2) hipLaunchKernelGGL(wino_wgrad_kernel<2>, dim3((total + 7) / 8 * 8), dim3(512), 0, st, k);
+  else hipLaunchKernelGGL(wino_wgrad_kernel<0>, dim3((total + 7) / 8 * 8), dim3(512), 0, st, k);
+  hwg_prof_close(prof, st);
+  HWG_LAUNCH_CHECK("wino_wgrad");
+  prof = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, (double)need, st);
+  const float* parts = (const float*)workspace;
+  int nparts = p.nsplit;
+  if (p.chunks > 1) {
+    float* stage = (float*)workspace + (size_t)p.nsplit * 16 * d->K * d->C;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(hwg_cdiv(d->C, 64), d->K, p.chunks), dim3(256), 0, st, parts, dw, stage, p.nsplit, p.per_chunk,
+                       d->K, d->C, sa, sb, sr, ss, accumulate);
+    parts = stage; nparts = p.chunks;
+  }
+  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(hwg_cdiv(d->C, 64), d->K, 1), dim3(256), 0, st, parts, dw, (float*)nullptr, nparts, nparts, d->K, d->C,
+                     sa, sb, sr, ss, accumulate);
+  hwg_prof_close(prof, st);
+  HWG_LAUNCH_CHECK("wino_wgrad_reduce");
+  return HWG_OK;
+}

@@ -343,6 +343,20 @@ def _wino_ok(N, H, W, C, K, R, S, stride, pad, dil, P, Q):
     return hit
 
 
+_wino_wgrad_choice = {}
+
+
+def _wino_wgrad_ok(d):
+    """weight gradient of a 3x3 stride-1 layer in the Winograd domain (conv_wino_wgrad.hip) - the library decides per geometry"""
+    if not WINOGRAD or d.R != 3 or d.S != 3:
+        return False
+    key = (d.N, d.H, d.W, d.C, d.K, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.dil_h, d.dil_w, d.P, d.Q)
+    hit = _wino_wgrad_choice.get(key)
+    if hit is None:
+        hit = _wino_wgrad_choice[key] = bool(L.query("hwg_wino_wgrad_preferred", ctypes.byref(d)))
+    return hit
+
+
 def _cpad(C, K, fractional=False):
     """channel count the contraction side must be zero-padded to: multiples of 16 for the MFMA path (always taken by the fractionally
     strided mode: conv-transpose with stride > 1, data gradient of a strided conv), multiples of 4 for the K <= 2 direct kernel,
@@ -471,7 +485,15 @@ class _Conv2d(Function):
             tiny_end = ((d.C == 1 and d.K % 4 == 0 and d.K > 2) or (d.K <= 2 and d.C % 4 == 0 and d.C < 16)) and d.N * d.P * d.Q < 8192
             # single gathered channel (first layers): the library runs the taps as the GEMM's N dimension, no padding needed
             tap_gemm = d.C == 1 and d.K > 2 and d.K % 4 == 0 and R * S <= 64
-            if (Kq != d.K or Cq != d.C) and not tiny_end and not tap_gemm:
+            if _wino_wgrad_ok(d):
+                need = L.query("hwg_wino_wgrad_workspace", ctypes.byref(d))
+                ws = workspace(need, x.device)
+                if PROF_SHAPES is not None:
+                    _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad", ctx.scope))
+                L.call("hwg_wino_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 1 if direct else 0, ws, ws.numel(), st)
+                if direct:
+                    dw_ = None
+            elif (Kq != d.K or Cq != d.C) and not tiny_end and not tap_gemm:
                 # channel counts that are not multiples of 4 (RIMES: 78 classes -> 206/334-channel inputs, 78 outputs): run the kernel
                 # on zero-padded copies and keep the valid block of the result
                 dK, dC = d.K, d.C

@@ -147,6 +147,40 @@ def test_winograd_agrees_with_direct_engine(cuda):
         _close(a, b, "winograd vs direct " + n, tol=2e-5)
 
 
+WINO_WGRAD_CASES = [(2, 12, 40, 64, 64, 1, 1), (3, 11, 37, 64, 96, 1, 1), (2, 9, 33, 80, 208, 0, 1), (1, 7, 130, 128, 64, 2, 2), (2, 3, 16, 256, 128, 0, 0),
+                    (4, 16, 64, 32, 48, 1, 1), (1, 5, 9, 16, 16, 1, 0)]
+
+
+@pytest.mark.parametrize("case", WINO_WGRAD_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_winograd_weight_gradient(cuda, case):
+    """F(3x3, 2x2) weight gradient (conv_wino_wgrad.hip) against autograd in fp64: odd tile counts, zero / wide padding, ragged channel blocks,
+    accumulation into an existing gradient"""
+    import os
+    from handwriting_line_generation_amd import ops
+    N, H, W, C, K, ph, pw = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, C, H, W, generator=g); w = torch.randn(K, C, 3, 3, generator=g) / (3 * C ** 0.5); b = torch.randn(K, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, 1, (ph, pw))
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+    os.environ["HWG_WINO_WGRAD"] = "2"
+    ops._wino_wgrad_choice.clear()
+    try:
+        xg = x.permute(0, 2, 3, 1).contiguous().to(cuda).requires_grad_(True)
+        wg, bg = w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+        for rep in range(2):          # the second backward accumulates through autograd
+            y = ops.conv2d(xg, wg, bg, 1, (ph, pw))
+            y.backward(gy.permute(0, 2, 3, 1).contiguous().to(cuda))
+        assert any(ops._wino_wgrad_choice.values()), "the Winograd weight-gradient kernel was not selected"
+    finally:
+        os.environ.pop("HWG_WINO_WGRAD", None)
+        ops._wino_wgrad_choice.clear()
+    _close(wg.grad, 2 * wr.grad.float(), "wino wgrad dw", tol=2e-5)
+    _close(bg.grad, 2 * br.grad.float(), "wino wgrad db", tol=2e-5)
+    _close(xg.grad.permute(0, 3, 1, 2), 2 * xr.grad.float(), "wino wgrad dx", tol=2e-5)
+
+
 def test_linear(cuda):
     from handwriting_line_generation_amd import ops
     g = torch.Generator().manual_seed(3)

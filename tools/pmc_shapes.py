@@ -82,9 +82,14 @@ def run(path, timing=False):
         if wgrad:
             u = torch.randn(N, P, Q, K, generator=g).to(dev)
             dw = torch.empty(K, C, R, S, dtype=torch.float32, device=dev)
-            need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
-            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
-            call = lambda: L.call("hwg_conv_wgrad", ctypes.byref(d), u, x, dw, C * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)  # noqa: E731
+            if L.query("hwg_wino_wgrad_preferred", ctypes.byref(d)):      # as ops.py chooses
+                need = L.query("hwg_wino_wgrad_workspace", ctypes.byref(d))
+                ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+                call = lambda: L.call("hwg_wino_wgrad", ctypes.byref(d), u, x, dw, C * R * S, R * S, S, 1, 0, ws, ws.numel(), st)  # noqa: E731
+            else:
+                need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
+                ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+                call = lambda: L.call("hwg_conv_wgrad", ctypes.byref(d), u, x, dw, C * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)  # noqa: E731
         elif kind == "wino_conv_kernel":
             w = torch.randn(L.query("hwg_wino_weight_floats", K, C), generator=g).to(dev)
             y = torch.empty(N, P, Q, K, dtype=torch.float32, device=dev)
