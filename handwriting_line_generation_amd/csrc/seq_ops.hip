@@ -47,9 +47,11 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* dy, c
 // ---------------- CTC (blank = 0), same recursions as ATen's ctc_loss_cpu ----------------
 __device__ __forceinline__ int ctc_ext(const int* tg, int s) { return (s & 1) ? tg[s >> 1] : 0; }
 
-// one block per batch item. lp: [T][B][C]; targets: [B][Lmax] int32; writes log_alpha [B][T][2*Lmax+1] and nll[B]
+// one block per batch item. lp: [T][B][C]; targets: [B][Lmax] int32; writes log_alpha [B][T][2*Lmax+1] and nll[B]. The recursion's rows
+// live in LDS (a chain of T dependent steps: one barrier each, no global-memory round trip); global log_alpha is written for the backward pass
 __global__ __launch_bounds__(256) void ctc_alpha_kernel(const float* lp, const int* targets, const int* in_len, const int* tg_len, int T, int B,
                                                         int C, int Lmax, float* log_alpha, float* nll) {
+  extern __shared__ float rows[];      // [2][NSmax] alpha rows, then NSmax ints: extended target
   const int b = blockIdx.x;
   const int S = tg_len[b];
   const int Tb = in_len[b];
@@ -57,6 +59,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_kernel(const float* lp, const i
   const int NSmax = 2 * Lmax + 1;
   const int* tg = targets + (long long)b * Lmax;
   float* la = log_alpha + (long long)b * T * NSmax;
+  int* ext = (int*)(rows + 2 * NSmax);
   const float NEG = -INFINITY;
   for (int s = threadIdx.x; s < NSmax; s += 256) {
     float v = NEG;
@@ -65,24 +68,28 @@ __global__ __launch_bounds__(256) void ctc_alpha_kernel(const float* lp, const i
       else if (s == 1 && S > 0) v = lp[((long long)0 * B + b) * C + tg[0]];
     }
     la[s] = v;
+    rows[s] = v;
+    ext[s] = s < NS ? ctc_ext(tg, s) : 0;
   }
   __syncthreads();
   for (int t = 1; t < Tb; ++t) {
-    const float* prev = la + (long long)(t - 1) * NSmax;
-    float* cur = la + (long long)t * NSmax;
+    const float* prev = rows + ((t - 1) & 1) * NSmax;
+    float* cur = rows + (t & 1) * NSmax;
     for (int s = threadIdx.x; s < NSmax; s += 256) {
       float v = NEG;
       if (s < NS) {
-        const int cs = ctc_ext(tg, s);
+        const int cs = ext[s];
+        const float l = lp[((long long)t * B + b) * C + cs];
         const float la1 = prev[s];
         float lamax = la1;
         float la2 = NEG, la3 = NEG;
         if (s > 0) { la2 = prev[s - 1]; if (la2 > lamax) lamax = la2; }
-        if (s > 1 && ctc_ext(tg, s - 2) != cs) { la3 = prev[s - 2]; if (la3 > lamax) lamax = la3; }
+        if (s > 1 && ext[s - 2] != cs) { la3 = prev[s - 2]; if (la3 > lamax) lamax = la3; }
         if (lamax == NEG) lamax = 0.f;
-        v = logf(expf(la1 - lamax) + expf(la2 - lamax) + expf(la3 - lamax)) + lamax + lp[((long long)t * B + b) * C + cs];
+        v = logf(expf(la1 - lamax) + expf(la2 - lamax) + expf(la3 - lamax)) + lamax + l;
       }
       cur[s] = v;
+      la[(long long)t * NSmax + s] = v;
     }
     __syncthreads();
   }
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_kernel(const float* lp, const i
     float r;
     if (Tb <= 0) r = (S == 0) ? 0.f : INFINITY;
     else {
-      const float* last = la + (long long)(Tb - 1) * NSmax;
+      const float* last = rows + ((Tb - 1) & 1) * NSmax;
       const float l1 = last[NS - 1];
       const float l2 = (S > 0) ? last[NS - 2] : NEG;
       float m = fmaxf(l1, l2);
@@ -111,80 +118,94 @@ __global__ void ctc_mean_kernel(const float* nll, const int* tg_len, int B, floa
     *loss = inf ? 0.f : s;
   }
 }
-// backward: beta recursion + gradient wrt log-probs (ATen ctc_loss_backward_cpu, eq. 16 of Graves et al.)
-__global__ __launch_bounds__(256) void ctc_beta_grad_kernel(const float* lp, const int* targets, const int* in_len, const int* tg_len, int T, int B,
-                                                            int C, int Lmax, const float* log_alpha, const float* nll, const float* grad_out,
-                                                            const int* finite_flag, float* log_beta /*[B][2][NSmax]*/, float* grad) {
-  extern __shared__ float lcab[];  // [C]
+// backward, part 1: beta recursion (eq. 10-11 of Graves et al., as ATen's ctc_loss_backward_cpu), one block per batch item, rows kept in LDS
+// (the recursion is a chain of T dependent steps: a global-memory round trip per step would cost more than the arithmetic); log_beta [B][T][NSmax]
+__global__ __launch_bounds__(256) void ctc_beta_kernel(const float* lp, const int* targets, const int* in_len, const int* tg_len, int T, int B,
+                                                       int C, int Lmax, float* log_beta) {
+  extern __shared__ float rows[];      // [2][NSmax] beta rows, then NSmax ints: extended target
   const int b = blockIdx.x;
   const int S = tg_len[b];
   const int Tb = in_len[b];
   const int NS = 2 * S + 1;
   const int NSmax = 2 * Lmax + 1;
   const int* tg = targets + (long long)b * Lmax;
-  const float* la = log_alpha + (long long)b * T * NSmax;
-  float* lb0 = log_beta + (long long)b * 2 * NSmax;
+  float* lb = log_beta + (long long)b * T * NSmax;
+  int* ext = (int*)(rows + 2 * NSmax);
   const float NEG = -INFINITY;
-  const float nl = nll[b];
-  const int tl = S > 1 ? S : 1;
-  const float gr = (*finite_flag) ? grad_out[0] / ((float)tl * (float)B) : 0.f;
-  const bool bad = !(*finite_flag) || isinf(nl);
-  // zero gradient beyond the input length
-  for (int t = Tb; t < T; ++t)
-    for (int c = threadIdx.x; c < C; c += 256) grad[((long long)t * B + b) * C + c] = 0.f;
+  for (int s = threadIdx.x; s < NSmax; s += 256) ext[s] = s < NS ? ctc_ext(tg, s) : 0;
+  __syncthreads();
   if (Tb <= 0) return;
   for (int t = Tb - 1; t >= 0; --t) {
-    float* cur = lb0 + (t & 1) * NSmax;
-    const float* nxt = lb0 + ((t + 1) & 1) * NSmax;
+    float* cur = rows + (t & 1) * NSmax;
+    const float* nxt = rows + ((t + 1) & 1) * NSmax;
     for (int s = threadIdx.x; s < NSmax; s += 256) {
       float v = NEG;
       if (s < NS) {
-        const int cs = ctc_ext(tg, s);
+        const int cs = ext[s];
+        const float l = lp[((long long)t * B + b) * C + cs];
         if (t == Tb - 1) {
-          if (s == NS - 1 || (S > 0 && s == NS - 2)) v = lp[((long long)t * B + b) * C + cs];
+          if (s == NS - 1 || (S > 0 && s == NS - 2)) v = l;
         } else {
           const float lb1 = nxt[s];
           float lbmax = lb1;
           float lb2 = NEG, lb3 = NEG;
           if (s < NS - 1) { lb2 = nxt[s + 1]; if (lb2 > lbmax) lbmax = lb2; }
-          if (s < NS - 2 && ctc_ext(tg, s + 2) != cs) { lb3 = nxt[s + 2]; if (lb3 > lbmax) lbmax = lb3; }
+          if (s < NS - 2 && ext[s + 2] != cs) { lb3 = nxt[s + 2]; if (lb3 > lbmax) lbmax = lb3; }
           if (lbmax == NEG) lbmax = 0.f;
-          v = logf(expf(lb1 - lbmax) + expf(lb2 - lbmax) + expf(lb3 - lbmax)) + lbmax + lp[((long long)t * B + b) * C + cs];
+          v = logf(expf(lb1 - lbmax) + expf(lb2 - lbmax) + expf(lb3 - lbmax)) + lbmax + l;
         }
       }
       cur[s] = v;
-    }
-    float* lmax = lcab;        // [C] running maximum of alpha+beta per class
-    float* lsum = lcab + C;    // [C] sum of exp(alpha+beta - max)
-    for (int c = threadIdx.x; c < C; c += 256) { lmax[c] = NEG; lsum[c] = 0.f; }
-    __syncthreads();
-    // log-sum of alpha*beta per class: one thread per class walks the extended target in state order (a fixed summation order: LDS atomics
-    // would make the gradient differ in its last bits from run to run, which Adam's sign-like first steps amplify)
-    for (int c = threadIdx.x; c < C; c += 256) {
-      float m = NEG;
-      for (int s = (c == 0 ? 0 : 1); s < NS; s += 2) {
-        if (ctc_ext(tg, s) != c) continue;
-        const float v = la[(long long)t * NSmax + s] + cur[s];
-        if (v > m) m = v;
-      }
-      float sum = 0.f;
-      if (m != NEG)
-        for (int s = (c == 0 ? 0 : 1); s < NS; s += 2) {
-          if (ctc_ext(tg, s) != c) continue;
-          const float v = la[(long long)t * NSmax + s] + cur[s];
-          if (v != NEG) sum += expf(v - m);
-        }
-      lmax[c] = m; lsum[c] = sum;
+      lb[(long long)t * NSmax + s] = v;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-      const float acc = (lsum[c] > 0.f) ? logf(lsum[c]) + lmax[c] : NEG;
-      const float l = lp[((long long)t * B + b) * C + c];
-      float g = (expf(l) - expf(acc + nl - l)) * gr;
-      if (bad) g = 0.f;
-      grad[((long long)t * B + b) * C + c] = g;
-    }
-    __syncthreads();
+  }
+}
+
+// backward, part 2: gradient wrt log-probs (eq. 16), one block per (t, b) - every (t, b, class) is independent once alpha and beta exist.
+// The log-sum of alpha*beta per class walks the extended target in state order: a fixed summation order (atomics would make the gradient
+// differ in its last bits from run to run, which Adam's sign-like first steps amplify).
+__global__ __launch_bounds__(128) void ctc_grad_kernel(const float* lp, const int* targets, const int* in_len, const int* tg_len, int T, int B, int C,
+                                                       int Lmax, const float* log_alpha, const float* log_beta, const float* nll, const float* grad_out,
+                                                       const int* finite_flag, float* grad) {
+  extern __shared__ float ab[];        // [NSmax] alpha + beta, then NSmax ints: extended target
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int S = tg_len[b];
+  const int Tb = in_len[b];
+  const int NS = 2 * S + 1;
+  const int NSmax = 2 * Lmax + 1;
+  float* g = grad + ((long long)t * B + b) * C;
+  if (t >= Tb) {                       // zero gradient beyond the input length
+    for (int c = threadIdx.x; c < C; c += 128) g[c] = 0.f;
+    return;
+  }
+  const int* tg = targets + (long long)b * Lmax;
+  int* ext = (int*)(ab + NSmax);
+  const long long row = ((long long)b * T + t) * NSmax;
+  for (int s = threadIdx.x; s < NS; s += 128) {
+    ab[s] = log_alpha[row + s] + log_beta[row + s];
+    ext[s] = ctc_ext(tg, s);
+  }
+  __syncthreads();
+  const float NEG = -INFINITY;
+  const float nl = nll[b];
+  const int tl = S > 1 ? S : 1;
+  const float gr = (*finite_flag) ? grad_out[0] / ((float)tl * (float)B) : 0.f;
+  const bool bad = !(*finite_flag) || isinf(nl);
+  const float* lpr = lp + ((long long)t * B + b) * C;
+  for (int c = threadIdx.x; c < C; c += 128) {
+    float m = NEG;
+    for (int s = (c == 0 ? 0 : 1); s < NS; s += 2)
+      if (ext[s] == c && ab[s] > m) m = ab[s];
+    float sum = 0.f;
+    if (m != NEG)
+      for (int s = (c == 0 ? 0 : 1); s < NS; s += 2)
+        if (ext[s] == c && ab[s] != NEG) sum += expf(ab[s] - m);
+    const float acc = (sum > 0.f) ? logf(sum) + m : NEG;
+    const float l = lpr[c];
+    float v = (expf(l) - expf(acc + nl - l)) * gr;
+    if (bad) v = 0.f;
+    g[c] = v;
   }
 }
 
@@ -300,8 +321,8 @@ extern "C" int hwg_log_softmax_bwd(const float* dy, const float* y, float* dx, l
 
 extern "C" size_t hwg_ctc_workspace(int T, int B, int Lmax) {
   const size_t NS = 2 * (size_t)Lmax + 1;
-  // log_alpha [B][T][NS] + log_beta [B][2][NS] + nll[B] + flag
-  return ((size_t)B * T * NS + (size_t)B * 2 * NS + B + 4) * sizeof(float);
+  // log_alpha [B][T][NS] + log_beta [B][T][NS] + nll[B] + flag
+  return (2 * (size_t)B * T * NS + B + 4) * sizeof(float);
 }
 extern "C" int hwg_ctc_fwd(const float* log_probs, const int* targets, const int* input_lengths, const int* target_lengths, int T, int B, int C,
                            int Lmax, float* loss, void* ws, size_t ws_bytes, void* stream) {
@@ -311,9 +332,9 @@ extern "C" int hwg_ctc_fwd(const float* log_probs, const int* targets, const int
   const size_t NS = 2 * (size_t)Lmax + 1;
   float* la = (float*)ws;
   float* lb = la + (size_t)B * T * NS;
-  float* nll = lb + (size_t)B * 2 * NS;
+  float* nll = lb + (size_t)B * T * NS;
   int* flag = (int*)(nll + B);
-  hipLaunchKernelGGL(ctc_alpha_kernel, dim3(B), dim3(256), 0, st, log_probs, targets, input_lengths, target_lengths, T, B, C, Lmax, la, nll);
+  hipLaunchKernelGGL(ctc_alpha_kernel, dim3(B), dim3(256), 3 * NS * sizeof(float), st, log_probs, targets, input_lengths, target_lengths, T, B, C, Lmax, la, nll);
   HWG_LAUNCH_CHECK("ctc_alpha");
   hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(64), 0, st, (const float*)nll, target_lengths, B, loss, flag);
   HWG_LAUNCH_CHECK("ctc_mean");
@@ -327,11 +348,14 @@ extern "C" int hwg_ctc_bwd(const float* log_probs, const int* targets, const int
   const size_t NS = 2 * (size_t)Lmax + 1;
   float* la = (float*)ws;
   float* lb = la + (size_t)B * T * NS;
-  float* nll = lb + (size_t)B * 2 * NS;
+  float* nll = lb + (size_t)B * T * NS;
   int* flag = (int*)(nll + B);
-  hipLaunchKernelGGL(ctc_beta_grad_kernel, dim3(B), dim3(256), 2 * C * sizeof(float), st, log_probs, targets, input_lengths, target_lengths, T, B, C,
-                     Lmax, (const float*)la, (const float*)nll, grad_out, (const int*)flag, lb, grad);
-  HWG_LAUNCH_CHECK("ctc_beta_grad");
+  const size_t lds = (2 * NS + NS) * sizeof(float);
+  hipLaunchKernelGGL(ctc_beta_kernel, dim3(B), dim3(256), lds, st, log_probs, targets, input_lengths, target_lengths, T, B, C, Lmax, lb);
+  HWG_LAUNCH_CHECK("ctc_beta");
+  hipLaunchKernelGGL(ctc_grad_kernel, dim3(T, B), dim3(128), 2 * NS * sizeof(float), st, log_probs, targets, input_lengths, target_lengths, T, B, C,
+                     Lmax, (const float*)la, (const float*)lb, (const float*)nll, grad_out, (const int*)flag, grad);
+  HWG_LAUNCH_CHECK("ctc_grad");
   return HWG_OK;
 }
 
