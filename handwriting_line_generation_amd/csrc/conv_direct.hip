@@ -80,21 +80,29 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(DirK a, int KG, int PG) {
   }
 }
 
-// ---- K <= 2 : one wave per output pixel, lanes sweep (tap, channel/4), wave reduction ----
+// ---- K <= 2 : LPP lanes per output pixel (64 / LPP pixels per wave) sweep (tap, channel/4), reduction inside the lane group.
+// LPP is the power of two covering the taps x channel-groups of a pixel: the generator's 16 -> 1 1x1 head keeps 16 pixels per wave busy
+// (one wave per pixel left 60 of 64 lanes idle there), the discriminator's 3x3 256 -> 1 heads use the whole wave per pixel.
+template <int LPP>
 __global__ __launch_bounds__(256) void conv_to1_kernel(DirK a) {
+  constexpr int PPW = 64 / LPP;
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * 256) >> 6;
+  const int sub = lane / LPP, li = lane % LPP;
+  const long long wave = (blockIdx.x * 256LL + threadIdx.x) >> 6;
+  const long long nwaves = (gridDim.x * 256LL) >> 6;
   const int C4 = a.C >> 2;
   const int E = a.R * a.S * C4;
   const long long M = (long long)a.N * a.P * a.Q;
-  for (long long m = wave; m < M; m += nwaves) {
-    const int q = (int)(m % a.Q);
-    const long long t = m / a.Q;
+  for (long long m0 = wave * PPW; m0 < M; m0 += nwaves * PPW) {
+    const long long m = m0 + sub;
+    const bool mv = m < M;
+    const long long mm = mv ? m : 0;
+    const int q = (int)(mm % a.Q);
+    const long long t = mm / a.Q;
     const int p = (int)(t % a.P);
     const int n = (int)(t / a.P);
     float acc0 = 0.f, acc1 = 0.f;
-    for (int e = lane; e < E; e += 64) {
+    for (int e = li; e < E && mv; e += LPP) {
       const int tap = e / C4, c4 = e % C4;
       const int r = tap / a.S, s = tap % a.S;
       const int ih = p * a.sh - a.ph + r * a.dh;
@@ -108,9 +116,12 @@ __global__ __launch_bounds__(256) void conv_to1_kernel(DirK a) {
         acc1 += xv.x * w1.x + xv.y * w1.y + xv.z * w1.z + xv.w * w1.w;
       }
     }
-    acc0 = wave_sum(acc0);
-    if (a.K > 1) acc1 = wave_sum(acc1);
-    if (lane == 0) {
+#pragma unroll
+    for (int o = LPP / 2; o > 0; o >>= 1) {
+      acc0 += __shfl_xor(acc0, o, 64);
+      acc1 += __shfl_xor(acc1, o, 64);
+    }
+    if (li == 0 && mv) {
       float v0 = acc0 + (a.bias ? a.bias[0] : 0.f);
       float* yo = a.y + m * a.K;
       yo[0] = a.accumulate ? yo[0] + v0 : v0;
@@ -296,10 +307,15 @@ int hwg_conv_to1_fwd_impl(const hwg_conv_desc* d, const float* x, const float* w
   k.sh = d->stride_h; k.sw = d->stride_w; k.ph = d->pad_h; k.pw = d->pad_w; k.dh = d->dil_h; k.dw = d->dil_w;
   k.P = d->P; k.Q = d->Q; k.accumulate = accumulate;
   const long long M = (long long)d->N * d->P * d->Q;
-  long long blocks = (M + 3) / 4;
+  const int E = d->R * d->S * (d->C / 4);
+  const int lpp = E <= 4 ? 4 : E <= 16 ? 16 : 64;
+  long long blocks = (M * lpp / 64 + 3) / 4;
   if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
   const int prof = hwg_prof_open(HWG_PROF_CONV_DIRECT, 2.0 * d->N * d->P * d->Q * d->K * d->C * d->R * d->S, st);
-  hipLaunchKernelGGL(conv_to1_kernel, dim3((unsigned)blocks), dim3(256), 0, st, k);
+  if (lpp == 4) hipLaunchKernelGGL(conv_to1_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, k);
+  else if (lpp == 16) hipLaunchKernelGGL(conv_to1_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL(conv_to1_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, st, k);
   hwg_prof_close(prof, st);
   HWG_LAUNCH_CHECK("conv_to1");
   return HWG_OK;

@@ -26,6 +26,7 @@ struct WinoWgK {
   int N, H, W, C, K, P, Q, ph, pw, TP, TQ2;
   int MP;            // tile pairs: N * TP * TQ2
   int kt, ct, nsplit;
+  float* bpart;      // [nsplit * 4][K] column sums of dy (the bias gradient) from the dy tiles that pass through anyway, or null
 };
 
 // slot of tile pair `pair` (0..3) inside the 8-float row of channel `ch`
@@ -45,7 +46,7 @@ constexpr int WG_BUF = 2 * WG_OPER;        // Z then V
 //   C  global loads for round r+2 (in flight during the next stage's MFMAs)
 // Rounds past the end of the pixel range run with everything masked (B writes zeros, C reads clamped addresses) - no control flow.
 template <bool XROLE, int DBG>
-__device__ __forceinline__ void wg_rounds(const WinoWgK& a, float* smem, f32x4 (&acc)[2][4][4], int widu, int lane, int ch0, int p_lo, int p_hi, int rounds) {
+__device__ __forceinline__ void wg_rounds(const WinoWgK& a, float* smem, f32x4 (&acc)[2][4][4], int widu, int lane, int ch0, int p_lo, int p_hi, int rounds, int bslot) {
   constexpr int NR = XROLE ? 24 : 8;
   constexpr int NQ = XROLE ? 6 : 4;       // columns of a fetched pair (x: 4x6 patch, dy: 2x4 pixels)
   const int pairw = widu & 3;
@@ -61,6 +62,7 @@ __device__ __forceinline__ void wg_rounds(const WinoWgK& a, float* smem, f32x4 (
   const int e_r = el / NQ, e_q = el - e_r * NQ;
   float raw[NR];
   float e_mask = 0.f;                     // lane i: 1.0 when element i of the fetched pair lies inside the image
+  float bsum = 0.f;                       // dy role: running column sum of this lane's channel
 
   auto fetch = [&](int rnd) {
     const int p = p_lo + rnd * 4 + pairw;
@@ -101,6 +103,7 @@ __device__ __forceinline__ void wg_rounds(const WinoWgK& a, float* smem, f32x4 (
     } else {
       // Z = A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]; d = rows (y0, y1) x columns (tile 0: 0,1; tile 1: 2,3)
       float rr[4][4];
+      bsum += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float y0 = d[q], y1 = d[4 + q];
@@ -165,6 +168,7 @@ __device__ __forceinline__ void wg_rounds(const WinoWgK& a, float* smem, f32x4 (
     }
     __syncthreads();
   }
+  if (!XROLE && a.bpart && ch0 + lane < a.K) a.bpart[(long long)(bslot * 4 + pairw) * a.K + ch0 + lane] = bsum;
 }
 
 template <int DBG>
@@ -199,8 +203,10 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgK a) {
       for (int j = 0; j < 4; ++j) acc[p][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // wavefronts 0-3 fetch and transform input patches (V), 4-7 the dy tiles (Z); all eight run the MFMAs of their two positions
-  if (widu < 4) wg_rounds<true, DBG>(a, smem, acc, widu, lane, c0, p_lo, p_hi, rounds);
-  else wg_rounds<false, DBG>(a, smem, acc, widu, lane, k0, p_lo, p_hi, rounds);
+  WinoWgK ab = a;
+  if (c0 != 0) ab.bpart = nullptr;          // one column of workgroups (c-tile 0) sees every dy element of its k-tile exactly once
+  if (widu < 4) wg_rounds<true, DBG>(ab, smem, acc, widu, lane, c0, p_lo, p_hi, rounds, split);
+  else wg_rounds<false, DBG>(ab, smem, acc, widu, lane, k0, p_lo, p_hi, rounds, split);
 
   // ---- partial image: [split][pos][K][C]; C/D layout of the 16x16 block: column (c) = lane & 15, row (k) = (lane >> 4) * 4 + e
   float* out = a.part + ((long long)split * 16 + 2 * wid) * a.K * a.C;
@@ -281,6 +287,24 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
   }
 }
 
+// dbias[k] (+)= sum of the nparts column-sum partials; block = 64 channels x 16 interleaved groups of partials, combined in a fixed order
+__global__ __launch_bounds__(1024) void wino_wgrad_bias_kernel(const float* __restrict__ bpart, int nparts, int K, float* __restrict__ dbias, int accumulate) {
+  __shared__ double red[16][64];
+  const int kl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kl;
+  double s = 0.0;
+  if (k < K)
+    for (int i = g; i < nparts; i += 16) s += (double)bpart[(long long)i * K + k];
+  red[g][kl] = s;
+  __syncthreads();
+  if (g == 0 && k < K) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j][kl];
+    dbias[k] = accumulate ? dbias[k] + (float)t : (float)t;
+  }
+}
+
 struct WgPlan { int kt, ct, nsplit, MP, chunks, per_chunk; };
 
 WgPlan plan_wino_wgrad(const hwg_conv_desc* d) {
@@ -330,11 +354,11 @@ extern "C" int hwg_wino_wgrad_preferred(const hwg_conv_desc* d) {
 extern "C" size_t hwg_wino_wgrad_workspace(const hwg_conv_desc* d) {
   if (!hwg_wino_wgrad_supported(d)) return 0;
   const WgPlan p = plan_wino_wgrad(d);
-  return (size_t)(p.nsplit + (p.chunks > 1 ? p.chunks : 0)) * 16 * d->K * d->C * sizeof(float);
+  return ((size_t)(p.nsplit + (p.chunks > 1 ? p.chunks : 0)) * 16 * d->K * d->C + (size_t)p.nsplit * 4 * d->K) * sizeof(float);
 }
 
 extern "C" int hwg_wino_wgrad(const hwg_conv_desc* d, const float* dy, const float* x, float* dw, long long sa, long long sb, long long sr,
-                              long long ss, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+                              long long ss, int accumulate, float* dbias, int bias_accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   HWG_REQUIRE(d && dy && x && dw, "wino_wgrad: null pointer");
   HWG_REQUIRE(hwg_wino_wgrad_supported(d), "wino_wgrad: needs a 3x3 stride-1 dilation-1 convolution with K, C >= 16");
   const size_t need = hwg_wino_wgrad_workspace(d);
@@ -349,6 +373,7 @@ extern "C" int hwg_wino_wgrad(const hwg_conv_desc* d, const float* dy, const flo
   k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.P = d->P; k.Q = d->Q; k.ph = d->pad_h; k.pw = d->pad_w;
   k.TP = hwg_cdiv(d->P, 2); k.TQ2 = hwg_cdiv(hwg_cdiv(d->Q, 2), 2);
   k.MP = p.MP; k.kt = p.kt; k.ct = p.ct; k.nsplit = p.nsplit;
+  k.bpart = dbias ? (float*)workspace + (size_t)(p.nsplit + (p.chunks > 1 ? p.chunks : 0)) * 16 * d->K * d->C : nullptr;
   const int total = p.kt * p.ct * p.nsplit;
   int prof = hwg_prof_open(HWG_PROF_WGRAD_WINO, 2.0 * d->N * d->P * d->Q * (double)d->K * d->C * 9.0, st);
   static const int dbg = [] { const char* e = getenv("HWG_WWG_DEBUG"); return e ? atoi(e) : 0; }();
@@ -368,6 +393,8 @@ extern "C" int hwg_wino_wgrad(const hwg_conv_desc* d, const float* dy, const flo
   }
   hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(hwg_cdiv(d->C, 64), d->K, 1), dim3(256), 0, st, parts, dw, (float*)nullptr, nparts, nparts, d->K, d->C,
                      sa, sb, sr, ss, accumulate);
+  if (dbias)
+    hipLaunchKernelGGL(wino_wgrad_bias_kernel, dim3(hwg_cdiv(d->K, 64)), dim3(1024), 0, st, (const float*)k.bpart, p.nsplit * 4, d->K, dbias, bias_accumulate);
   hwg_prof_close(prof, st);
   HWG_LAUNCH_CHECK("wino_wgrad_reduce");
   return HWG_OK;

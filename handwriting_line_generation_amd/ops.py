@@ -490,7 +490,15 @@ class _Conv2d(Function):
                 ws = workspace(need, x.device)
                 if PROF_SHAPES is not None:
                     _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad", ctx.scope))
-                L.call("hwg_wino_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 1 if direct else 0, ws, ws.numel(), st)
+                dbias = bacc = None
+                if ctx.has_bias and ctx.needs_input_grad[2] and not transposed:     # dy is the kernel's anchor operand: its column sums ride along
+                    bdirect = _direct(bref)
+                    dbias = _grad_buffer(bref) if bdirect else torch.empty((K,), dtype=torch.float32, device=x.device)
+                    bacc = 1 if bdirect else 0
+                    bias_done = True
+                    if not bdirect:
+                        db = dbias
+                L.call("hwg_wino_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 1 if direct else 0, dbias, bacc or 0, ws, ws.numel(), st)
                 if direct:
                     dw_ = None
             elif (Kq != d.K or Cq != d.C) and not tiny_end and not tap_gemm:

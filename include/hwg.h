@@ -126,12 +126,13 @@ int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const float* u, co
 
 /* Weight gradient of a 3x3 stride-1 dilation-1 convolution in the Winograd domain F(3x3, 2x2) (conv_wino_wgrad.hip): same operands and weight
  * strides as hwg_conv_wgrad (dy = anchor [N,P,Q,K], x = gathered [N,H,W,C]; reference: the weight gradients autograd produces for
- * model/pure_gen.py, model/discriminator_ap.py and model/cnn_only_hwr.py's 3x3 layers). No fused bias gradient. */
+ * model/pure_gen.py, model/discriminator_ap.py and model/cnn_only_hwr.py's 3x3 layers). dbias (or null): the bias gradient, column sums of dy,
+ * taken from the dy tiles on their way through the kernel. */
 int hwg_wino_wgrad_supported(const hwg_conv_desc* d);
 int hwg_wino_wgrad_preferred(const hwg_conv_desc* d);
 size_t hwg_wino_wgrad_workspace(const hwg_conv_desc* d);
 int hwg_wino_wgrad(const hwg_conv_desc* d, const float* dy, const float* x, float* dw, long long sa, long long sb, long long sr, long long ss,
-                   int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+                   int accumulate, float* dbias, int bias_accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[C] (+)= sum over rows of x[rows][C]  (bias gradients, channel sums) */
 size_t hwg_colsum_workspace(long long rows, int C);

@@ -85,7 +85,7 @@ def run(path, timing=False):
             if L.query("hwg_wino_wgrad_preferred", ctypes.byref(d)):      # as ops.py chooses
                 need = L.query("hwg_wino_wgrad_workspace", ctypes.byref(d))
                 ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
-                call = lambda: L.call("hwg_wino_wgrad", ctypes.byref(d), u, x, dw, C * R * S, R * S, S, 1, 0, ws, ws.numel(), st)  # noqa: E731
+                call = lambda: L.call("hwg_wino_wgrad", ctypes.byref(d), u, x, dw, C * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)  # noqa: E731
             else:
                 need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
                 ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
