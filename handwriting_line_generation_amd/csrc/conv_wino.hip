@@ -283,6 +283,231 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoK a) {
   }
 }
 
+// 64 tile x 64 channel workgroup tile with register-level operand reuse. Same producer side as wino_conv_kernel (round = one transform
+// row a of a 16-channel chunk: positions (a, b = 0..3)), but wavefront (b, nh) keeps ONE position column b for all four rows a as a
+// 64 tile x 32 channel block (4 x 2 MFMA blocks x 4 rows = 128 accumulator registers): 6 ds_read_b128 feed 32 MFMAs (the 16 x 16 wave
+// tiles above read 8 fragments per 16 MFMAs and spend ~70 % of the LDS cycles), and a round carries twice the MFMA work per barrier.
+// The output transform Y = A^T M A is register-local over a; the sum over b crosses wavefronts through LDS once per workgroup
+// ([b][i][tile][channel] exchange image, 136 KB, aliases the operand buffers).
+__global__ __launch_bounds__(512) void wino_conv64_kernel(WinoK a) {
+  constexpr int NT = 512, TM = 64, TN = 64;
+  constexpr int PSV = TM * 16 + 8, PSU = TN * 16 + 8;
+  constexpr int XI = TM * 16 / NT;                   // 2 x work items per thread: (tile, 4-channel group, patch column)
+  constexpr int UI = TN * 16 / NT;                   // 2 u work items per thread per round: (position, k, 4-channel group)
+  constexpr int BUF = 4 * (PSV + PSU);
+  constexpr int LDK = 68;                            // exchange row stride (floats): the 4 row groups of a C/D block land 16 banks apart
+  constexpr int XCH = 8 * 64 * LDK;
+  __shared__ __attribute__((aligned(16))) float smem[(2 * BUF > XCH) ? 2 * BUF : XCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int bq = wid & 3, nh = wid >> 2;
+  int mtile, ntile, split;
+  if (!wino_work_item(a, mtile, ntile, split)) return;
+  const int m0 = mtile * TM;
+  const int n0 = ntile * TN;
+  const int T_all = a.C >> 4;
+  const int t0 = (int)((long long)T_all * split / a.nsplit);
+  const int t1 = (int)((long long)T_all * (split + 1) / a.nsplit);
+
+  int x_off[XI], x_ok[XI], x_row[XI], x_c4[XI], x_b[XI];
+  const int row_stride = a.W * a.C;
+#pragma unroll
+  for (int it = 0; it < XI; ++it) {
+    const int id = tid + it * NT;
+    const int b = id & 3, c4 = (id >> 2) & 3, row = id >> 4;
+    x_b[it] = b; x_c4[it] = c4; x_row[it] = row;
+    const int m = m0 + row;
+    const bool mok = m < a.M;
+    const int mm = mok ? m : 0;
+    const int tj = mm % a.TQ;
+    const int t2 = mm / a.TQ;
+    const int ti = t2 % a.TP;
+    const int n = t2 / a.TP;
+    const int w = 2 * tj - a.pw + b;
+    const bool wok = mok && w >= 0 && w < a.W;
+    const int h0 = 2 * ti - a.ph;
+    x_off[it] = ((n * a.H + h0) * a.W + (wok ? w : 0)) * a.C + c4 * 4;
+    int okm = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (wok && h0 + r >= 0 && h0 + r < a.H) okm |= 1 << r;
+    x_ok[it] = okm;
+  }
+  int u_off[UI], u_lds[UI];
+  bool u_item[UI];
+#pragma unroll
+  for (int it = 0; it < UI; ++it) {
+    const int id = tid + it * NT;
+    const int c4 = id & 3, k = (id >> 2) % TN, pb = (id >> 2) / TN;
+    u_off[it] = (pb * a.Kpad + n0 + k) * 16 + c4 * 4;
+    u_lds[it] = pb * PSU + swz(k, c4);
+    u_item[it] = n0 + k < a.Kpad;
+  }
+
+  f32x4 acc[4][4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[r][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 raw[XI][4], tr[XI][4], ur[UI];
+  auto load_x = [&](int t) {
+#pragma unroll
+    for (int it = 0; it < XI; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int off = (x_ok[it] >> r) & 1 ? x_off[it] + r * row_stride + t * 16 : 0;
+        raw[it][r] = *reinterpret_cast<const float4*>(a.x + off);
+      }
+  };
+  auto col_transform = [&]() {
+#pragma unroll
+    for (int it = 0; it < XI; ++it) {
+      float4 d[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d[r] = raw[it][r];
+        if (!((x_ok[it] >> r) & 1)) d[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      tr[it][0] = make_float4(d[0].x - d[2].x, d[0].y - d[2].y, d[0].z - d[2].z, d[0].w - d[2].w);
+      tr[it][1] = make_float4(d[1].x + d[2].x, d[1].y + d[2].y, d[1].z + d[2].z, d[1].w + d[2].w);
+      tr[it][2] = make_float4(d[2].x - d[1].x, d[2].y - d[1].y, d[2].z - d[1].z, d[2].w - d[1].w);
+      tr[it][3] = make_float4(d[1].x - d[3].x, d[1].y - d[3].y, d[1].z - d[3].z, d[1].w - d[3].w);
+    }
+  };
+  auto load_u = [&](int t, int r) {
+    const float* base = a.u + ((long long)t * 16 + r * 4) * a.Kpad * 16;
+#pragma unroll
+    for (int it = 0; it < UI; ++it) ur[it] = *reinterpret_cast<const float4*>(base + (u_item[it] ? u_off[it] : 0));
+  };
+  auto store_round = [&](int buf, int r) {
+    float* Vb = smem + buf * BUF;
+    float* Ub = Vb + 4 * PSV;
+#pragma unroll
+    for (int it = 0; it < XI; ++it) {
+      const float4 v = tr[it][r];
+      const float sa = (x_b[it] == 3) ? -1.f : 1.f;
+      const float sb = (x_b[it] & 1) ? 1.f : -1.f;
+      float4 o;
+      o.x = sa * v.x + sb * quad_partner(v.x);
+      o.y = sa * v.y + sb * quad_partner(v.y);
+      o.z = sa * v.z + sb * quad_partner(v.z);
+      o.w = sa * v.w + sb * quad_partner(v.w);
+      *reinterpret_cast<float4*>(Vb + x_b[it] * PSV + swz(x_row[it], x_c4[it])) = o;
+    }
+#pragma unroll
+    for (int it = 0; it < UI; ++it) {
+      float4 v = ur[it];
+      if (!u_item[it]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(Ub + u_lds[it]) = v;
+    }
+  };
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  int a_off[4], b_off[2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) a_off[m] = bq * PSV + swz(m * 16 + frow, fchunk);
+#pragma unroll
+  for (int n = 0; n < 2; ++n) b_off[n] = 4 * PSV + bq * PSU + swz((nh * 2 + n) * 16 + frow, fchunk);
+
+  if (t1 > t0) {
+    load_x(t0);
+    load_u(t0, 0);
+    col_transform();
+    store_round(0, 0);
+  }
+  __syncthreads();
+
+  for (int t = t0; t < t1; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cur = r & 1;
+      const bool more = (r < 3) || (t + 1 < t1);
+      if (r == 1 && t + 1 < t1) load_x(t + 1);
+      if (more) load_u(r < 3 ? t : t + 1, (r + 1) & 3);
+      const float* Sb = smem + cur * BUF;
+      float4 af[4], bf[2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const float4*>(Sb + a_off[m]);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bf[n] = *reinterpret_cast<const float4*>(Sb + b_off[n]);
+      // element j of both fragments belongs to channel 4*(lane>>4)+j: MFMA j contracts channels {j, 4+j, 8+j, 12+j} of the chunk
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[r][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, bf[n].x, acc[r][m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[r][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, bf[n].y, acc[r][m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[r][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, bf[n].z, acc[r][m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[r][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, bf[n].w, acc[r][m][n], 0, 0, 0);
+      if (more) {
+        if (r == 3) col_transform();
+        store_round(cur ^ 1, (r + 1) & 3);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- output transform: over the rows a in registers (s0 = m0+m1+m2, s1 = m1-m2-m3), over the columns b through LDS ----------------
+  // exchange image X[b][i][tile][channel]; C/D layout of a block: channel = lane & 15, tile = (lane >> 4) * 4 + e
+  float* X = smem;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s0 = acc[0][m][n][e] + acc[1][m][n][e] + acc[2][m][n][e];
+        const float s1 = acc[1][m][n][e] - acc[2][m][n][e] - acc[3][m][n][e];
+        const int tile = m * 16 + (lane >> 4) * 4 + e, kk = (nh * 2 + n) * 16 + (lane & 15);
+        X[((bq * 2 + 0) * 64 + tile) * LDK + kk] = s0;
+        X[((bq * 2 + 1) * 64 + tile) * LDK + kk] = s1;
+      }
+  __syncthreads();
+  const int kk = tid & 63;
+  const int k = n0 + kk;
+  const bool direct = a.nsplit == 1;
+  float* yg = direct ? a.y : a.part + (long long)split * ((long long)a.N * a.P * a.Q * a.K);
+  const float bv = (direct && a.bias && k < a.K) ? a.bias[k] : 0.f;
+  const bool accum = direct && a.accumulate;
+#pragma unroll 2
+  for (int tile = tid >> 6; tile < 64; tile += 8) {
+    const int m = m0 + tile;
+    if (m >= a.M || k >= a.K) continue;
+    const int tj = m % a.TQ;
+    const int t2 = m / a.TQ;
+    const int ti = t2 % a.TP;
+    const int n = t2 / a.TP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float r0 = X[((0 * 2 + i) * 64 + tile) * LDK + kk], r1 = X[((1 * 2 + i) * 64 + tile) * LDK + kk];
+      const float r2 = X[((2 * 2 + i) * 64 + tile) * LDK + kk], r3 = X[((3 * 2 + i) * 64 + tile) * LDK + kk];
+      const int p = 2 * ti + i;
+      if (p >= a.P) continue;
+      const float y0 = r0 + r1 + r2, y1 = r1 - r2 - r3;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int q = 2 * tj + j;
+        if (q >= a.Q) continue;
+        const long long o = (((long long)n * a.P + p) * a.Q + q) * a.K + k;
+        float v = (j == 0 ? y0 : y1) + bv;
+        if (accum) v += yg[o];
+        yg[o] = v;
+      }
+    }
+  }
+}
+
 // Wave-specialised variant for layers with >= 32 output channels: wavefronts 0-3 ("consumers", one per SIMD) issue nothing but fragment
 // reads and MFMAs on a 32 tile x 16 channel x 16 position block each (128 accumulator registers), wavefronts 4-7 ("producers", the
 // second wave of every SIMD) feed LDS ahead of them:
@@ -849,18 +1074,19 @@ __global__ __launch_bounds__(256) void wino_pack_weight_kernel(const float* src,
 }
 
 struct WinoPlan {
-  int cfg;      // 0: 64 tiles x 32 k, 1: 32 x 64, 2: 128 x 16 (all-purpose kernel); 4: 32 x 64 (wave-specialised kernel); 3 unused
+  int cfg;      // 0: 64 tiles x 32 k, 1: 32 x 64, 2: 128 x 16 (all-purpose kernel); 4: 32 x 64 (wave-specialised kernel); 5: 64 x 64 (12 waves);
+                // 6: 64 x 64 with register-level operand reuse (wino_conv64_kernel); 3 unused
   int tm, tn, nsplit;
 };
 static void wino_cfg(WinoPlan& p, int cfg) {
-  static const int tms[6] = {64, 32, 128, 64, 32, 64}, tns[6] = {32, 64, 16, 32, 64, 64};
+  static const int tms[7] = {64, 32, 128, 64, 32, 64, 64}, tns[7] = {32, 64, 16, 32, 64, 64, 64};
   p.cfg = cfg; p.tm = tms[cfg]; p.tn = tns[cfg];
 }
 // Schedule = (kernel variant, channel split) with the smallest modelled time. Model (fitted to tools/wino_check.py sweeps on MI355X,
 // profiles/r02_wino_shapes.txt): one workgroup per CU at a time, so the launch takes ceil(workgroups / 256) rounds of
 // (fixed + rounds-of-the-channel-loop x step) microseconds; a channel split adds the pass that sums the partial outputs.
 struct WinoCost { int cfg; double fixed_us, step_us; };
-static const WinoCost kWinoCost[4] = {{1, 2.5, 1.17}, {5, 11.0, 2.09}, {0, 8.0, 1.2}, {2, 6.5, 1.5}};
+static const WinoCost kWinoCost[5] = {{1, 2.5, 1.17}, {5, 11.0, 2.09}, {0, 8.0, 1.2}, {2, 6.5, 1.5}, {6, 15.7, 1.04}};
 static WinoPlan plan_wino(const hwg_conv_desc* d, double* model_s = nullptr) {
   WinoPlan best;
   wino_cfg(best, d->K <= 16 ? 2 : d->K <= 48 ? 0 : 1);
@@ -869,11 +1095,11 @@ static WinoPlan plan_wino(const hwg_conv_desc* d, double* model_s = nullptr) {
   const int chunks = d->C / 16;
   const double out_bytes = 4.0 * d->N * d->P * d->Q * d->K;
   double best_t = 1e30;
-  for (int ci = 0; ci < 4; ++ci) {
+  for (int ci = 0; ci < 5; ++ci) {
     const WinoCost& wc = kWinoCost[ci];
     if (wc.cfg == 2 && d->K > 16) continue;
     if (wc.cfg == 0 && d->K > 48) continue;
-    if ((wc.cfg == 1 || wc.cfg == 5) && d->K <= 48) continue;
+    if ((wc.cfg == 1 || wc.cfg == 5 || wc.cfg == 6) && d->K <= 48) continue;
     if (wc.cfg == 5 && d->C < 64) continue;
     WinoPlan p;
     wino_cfg(p, wc.cfg);
@@ -889,7 +1115,7 @@ static WinoPlan plan_wino(const hwg_conv_desc* d, double* model_s = nullptr) {
   if (const char* f = getenv("HWG_WINO_FORCE")) {   // tuning aid: "cfg[,nsplit]"
     int fc = -1, fs = 0;
     const int n = sscanf(f, "%d,%d", &fc, &fs);
-    if (n >= 1 && fc >= 0 && fc <= 5 && fc != 3 && fc != 4 && (fc == 2 || d->K > 16)) wino_cfg(best, fc);
+    if (n >= 1 && fc >= 0 && fc <= 6 && fc != 3 && fc != 4 && (fc == 2 || d->K > 16)) wino_cfg(best, fc);
     if (n >= 2 && fs >= 1) best.nsplit = fs > chunks ? chunks : fs;
   }
   if (model_s) *model_s = best_t;
@@ -972,6 +1198,7 @@ extern "C" int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const f
   else if (p.cfg == 1) hipLaunchKernelGGL((wino_conv_kernel<2, 4>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 2) hipLaunchKernelGGL((wino_conv_kernel<8, 1>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 5) hipLaunchKernelGGL(wino_conv_big_kernel, grid, dim3(768), 0, st, k);
+  else if (p.cfg == 6) hipLaunchKernelGGL(wino_conv64_kernel, grid, dim3(512), 0, st, k);
   else hipLaunchKernelGGL((wino_conv_ws_kernel<1, 4>), grid, dim3(512), 0, st, k);
   hwg_prof_close(prof, st);
   HWG_LAUNCH_CHECK("wino_conv_fwd");
