@@ -10,7 +10,7 @@ def per_kernel(path, counter):
 f = per_kernel(sys.argv[1], "FETCH_SIZE"); w = per_kernel(sys.argv[2], "WRITE_SIZE")
 rows = []
 for k in f:
-    if "mfma" not in k and "wino_conv" not in k: continue
+    if ("mfma" not in k and "wino_conv" not in k and "wino_wgrad_kernel" not in k) or "reduce" in k: continue
     n, fs = f[k]; nw, wsz = w.get(k, (0, 0.0))
     rows.append((k, n, fs / n * 1024, (wsz / nw * 1024 if nw else 0.0)))
 agg = {}
