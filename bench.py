@@ -63,7 +63,7 @@ def peaked_offset_fn(num_class, seed=5, blank_frac=0.7, gain=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=56)
+    ap.add_argument("--steps", type=int, default=140)
     ap.add_argument("--warmup", type=int, default=14)
     ap.add_argument("--workload", default="iam_gan_b4a2_w512", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")

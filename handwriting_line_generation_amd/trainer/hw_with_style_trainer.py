@@ -238,6 +238,8 @@ class HWWithStyleTrainer(BaseTrainer):
             else:
                 self.optimizer.step()
         elif not self.curriculum:
+            if self.pre_clip_hook is not None:
+                self.pre_clip_hook(iteration)
             self.optimizer.step()
 
         # one device->host transfer for everything that is logged

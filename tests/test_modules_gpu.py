@@ -20,6 +20,7 @@ PERTURB = 1e-6      # relative size of the conditioning probe: what fp32 kernels
 
 
 def hip_forward(name, m, i):
+    name = cases.kind(name)
     if name == "generator":
         return [m(i["content"], i["style"])]
     if name == "discriminator":
@@ -151,11 +152,11 @@ def test_module_parity(cuda, name):
         eh, eo = l2(g, od), l2(og, od)
         if eh > max(TOL, 2 * eo, 3 * cond[k]):
             bad.append("grad %s: error vs fp64 %.2e (fp32 oracle %.2e, sensitivity %.2e)" % (k, eh, eo, cond[k]))
-    if name == "discriminator":  # spectral-norm u vectors mutate identically
+    if cases.kind(name) == "discriminator":  # spectral-norm u vectors mutate identically
         for k, v in m.state_dict().items():
             if k.endswith("weight_u") and rel(v.cpu(), gold["post_" + k.replace(".", "__")]) >= TOL:
                 bad.append("post-forward %s" % k)
-    if name == "hwr":  # BatchNorm running statistics
+    if cases.kind(name) == "hwr":  # BatchNorm running statistics
         for k, v in m.state_dict().items():
             if "running_mean" in k and rel(v.cpu(), gold["post_" + k.replace(".", "__")]) >= TOL:
                 bad.append("post-forward %s: %.2e" % (k, rel(v.cpu(), gold["post_" + k.replace(".", "__")])))

@@ -11,7 +11,14 @@ from oracle import cases, seq_oracle, torch_ref
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
-ORACLE_FWD = {
+class _ByKind(dict):
+    """case name -> entry of the network it exercises (the RIMES cases reuse their base case's definitions)"""
+
+    def __getitem__(self, name):
+        return dict.__getitem__(self, cases.kind(name))
+
+
+ORACLE_FWD = _ByKind({
     "generator": lambda sd, i: [torch_ref.generator(sd, i["content"], i["style"])],
     "discriminator": lambda sd, i: torch_ref.discriminator(sd, i["x"]),
     "hwr": lambda sd, i: [torch_ref.hwr(sd, i["image"])],
@@ -20,16 +27,16 @@ ORACLE_FWD = {
     "encoder2": lambda sd, i: list(torch_ref.encoder2(sd, i["x"])),
     "decoder": lambda sd, i: [torch_ref.decoder_noskip(sd, i["x"])],
     "e_hwr": lambda sd, i: [torch_ref.e_hwr(sd, i["x"])],
-}
-GRAD_INPUTS = {"generator": ["style"], "discriminator": ["x"], "hwr": ["image"], "spacer": ["style"], "style_extractor": ["recog"],
-               "encoder2": ["x"], "decoder": ["x"], "e_hwr": ["x"]}
+})
+GRAD_INPUTS = _ByKind({"generator": ["style"], "discriminator": ["x"], "hwr": ["image"], "spacer": ["style"], "style_extractor": ["recog"],
+                       "encoder2": ["x"], "decoder": ["x"], "e_hwr": ["x"]})
 
 
 def product_module(name):
     """the product's module class, used here on CPU only for its parameter names/shapes (no forward is run)"""
     from handwriting_line_generation_amd import model as M
     cls = dict(generator=M.SpacedGenerator, discriminator=M.DiscriminatorAP, hwr=M.CNNOnlyHWR, spacer=M.CountCNN,
-               style_extractor=M.CharStyleEncoder, encoder2=M.Encoder2, decoder=M.DecoderNoSkip, e_hwr=M.E_HWR)[name]
+               style_extractor=M.CharStyleEncoder, encoder2=M.Encoder2, decoder=M.DecoderNoSkip, e_hwr=M.E_HWR)[cases.kind(name)]
     return cls(**cases.CASES[name]["ctor"])
 
 

@@ -52,6 +52,7 @@ ORACLE_FWD = {
 
 
 def module_fwd(name, m, i):
+    name = cases.kind(name)
     if name == "generator":
         return [m(i["content"], i["style"])]
     if name == "discriminator":
@@ -77,14 +78,14 @@ GRAD_INPUTS = {"generator": ["style"], "discriminator": ["x"], "hwr": ["image"],
 
 def run_case(name, fwd, params, inp):
     """common protocol: seed, forward, probe loss, backward -> (outs, input grads, param-grad fingerprint)"""
-    for k in GRAD_INPUTS[name]:
+    for k in GRAD_INPUTS[cases.kind(name)]:
         inp[k] = inp[k].clone().requires_grad_(True)
     torch.manual_seed(cases.FWD_SEED)
     outs = fwd(inp)
     ws = cases.probe_weights(outs)
     loss = sum((o * w).sum() for o, w in zip(outs, ws))
     loss.backward()
-    igr = {k: inp[k].grad.detach().clone() for k in GRAD_INPUTS[name]}
+    igr = {k: inp[k].grad.detach().clone() for k in GRAD_INPUTS[cases.kind(name)]}
     pgr = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in params.items() if p.requires_grad}
     return [o.detach().clone() for o in outs], igr, pgr
 
@@ -92,7 +93,9 @@ def run_case(name, fwd, params, inp):
 def gen_modules():
     mods = ref_modules()
     for name, case in cases.CASES.items():
-        m = mods[name](**case["ctor"])
+        if os.environ.get("HWG_GOLDEN_ONLY") and name not in os.environ["HWG_GOLDEN_ONLY"].split(","):
+            continue
+        m = mods[cases.kind(name)](**case["ctor"])
         m.train()
         sd = torch_ref.seeded_state_dict(m, case["wseed"])
         m.load_state_dict(sd)
@@ -100,7 +103,7 @@ def gen_modules():
         # oracle on the same weights (fresh copies: spectral u/v and BN running stats are mutated by a forward)
         sd2 = {k: v.clone() for k, v in sd.items()}
         oparams = {k: sd2[k].requires_grad_(True) for k, p in m.named_parameters() if p.requires_grad}
-        oouts, oigr, opgr = run_case(name, lambda i: ORACLE_FWD[name](sd2, i), oparams, cases.inputs(name))
+        oouts, oigr, opgr = run_case(name, lambda i: ORACLE_FWD[cases.kind(name)](sd2, i), oparams, cases.inputs(name))
         worst = 0.0
         for a, b in zip(outs, oouts):
             worst = max(worst, float((a - b).abs().max() / max(a.abs().max(), 1e-6)))
@@ -112,9 +115,9 @@ def gen_modules():
         assert worst < 2e-5, name
         names, fp = cases.fingerprint(pgr)
         post = {}
-        if name == "discriminator":  # spectral-norm vectors after the forward
+        if cases.kind(name) == "discriminator":  # spectral-norm vectors after the forward
             post = {k.replace(".", "__"): v.detach().numpy() for k, v in m.state_dict().items() if k.endswith("weight_u")}
-        if name == "hwr":
+        if cases.kind(name) == "hwr":
             post = {k.replace(".", "__"): v.detach().numpy() for k, v in m.state_dict().items() if "running_mean" in k}
         np.savez_compressed(os.path.join(GOLD, "module_%s.npz" % name),
                             **{"out%d" % i: o.numpy() for i, o in enumerate(outs)},
