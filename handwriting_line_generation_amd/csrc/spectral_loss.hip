@@ -17,13 +17,17 @@ __global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* W, const floa
   if (rl == 0 && k < K) t[k] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
 // v = t / (||t|| + eps)   (single block)
-__global__ __launch_bounds__(1024) void sn_normalize_kernel(const float* t, float* v, int n, float eps, float* norm_out) {
+__global__ __launch_bounds__(1024) void sn_normalize_kernel(const float* t, float* v, int n, float eps, float* norm_out, float* v_copy = nullptr) {
   __shared__ double sm[16];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)t[i] * (double)t[i];
   s = block_sum_d(s, sm);
   const float nrm = (float)sqrt(s);
-  for (int i = threadIdx.x; i < n; i += blockDim.x) v[i] = t[i] / (nrm + eps);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float vi = t[i] / (nrm + eps);
+    v[i] = vi;
+    if (v_copy) v_copy[i] = vi;
+  }
   if (norm_out && threadIdx.x == 0) *norm_out = nrm;
 }
 // s[r] = sum_k W[r][k] * v[k]   (one wave per row)
@@ -37,7 +41,7 @@ __global__ __launch_bounds__(256) void sn_w_v_kernel(const float* W, const float
   if (lane == 0) s[r] = acc;
 }
 // u = s/(||s||+eps); sigma = u . s ; inv_sigma = 1/sigma
-__global__ __launch_bounds__(1024) void sn_finish_kernel(const float* s, float* u, int R, float eps, float* sigma, float* inv_sigma) {
+__global__ __launch_bounds__(1024) void sn_finish_kernel(const float* s, float* u, int R, float eps, float* sigma, float* inv_sigma, float* u_copy = nullptr) {
   __shared__ double sm[16];
   double q = 0.0;
   for (int i = threadIdx.x; i < R; i += blockDim.x) q += (double)s[i] * (double)s[i];
@@ -47,6 +51,7 @@ __global__ __launch_bounds__(1024) void sn_finish_kernel(const float* s, float* 
   for (int i = threadIdx.x; i < R; i += blockDim.x) {
     const float ui = s[i] / (nrm + eps);
     u[i] = ui;
+    if (u_copy) u_copy[i] = ui;
     d += (double)ui * (double)s[i];
   }
   d = block_sum_d(d, sm);
@@ -210,8 +215,8 @@ extern "C" size_t hwg_spectral_workspace(int R, int K) { return ((size_t)R + K +
 
 // One power iteration: v <- normalize(W^T u); u <- normalize(W v); sigma = u.(W v). u and v are updated in place,
 // sigma/inv_sigma are single floats on the device (consumed by hwg_scale_by_ptr / the weight packer).
-extern "C" int hwg_spectral_update(const float* W, float* u, float* v, int R, int K, float eps, float* sigma, float* inv_sigma, void* ws,
-                                   size_t ws_bytes, void* stream) {
+extern "C" int hwg_spectral_update_to(const float* W, float* u, float* v, float* u_copy, float* v_copy, int R, int K, float eps, float* sigma,
+                                      float* inv_sigma, void* ws, size_t ws_bytes, void* stream) {
   HWG_REQUIRE(W && u && v && sigma && inv_sigma && R > 0 && K > 0, "spectral_update: bad arguments");
   if (!ws || ws_bytes < hwg_spectral_workspace(R, K)) { hwg_set_error("spectral_update: workspace too small"); return HWG_ERR_WORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
@@ -219,13 +224,17 @@ extern "C" int hwg_spectral_update(const float* W, float* u, float* v, int R, in
   float* s = t + K;            // [R]
   hipLaunchKernelGGL(sn_wt_u_kernel, dim3(hwg_cdiv(K, 64)), dim3(256), 0, st, W, (const float*)u, t, R, K);
   HWG_LAUNCH_CHECK("sn_wt_u");
-  hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)t, v, K, eps, (float*)nullptr);
+  hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)t, v, K, eps, (float*)nullptr, v_copy);
   HWG_LAUNCH_CHECK("sn_normalize");
   hipLaunchKernelGGL(sn_w_v_kernel, dim3(hwg_cdiv(R, 4)), dim3(256), 0, st, W, (const float*)v, s, R, K);
   HWG_LAUNCH_CHECK("sn_w_v");
-  hipLaunchKernelGGL(sn_finish_kernel, dim3(1), dim3(1024), 0, st, (const float*)s, u, R, eps, sigma, inv_sigma);
+  hipLaunchKernelGGL(sn_finish_kernel, dim3(1), dim3(1024), 0, st, (const float*)s, u, R, eps, sigma, inv_sigma, u_copy);
   HWG_LAUNCH_CHECK("sn_finish");
   return HWG_OK;
+}
+extern "C" int hwg_spectral_update(const float* W, float* u, float* v, int R, int K, float eps, float* sigma, float* inv_sigma, void* ws,
+                                   size_t ws_bytes, void* stream) {
+  return hwg_spectral_update_to(W, u, v, nullptr, nullptr, R, K, eps, sigma, inv_sigma, ws, ws_bytes, stream);
 }
 extern "C" int hwg_scale_by_ptr(const float* x, const float* scale, float* out, long long n, void* stream) {
   HWG_REQUIRE(x && scale && out && n > 0, "scale_by_ptr: bad arguments");

@@ -1168,9 +1168,11 @@ def spectral_normalize(w_bar, u, v, eps=1e-12):
     K = w_bar.numel() // R
     sig = torch.empty((2,), dtype=torch.float32, device=w_bar.device)
     ws = workspace(L.query("hwg_spectral_workspace", R, K), w_bar.device)
+    # the kernels that update u and v in place also write the snapshot this forward's backward pass will read (the reference clones them)
+    un, vn = torch.empty_like(u), torch.empty_like(v)
     with torch.no_grad():
-        L.call("hwg_spectral_update", w_bar.detach(), u, v, R, K, eps, sig[0:1], sig[1:2], ws, ws.numel(), _stream())
-    return _SpectralScale.apply(w_bar, u.detach().clone(), v.detach().clone(), sig[0:1], sig[1:2])
+        L.call("hwg_spectral_update_to", w_bar.detach(), u, v, un, vn, R, K, eps, sig[0:1], sig[1:2], ws, ws.numel(), _stream())
+    return _SpectralScale.apply(w_bar, un, vn, sig[0:1], sig[1:2])
 
 
 # ----------------------------------------------------------------------------------------------

@@ -238,6 +238,10 @@ int hwg_gt_counts(const long long* index_spaced, const int* label, int Tp, int B
 size_t hwg_spectral_workspace(int R, int K);
 int hwg_spectral_update(const float* W, float* u, float* v, int R, int K, float eps, float* sigma, float* inv_sigma, void* ws,
                         size_t ws_bytes, void* stream);
+/* the same iteration (u, v updated in place) that also writes the new vectors to u_copy / v_copy (either may be null): the snapshot a forward
+ * pass keeps for its backward pass, without a separate copy (discriminator_ap.py:31-45 clones them) */
+int hwg_spectral_update_to(const float* W, float* u, float* v, float* u_copy, float* v_copy, int R, int K, float eps, float* sigma,
+                           float* inv_sigma, void* workspace, size_t workspace_bytes, void* stream);
 int hwg_scale_by_ptr(const float* x, const float* scale, float* out, long long n, void* stream);
 int hwg_spectral_bwd(const float* dWsn, const float* Wbar, const float* u, const float* v, const float* sigma, float* dWbar, int R, int K,
                      int accumulate, void* ws, size_t ws_bytes, void* stream);
