@@ -9,9 +9,8 @@
 // lane: wavefront w keeps positions 2w and 2w+1 as 4x4 blocks of 16x16 (v_mfma_f32_16x16x4_f32, contraction over tiles). A round
 // covers 8 tiles (4 horizontally adjacent pairs): wavefronts 0-3 fetch the 4x6 input patch of one pair for 64 channels (one channel
 // per lane: 256-byte coalesced rows), transform it in registers and store V, wavefronts 4-7 do the same for the 2x4 dy pixels (Z).
-// LDS image of a round: [Z | V][16 positions][64 channels][8 tiles], 64 KB, double buffered; a row of 8 tiles is four 2-tile slots,
-// XOR-swizzled by the channel so that both the ds_write_b64 stores (lane = channel) and the ds_read_b64 fragment reads
-// (lane = 16 channels x 4 slots) are bank-conflict free. The matrix pipe sees 64 MFMAs per wavefront per round against ~200 VALU
+// LDS image of a round: [Z | V][16 positions][4 channel blocks][4 tile pairs][16 channels][2 tiles], 64 KB, double buffered (wg_elem: pair
+// slots rotated by the block index, so the ds_write_b64 stores (lane = channel) and the ds_read_b64 fragment reads are conflict free). The matrix pipe sees 64 MFMAs per wavefront per round against ~200 VALU
 // instructions of transform work, which the second wavefront of each SIMD overlaps.
 // Partial images go to [split][16][K][C]; wino_wgrad_reduce_kernel sums the splits and applies G^T . G.
 #include "hwg_common.h"
@@ -29,10 +28,12 @@ struct WinoWgK {
   float* bpart;      // [nsplit * 4][K] column sums of dy (the bias gradient) from the dy tiles that pass through anyway, or null
 };
 
-// slot of tile pair `pair` (0..3) inside the 8-float row of channel `ch`
-__device__ __forceinline__ int wg_slot(int ch, int pair) {
-  const int j = (ch >> 3) & 3;
-  return pair ^ (((j & 1) << 1) | (j >> 1));
+// LDS image of one position of one operand: [16-channel block b][slot (pair + b) & 3][channel & 15][2 tiles]. A fragment read (lane = row fr,
+// pair fg) of block b covers its 128 floats exactly once - linear in the lane up to the rotation of the four 32-float segments - and the
+// transform's ds_write_b64 (lane = channel, fixed pair) lands neighbouring 16-lane groups on opposite halves of the 64 banks.
+__device__ __forceinline__ int wg_elem(int ch, int pair) {
+  const int b = ch >> 4;
+  return b * 128 + ((((pair + b) & 3) << 4) + (ch & 15)) * 2;
 }
 
 constexpr int WG_PLANE = 64 * 8;           // floats of one position of one operand
@@ -81,7 +82,7 @@ __device__ __forceinline__ void wg_rounds(const WinoWgK& a, float* smem, f32x4 (
   };
   // transform the fetched pair and store its two tiles (one ds_write_b64 per position)
   auto transform_store = [&](int buf) {
-    float* dst = smem + buf * WG_BUF + (XROLE ? WG_OPER : 0) + lane * 8 + 2 * wg_slot(lane, pairw);
+    float* dst = smem + buf * WG_BUF + (XROLE ? WG_OPER : 0) + wg_elem(lane, pairw);
     float d[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) d[i] = raw[i] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e_mask), i));
@@ -123,7 +124,7 @@ __device__ __forceinline__ void wg_rounds(const WinoWgK& a, float* smem, f32x4 (
   const int fr = lane & 15, fg = lane >> 4;
   int f_off[4];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) f_off[b] = (b * 16 + fr) * 8 + 2 * wg_slot(b * 16 + fr, fg);
+  for (int b = 0; b < 4; ++b) f_off[b] = wg_elem(b * 16 + fr, fg);
 
   fetch(0);
   transform_store(0);
