@@ -181,6 +181,37 @@ def test_winograd_weight_gradient(cuda, case):
     _close(xg.grad.permute(0, 3, 1, 2), 2 * xr.grad.float(), "wino wgrad dx", tol=2e-5)
 
 
+@pytest.mark.parametrize("shape", [(16, 58, 512, 64, 64, 0, 1), (8, 8, 129, 512, 512, 0, 0), (4, 32, 514, 128, 128, 0, 0)], ids=lambda c: "x".join(map(str, c)))
+def test_winograd_engines_agree_at_bench_sizes(cuda, shape):
+    """full-size layers of the bench step (discriminator 64 ch at 58x512, recogniser 512 ch, style extractor 128 ch): the Winograd forward,
+    data-gradient and weight-gradient kernels against the direct implicit-GEMM engine on the same tensors (relative L2; the CPU reference
+    would take minutes at these sizes)"""
+    import os
+    from handwriting_line_generation_amd import ops
+    N, H, W, C, K, ph, pw = shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(N, H, W, C, generator=g).to(cuda)
+    w = (torch.randn(K, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(cuda)
+    b = torch.randn(K, generator=g).to(cuda)
+    outs = []
+    for wino in ("2", "0"):
+        os.environ["HWG_WINO"] = wino
+        os.environ["HWG_WINO_WGRAD"] = wino
+        ops._wino_choice.clear(); ops._wino_wgrad_choice.clear()
+        try:
+            xg, wg, bg = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            y = ops.conv2d(xg, wg, bg, 1, (ph, pw))
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(cuda)
+            y.backward(gy)
+            outs.append((y.detach(), xg.grad, wg.grad, bg.grad))
+        finally:
+            os.environ.pop("HWG_WINO", None); os.environ.pop("HWG_WINO_WGRAD", None)
+            ops._wino_choice.clear(); ops._wino_wgrad_choice.clear()
+    for a, r, n in zip(outs[0], outs[1], ("y", "dx", "dw", "db")):
+        err = float((a.double() - r.double()).norm() / r.double().norm())
+        assert err < 1e-5, "winograd vs direct %s at %s: rel L2 %.2e" % (n, shape, err)
+
+
 def test_linear(cuda):
     from handwriting_line_generation_amd import ops
     g = torch.Generator().manual_seed(3)
