@@ -300,6 +300,76 @@ extern "C" int hwg_mt_adam(const void* ptrs_p, const void* ptrs_g, const void* p
   return HWG_OK;
 }
 
+// ---- insert_spaces on the device (hw_with_style.py:302-328 with the device generator instead of numpy's): per character of every line
+// blanks ~ round(N(count, count_std)), repeats ~ round(N(duplicates, dup_std)) (round half to even, negative -> 0); one Philox4x32 block per
+// (line, character). Single workgroup: the whole plan is a few thousand elements.
+__global__ __launch_bounds__(256) void insert_spaces_plan_kernel(const float* counts /*[L][B][2]*/, const int* lens_in, int L, int B, float count_std,
+                                                                float dup_std, int count_duplicates, uint64_t seed, uint64_t offset,
+                                                                int* reps /*[B][2L]*/, int* starts /*[B][L]*/, int* lens_max /*[B+1]*/) {
+  __shared__ float smax[256];
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < L * B * 2; i += 256) m = fmaxf(m, counts[i]);
+  smax[threadIdx.x] = m;
+  for (int i = threadIdx.x; i < L * B; i += 256) {
+    const int b = i / L, j = i % L;
+    int r0 = 0, r1 = 0;
+    if (j < lens_in[b]) {
+      uint32_t r[4];
+      philox4(seed, offset + (uint64_t)i, r);
+      const float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]), u3 = u01(r[3]);
+      const float z0 = sqrtf(-2.f * logf(u0)) * cosf(6.2831853071795864f * u1);
+      const float z1 = sqrtf(-2.f * logf(u2)) * cosf(6.2831853071795864f * u3);
+      const float* c = counts + ((long long)j * B + b) * 2;
+      r0 = max((int)rintf(c[0] + count_std * z0), 0);
+      r1 = count_duplicates ? max((int)rintf(c[1] + dup_std * z1), 0) : 1;
+    }
+    reps[(long long)b * 2 * L + 2 * j] = r0;
+    reps[(long long)b * 2 * L + 2 * j + 1] = r1;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += 256) {
+    int pos = 0;
+    for (int j = 0; j < lens_in[b]; ++j) {
+      pos += reps[(long long)b * 2 * L + 2 * j];
+      starts[b * L + j] = pos;
+      pos += reps[(long long)b * 2 * L + 2 * j + 1];
+    }
+    lens_max[b] = pos;
+  }
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) lens_max[B] = max((int)ceilf(smax[0]), 3);
+}
+// idx [T][B] (zero = blank, pre-cleared): the run of every character
+__global__ __launch_bounds__(256) void insert_spaces_fill_kernel(const int* label /*[L][B]*/, const int* lens_in, const int* reps, const int* starts, int L,
+                                                                int B, int T, int* idx) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= L * B) return;
+  const int b = i / L, j = i % L;
+  if (j >= lens_in[b]) return;
+  const int n = reps[(long long)b * 2 * L + 2 * j + 1], s = starts[b * L + j], c = label[j * B + b];
+  for (int t = 0; t < n && s + t < T; ++t) idx[(long long)(s + t) * B + b] = c;
+}
+
+extern "C" int hwg_insert_spaces_plan(const float* counts, const int* label_lengths, int L, int B, float count_std, float dup_std, int count_duplicates,
+                                      unsigned long long seed, unsigned long long offset, int* reps, int* starts, int* lens_max, void* stream) {
+  HWG_REQUIRE(counts && label_lengths && reps && starts && lens_max && L > 0 && B > 0, "insert_spaces_plan: bad arguments");
+  hipLaunchKernelGGL(insert_spaces_plan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counts, label_lengths, L, B, count_std, dup_std,
+                     count_duplicates, (uint64_t)seed, (uint64_t)offset, reps, starts, lens_max);
+  HWG_LAUNCH_CHECK("insert_spaces_plan");
+  return HWG_OK;
+}
+extern "C" int hwg_insert_spaces_fill(const int* label, const int* label_lengths, const int* reps, const int* starts, int L, int B, int T, int* idx,
+                                      void* stream) {
+  HWG_REQUIRE(label && label_lengths && reps && starts && idx && L > 0 && B > 0 && T > 0, "insert_spaces_fill: bad arguments");
+  hipLaunchKernelGGL(insert_spaces_fill_kernel, dim3(hwg_cdiv((long long)L * B, 256)), dim3(256), 0, (hipStream_t)stream, label, label_lengths, reps,
+                     starts, L, B, T, idx);
+  HWG_LAUNCH_CHECK("insert_spaces_fill");
+  return HWG_OK;
+}
+
 extern "C" int hwg_randn(float* out, long long n, unsigned long long seed, unsigned long long offset, void* stream) {
   HWG_REQUIRE(out && n > 0, "randn: bad arguments");
   hipLaunchKernelGGL(randn_kernel, dim3(hwg_stream_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n, (uint64_t)seed, (uint64_t)offset);

@@ -10,20 +10,26 @@ the next generator pass queued. Per request the kernels, their order within the 
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, rng
 from .utils import string_utils
 
 
 def _begin(model, label, label_lengths, style):
     """enqueue the spacer of one request and start the device->host copy of its counts"""
     counts = model.spacer(model.onehot(label), style)
+    if rng.mode() == "device":      # device generator: the expansion plan is drawn on the GPU, only the expanded lengths come back
+        return model.insert_spaces_device(label, label_lengths, counts, begin_only=True)
     return ops.AsyncFetch(counts)
 
 
 def _render(model, label_host, label_lengths, style, fetch, device):
-    counts = fetch.get()
-    idx, padded = model.insert_spaces_index(label_host, label_lengths, counts)
-    spaced = model.onehot(ops.h2d(idx.astype(np.int32), device))
+    if isinstance(fetch, tuple):
+        idx, padded = rng.device_rng().insert_spaces_finish(fetch)
+        spaced = model.onehot(idx)
+    else:
+        counts = fetch.get()
+        idx, padded = model.insert_spaces_index(label_host, label_lengths, counts)
+        spaced = model.onehot(ops.h2d(idx.astype(np.int32), device))
     spaced = model._clip_spaced(spaced)
     return model.generator(spaced, style), padded
 

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import torch
 
-from .. import ops
+from .. import ops, rng
 from ..logger import load_checkpoint
 from ..base.base_model import BaseModel
 from .char_style import CharStyleEncoder
@@ -120,8 +120,13 @@ class HWWithStyle(BaseModel):
         if spaced is None:
             label_onehot = self.onehot(label)
             self.counts = self.spacer(label_onehot, style)
-            idx, padded = self.insert_spaces_index(label, label_lengths, self.counts)
-            spaced = self.onehot(ops.h2d(idx.astype(np.int32), label.device))     # the one-hot is built on the device from [T,B] indices
+            if rng.mode() == "device" and self.counts.is_cuda:
+                # device generator: the expansion never leaves the GPU (only the expanded lengths are read back to size the result)
+                idx, padded = self.insert_spaces_device(label, label_lengths, self.counts)
+                spaced = self.onehot(idx)
+            else:
+                idx, padded = self.insert_spaces_index(label, label_lengths, self.counts)
+                spaced = self.onehot(ops.h2d(idx.astype(np.int32), label.device))     # the one-hot is built on the device from [T,B] indices
             self.gen_padded = padded
             spaced = self._clip_spaced(spaced)
             self.gen_spaced = spaced
@@ -232,6 +237,17 @@ class HWWithStyle(BaseModel):
             idx[: len(line), b] = line
             padded.append((T - len(line)) / T)
         return idx, padded
+
+    def insert_spaces_device(self, label, label_lengths, counts, begin_only=False):
+        """`insert_spaces_index` with the device generator (rng mode "device"): same expansion rule, draws from the Philox stream instead of
+        numpy's global generator -> (idx int32 [T,B] on the GPU, padded list); `begin_only` returns the plan for `ops.DeviceRNG.insert_spaces_finish`
+        (generation stream: the lengths travel to the host while the previous request renders)"""
+        dev = counts.device
+        lab = label if label.is_cuda else ops.h2d(label, dev)
+        lens = ops.h2d(torch.as_tensor([int(n) for n in label_lengths], dtype=torch.int32), dev)
+        plan = rng.device_rng().insert_spaces_begin(counts.detach(), lab.to(torch.int32).contiguous(), lens, self.count_std, self.dup_std,
+                                                    self.count_duplicates)
+        return plan if begin_only else rng.device_rng().insert_spaces_finish(plan)
 
     def insert_spaces(self, label, label_lengths, counts):
         """reference signature: (one-hot content [T,B,num_class] on the host, padded fractions)"""

@@ -1243,6 +1243,8 @@ class DeviceRNG:
     def __init__(self, seed=0):
         self.seed = int(seed)
         self.offset = 0
+        self.text_offset = 0      # `insert_spaces` draws from its own Philox stream (seed + 1): the pipelined generation loop plans request
+        # i+1 before it renders request i, and both orders must consume the noise stream and the text stream identically
 
     def randn(self, shape, device):
         out = torch.empty(shape, dtype=torch.float32, device=device)
@@ -1250,6 +1252,30 @@ class DeviceRNG:
         L.call("hwg_randn", out, n, self.seed, self.offset, _stream())
         self.offset += (n + 3) // 4
         return out
+
+    def insert_spaces_begin(self, counts, label, label_lengths, count_std, dup_std, count_duplicates):
+        """device `insert_spaces`, first half: counts [L,B,2] float, label [L,B] int32, label_lengths [B] int32 (all on the GPU); draws the plan
+        and starts the small device->host copy of the expanded lengths that will size the result"""
+        Lc, B = label.shape
+        dev = counts.device
+        reps = torch.empty((B, 2 * Lc), dtype=torch.int32, device=dev)
+        starts = torch.empty((B, Lc), dtype=torch.int32, device=dev)
+        lens_max = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+        L.call("hwg_insert_spaces_plan", counts.contiguous(), label_lengths, Lc, B, float(count_std), float(dup_std), int(bool(count_duplicates)),
+               self.seed + 1, self.text_offset, reps, starts, lens_max, _stream())
+        self.text_offset += Lc * B
+        return (label, label_lengths, reps, starts, AsyncFetch(lens_max))
+
+    def insert_spaces_finish(self, plan):
+        """-> (idx int32 [T,B] on the GPU, padded fractions)"""
+        label, label_lengths, reps, starts, fetch = plan
+        Lc, B = label.shape
+        host = fetch.get().tolist()
+        lens, max_count = host[:B], host[B]
+        T = max(lens) + max_count
+        idx = torch.zeros((T, B), dtype=torch.int32, device=label.device)
+        L.call("hwg_insert_spaces_fill", label, label_lengths, reps, starts, Lc, B, T, idx, _stream())
+        return idx, [(T - n) / T for n in lens]
 
     def dropmask(self, shape, p, device):
         out = torch.empty(shape, dtype=torch.float32, device=device)

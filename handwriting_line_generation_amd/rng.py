@@ -42,7 +42,7 @@ def get_state():
     """what a checkpoint keeps so that a resumed run continues the Philox stream instead of replaying it"""
     r = _state["rng"]
     return {"mode": _state["mode"], "base_seed": _state.get("base_seed"), "seed": r.seed if r is not None else None,
-            "offset": r.offset if r is not None else 0}
+            "offset": r.offset if r is not None else 0, "text_offset": r.text_offset if r is not None else 0}
 
 
 def set_state(st, rank=0):
@@ -53,6 +53,7 @@ def set_state(st, rank=0):
     seed = st["seed"] if base is None else (int(base) * 1000003 + int(rank)) & 0x7FFFFFFFFFFFFFFF
     set_mode("device", seed=seed)
     _state["rng"].offset = int(st["offset"])
+    _state["rng"].text_offset = int(st.get("text_offset", 0))
     _state["base_seed"] = base
 
 
@@ -60,6 +61,11 @@ def _dev_rng():
     if _state["rng"] is None:
         _state["rng"] = ops.DeviceRNG(0)
     return _state["rng"]
+
+
+def device_rng():
+    """the process's device generator (Philox stream; its (seed, offset) pair is part of a checkpoint)"""
+    return _dev_rng()
 
 
 def noise_like_nhwc(x):

@@ -334,6 +334,15 @@ int hwg_mt_adam(const void* ptrs_p, const void* ptrs_g, const void* ptrs_m, cons
 int hwg_randn(float* out, long long n, unsigned long long seed, unsigned long long offset, void* stream);
 int hwg_dropmask(float* out, long long n, float p, unsigned long long seed, unsigned long long offset, void* stream);
 
+/* `insert_spaces` (model/hw_with_style.py:302-328) with the device generator: plan = per character of every line the number of blank columns
+ * before it and of repeats, drawn as round(N(count, count_std)) / round(N(duplicates, dup_std)) (half to even, negative -> 0) from Philox block
+ * offset + (line * L + character); lens_max [B+1] = expanded length per line, then max(ceil(max counts), 3) (the reference's tail padding);
+ * fill writes the character runs into the zero-initialised index map idx [T][B] (0 = blank). counts [L][B][2], label [L][B]. */
+int hwg_insert_spaces_plan(const float* counts, const int* label_lengths, int L, int B, float count_std, float dup_std, int count_duplicates,
+                           unsigned long long seed, unsigned long long offset, int* reps, int* starts, int* lens_max, void* stream);
+int hwg_insert_spaces_fill(const int* label, const int* label_lengths, const int* reps, const int* starts, int L, int B, int T, int* idx,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif
