@@ -1003,6 +1003,163 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
 }
 
 // C == 1 with at most 64 taps: taps-as-N MFMA kernel; other single/double channel ends: direct kernels (conv_direct.hip)
+// ---- narrow layers (K, C <= 32: the generator's 16 / 32-channel tail at 64x488 and 32x244) -----------------------------------------
+// These products are memory bound (36 FLOP/B at 16x16 channels) and fill a quarter of the 32-wide tiles of the kernel above, which also
+// re-reads u and v once per tap. Here one wavefront owns a 16 (k) x 16 (c) block for ALL taps (R*S accumulator blocks of
+// v_mfma_f32_16x16x4_f32, contraction = 4 output pixels per instruction) and walks a range of output pixels: dy is read once, every tap's
+// operand is the same input neighbourhood (L1 / L2 hits after the first tap). The wavefronts of a workgroup that share a block are summed
+// through LDS in a fixed tree, one partial image per workgroup goes to the usual [split][tap][K][C] (+ K bias sums) layout.
+// Measured (8 x 64 x 488, 16 -> 16, 3x3): 34 + 8 us against 87 + 8 us; with 2 or 4 channel blocks the block-sharing wavefronts re-read each
+// other's operands and the 32 x 32 tiles of the kernel above are no longer half empty - those layers stay there (HWG_WGRAD_NARROW=2 forces
+// this kernel for them, used by the tests).
+template <int R, int S>
+__global__ __launch_bounds__(512) void wgrad_narrow_kernel(WgK a, int kbn, int cbn) {
+  constexpr int NT = R * S;
+  __shared__ __attribute__((aligned(16))) float red[4 * (NT * 256 + 16)];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = kbn * cbn, role = wid % nblk, stream = wid / nblk, streams = 8 / nblk;
+  const int kb = role / cbn, cb = role % cbn;
+  const int ch = lane & 15, j = lane >> 4;
+  const int kch = min(kb * 16 + ch, a.K - 1), cch = min(cb * 16 + ch, a.C - 1);      // clamped: ragged blocks are masked at the store
+  const long long G4 = ((long long)a.Mtot + 3) >> 2;
+  const long long gs = (long long)blockIdx.x * streams + stream, GS = (long long)gridDim.x * streams;
+  const long long g0 = G4 * gs / GS, g1 = G4 * (gs + 1) / GS;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const int PQ = a.P * a.Q;
+  // operands of one group of 4 pixels: loads from clamped coordinates (no control flow), validity as a bit mask applied at use;
+  // the next group's loads are issued before the current group's MFMAs (a wavefront only walks ~15-60 groups: without the prefetch
+  // every one of them would expose a full memory latency)
+  constexpr int GB = 1;                    // groups fetched together (measured: 1 -> 34 us, 4 -> 40 us on 8 x 64 x 488 x 16 x 16: occupancy wins)
+  float av_c[GB], av_n[GB], bv_c[GB][NT], bv_n[GB][NT];
+  int ok_c[GB], ok_n[GB];
+  // pixel coordinates of this lane's pixel in the group to fetch next: decoded once, then advanced by 4 pixels per group (the integer
+  // divisions of a per-group decode cost more VALU time than the nine MFMAs of the group)
+  int cn, cp, cq;
+  {
+    const long long m0 = g0 * 4 + j;
+    const int mm0 = m0 < a.Mtot ? (int)m0 : 0;
+    cn = mm0 / PQ;
+    const int pq0 = mm0 - cn * PQ;
+    cp = pq0 / a.Q;
+    cq = pq0 - cp * a.Q;
+  }
+  auto fetch = [&](long long g, float& av, float (&bv)[NT], int& okm) {
+    const long long m = g * 4 + j;
+    const bool mv = m < a.Mtot;
+    const int mm = mv ? (int)m : 0;
+    const int n = mv ? cn : 0, p = mv ? cp : 0, q = mv ? cq : 0;
+    // advance to the pixel of the next group (rows shorter than 4 pixels may wrap more than once)
+    cq += 4;
+    while (cq >= a.Q) {
+      cq -= a.Q;
+      if (++cp == a.P) { cp = 0; ++cn; }
+    }
+    av = a.u[(long long)mm * a.K + kch];
+    const int ih0 = p * a.sh - a.ph, iw0 = q * a.sw - a.pw;
+    int roff[R], coff[S], rokm = 0, cokm = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ih = ih0 + r;
+      rokm |= (ih >= 0 && ih < a.H ? 1 : 0) << r;
+      roff[r] = ((n * a.H + min(max(ih, 0), a.H - 1)) * a.W) * a.C + cch;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < S; ++s2) {
+      const int iw = iw0 + s2;
+      cokm |= (iw >= 0 && iw < a.W ? 1 : 0) << s2;
+      coff[s2] = min(max(iw, 0), a.W - 1) * a.C;
+    }
+    int m2 = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) bv[r * S + s2] = a.v[roff[r] + coff[s2]];
+      m2 |= ((rokm >> r) & 1 ? cokm : 0) << (r * S);
+    }
+    okm = mv ? (m2 | (1 << NT)) : 0;
+  };
+#pragma unroll
+  for (int u = 0; u < GB; ++u) fetch(g0 + u, av_c[u], bv_c[u], ok_c[u]);       // groups past g1 are masked by their pixel index only when
+  // they also pass Mtot; the range check below drops the others
+  for (long long g = g0; g < g1; g += GB) {
+#pragma unroll
+    for (int u = 0; u < GB; ++u) fetch(g + GB + u, av_n[u], bv_n[u], ok_n[u]);
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      const int okm = g + u < g1 ? ok_c[u] : 0;
+      const float av = (okm >> NT) & 1 ? av_c[u] : 0.f;
+      bsum += av;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float b = (okm >> t) & 1 ? bv_c[u][t] : 0.f;
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      av_c[u] = av_n[u]; ok_c[u] = ok_n[u];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv_c[u][t] = bv_n[u][t];
+    }
+  }
+  // bias: sum over the four pixel groups of the wavefront -> lanes 0..15 hold the column sums of their channel
+  bsum += __shfl_xor(bsum, 16, 64);
+  bsum += __shfl_xor(bsum, 32, 64);
+  // fixed-order tree over the streams that share a block: the upper half writes, the lower half adds
+  for (int half = streams >> 1; half >= 1; half >>= 1) {
+    float* slot = red + ((stream - half) * nblk + role) * (NT * 256 + 16);
+    if (stream >= half && stream < 2 * half) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(slot + t * 256 + lane * 4) = acc[t];
+      if (lane < 16) slot[NT * 256 + lane] = bsum;
+    }
+    __syncthreads();
+    if (stream < half) {
+      const float* src = red + (stream * nblk + role) * (NT * 256 + 16);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(src + t * 256 + lane * 4);
+        acc[t] += o;
+      }
+      if (lane < 16) bsum += src[NT * 256 + lane];
+    }
+    __syncthreads();
+  }
+  if (stream == 0) {
+    float* pout = a.part + (long long)blockIdx.x * a.pstride;
+    const int c = cb * 16 + (lane & 15);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = kb * 16 + (lane >> 4) * 4 + e;
+        if (k < a.K && c < a.C) pout[((long long)t * a.K + k) * a.C + c] = acc[t][e];
+      }
+    if (a.bias_on && cb == 0 && lane < 16 && kb * 16 + lane < a.K) pout[(long long)NT * a.K * a.C + kb * 16 + lane] = bsum;
+  }
+}
+static bool wgrad_is_narrow(const hwg_conv_desc* d) {
+  const char* env = getenv("HWG_WGRAD_NARROW");          // 0: never, 2: also layers with 2 / 4 channel blocks (tests)
+  const bool off = env && atoi(env) == 0, all = env && atoi(env) == 2;
+  const bool taps = (d->R == 3 && d->S == 3) || (d->R == 4 && d->S == 4);
+  // LDS tree needs streams = 8 / blocks >= 1 and a power of two: 1, 2 or 4 blocks of 16 x 16
+  const int kbn = hwg_cdiv(d->K, 16), cbn = hwg_cdiv(d->C, 16), nb = kbn * cbn;
+  return !off && taps && d->dil_h == 1 && d->dil_w == 1 && d->C >= 4 && d->K > 2 && (nb == 1 || (all && (nb == 2 || nb == 4))) &&
+         (long long)d->N * d->P * d->Q >= 16384 && (long long)d->N * d->H * d->W * d->C < (1ll << 31) && !d->transposed;
+}
+static int narrow_blocks(const hwg_conv_desc* d) {
+  const int nb = hwg_cdiv(d->K, 16) * hwg_cdiv(d->C, 16), streams = 8 / nb;
+  const long long G4 = ((long long)d->N * d->P * d->Q + 3) / 4;
+  long long blocks = G4 / ((long long)streams * 8);          // at least 8 MFMA groups per wavefront
+  if (blocks > 512) blocks = 512;                           // two workgroups per CU
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
 static bool wgrad_is_tapn(const hwg_conv_desc* d) { return d->C == 1 && d->K > 2 && d->K % 4 == 0 && d->R * d->S <= 64; }
 static bool wgrad_is_direct(const hwg_conv_desc* d) { return (d->K <= 2 || d->C <= 2) && !wgrad_is_tapn(d); }
 static WgPlan plan_wgrad_tapn(const hwg_conv_desc* d) {
@@ -1016,6 +1173,7 @@ static WgPlan plan_wgrad_tapn(const hwg_conv_desc* d) {
 extern "C" size_t hwg_conv_wgrad_workspace(const hwg_conv_desc* d) {
   if (!d) return 0;
   if (wgrad_is_direct(d)) return hwg_conv_wgrad_direct_workspace(d);
+  if (wgrad_is_narrow(d)) return (size_t)narrow_blocks(d) * ((size_t)d->R * d->S * d->K * d->C + d->K) * sizeof(float);
   WgPlan p = wgrad_is_tapn(d) ? plan_wgrad_tapn(d) : plan_wgrad(d);
   return (size_t)p.nsplit * ((size_t)d->R * d->S * d->K * d->C + d->K) * sizeof(float);
 }
@@ -1038,7 +1196,9 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
     hwg_set_error("conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     return HWG_ERR_WORKSPACE;
   }
+  const bool narrow = wgrad_is_narrow(d);
   WgPlan p = tapn ? plan_wgrad_tapn(d) : plan_wgrad(d);
+  if (narrow) p.nsplit = narrow_blocks(d);
   WgK k;
   k.u = u; k.v = v; k.part = (float*)workspace;
   k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.R = d->R; k.S = d->S;
@@ -1051,8 +1211,10 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
   k.pstride = (long long)d->R * d->S * d->K * d->C + d->K;
   dim3 grid(p.nsplit, p.tiles_u * p.tiles_v, tapn ? 1 : d->R * d->S);
   const int prof = hwg_prof_open(HWG_PROF_WGRAD, 2.0 * k.Mtot * d->K * d->C * d->R * d->S, st);
+  if (narrow && d->R == 3) hipLaunchKernelGGL((wgrad_narrow_kernel<3, 3>), dim3(p.nsplit), dim3(512), 0, st, k, hwg_cdiv(d->K, 16), hwg_cdiv(d->C, 16));
+  else if (narrow) hipLaunchKernelGGL((wgrad_narrow_kernel<4, 4>), dim3(p.nsplit), dim3(512), 0, st, k, hwg_cdiv(d->K, 16), hwg_cdiv(d->C, 16));
   // 16 waves and 32-pixel K steps on the big tile: +10 % over 8 waves x 16 pixels (331 -> 299 us on 512x512x3x3 at 6096 pixels)
-  if (p.cfg == 0) hipLaunchKernelGGL((wgrad_mfma_kernel<128, 128, 32, 4, 4, 1>), grid, dim3(1024), 0, st, k);
+  else if (p.cfg == 0) hipLaunchKernelGGL((wgrad_mfma_kernel<128, 128, 32, 4, 4, 1>), grid, dim3(1024), 0, st, k);
   // 64x64: two wave groups split every 32-pixel K step between them (8 waves; 5..10 % over 4 waves on every measured shape)
   else if (p.cfg == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<64, 64, 32, 2, 2, 2>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 3) hipLaunchKernelGGL((wgrad_mfma_kernel<64, 64, 32, 2, 2, 2, true>), grid, dim3(512), 0, st, k);

@@ -64,6 +64,11 @@ CONV_CASES = [
     ("wino_c24_padded", 2, 5, 11, 24, 32, 3, 3, (1, 1), (1, 1), (1, 1), False),
     ("wino_big_tiles", 4, 20, 130, 64, 128, 3, 3, (1, 1), (0, 1), (1, 1), False),
     ("wino_1row", 2, 3, 40, 128, 256, 3, 3, (1, 1), (0, 1), (1, 1), False),
+    # narrow layers (K, C <= 32, >= 16 k output pixels): the all-taps 16x16x4 weight-gradient kernel, 1 / 2 / 4 channel blocks, ragged blocks
+    ("narrow_16x16_3x3", 2, 64, 160, 16, 16, 3, 3, (1, 1), (1, 1), (1, 1), False),
+    ("narrow_16to32_4x4s2", 3, 128, 200, 16, 32, 4, 4, (2, 2), (1, 1), (1, 1), False),
+    ("narrow_32x32_3x3_pad0", 2, 42, 258, 32, 32, 3, 3, (1, 1), (0, 0), (1, 1), False),
+    ("narrow_c20_k24", 2, 64, 161, 20, 24, 3, 3, (1, 1), (1, 1), (1, 1), False),
     # RIMES (78 classes): channel counts that are not multiples of 4
     ("rimes_convT_lift_206", 2, 1, 20, 206, 64, 4, 3, (1, 1), (0, 1), (1, 1), True),
     ("rimes_conv1d_to78", 2, 1, 30, 64, 78, 1, 3, (1, 1), (0, 0), (1, 1), False),
@@ -85,6 +90,13 @@ def test_conv_fwd_bwd(cuda, case):
         finally:
             os.environ.pop("HWG_WINO", None)
             ops._wino_choice.clear()
+    if name.startswith("narrow_"):
+        import os
+        os.environ["HWG_WGRAD_NARROW"] = "2"      # the all-taps narrow-layer weight-gradient kernel also for 2 / 4 channel blocks
+        try:
+            return _conv_case(cuda, ops, case)
+        finally:
+            os.environ.pop("HWG_WGRAD_NARROW", None)
     return _conv_case(cuda, ops, case)
 
 
