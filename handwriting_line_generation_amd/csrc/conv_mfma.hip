@@ -1170,6 +1170,27 @@ static WgPlan plan_wgrad_tapn(const hwg_conv_desc* d) {
   return p;
 }
 
+// sums the partial images part[split][tap][K][C] (+ K bias sums at the end of every image, pstride floats apart) in a fixed order and writes
+// dw through the weight's strides (shared by the direct and the Winograd weight-gradient kernels)
+int hwg_wgrad_reduce_launch(const float* part, float* dw, int nsplit, int RS, int S, int K, int C, long long sa, long long sb, long long sr,
+                            long long ss, int accumulate, long long pstride, float* dbias, int bias_accumulate, hipStream_t st) {
+  const long long total = (long long)RS * K * C + (dbias ? K : 0);
+  if (nsplit >= 64 && total <= 65536)
+    hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<32>, dim3(hwg_cdiv(total, 8)), dim3(256), 0, st, part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss,
+                       accumulate, pstride, dbias, bias_accumulate);
+  else if (nsplit >= 8 && total <= 262144)
+    hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<4>, dim3(hwg_cdiv(total, 64)), dim3(256), 0, st, part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss,
+                       accumulate, pstride, dbias, bias_accumulate);
+  else if (C % 4 == 0)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hwg_stream_grid(total / 4, 256)), dim3(256), 0, st, part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss,
+                       accumulate, pstride, dbias, bias_accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, st, part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss,
+                       accumulate, pstride, dbias, bias_accumulate);
+  HWG_LAUNCH_CHECK("conv_wgrad_reduce");
+  return HWG_OK;
+}
+
 extern "C" size_t hwg_conv_wgrad_workspace(const hwg_conv_desc* d) {
   if (!d) return 0;
   if (wgrad_is_direct(d)) return hwg_conv_wgrad_direct_workspace(d);
@@ -1221,22 +1242,11 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
   else hipLaunchKernelGGL((wgrad_mfma_kernel<32, 32, 32, 1, 1, 4>), grid, dim3(256), 0, st, k);
   hwg_prof_close(prof, st);
   HWG_LAUNCH_CHECK("conv_wgrad");
-  const long long total = (long long)d->R * d->S * d->K * d->C + (dbias ? d->K : 0);
-  const int prof2 = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, 4.0 * total * (p.nsplit + 1), st);
-  if (p.nsplit >= 64 && total <= 65536)
-    hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<32>, dim3(hwg_cdiv(total, 8)), dim3(256), 0, st, (const float*)workspace, dw, p.nsplit, d->R * d->S, d->S,
-                       d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias, bias_accumulate);
-  else if (p.nsplit >= 8 && total <= 262144)
-    hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<4>, dim3(hwg_cdiv(total, 64)), dim3(256), 0, st, (const float*)workspace, dw, p.nsplit, d->R * d->S, d->S,
-                       d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias, bias_accumulate);
-  else if (d->C % 4 == 0)
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hwg_stream_grid(total / 4, 256)), dim3(256), 0, st, (const float*)workspace, dw,
-                       p.nsplit, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias, bias_accumulate);
-  else
-    hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
-                       p.nsplit, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias, bias_accumulate);
+  const int prof2 = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, 4.0 * ((double)d->R * d->S * d->K * d->C + (dbias ? d->K : 0)) * (p.nsplit + 1), st);
+  rc = hwg_wgrad_reduce_launch((const float*)workspace, dw, p.nsplit, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias,
+                               bias_accumulate, st);
   hwg_prof_close(prof2, st);
-  HWG_LAUNCH_CHECK("conv_wgrad_reduce");
+  if (rc) return rc;
   return HWG_OK;
 }
 

@@ -1,7 +1,7 @@
 // Weight gradient of 3x3 stride-1 convolutions in the Winograd domain, F(3x3, 2x2) (the transpose of conv_wino.hip's F(2x2, 3x3)):
 //   forward   Y = A^T [ (G g G^T) . (B^T d B) ] A        per 2x2 output tile, summed over input channels
 //   backward  dU[pos][k][c] = sum over tiles  Z[pos][k] * V[pos][c],   Z = A dY A^T (4x4 from the 2x2 tile of dy),  V = B^T d B
-//             dg[k][c]      = G^T dU[.][k][c] G                       (3x3 from 4x4, done by the reduce kernel)
+//             dg[k][c]      = G^T dU[.][k][c] G                       (3x3 from 4x4, in the epilogue)
 // 16 multiplies per tile and channel pair instead of 36: 2.25x fewer matrix-core FLOPs than the direct tap-by-tap product, and every
 // input patch / dy tile is read ONCE for all nine taps (the direct kernel streams them once per tap).
 //
@@ -12,7 +12,8 @@
 // LDS image of a round: [Z | V][16 positions][4 channel blocks][4 tile pairs][16 channels][2 tiles], 64 KB, double buffered (wg_elem: pair
 // slots rotated by the block index, so the ds_write_b64 stores (lane = channel) and the ds_read_b64 fragment reads are conflict free). The matrix pipe sees 64 MFMAs per wavefront per round against ~200 VALU
 // instructions of transform work, which the second wavefront of each SIMD overlaps.
-// Partial images go to [split][16][K][C]; wino_wgrad_reduce_kernel sums the splits and applies G^T . G.
+// The epilogue applies G^T . G (two 32-row halves through an LDS exchange image), partial images go to [split][9][K][C] (+ K bias sums) and are
+// summed by the direct kernel's fixed-order reduce (hwg_wgrad_reduce_launch).
 #include "hwg_common.h"
 #include <stdlib.h>
 
@@ -21,11 +22,12 @@ namespace {
 struct WinoWgK {
   const float* x;    // [N,H,W,C]
   const float* dy;   // [N,P,Q,K]
-  float* part;       // [nsplit][16][K][C]
+  float* part;       // [nsplit][9 taps][K][C] (+ K bias sums): pstride floats per split
   int N, H, W, C, K, P, Q, ph, pw, TP, TQ2;
   int MP;            // tile pairs: N * TP * TQ2
   int kt, ct, nsplit;
-  float* bpart;      // [nsplit * 4][K] column sums of dy (the bias gradient) from the dy tiles that pass through anyway, or null
+  int bias_on;       // also emit the column sums of dy (the bias gradient) from the dy tiles that pass through anyway
+  long long pstride; // 9*K*C + K
 };
 
 // LDS image of one position of one operand: [16-channel block b][slot (pair + b) & 3][channel & 15][2 tiles]. A fragment read (lane = row fr,
@@ -47,7 +49,7 @@ constexpr int WG_BUF = 2 * WG_OPER;        // Z then V
 //   C  global loads for round r+2 (in flight during the next stage's MFMAs)
 // Rounds past the end of the pixel range run with everything masked (B writes zeros, C reads clamped addresses) - no control flow.
 template <bool XROLE, int DBG>
-__device__ __forceinline__ void wg_rounds(const WinoWgK& a, float* smem, f32x4 (&acc)[2][4][4], int widu, int lane, int ch0, int p_lo, int p_hi, int rounds, int bslot) {
+__device__ __forceinline__ void wg_rounds(const WinoWgK& a, float* smem, f32x4 (&acc)[2][4][4], int widu, int lane, int ch0, int p_lo, int p_hi, int rounds, float& bias_sum) {
   constexpr int NR = XROLE ? 24 : 8;
   constexpr int NQ = XROLE ? 6 : 4;       // columns of a fetched pair (x: 4x6 patch, dy: 2x4 pixels)
   const int pairw = widu & 3;
@@ -169,12 +171,14 @@ __device__ __forceinline__ void wg_rounds(const WinoWgK& a, float* smem, f32x4 (
     }
     __syncthreads();
   }
-  if (!XROLE && a.bpart && ch0 + lane < a.K) a.bpart[(long long)(bslot * 4 + pairw) * a.K + ch0 + lane] = bsum;
+  bias_sum = bsum;
 }
 
 template <int DBG>
 __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgK a) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * WG_BUF];      // 128 KB
+  constexpr int LDC = 68;                 // exchange row stride: the four row groups of a C/D block land 16 banks apart
+  constexpr int XCH = 16 * 32 * LDC;      // epilogue exchange image [16 positions][32 k][64 c], aliases the operand buffers
+  __shared__ __attribute__((aligned(16))) float smem[(2 * WG_BUF > XCH + 256) ? 2 * WG_BUF : XCH + 256];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // work item: every XCD takes a contiguous run of the (split, k-tile, c-tile) sequence - the workgroups of one pixel range share
@@ -204,109 +208,68 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgK a) {
       for (int j = 0; j < 4; ++j) acc[p][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // wavefronts 0-3 fetch and transform input patches (V), 4-7 the dy tiles (Z); all eight run the MFMAs of their two positions
-  WinoWgK ab = a;
-  if (c0 != 0) ab.bpart = nullptr;          // one column of workgroups (c-tile 0) sees every dy element of its k-tile exactly once
-  if (widu < 4) wg_rounds<true, DBG>(ab, smem, acc, widu, lane, c0, p_lo, p_hi, rounds, split);
-  else wg_rounds<false, DBG>(ab, smem, acc, widu, lane, k0, p_lo, p_hi, rounds, split);
+  float bias_sum = 0.f;
+  if (widu < 4) wg_rounds<true, DBG>(a, smem, acc, widu, lane, c0, p_lo, p_hi, rounds, bias_sum);
+  else wg_rounds<false, DBG>(a, smem, acc, widu, lane, k0, p_lo, p_hi, rounds, bias_sum);
 
-  // ---- partial image: [split][pos][K][C]; C/D layout of the 16x16 block: column (c) = lane & 15, row (k) = (lane >> 4) * 4 + e
-  float* out = a.part + ((long long)split * 16 + 2 * wid) * a.K * a.C;
+  // ---- epilogue: dg = G^T dU G (16 positions -> 9 taps) before anything leaves the CU: the positions of a (k, c) pair live in eight
+  // wavefronts, so the blocks cross through LDS (two halves of 32 k rows); partial image [split][tap][K][C] like the direct kernel's.
+  // C/D layout of a 16x16 block: column (c) = lane & 15, row (k) = (lane >> 4) * 4 + e
+  float* X = smem;
+  float* out = a.part + (long long)split * a.pstride;
+  if (a.bias_on && c0 == 0) {              // the four dy wavefronts saw every dy element of this k-tile and pixel range exactly once
+    float* bs = smem + XCH;
+    __syncthreads();
+    if (widu >= 4) bs[(widu - 4) * 64 + lane] = bias_sum;
+    __syncthreads();
+    if (tid < 64 && k0 + tid < a.K) out[9ll * a.K * a.C + k0 + tid] = (bs[tid] + bs[64 + tid]) + (bs[128 + tid] + bs[192 + tid]);
+  }
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            X[((2 * wid + p) * 32 + i2 * 16 + (lane >> 4) * 4 + e) * LDC + j * 16 + (lane & 15)] = acc[p][2 * h + i2][j][e];
+    __syncthreads();
+    const int c = tid & 63;
+#pragma unroll 1
+    for (int kl = tid >> 6; kl < 32; kl += 8) {
+      const int kk = k0 + h * 32 + kl;
+      if (kk >= a.K || c0 + c >= a.C) continue;
+      float t[3][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int c = c0 + j * 16 + (lane & 15);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k = k0 + i * 16 + (lane >> 4) * 4 + e;
-          if (k < a.K && c < a.C) out[((long long)p * a.K + k) * a.C + c] = acc[p][i][j][e];
-        }
+        const float u0 = X[((0 * 4 + j) * 32 + kl) * LDC + c], u1 = X[((1 * 4 + j) * 32 + kl) * LDC + c];
+        const float u2 = X[((2 * 4 + j) * 32 + kl) * LDC + c], u3 = X[((3 * 4 + j) * 32 + kl) * LDC + c];
+        t[0][j] = u0 + 0.5f * (u1 + u2);
+        t[1][j] = 0.5f * (u1 - u2);
+        t[2][j] = 0.5f * (u1 + u2) + u3;
       }
-}
-
-// dw[k][c][r][s] (+)= G^T ( sum over splits of dU[.][k][c] ) G,  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
-// block: 64 consecutive c (coalesced rows of the partial images) x 4 position groups; grid (ceil(C/64), K, chunks). With chunks > 1
-// (many pixel ranges, few output blocks: the 64-channel layers have 256 partial images of one block) a first pass only sums its
-// chunk of the splits into [chunk][16][K][C] (stage_out), a second pass over those finishes - fixed summation order, no atomics.
-__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ stage_out,
-                                                                int nsplit, int per_chunk, int K, int C,
-                                                                long long sa, long long sb, long long sr, long long ss, int accumulate) {
-  __shared__ float S[16][65];
-  const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl, k = blockIdx.y;
-  const long long plane = (long long)K * C;
-  const int s_lo = blockIdx.z * per_chunk, s_hi = min(s_lo + per_chunk, nsplit);
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  if (c < C) {
-    const float* p0 = part + ((long long)s_lo * 16 + pg * 4) * plane + (long long)k * C + c;
-    int sp = s_lo;
-    for (; sp + 4 <= s_hi; sp += 4) {       // 16 independent loads in flight
-      float v[4][4];
+      float* o = out + (long long)kk * a.C + c0 + c;
+      const long long plane = (long long)a.K * a.C;
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[u][q] = p0[(u * 16 + q) * plane];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s[q] += v[u][q];
-      p0 += 64 * plane;
+      for (int r = 0; r < 3; ++r) {
+        o[(r * 3 + 0) * plane] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+        o[(r * 3 + 1) * plane] = 0.5f * (t[r][1] - t[r][2]);
+        o[(r * 3 + 2) * plane] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+      }
     }
-    for (; sp < s_hi; ++sp) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) s[q] += p0[q * plane];
-      p0 += 16 * plane;
-    }
-  }
-  if (stage_out) {
-    if (c < C) {
-      float* o = stage_out + ((long long)blockIdx.z * 16 + pg * 4) * plane + (long long)k * C + c;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) o[q * plane] = s[q];
-    }
-    return;
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) S[pg * 4 + q][cl] = s[q];
-  __syncthreads();
-  if (pg < 3 && c < C) {
-    // row r = pg of dg: first contract the rows (i) with column r of G, then the columns (j)
-    float t[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float u0 = S[0 * 4 + j][cl], u1 = S[1 * 4 + j][cl], u2 = S[2 * 4 + j][cl], u3 = S[3 * 4 + j][cl];
-      t[j] = pg == 0 ? u0 + 0.5f * (u1 + u2) : pg == 1 ? 0.5f * (u1 - u2) : 0.5f * (u1 + u2) + u3;
-    }
-    const float g0 = t[0] + 0.5f * (t[1] + t[2]);
-    const float g1 = 0.5f * (t[1] - t[2]);
-    const float g2 = 0.5f * (t[1] + t[2]) + t[3];
-    float* o = dw + k * sa + c * sb + pg * sr;
-    if (accumulate) { o[0] += g0; o[ss] += g1; o[2 * ss] += g2; }
-    else { o[0] = g0; o[ss] = g1; o[2 * ss] = g2; }
   }
 }
 
-// dbias[k] (+)= sum of the nparts column-sum partials; block = 64 channels x 16 interleaved groups of partials, combined in a fixed order
-__global__ __launch_bounds__(1024) void wino_wgrad_bias_kernel(const float* __restrict__ bpart, int nparts, int K, float* __restrict__ dbias, int accumulate) {
-  __shared__ double red[16][64];
-  const int kl = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + kl;
-  double s = 0.0;
-  if (k < K)
-    for (int i = g; i < nparts; i += 16) s += (double)bpart[(long long)i * K + k];
-  red[g][kl] = s;
-  __syncthreads();
-  if (g == 0 && k < K) {
-    double t = 0.0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) t += red[j][kl];
-    dbias[k] = accumulate ? dbias[k] + (float)t : (float)t;
-  }
-}
+}  // namespace
 
-struct WgPlan { int kt, ct, nsplit, MP, chunks, per_chunk; };
+int hwg_wgrad_reduce_launch(const float* part, float* dw, int nsplit, int RS, int S, int K, int C, long long sa, long long sb, long long sr,
+                            long long ss, int accumulate, long long pstride, float* dbias, int bias_accumulate, hipStream_t st);
+
+namespace {
+struct WgPlan { int kt, ct, nsplit, MP; };
 
 WgPlan plan_wino_wgrad(const hwg_conv_desc* d) {
   WgPlan p;
@@ -323,13 +286,6 @@ WgPlan plan_wino_wgrad(const hwg_conv_desc* d) {
   static const int force = [] { const char* e = getenv("HWG_WINO_WGRAD_SPLIT"); return e ? atoi(e) : 0; }();
   if (force > 0) ns = force < rounds_all ? force : rounds_all;
   p.nsplit = ns;
-  // two-pass reduce when the final pass alone would have few blocks with long serial sums
-  const int blocks = hwg_cdiv(d->C, 64) * d->K;
-  p.chunks = 1; p.per_chunk = ns;
-  if (ns >= 32 && blocks < 1024) {
-    p.per_chunk = 16;
-    p.chunks = hwg_cdiv(ns, 16);
-  }
   return p;
 }
 
@@ -355,7 +311,7 @@ extern "C" int hwg_wino_wgrad_preferred(const hwg_conv_desc* d) {
 extern "C" size_t hwg_wino_wgrad_workspace(const hwg_conv_desc* d) {
   if (!hwg_wino_wgrad_supported(d)) return 0;
   const WgPlan p = plan_wino_wgrad(d);
-  return ((size_t)(p.nsplit + (p.chunks > 1 ? p.chunks : 0)) * 16 * d->K * d->C + (size_t)p.nsplit * 4 * d->K) * sizeof(float);
+  return (size_t)p.nsplit * (9 * (size_t)d->K * d->C + d->K) * sizeof(float);
 }
 
 extern "C" int hwg_wino_wgrad(const hwg_conv_desc* d, const float* dy, const float* x, float* dw, long long sa, long long sb, long long sr,
@@ -374,7 +330,8 @@ extern "C" int hwg_wino_wgrad(const hwg_conv_desc* d, const float* dy, const flo
   k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.P = d->P; k.Q = d->Q; k.ph = d->pad_h; k.pw = d->pad_w;
   k.TP = hwg_cdiv(d->P, 2); k.TQ2 = hwg_cdiv(hwg_cdiv(d->Q, 2), 2);
   k.MP = p.MP; k.kt = p.kt; k.ct = p.ct; k.nsplit = p.nsplit;
-  k.bpart = dbias ? (float*)workspace + (size_t)(p.nsplit + (p.chunks > 1 ? p.chunks : 0)) * 16 * d->K * d->C : nullptr;
+  k.bias_on = dbias ? 1 : 0;
+  k.pstride = 9ll * d->K * d->C + d->K;
   const int total = p.kt * p.ct * p.nsplit;
   int prof = hwg_prof_open(HWG_PROF_WGRAD_WINO, 2.0 * d->N * d->P * d->Q * (double)d->K * d->C * 9.0, st);
   static const int dbg = [] { const char* e = getenv("HWG_WWG_DEBUG"); return e ? atoi(e) : 0; }();
@@ -383,20 +340,11 @@ extern "C" int hwg_wino_wgrad(const hwg_conv_desc* d, const float* dy, const flo
   else hipLaunchKernelGGL(wino_wgrad_kernel<0>, dim3((total + 7) / 8 * 8), dim3(512), 0, st, k);
   hwg_prof_close(prof, st);
   HWG_LAUNCH_CHECK("wino_wgrad");
+  // the partial images have the direct kernel's layout ([split][tap][K][C] + K bias sums): same fixed-order reduce into the weight's layout
   prof = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, (double)need, st);
-  const float* parts = (const float*)workspace;
-  int nparts = p.nsplit;
-  if (p.chunks > 1) {
-    float* stage = (float*)workspace + (size_t)p.nsplit * 16 * d->K * d->C;
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(hwg_cdiv(d->C, 64), d->K, p.chunks), dim3(256), 0, st, parts, dw, stage, p.nsplit, p.per_chunk,
-                       d->K, d->C, sa, sb, sr, ss, accumulate);
-    parts = stage; nparts = p.chunks;
-  }
-  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(hwg_cdiv(d->C, 64), d->K, 1), dim3(256), 0, st, parts, dw, (float*)nullptr, nparts, nparts, d->K, d->C,
-                     sa, sb, sr, ss, accumulate);
-  if (dbias)
-    hipLaunchKernelGGL(wino_wgrad_bias_kernel, dim3(hwg_cdiv(d->K, 64)), dim3(1024), 0, st, (const float*)k.bpart, p.nsplit * 4, d->K, dbias, bias_accumulate);
+  const int rc = hwg_wgrad_reduce_launch((const float*)workspace, dw, p.nsplit, 9, 3, d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias,
+                                         bias_accumulate, st);
   hwg_prof_close(prof, st);
-  HWG_LAUNCH_CHECK("wino_wgrad_reduce");
+  if (rc) return rc;
   return HWG_OK;
 }
