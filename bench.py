@@ -82,11 +82,13 @@ def main():
         raise SystemExit("%d ranks but only %d GPUs visible" % (world, ndev))
     local = local % ndev
     torch.cuda.set_device(local)
-    if world > 1:
+    force_dp = bool(int(os.environ.get("HWG_FORCE_DP", "0") or 0))     # one-rank process group with the data-parallel exchange switched on
+    if world > 1 or force_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
 
     # The step's host side is thousands of tiny torch-CPU / numpy ops; torch's default intra-op pool (one thread per visible core, 256 on
@@ -300,7 +302,7 @@ def main():
             # GPU time between the starts of consecutive steps (HIP events on the step stream), averaged per lesson of the curriculum
             "per_lesson_ms": per_lesson_ms,
             # data parallel: ranks in the process group and this rank's all-reduce traffic (gradient sets + None-masks) per step
-            "data_parallel": {"world_size": world, "backend": (dist.get_backend() if world > 1 else None),
+            "data_parallel": {"world_size": world, "backend": (dist.get_backend() if dist.is_initialized() else None), "forced_single_rank_exchange": force_dp,
                               "collectives_per_step": round(flat_params.COMM["collectives"] / args.steps, 2),
                               "allreduce_mbytes_per_step": round(flat_params.COMM["bytes"] / args.steps / 1e6, 2)},
             "inputs_resident": True,     # one synthetic batch per step built and uploaded before the timed region (SyntheticLoader.make_resident)
@@ -310,7 +312,7 @@ def main():
                                      "experts_present_per_call": round(st["experts"] / max(st["calls"], 1), 1)},
         }
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -15,6 +15,8 @@ for the kernels, so the semantics are identical without any device->host traffic
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -182,13 +184,19 @@ def _count(t):
     COMM["bytes"] += t.numel() * t.element_size()
 
 
+# HWG_FORCE_DP=1: run the data-parallel exchange even in a one-rank process group (the collectives are identities there). It exists so that
+# the RCCL code path - asynchronous whole-buffer reductions under the backward passes, span reductions, the mask exchange - can be
+# exercised and timed on a single GPU; results are bit-identical to the plain single-process step.
+FORCE_DP = bool(int(os.environ.get("HWG_FORCE_DP", "0") or 0))
+
+
 def start_stash_allreduce(stash, world):
     """Data parallel: begin the SUM all-reduce of a freshly stashed gradient set without waiting for it. The collective runs on the
     communicator's stream behind the stash copy, so it overlaps the backward passes that follow (an `auto` lesson stashes four sets
     before it balances them). `allreduce_gradient_sets` collects it. Returns the stash as a list [buffer, mask, pending work]."""
     import torch.distributed as dist
     st = [stash[0], stash[1], None]
-    if world > 1:
+    if world > 1 or FORCE_DP:
         _count(st[0])
         st[2] = dist.all_reduce(st[0], op=dist.ReduceOp.SUM, async_op=True)
     return st
@@ -225,7 +233,7 @@ def allreduce_gradient_sets(flat, stashes, world, device):
     waited for; everything reduced here - the current set, which sits on the critical path - is exchanged only over the ranges that
     hold touched tensors."""
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not FORCE_DP:
         return
     ops.join_side_stream()
     masks = [flat.touched] + [s[1] for s in stashes]

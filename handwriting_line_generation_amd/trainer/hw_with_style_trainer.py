@@ -21,6 +21,7 @@ import torch.distributed as dist
 from .. import ops
 from ..base.base_trainer import BaseTrainer
 from ..logger import load_checkpoint
+from . import flat_params as flat_params_mod
 from .flat_params import allreduce_gradient_sets, start_stash_allreduce
 from ..data.text_data import TextData
 from ..model.autoencoder import Encoder2
@@ -108,7 +109,8 @@ class HWWithStyleTrainer(BaseTrainer):
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # control-plane group for host-side decisions every rank must take together (skip an iteration): CPU tensors over gloo, so
         # the exchange never waits for the GPU stream the way a device collective + .item() would
-        self._ctl_group = dist.new_group(backend="gloo") if self.world > 1 else None
+        self._dp = self.world > 1 or (flat_params_mod.FORCE_DP and dist.is_available() and dist.is_initialized())
+        self._ctl_group = dist.new_group(backend="gloo") if self._dp else None
         self.async_log = tr.get("async_log", False)
         # optional: weight-gradient kernels on a second HIP stream (fills the CUs the data-gradient chain leaves idle: +2.7 % steps/s);
         # off by default because co-running kernels inflate the per-kernel durations the roofline measurement relies on
@@ -224,7 +226,7 @@ class HWWithStyleTrainer(BaseTrainer):
             for s in self.saved_grads:
                 f.release(s)
             self.saved_grads = []
-        elif self.world > 1:
+        elif self._dp:
             self._allreduce_grads()
 
         flag = None

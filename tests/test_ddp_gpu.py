@@ -232,3 +232,47 @@ def test_two_ranks_equal_sequential_shards_averaged(cuda, tmp_path):
     num = sum(float((v - sq["params"][k]).pow(2).sum()) for k, v in dp["params"].items())
     den = sum(float(v.pow(2).sum()) for v in sq["params"].values())
     assert (num / den) ** 0.5 < 1e-4, "weights after the cycle differ by %.2e relative" % ((num / den) ** 0.5)
+
+
+def _rccl_worker(force, port, out_path, workdir):
+    """one rank, backend nccl (RCCL): a curriculum cycle with (force) or without the data-parallel exchange switched on"""
+    import random
+
+    import numpy as np
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HWG_FORCE_DP="1" if force else "0")
+    torch.cuda.set_device(0)
+    if force:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from handwriting_line_generation_amd import rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    from handwriting_line_generation_amd.trainer import flat_params
+    assert flat_params.FORCE_DP == bool(force)
+    torch.manual_seed(0); np.random.seed(0); random.seed(0)
+    rng.set_mode("device", seed=7)
+    trainer, _ = build_gan_trainer("iam_gan", 2, 2, width=256, label_len=12, workdir=workdir)
+    for it in range(7):
+        trainer._train_iteration(it)
+    torch.cuda.synchronize()
+    torch.save({"params": {k: v.detach().cpu() for k, v in trainer.model.state_dict().items()}, "comm": dict(flat_params.COMM)}, out_path)
+    if force:
+        dist.destroy_process_group()
+
+
+def test_single_rank_rccl_exchange_is_the_identity(cuda, tmp_path):
+    """The RCCL code path itself (backend "nccl": asynchronous whole-buffer reductions of the stashed sets under the following backward passes,
+    the int32 MAX exchange of the None-masks, span reductions of the current set, the gloo control group) on the one GPU a test box has: with
+    HWG_FORCE_DP=1 a one-rank process group runs every collective of the data-parallel step, and the weights after a curriculum cycle must be
+    bit-identical to the plain single-process step."""
+    ctx = mp.get_context("spawn")
+    outs = []
+    for force in (1, 0):
+        path = os.path.join(str(tmp_path), "w%d.pt" % force)
+        p = ctx.Process(target=_rccl_worker, args=(force, _free_port(), path, str(tmp_path / ("wd%d" % force))))
+        p.start(); p.join(900)
+        assert p.exitcode == 0
+        outs.append(torch.load(path))
+    forced, plain = outs
+    assert forced["comm"]["collectives"] > 20 and forced["comm"]["bytes"] > 500e6 and plain["comm"]["collectives"] == 0
+    for k, v in plain["params"].items():
+        assert torch.equal(v, forced["params"][k]), "%s differs after a cycle with the one-rank RCCL exchange" % k
