@@ -110,7 +110,7 @@ class HWWithStyleTrainer(BaseTrainer):
         # control-plane group for host-side decisions every rank must take together (skip an iteration): CPU tensors over gloo, so
         # the exchange never waits for the GPU stream the way a device collective + .item() would
         self._dp = self.world > 1 or (flat_params_mod.FORCE_DP and dist.is_available() and dist.is_initialized())
-        self._ctl_group = dist.new_group(backend="gloo") if self._dp else None
+        self._ctl_group = flat_params_mod.control_group() if self._dp else None
         self.async_log = tr.get("async_log", False)
         # optional: weight-gradient kernels on a second HIP stream (fills the CUs the data-gradient chain leaves idle: +2.7 % steps/s);
         # off by default because co-running kernels inflate the per-kernel durations the roofline measurement relies on
