@@ -202,15 +202,29 @@ def control_group():
     return _CTL[0]
 
 
-def start_stash_allreduce(stash, world):
-    """Data parallel: begin the SUM all-reduce of a freshly stashed gradient set without waiting for it. The collective runs on the
-    communicator's stream behind the stash copy, so it overlaps the backward passes that follow (an `auto` lesson stashes four sets
-    before it balances them). `allreduce_gradient_sets` collects it. Returns the stash as a list [buffer, mask, pending work]."""
+def start_stash_allreduce(stash, world, flat=None):
+    """Data parallel: begin the SUM all-reduce of a freshly stashed gradient set without waiting for it. The collectives run on the
+    communicator's stream behind the stash copy, so they overlap the backward passes that follow (an `auto` lesson stashes four sets
+    before it balances them). With `flat` given the set's None-mask is OR-ed over the control group first (host only) and just the ranges
+    that hold touched tensors travel (a text lesson's recogniser-loss set touches a quarter of the buffer); `allreduce_gradient_sets`
+    collects the handles. Returns the stash as a list [buffer, mask, pending work(s), mask already exchanged]."""
     import torch.distributed as dist
-    st = [stash[0], stash[1], None]
+    st = [stash[0], stash[1], None, False]
     if world > 1 or FORCE_DP:
-        _count(st[0])
-        st[2] = dist.all_reduce(st[0], op=dist.ReduceOp.SUM, async_op=True)
+        if flat is None:
+            _count(st[0])
+            st[2] = [(dist.all_reduce(st[0], op=dist.ReduceOp.SUM, async_op=True), st[0])]
+        else:
+            m = torch.from_numpy(np.asarray(st[1]).astype(np.int32))
+            _count(m)
+            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=control_group())
+            st[1][:] = m.numpy().astype(bool)
+            st[3] = True
+            st[2] = []
+            for a, b in touched_spans(flat, st[1]):
+                view = st[0][a:b]
+                _count(view)
+                st[2].append((dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True), view))
     return st
 
 
@@ -250,21 +264,22 @@ def allreduce_gradient_sets(flat, stashes, world, device):
     ops.join_side_stream()
     # the None-masks are host state (set while the backward pass is being enqueued), so they are OR-ed over the gloo control group: no
     # device collective + read-back, the host keeps its run-ahead over the GPU (a device MAX all-reduce here cost 4 % of the step)
-    masks = [flat.touched] + [s[1] for s in stashes]
+    todo = [k for k, s in enumerate(stashes) if not (len(s) > 3 and s[3])]       # stashes whose mask has not been exchanged yet
+    masks = [flat.touched] + [stashes[k][1] for k in todo]
     m = torch.from_numpy(np.stack(masks).astype(np.int32))
     _count(m)
     dist.all_reduce(m, op=dist.ReduceOp.MAX, group=control_group())
     m = m.numpy().astype(bool)
     flat.touched[:] = m[0]
-    for k, s in enumerate(stashes):
-        s[1][:] = m[1 + k]
+    for i, k in enumerate(todo):
+        stashes[k][1][:] = m[1 + i]
     pending = []
     for k, s in enumerate(stashes):
-        work = s[2] if len(s) > 2 else None
-        if work is not None:
-            pending.append((work, s[0]))
+        works = s[2] if len(s) > 2 else None
+        if works is not None:
+            pending.extend(works)
         else:
-            for a, b in touched_spans(flat, m[1 + k]):
+            for a, b in touched_spans(flat, s[1]):
                 view = s[0][a:b]
                 _count(view)
                 pending.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True), view))

@@ -148,7 +148,7 @@ class HWWithStyleTrainer(BaseTrainer):
 
     def _stash(self):
         """clone-and-zero the current gradients (trainer :305-338); data parallel: their all-reduce starts right away"""
-        return start_stash_allreduce(self.flat.stash(), self.world)
+        return start_stash_allreduce(self.flat.stash(), self.world, self.flat)
 
     def _train_iteration(self, iteration):
         if not self.model.training:   # nn.Module.train() walks all ~3000 sub-modules; only do it when the mode actually changes

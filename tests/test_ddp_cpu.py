@@ -38,15 +38,20 @@ def _worker(rank, world, port, out):
     from handwriting_line_generation_amd.trainer.flat_params import start_stash_allreduce
     early_buf = masked_randn()
     early = start_stash_allreduce((early_buf.clone(), stash_mask.copy()), world)    # reduction started before the others (overlap path)
-    stashes = [(stash_buf.clone(), stash_mask.copy()), early]
+    # ... and one whose mask is exchanged at stash time so that only the touched ranges travel (what the trainer does)
+    span_buf = masked_randn()
+    span = start_stash_allreduce((span_buf.clone(), stash_mask.copy()), world, flat)
+    stashes = [(stash_buf.clone(), stash_mask.copy()), early, span]
     mine = flat.flat_grad.clone()
     allreduce_gradient_sets(flat, stashes, world, torch.device("cpu"))
     # gather every rank's original sets to rank-independent expectation
     gl = [torch.zeros_like(mine) for _ in range(world)]; dist.all_gather(gl, mine)
     sl = [torch.zeros_like(stash_buf) for _ in range(world)]; dist.all_gather(sl, stash_buf)
     el = [torch.zeros_like(early_buf) for _ in range(world)]; dist.all_gather(el, early_buf)
+    pl = [torch.zeros_like(span_buf) for _ in range(world)]; dist.all_gather(pl, span_buf)
     ok = torch.allclose(flat.flat_grad, sum(gl) / world) and torch.allclose(stashes[0][0], sum(sl) / world)
     ok = ok and torch.allclose(early[0], sum(el) / world) and early[2] is None
+    ok = ok and torch.allclose(span[0], sum(pl) / world) and span[2] is None and span[1].tolist() == stashes[0][1].tolist()
     ok = ok and flat.touched.tolist() == [True, True, True, False, False, True]
     ok = ok and stashes[0][1].tolist() == ([False, False, False, True, True, False] if world >= 2 else stash_mask.tolist())
     # parameter .grad views still alias the flat buffer
