@@ -12,11 +12,10 @@ import pytest
 import torch
 
 from oracle import cases, torch_ref
-from test_oracle_golden import GOLD, GRAD_INPUTS, ORACLE_FWD, product_module, rel
+from test_oracle_golden import GOLD, GRAD_INPUTS, ORACLE_FWD, PERTURB, _oracle_grads64, product_module, rel
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-PERTURB = 1e-6      # relative size of the conditioning probe: what fp32 kernels of different summation order differ by at intermediate layers
 
 
 def hip_forward(name, m, i):
@@ -37,36 +36,6 @@ def hip_forward(name, m, i):
         return [m(i["x"], None)]
     if name == "e_hwr":
         return [m(i["x"])]
-
-
-def _oracle_grads64(name, sd, pnames, ws, loss_fn=None, inputs=None, perturb=None):
-    """parameter and input gradients of the oracle evaluated in fp64 with the draws of the fp32 run (noise is drawn in fp32 and widened;
-    Dropout2d's Bernoulli masks do not depend on the dtype)"""
-    sd64 = {k: (v.detach().double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
-    for k in pnames:
-        sd64[k].requires_grad_(True)
-    oin = inputs if inputs is not None else cases.inputs(name)
-    oin = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in oin.items()}
-    if perturb is not None:   # fp32-rounding sized relative noise on every continuous input and weight: probes how well conditioned the gradients are
-        g = torch.Generator().manual_seed(perturb)
-        oin = {k: (v * (1 + PERTURB * torch.randn(v.shape, generator=g, dtype=torch.float64)) if v.dtype.is_floating_point else v) for k, v in oin.items()}
-        for k in pnames:
-            with torch.no_grad():
-                sd64[k].mul_(1 + PERTURB * torch.randn(sd64[k].shape, generator=g, dtype=torch.float64))
-    for k in GRAD_INPUTS[name]:
-        oin[k] = oin[k].clone().requires_grad_(True)
-    rl, rn = torch.randn_like, torch.randn
-    torch.randn_like = lambda t, **kw: rl(t.to(torch.float32), **kw).double()
-    torch.manual_seed(cases.FWD_SEED)
-    try:
-        outs = ORACLE_FWD[name](sd64, oin)
-    finally:
-        torch.randn_like = rl
-    if loss_fn is None:
-        sum((o * w.double()).sum() for o, w in zip(outs, ws)).backward()
-    else:
-        loss_fn(outs).backward()
-    return {k: sd64[k].grad for k in pnames}, {k: oin[k].grad for k in GRAD_INPUTS[name]}
 
 
 @pytest.mark.parametrize("name", list(cases.CASES))
