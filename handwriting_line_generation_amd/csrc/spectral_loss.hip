@@ -5,7 +5,7 @@
 namespace {
 
 // t[k] = sum_r W[r][k] * u[r]    (W is [R][K] row major, the OIHW weight viewed as [C_out, -1])
-__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* W, const float* u, float* t, int R, int K) {
+__device__ __forceinline__ void sn_wt_u_body(const float* W, const float* u, float* t, int R, int K) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + cl;
@@ -16,8 +16,9 @@ __global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* W, const floa
   __syncthreads();
   if (rl == 0 && k < K) t[k] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* W, const float* u, float* t, int R, int K) { sn_wt_u_body(W, u, t, R, K); }
 // v = t / (||t|| + eps)   (single block)
-__global__ __launch_bounds__(1024) void sn_normalize_kernel(const float* t, float* v, int n, float eps, float* norm_out, float* v_copy = nullptr) {
+__device__ __forceinline__ void sn_normalize_body(const float* t, float* v, int n, float eps, float* norm_out, float* v_copy) {
   __shared__ double sm[16];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)t[i] * (double)t[i];
@@ -30,8 +31,11 @@ __global__ __launch_bounds__(1024) void sn_normalize_kernel(const float* t, floa
   }
   if (norm_out && threadIdx.x == 0) *norm_out = nrm;
 }
+__global__ __launch_bounds__(1024) void sn_normalize_kernel(const float* t, float* v, int n, float eps, float* norm_out, float* v_copy = nullptr) {
+  sn_normalize_body(t, v, n, eps, norm_out, v_copy);
+}
 // s[r] = sum_k W[r][k] * v[k]   (one wave per row)
-__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* W, const float* v, float* s, int R, int K) {
+__device__ __forceinline__ void sn_w_v_body(const float* W, const float* v, float* s, int R, int K) {
   const int lane = threadIdx.x & 63;
   const int r = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (r >= R) return;
@@ -40,8 +44,9 @@ __global__ __launch_bounds__(256) void sn_w_v_kernel(const float* W, const float
   acc = wave_sum(acc);
   if (lane == 0) s[r] = acc;
 }
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* W, const float* v, float* s, int R, int K) { sn_w_v_body(W, v, s, R, K); }
 // u = s/(||s||+eps); sigma = u . s ; inv_sigma = 1/sigma
-__global__ __launch_bounds__(1024) void sn_finish_kernel(const float* s, float* u, int R, float eps, float* sigma, float* inv_sigma, float* u_copy = nullptr) {
+__device__ __forceinline__ void sn_finish_body(const float* s, float* u, int R, float eps, float* sigma, float* inv_sigma, float* u_copy) {
   __shared__ double sm[16];
   double q = 0.0;
   for (int i = threadIdx.x; i < R; i += blockDim.x) q += (double)s[i] * (double)s[i];
@@ -56,6 +61,34 @@ __global__ __launch_bounds__(1024) void sn_finish_kernel(const float* s, float* 
   }
   d = block_sum_d(d, sm);
   if (threadIdx.x == 0) { *sigma = (float)d; *inv_sigma = (float)(1.0 / d); }
+}
+__global__ __launch_bounds__(1024) void sn_finish_kernel(const float* s, float* u, int R, float eps, float* sigma, float* inv_sigma, float* u_copy = nullptr) {
+  sn_finish_body(s, u, R, eps, sigma, inv_sigma, u_copy);
+}
+// ---- all spectral-norm layers of a network in four launches (blockIdx.y = layer): the ten layers of the discriminator used to cost 40 ----
+struct SnEntry {
+  const float* W; float* u; float* v;
+  long long copy_off;   // floats into the snapshot buffer: u copy [R], then v copy [K]
+  long long ws_off;     // floats into the workspace: t [K], then s [R]
+  int R, K;
+};
+__global__ __launch_bounds__(256) void sn_wt_u_multi_kernel(const SnEntry* tab, float* ws) {
+  const SnEntry e = tab[blockIdx.y];
+  if ((int)blockIdx.x * 64 >= e.K) return;
+  sn_wt_u_body(e.W, e.u, ws + e.ws_off, e.R, e.K);
+}
+__global__ __launch_bounds__(1024) void sn_normalize_multi_kernel(const SnEntry* tab, const float* ws, float* copies, float eps) {
+  const SnEntry e = tab[blockIdx.x];
+  sn_normalize_body(ws + e.ws_off, e.v, e.K, eps, nullptr, copies + e.copy_off + e.R);
+}
+__global__ __launch_bounds__(256) void sn_w_v_multi_kernel(const SnEntry* tab, float* ws) {
+  const SnEntry e = tab[blockIdx.y];
+  if ((int)blockIdx.x * 4 >= e.R) return;
+  sn_w_v_body(e.W, e.v, ws + e.ws_off + e.K, e.R, e.K);
+}
+__global__ __launch_bounds__(1024) void sn_finish_multi_kernel(const SnEntry* tab, const float* ws, float* copies, float* sig, float eps) {
+  const SnEntry e = tab[blockIdx.x];
+  sn_finish_body(ws + e.ws_off + e.K, e.u, e.R, eps, sig + 2 * blockIdx.x, sig + 2 * blockIdx.x + 1, copies + e.copy_off);
 }
 // out = W * (*scale)
 __global__ void scale_by_ptr_kernel(const float* W, const float* scale, float* out, long long n) {
@@ -230,6 +263,17 @@ extern "C" int hwg_spectral_update_to(const float* W, float* u, float* v, float*
   HWG_LAUNCH_CHECK("sn_w_v");
   hipLaunchKernelGGL(sn_finish_kernel, dim3(1), dim3(1024), 0, st, (const float*)s, u, R, eps, sigma, inv_sigma, u_copy);
   HWG_LAUNCH_CHECK("sn_finish");
+  return HWG_OK;
+}
+extern "C" int hwg_spectral_update_multi(const void* table, int n, int max_R, int max_K, float eps, float* ws, float* copies, float* sig, void* stream) {
+  HWG_REQUIRE(table && n > 0 && max_R > 0 && max_K > 0 && ws && copies && sig, "spectral_update_multi: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const SnEntry* tab = (const SnEntry*)table;
+  hipLaunchKernelGGL(sn_wt_u_multi_kernel, dim3(hwg_cdiv(max_K, 64), n), dim3(256), 0, st, tab, ws);
+  hipLaunchKernelGGL(sn_normalize_multi_kernel, dim3(n), dim3(1024), 0, st, tab, (const float*)ws, copies, eps);
+  hipLaunchKernelGGL(sn_w_v_multi_kernel, dim3(hwg_cdiv(max_R, 4), n), dim3(256), 0, st, tab, ws);
+  hipLaunchKernelGGL(sn_finish_multi_kernel, dim3(n), dim3(1024), 0, st, tab, (const float*)ws, copies, sig, eps);
+  HWG_LAUNCH_CHECK("spectral_update_multi");
   return HWG_OK;
 }
 extern "C" int hwg_spectral_update(const float* W, float* u, float* v, int R, int K, float eps, float* sigma, float* inv_sigma, void* ws,

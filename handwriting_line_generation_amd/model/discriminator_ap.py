@@ -33,7 +33,11 @@ class SpectralConv2d(nn.Module):
 
     def forward(self, x, with_bias=True):
         m = self.module
-        w = ops.spectral_normalize(m.weight_bar, m.weight_u.data, m.weight_v.data)
+        fresh, self._fresh = getattr(self, "_fresh", None), None
+        if fresh is not None:      # the network ran this forward pass's power iterations for all its layers at once (DiscriminatorAP._power_iterations)
+            w = ops.spectral_scale(m.weight_bar, fresh)
+        else:
+            w = ops.spectral_normalize(m.weight_bar, m.weight_u.data, m.weight_v.data)
         return ops.conv2d(x, w, m.bias if with_bias else None, 1, self.padding)
 
 
@@ -82,8 +86,26 @@ class DiscriminatorAP(nn.Module):
         with ops.scope("D"):
             return self._forward(x, return_features)
 
+    def _power_iterations(self, return_features):
+        """one power iteration of every spectral-norm layer this forward pass is going to use (the reference runs them layer by layer inside
+        the forward; they are independent of each other and of the activations), batched into four launches"""
+        layers = [self.convs1[0], self.convs1[3], self.convs2[0], self.convs3[4]]
+        if self.use_med and not return_features:
+            layers.append(self.finalMed[0])
+        if self.use_low or return_features:
+            layers += [self.convs4[i] for i in (0, 4, 7, 11, 14)]
+        key = bool(return_features)
+        banks = self.__dict__.setdefault("_sn_banks", {})
+        bank = banks.get(key)
+        if bank is None or not bank.valid():
+            bank = banks[key] = ops.SpectralBank([(l.module.weight_bar, l.module.weight_u, l.module.weight_v) for l in layers])
+        for l, fresh in zip(layers, bank.update()):
+            l._fresh = fresh
+
     def _forward(self, x, return_features=False):
         """x: NCHW [N,1,64,W] (as the reference passes it) -> list of [N, -1] patch predictions"""
+        if x.is_cuda:
+            self._power_iterations(return_features)
         batch = x.shape[0]
         h = ops.to_nhwc(x)
         h = self.in_conv[0](h)

@@ -1175,6 +1175,51 @@ def spectral_normalize(w_bar, u, v, eps=1e-12):
     return _SpectralScale.apply(w_bar, un, vn, sig[0:1], sig[1:2])
 
 
+class SpectralBank:
+    """The power iterations of all spectral-norm layers a network runs in one forward pass, as four launches (hwg_spectral_update_multi)
+    instead of four per layer. Built once per (network, set of layers): the parameters' storage is persistent, only the snapshot buffer and
+    the sigma outputs are fresh per forward."""
+
+    def __init__(self, layers):
+        import numpy as np
+        self.layers = list(layers)                 # [(w_bar, u, v)] parameters
+        rec = np.zeros(len(self.layers), dtype=np.dtype([("W", "<u8"), ("u", "<u8"), ("v", "<u8"), ("copy_off", "<i8"), ("ws_off", "<i8"), ("R", "<i4"), ("K", "<i4")]))
+        off = 0
+        self.spans = []
+        for i, (w, u, v) in enumerate(self.layers):
+            R = w.shape[0]
+            K = w.numel() // R
+            rec[i] = (w.data_ptr(), u.data_ptr(), v.data_ptr(), off, off, R, K)
+            self.spans.append((off, R, K))
+            off += (R + K + 3) // 4 * 4
+        self.total = off
+        self.max_R = max(R for _, R, _ in self.spans)
+        self.max_K = max(K for _, _, K in self.spans)
+        self.ptrs = [(w.data_ptr(), u.data_ptr(), v.data_ptr()) for w, u, v in self.layers]
+        dev = self.layers[0][0].device
+        self.table = h2d(torch.from_numpy(rec.view(np.uint8)), dev)
+        self.ws = torch.empty(self.total, dtype=torch.float32, device=dev)
+
+    def valid(self):
+        return all((w.data_ptr(), u.data_ptr(), v.data_ptr()) == p for (w, u, v), p in zip(self.layers, self.ptrs))
+
+    def update(self, eps=1e-12):
+        """-> per layer (u snapshot, v snapshot, sigma[0:1], sigma[1:2]) for `spectral_scale`"""
+        dev = self.ws.device
+        copies = torch.empty(self.total, dtype=torch.float32, device=dev)
+        sig = torch.empty(2 * len(self.layers), dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            L.call("hwg_spectral_update_multi", self.table, len(self.layers), self.max_R, self.max_K, eps, self.ws, copies, sig, _stream())
+        return [(copies[off: off + R], copies[off + R: off + R + K], sig[2 * i: 2 * i + 1], sig[2 * i + 1: 2 * i + 2])
+                for i, (off, R, K) in enumerate(self.spans)]
+
+
+def spectral_scale(w_bar, fresh):
+    """W / sigma from a SpectralBank.update() record (the power iteration already ran)"""
+    un, vn, sigma, inv_sigma = fresh
+    return _SpectralScale.apply(w_bar, un, vn, sigma, inv_sigma)
+
+
 # ----------------------------------------------------------------------------------------------
 # style extraction helpers
 # ----------------------------------------------------------------------------------------------

@@ -242,6 +242,10 @@ int hwg_spectral_update(const float* W, float* u, float* v, int R, int K, float 
  * pass keeps for its backward pass, without a separate copy (discriminator_ap.py:31-45 clones them) */
 int hwg_spectral_update_to(const float* W, float* u, float* v, float* u_copy, float* v_copy, int R, int K, float eps, float* sigma,
                            float* inv_sigma, void* workspace, size_t workspace_bytes, void* stream);
+/* the same iteration for n layers at once (four launches in total): `table` = n device records {const float* W; float* u; float* v;
+ * long long copy_off; long long ws_off; int R; int K;} (48 bytes); layer i writes its snapshot to copies + copy_off (u [R], then v [K]), uses
+ * ws + ws_off (K + R floats) as scratch and leaves (sigma, 1/sigma) in sig[2i], sig[2i+1] */
+int hwg_spectral_update_multi(const void* table, int n, int max_R, int max_K, float eps, float* workspace, float* copies, float* sig, void* stream);
 int hwg_scale_by_ptr(const float* x, const float* scale, float* out, long long n, void* stream);
 int hwg_spectral_bwd(const float* dWsn, const float* Wbar, const float* u, const float* v, const float* sigma, float* dWbar, int R, int K,
                      int accumulate, void* ws, size_t ws_bytes, void* stream);
