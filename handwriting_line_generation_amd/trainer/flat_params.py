@@ -198,6 +198,10 @@ def control_group():
     iteration): CPU tensors, so the exchange never waits for a GPU stream. Created collectively on first use."""
     import torch.distributed as dist
     if _CTL[0] is None:
+        # single-node jobs (all ranks local): pin gloo to the loopback interface - its default picks the interface by resolving the host
+        # name, which containers do not always provide
+        if os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) == os.environ.get("WORLD_SIZE", "1"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         _CTL[0] = dist.new_group(backend="gloo")
     return _CTL[0]
 
