@@ -801,6 +801,253 @@ __global__ __launch_bounds__(512) void wino_conv_ws_kernel(WinoK a) {
 // a Winograd tile is only 4 pixels, so operand traffic (L2 -> LDS), not the matrix pipe, bounds the smaller tiles. The register file is
 // the limit: 12 waves x 168 registers is all of it, hence the fragments are read one position ahead (24 registers) instead of one
 // round ahead; the second consumer of each SIMD covers the LDS latency behind the barrier.
+__global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
+  constexpr int NT = 512, TM = 64, TN = 64;
+  constexpr int PSV = TM * 16 + 8, PSU = TN * 16 + 8;
+  constexpr int XI = TM * 16 / NT;                   // 2 x work items per thread: (tile, 4-channel group, patch column)
+  constexpr int UI = TN * 16 / NT;                   // 2 u work items per thread per round: (position, k, 4-channel group)
+  constexpr int VBUF = 4 * PSV, UBUF = 4 * PSU;      // two patch buffers; ring of four filter rounds = the four rounds of a chunk, each its own array:
+  // the compiler tracks pending LDS DMA per underlying object, so reading the array of round r does not force a wait for the DMA that is
+  // filling the array of round r + 2 (one shared array costs a vmcnt(0) before every fragment read)
+  constexpr int LDK = 68;                            // exchange row stride (floats): the 4 row groups of a C/D block land 16 banks apart
+  constexpr int XP = 64 * LDK;                       // one (b, i) plane of the exchange image
+  static_assert(XP >= UBUF && 4 * XP >= 2 * VBUF, "exchange planes alias the operand buffers");
+  __shared__ __attribute__((aligned(16))) float smem[4 * XP];
+  __shared__ __attribute__((aligned(16))) float U0[XP], U1[XP], U2[XP], U3[XP];
+  float* const Vs = smem;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int bq = wid & 3, nh = wid >> 2;
+  int mtile, ntile, split;
+  if (!wino_work_item(a, mtile, ntile, split)) return;
+  const int m0 = mtile * TM;
+  const int n0 = ntile * TN;
+  const int T_all = a.C >> 4;
+  const int t0 = (int)((long long)T_all * split / a.nsplit);
+  const int t1 = (int)((long long)T_all * (split + 1) / a.nsplit);
+
+  int x_off[XI], x_ok[XI], x_row[XI], x_c4[XI], x_b[XI];
+  const int row_stride = a.W * a.C;
+#pragma unroll
+  for (int it = 0; it < XI; ++it) {
+    const int id = tid + it * NT;
+    const int b = id & 3, c4 = (id >> 2) & 3, row = id >> 4;
+    x_b[it] = b; x_c4[it] = c4; x_row[it] = row;
+    const int m = m0 + row;
+    const bool mok = m < a.M;
+    const int mm = mok ? m : 0;
+    const int tj = mm % a.TQ;
+    const int t2 = mm / a.TQ;
+    const int ti = t2 % a.TP;
+    const int n = t2 / a.TP;
+    const int w = 2 * tj - a.pw + b;
+    const bool wok = mok && w >= 0 && w < a.W;
+    const int h0 = 2 * ti - a.ph;
+    x_off[it] = ((n * a.H + h0) * a.W + (wok ? w : 0)) * a.C + c4 * 4;
+    int okm = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (wok && h0 + r >= 0 && h0 + r < a.H) okm |= 1 << r;
+    x_ok[it] = okm;
+  }
+  // Filters: every round's 4 positions x 64 channels x 16 input channels (16 KB, already in the transform domain) go global -> LDS by DMA
+  // (global_load_lds_dwordx4: no registers, no VALU, no ds_write), TWO rounds ahead into a ring of three buffers - the L2 latency of
+  // the filter stream used to sit on every round's critical path (loads issued at the top of a round, stored at its end). A wave
+  // instruction fills 16 rows x 64 B linearly; the XOR swizzle of the image is applied on the global side (each lane fetches the 16-byte
+  // piece that belongs into its linear slot). Wavefront w moves instructions 2w, 2w+1 of the round's 16.
+  const int widu = __builtin_amdgcn_readfirstlane(wid);
+  int u_src[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int inst = 2 * widu + j, plane = inst >> 2, i = inst & 3;
+    const int row = 16 * i + (lane >> 2), slot = lane & 3;
+    int kk = n0 + row;
+    if (kk >= a.Kpad) kk = a.Kpad - 1;              // rows past the padded channel count re-read the last row (never stored)
+    u_src[j] = (plane * a.Kpad + kk) * 16 + 4 * (slot ^ ((row >> 1) & 3));
+  }
+  const long long u_round = 4LL * a.Kpad * 16;        // floats per round in the filter image
+  const int R_all = 4 * (t1 - t0);                    // rounds of this workgroup
+  auto dma_u = [&](int R, float* dst) {              // round index relative to t0; rounds past the end re-fetch the last one (unused)
+    const int Rc = R < R_all ? R : R_all - 1;
+    const float* base = a.u + ((long long)t0 * 4 + Rc) * u_round;
+    // issued as inline assembly: for a DMA it can see, the compiler makes EVERY later LDS access (and the barrier's fence) wait for all pending
+    // DMA (vmcnt(0)) - here two rounds are meant to stay in flight; the waits that matter are placed by hand before the round barriers
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int inst = 2 * widu + j;
+      const float* src = base + u_src[j];
+      const unsigned ldst = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(dst + (inst >> 2) * PSU + (inst & 3) * 256);
+      asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(ldst) : "memory");   // (m0 is written; clang reserves it and rejects it as a clobber - nothing else in this kernel uses it)
+    }
+  };
+
+  f32x4 acc[4][4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[r][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 raw[XI][4], tr[XI][4];
+  auto load_x = [&](int t) {
+#pragma unroll
+    for (int it = 0; it < XI; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int off = (x_ok[it] >> r) & 1 ? x_off[it] + r * row_stride + t * 16 : 0;
+        raw[it][r] = *reinterpret_cast<const float4*>(a.x + off);
+      }
+  };
+  auto col_transform = [&]() {
+#pragma unroll
+    for (int it = 0; it < XI; ++it) {
+      float4 d[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d[r] = raw[it][r];
+        if (!((x_ok[it] >> r) & 1)) d[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      tr[it][0] = make_float4(d[0].x - d[2].x, d[0].y - d[2].y, d[0].z - d[2].z, d[0].w - d[2].w);
+      tr[it][1] = make_float4(d[1].x + d[2].x, d[1].y + d[2].y, d[1].z + d[2].z, d[1].w + d[2].w);
+      tr[it][2] = make_float4(d[2].x - d[1].x, d[2].y - d[1].y, d[2].z - d[1].z, d[2].w - d[1].w);
+      tr[it][3] = make_float4(d[1].x - d[3].x, d[1].y - d[3].y, d[1].z - d[3].z, d[1].w - d[3].w);
+    }
+  };
+  auto store_round = [&](int buf, int r) {
+    float* Vb = Vs + buf * VBUF;
+#pragma unroll
+    for (int it = 0; it < XI; ++it) {
+      const float4 v = tr[it][r];
+      const float sa = (x_b[it] == 3) ? -1.f : 1.f;
+      const float sb = (x_b[it] & 1) ? 1.f : -1.f;
+      float4 o;
+      o.x = sa * v.x + sb * quad_partner(v.x);
+      o.y = sa * v.y + sb * quad_partner(v.y);
+      o.z = sa * v.z + sb * quad_partner(v.z);
+      o.w = sa * v.w + sb * quad_partner(v.w);
+      *reinterpret_cast<float4*>(Vb + x_b[it] * PSV + swz(x_row[it], x_c4[it])) = o;
+    }
+  };
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  int a_off[4], b_off[2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) a_off[m] = bq * PSV + swz(m * 16 + frow, fchunk);
+#pragma unroll
+  for (int n = 0; n < 2; ++n) b_off[n] = bq * PSU + swz((nh * 2 + n) * 16 + frow, fchunk);
+
+  if (t1 > t0) {
+    dma_u(0, U0);
+    dma_u(1, U1);
+    load_x(t0);
+    col_transform();
+    store_round(0, 0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt((2 & 15) | (7 << 4) | (0 << 8));       // vmcnt(2): round 0's filters have landed, round 1's may be in flight
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  for (int t = t0; t < t1; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int R = 4 * (t - t0) + r;
+      const int cur = r & 1;
+      // VMEM order of a round: filter DMA of round R + 2 (2 operations), then - in rounds r == 1 - the 8 patch loads of the next chunk
+      // (the last chunk re-fetches itself, so the counts below are the same in every round)
+      if (r == 3) { col_transform(); __builtin_amdgcn_sched_barrier(0); }   // needs the patch loads of round 1: before this round's DMA joins the queue behind them
+      dma_u(R + 2, r == 0 ? U2 : r == 1 ? U3 : r == 2 ? U0 : U1);
+      if (r == 1) load_x(t + 1 < t1 ? t + 1 : t);
+      const float* Vb = Vs + cur * VBUF;
+      const float* Ub = r == 0 ? U0 : r == 1 ? U1 : r == 2 ? U2 : U3;
+      float4 af[4], bf[2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const float4*>(Vb + a_off[m]);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bf[n] = *reinterpret_cast<const float4*>(Ub + b_off[n]);
+      // element j of both fragments belongs to channel 4*(lane>>4)+j: MFMA j contracts channels {j, 4+j, 8+j, 12+j} of the chunk
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[r][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, bf[n].x, acc[r][m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[r][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, bf[n].y, acc[r][m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[r][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, bf[n].z, acc[r][m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[r][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, bf[n].w, acc[r][m][n], 0, 0, 0);
+      store_round(cur ^ 1, (r + 1) & 3);
+      // filters of round R + 1 (issued one round ago) must have landed before the barrier lets the consumers at them; younger in the
+      // in-order VMEM queue: this round's DMA (2) and the patch loads of rounds r == 1 (this round) / r == 2 (issued last round)
+      // Raw barrier instead of __syncthreads(): its workgroup fence would wait for ALL pending LDS DMA (vmcnt(0)), i.e. also for the rounds
+      // that are meant to stay in flight. The LDS stores of this round (patches) are drained with lgkmcnt(0).
+      __builtin_amdgcn_sched_barrier(0);      // nothing of a later round (e.g. the masking of the patch loads) is to be pulled up into this one
+      asm volatile("" ::: "memory");
+      if (r == 1 || r == 2) __builtin_amdgcn_s_waitcnt((10 & 15) | (7 << 4) | (0 << 8));
+      else __builtin_amdgcn_s_waitcnt((2 & 15) | (7 << 4) | (0 << 8));
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  }
+
+  // ---- output transform: over the rows a in registers (s0 = m0+m1+m2, s1 = m1-m2-m3), over the columns b through LDS ----------------
+  // exchange image X[b][i][tile][channel]; C/D layout of a block: channel = lane & 15, tile = (lane >> 4) * 4 + e
+  auto xplane = [&](int pl) -> float* { return pl < 4 ? smem + pl * XP : pl == 4 ? U0 : pl == 5 ? U1 : pl == 6 ? U2 : U3; };
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s0 = acc[0][m][n][e] + acc[1][m][n][e] + acc[2][m][n][e];
+        const float s1 = acc[1][m][n][e] - acc[2][m][n][e] - acc[3][m][n][e];
+        const int tile = m * 16 + (lane >> 4) * 4 + e, kk = (nh * 2 + n) * 16 + (lane & 15);
+        xplane(bq * 2 + 0)[tile * LDK + kk] = s0;
+        xplane(bq * 2 + 1)[tile * LDK + kk] = s1;
+      }
+  __syncthreads();
+  const int kk = tid & 63;
+  const int k = n0 + kk;
+  const bool direct = a.nsplit == 1;
+  float* yg = direct ? a.y : a.part + (long long)split * ((long long)a.N * a.P * a.Q * a.K);
+  const float bv = (direct && a.bias && k < a.K) ? a.bias[k] : 0.f;
+  const bool accum = direct && a.accumulate;
+#pragma unroll 2
+  for (int tile = tid >> 6; tile < 64; tile += 8) {
+    const int m = m0 + tile;
+    if (m >= a.M || k >= a.K) continue;
+    const int tj = m % a.TQ;
+    const int t2 = m / a.TQ;
+    const int ti = t2 % a.TP;
+    const int n = t2 / a.TP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float r0 = xplane(0 * 2 + i)[tile * LDK + kk], r1 = xplane(1 * 2 + i)[tile * LDK + kk];
+      const float r2 = xplane(2 * 2 + i)[tile * LDK + kk], r3 = xplane(3 * 2 + i)[tile * LDK + kk];
+      const int p = 2 * ti + i;
+      if (p >= a.P) continue;
+      const float y0 = r0 + r1 + r2, y1 = r1 - r2 - r3;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int q = 2 * tj + j;
+        if (q >= a.Q) continue;
+        const long long o = (((long long)n * a.P + p) * a.Q + q) * a.K + k;
+        float v = (j == 0 ? y0 : y1) + bv;
+        if (accum) v += yg[o];
+        yg[o] = v;
+      }
+    }
+  }
+}
+
+
 constexpr int WINO_DB = 4;      // filter rounds in the ring of the big kernel
 
 __global__ __launch_bounds__(768) void wino_conv_big_kernel(WinoK a) {
@@ -1198,6 +1445,7 @@ extern "C" int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const f
   else if (p.cfg == 1) hipLaunchKernelGGL((wino_conv_kernel<2, 4>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 2) hipLaunchKernelGGL((wino_conv_kernel<8, 1>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 5) hipLaunchKernelGGL(wino_conv_big_kernel, grid, dim3(768), 0, st, k);
+  else if (p.cfg == 6 && !getenv("HWG_W64_NODMA")) hipLaunchKernelGGL(wino_conv64d_kernel, grid, dim3(512), 0, st, k);
   else if (p.cfg == 6) hipLaunchKernelGGL(wino_conv64_kernel, grid, dim3(512), 0, st, k);
   else hipLaunchKernelGGL((wino_conv_ws_kernel<1, 4>), grid, dim3(512), 0, st, k);
   hwg_prof_close(prof, st);
