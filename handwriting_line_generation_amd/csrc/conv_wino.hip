@@ -801,6 +801,9 @@ __global__ __launch_bounds__(512) void wino_conv_ws_kernel(WinoK a) {
 // a Winograd tile is only 4 pixels, so operand traffic (L2 -> LDS), not the matrix pipe, bounds the smaller tiles. The register file is
 // the limit: 12 waves x 168 registers is all of it, hence the fragments are read one position ahead (24 registers) instead of one
 // round ahead; the second consumer of each SIMD covers the LDS latency behind the barrier.
+#ifndef HWG_W64D_SCHED
+#define HWG_W64D_SCHED 6
+#endif
 __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
   constexpr int NT = 512, TM = 64, TN = 64;
   constexpr int PSV = TM * 16 + 8, PSU = TN * 16 + 8;
@@ -984,6 +987,15 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[r][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, bf[n].w, acc[r][m][n], 0, 0, 0);
       store_round(cur ^ 1, (r + 1) & 3);
+#if HWG_W64D_SCHED
+      // the next round's patch transform (DPP + FMA) and its LDS stores in the shadow of this round's MFMAs
+#pragma unroll
+      for (int g = 0; g < 32; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, HWG_W64D_SCHED, 0);
+        if ((g & 7) == 7) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+#endif
       // filters of round R + 1 (issued one round ago) must have landed before the barrier lets the consumers at them; younger in the
       // in-order VMEM queue: this round's DMA (2) and the patch loads of rounds r == 1 (this round) / r == 2 (issued last round)
       // Raw barrier instead of __syncthreads(): its workgroup fence would wait for ALL pending LDS DMA (vmcnt(0)), i.e. also for the rounds
