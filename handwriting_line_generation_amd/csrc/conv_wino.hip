@@ -1009,6 +1009,10 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
     }
   }
 
+  // the last two rounds issued filter DMAs for rounds that do not exist (kept so that the VMEM counts are the same in every round): they must
+  // have landed before the exchange image below reuses their LDS arrays
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   // ---- output transform: over the rows a in registers (s0 = m0+m1+m2, s1 = m1-m2-m3), over the columns b through LDS ----------------
   // exchange image X[b][i][tile][channel]; C/D layout of a block: channel = lane & 15, tile = (lane >> 4) * 4 + e
   auto xplane = [&](int pl) -> float* { return pl < 4 ? smem + pl * XP : pl == 4 ? U0 : pl == 5 ? U1 : pl == 6 ? U2 : U3; };
