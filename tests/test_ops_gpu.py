@@ -224,6 +224,38 @@ def test_winograd_engines_agree_at_bench_sizes(cuda, shape):
         assert err < 1e-5, "winograd vs direct %s at %s: rel L2 %.2e" % (n, shape, err)
 
 
+@pytest.mark.parametrize("shape", [(4, 20, 130, 64, 128, 0, 1), (2, 8, 129, 512, 256, 1, 1)], ids=lambda c: "x".join(map(str, c)))
+def test_winograd_dma_kernel_repeatable_under_contention(cuda, shape):
+    """The 64x64 Winograd kernel streams its filters by LDS DMA with hand-placed wait counts and raw barriers: 60 launches, while a second
+    stream keeps other kernels running next to it (different timing every launch), must all produce the bit pattern of the first one
+    (a missing wait shows up as run-to-run differences long before it shows up as a wrong mean)"""
+    import os
+    from handwriting_line_generation_amd import ops
+    N, H, W, C, K, ph, pw = shape
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(N, H, W, C, generator=g).to(cuda)
+    w = (torch.randn(K, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(cuda)
+    noise_a = torch.randn(1 << 22, device=cuda)
+    side = torch.cuda.Stream()
+    os.environ["HWG_WINO"] = "2"; os.environ["HWG_WINO_FORCE"] = "6"
+    ops._wino_choice.clear()
+    try:
+        first = None
+        for rep in range(60):
+            with torch.cuda.stream(side):
+                for _ in range(1 + rep % 3):
+                    noise_a = noise_a * 1.0000001 + 1e-9
+            y = ops.conv2d(x, w, None, 1, (ph, pw))
+            if first is None:
+                first = y.clone()
+            else:
+                assert torch.equal(y, first), "launch %d differs from launch 0 in %d elements" % (rep, int((y != first).sum()))
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("HWG_WINO", None); os.environ.pop("HWG_WINO_FORCE", None)
+        ops._wino_choice.clear()
+
+
 def test_linear(cuda):
     from handwriting_line_generation_amd import ops
     g = torch.Generator().manual_seed(3)
