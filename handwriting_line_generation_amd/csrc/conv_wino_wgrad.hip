@@ -16,6 +16,10 @@
 // summed by the direct kernel's fixed-order reduce (hwg_wgrad_reduce_launch).
 #include "hwg_common.h"
 #include <stdlib.h>
+#ifndef HWG_WWG_SX
+#define HWG_WWG_SX 8
+#define HWG_WWG_SY 4
+#endif
 
 namespace {
 
@@ -167,7 +171,7 @@ __device__ __forceinline__ void wg_rounds(const WinoWgK& a, float* smem, f32x4 (
 #pragma unroll
     for (int g = 0; g < 64; ++g) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x096, XROLE ? 8 : 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x096, XROLE ? HWG_WWG_SX : HWG_WWG_SY, 0);
     }
     __syncthreads();
   }
