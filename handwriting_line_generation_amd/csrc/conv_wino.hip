@@ -1358,8 +1358,13 @@ static WinoPlan plan_wino(const hwg_conv_desc* d, double* model_s = nullptr) {
   const int chunks = d->C / 16;
   const double out_bytes = 4.0 * d->N * d->P * d->Q * d->K;
   double best_t = 1e30;
+  static const WinoCost cost6 = [] {         // tuning aid: HWG_WINO_COST6="fixed_us,step_us" overrides the 64x64 DMA kernel's model constants
+    WinoCost c = kWinoCost[4];
+    if (const char* e = getenv("HWG_WINO_COST6")) { double f = 0, s2 = 0; if (sscanf(e, "%lf,%lf", &f, &s2) == 2) { c.fixed_us = f; c.step_us = s2; } }
+    return c;
+  }();
   for (int ci = 0; ci < 5; ++ci) {
-    const WinoCost& wc = kWinoCost[ci];
+    const WinoCost& wc = ci == 4 ? cost6 : kWinoCost[ci];
     if (wc.cfg == 2 && d->K > 16) continue;
     if (wc.cfg == 0 && d->K > 48) continue;
     if ((wc.cfg == 1 || wc.cfg == 5 || wc.cfg == 6) && d->K <= 48) continue;

@@ -90,7 +90,8 @@ def run(path, timing=False):
                 need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
                 ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
                 call = lambda: L.call("hwg_conv_wgrad", ctypes.byref(d), u, x, dw, C * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)  # noqa: E731
-        elif kind == "wino_conv_kernel":
+        elif (kind == "wino_conv_kernel" if not os.environ.get("PMC_FREE_CHOICE") else
+              (not transposed and L.query("hwg_wino_supported", ctypes.byref(d)) and L.query("hwg_wino_preferred", ctypes.byref(d)))):
             w = torch.randn(L.query("hwg_wino_weight_floats", K, C), generator=g).to(dev)
             y = torch.empty(N, P, Q, K, dtype=torch.float32, device=dev)
             need = L.query("hwg_wino_conv_workspace", ctypes.byref(d))
