@@ -150,8 +150,23 @@ class BaseTrainer:
         self.swa = False
         if tr.get("swa") or tr.get("weight_averaging"):
             raise NotImplementedError("weight averaging is not used by any shipped config")
+        self._stop = False
         if resume:
             self._resume_checkpoint(resume)
+
+    def request_stop(self):
+        """async-signal-safe: train() saves a checkpoint and returns at the next iteration boundary (on every rank together)"""
+        self._stop = True
+
+    def _stop_agreed(self):
+        """SIGINT may reach one rank only (or the ranks at different iterations): the flag is OR-ed over the gloo control group so that all
+        ranks save - and enter _save_checkpoint's barrier - at the same iteration. Single process: just the flag."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return self._stop
+        from ..trainer.flat_params import control_group
+        flag = torch.tensor([1 if self._stop else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=control_group())
+        return bool(flag.item())
 
     def _make_schedule(self, tr):
         return lr_schedule(self.useLearningSchedule, tr, self.iterations)
@@ -165,6 +180,10 @@ class BaseTrainer:
     def train(self):
         sum_log = {}
         for self.iteration in range(self.start_iteration, self.iterations + 1):
+            if self._stop_agreed():
+                self.iteration -= 1          # the last completed iteration is what the checkpoint holds
+                self.save()
+                return
             t0 = timeit.default_timer()
             if self.lr_lambda is not None:
                 self.optimizer.param_groups[0]["lr"] = self.scheduled_lr(self.iteration)

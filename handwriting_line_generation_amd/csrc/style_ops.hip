@@ -5,7 +5,7 @@
 namespace {
 
 // patches[i][j][c] = x[b_i][pos_i - w + j][c] (zero outside [0,Wx)), j in [0, 2w+1)
-__global__ void gather_windows_kernel(const float* x, int Wx, int C, const int* idx_b, const int* idx_pos, int n, int w, float* patches) {
+__global__ void gather_windows_kernel(const float* x, int B, int Wx, int C, const int* idx_b, const int* idx_pos, int n, int w, float* patches) {
   const int WW = 2 * w + 1;
   const long long total = (long long)n * WW * C;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -14,15 +14,21 @@ __global__ void gather_windows_kernel(const float* x, int Wx, int C, const int* 
     const int j = (int)(t % WW);
     const int k = (int)(t / WW);
     const int pos = idx_pos[k] - w + j;
-    patches[i] = (pos >= 0 && pos < Wx) ? x[((long long)idx_b[k] * Wx + pos) * C + c] : 0.f;
+    const int b = idx_b[k];
+    patches[i] = (pos >= 0 && pos < Wx && b >= 0 && b < B) ? x[((long long)b * Wx + pos) * C + c] : 0.f;
   }
 }
 // dx[b][pos][c] = sum over the windows that cover (b, pos) of dpatches[k][j][c]. The windows overlap, so a scatter would need floating
 // point atomics (non-deterministic summation order); instead the window list is inverted once (at most ONE window is centred on a given
 // (sample, column): the column's arg-max class) and every output element gathers its <= 2w+1 contributions in a fixed order.
-__global__ void window_index_kernel(const int* idx_b, const int* idx_pos, int n, int Wx, int* win_of) {
+// PRECONDITION (ops.gather_windows states and, under HWG_DEBUG=1, asserts it): window centres (idx_b, idx_pos) are unique. Centres outside
+// the tensor are ignored (their windows lie outside it entirely or were zero-filled by the gather); with duplicate centres the window with
+// the largest list index would be the only one to contribute - atomicMax keeps even that case deterministic.
+__global__ void window_index_kernel(const int* idx_b, const int* idx_pos, int n, int B, int Wx, int* win_of) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) win_of[idx_b[k] * Wx + idx_pos[k]] = k;
+  if (k >= n) return;
+  const int b = idx_b[k], p = idx_pos[k];
+  if (b >= 0 && b < B && p >= 0 && p < Wx) atomicMax(&win_of[b * Wx + p], k);
 }
 __global__ void scatter_windows_kernel(const float* dpatches, int B, int Wx, int C, const int* win_of, int w, float* dx) {
   const int WW = 2 * w + 1;
@@ -308,7 +314,7 @@ extern "C" int hwg_gather_windows(const float* x, int B, int Wx, int C, const in
                                   void* stream) {
   HWG_REQUIRE(x && idx_b && idx_pos && patches && B > 0 && Wx > 0 && C > 0 && n > 0 && window >= 0, "gather_windows: bad arguments");
   const long long total = (long long)n * (2 * window + 1) * C;
-  hipLaunchKernelGGL(gather_windows_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, Wx, C, idx_b, idx_pos, n, window,
+  hipLaunchKernelGGL(gather_windows_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, B, Wx, C, idx_b, idx_pos, n, window,
                      patches);
   HWG_LAUNCH_CHECK("gather_windows");
   return HWG_OK;
@@ -321,7 +327,7 @@ extern "C" int hwg_scatter_windows(const float* dpatches, int B, int Wx, int C, 
     hwg_set_error("scatter_windows: memset failed");
     return HWG_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(window_index_kernel, dim3(hwg_cdiv(n, 256)), dim3(256), 0, st, idx_b, idx_pos, n, Wx, win_of);
+  hipLaunchKernelGGL(window_index_kernel, dim3(hwg_cdiv(n, 256)), dim3(256), 0, st, idx_b, idx_pos, n, B, Wx, win_of);
   hipLaunchKernelGGL(scatter_windows_kernel, dim3(hwg_stream_grid((long long)B * Wx * C, 256)), dim3(256), 0, st, dpatches, B, Wx, C, (const int*)win_of,
                      window, dx);
   HWG_LAUNCH_CHECK("scatter_windows");

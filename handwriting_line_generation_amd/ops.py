@@ -9,6 +9,7 @@ libhwg_hip.so on torch's current stream. torch is used for memory, autograd book
 """
 import ctypes
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -1246,6 +1247,13 @@ class _GatherWindows(Function):
 
 
 def gather_windows(x_BWC, idx_b, idx_pos, window):
+    """patches[i] = x[idx_b[i], idx_pos[i]-window : idx_pos[i]+window+1, :] (zero outside). PRECONDITION of the deterministic backward
+    (hwg_scatter_windows inverts the window list instead of scattering with atomics): the centres (idx_b[i], idx_pos[i]) are unique - true for
+    the caller (CharStyleEncoder: one arg-max class per column). HWG_DEBUG=1 checks it on the host."""
+    if os.environ.get("HWG_DEBUG"):
+        key = (idx_b.long() * x_BWC.shape[1] + idx_pos.long()).cpu()
+        assert key.unique().numel() == key.numel(), "gather_windows: duplicate window centres (their gradients would be dropped)"
+        assert int(idx_pos.min()) >= 0 and int(idx_pos.max()) < x_BWC.shape[1] and int(idx_b.min()) >= 0 and int(idx_b.max()) < x_BWC.shape[0]
     return _GatherWindows.apply(x_BWC, idx_b, idx_pos, window)
 
 

@@ -30,10 +30,9 @@ class AutoTrainer(BaseTrainer):
         with open(config["data_loader"]["char_file"]) as f:
             self.idx_to_char = {int(k): v for k, v in json.load(f)["idx_to_char"].items()}
         self.num_class = len(self.idx_to_char) + 1
-        self.center_pad = tr.get("center_pad", True)
-        self.no_bg_loss = tr.get("no_bg_loss", False)
-        if self.no_bg_loss:
-            raise NotImplementedError("fg-mask weighted loss is not used by the shipped autoencoder config")
+        # the reference hard-codes both (trainer/auto_trainer.py:40-41): width differences are padded on the right, no fg-mask weighting
+        self.center_pad = False
+        self.no_bg_loss = False
         import torch.distributed as dist
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         ops.SIDE_WGRAD = bool(tr.get("side_stream_wgrad", False))   # process-global switch: every trainer states its own choice
@@ -94,9 +93,44 @@ class AutoTrainer(BaseTrainer):
             return losses, {k: v for k, v in (("recon", recon), ("pred", pred)) if k in get}
         return losses
 
-    def getCER(self, gt, pred):
-        cer = 0
+    def getCER(self, gt, pred, individual=False):
+        """mean CER and WER over the lines of a batch + the decoded strings (trainer/auto_trainer.py:321-342)"""
+        cer = wer = 0
+        pred_strs, all_cer = [], []
         for i, g in enumerate(gt):
             s, _ = string_utils.naive_decode(pred[:, i])
-            cer += string_utils.cer(g, string_utils.label2str_single(s, self.idx_to_char, False))
-        return cer / len(gt)
+            s = string_utils.label2str_single(s, self.idx_to_char, False)
+            this = string_utils.cer(g, s)
+            cer += this
+            all_cer.append(this)
+            wer += string_utils.wer(g, s)
+            pred_strs.append(s)
+        if individual:
+            return cer / len(gt), wer / len(gt), pred_strs, all_cer
+        return cer / len(gt), wer / len(gt), pred_strs
+
+    def _valid_epoch(self):
+        """validation pass (trainer/auto_trainer.py:199-245): weighted losses of every validation batch under no_grad, averaged over the
+        batches; CER / WER of the E_HWR head when the config has a 'recog' loss"""
+        self.model.eval()
+        totals = {}
+        total_loss = total_cer = total_wer = 0.0
+        n = 0
+        with torch.no_grad():
+            for instance in self.valid_data_loader:
+                losses, got = self.run_gen(instance, ["pred"] if "recog" in self.loss else ["none"])
+                for name, v in losses.items():
+                    w = float(v) * self.lossWeights[name[:-4]]
+                    total_loss += w
+                    totals["val_" + name] = totals.get("val_" + name, 0.0) + w
+                if "recog" in self.loss:
+                    cer, wer, _ = self.getCER(instance["gt"], got["pred"].detach().cpu().numpy())
+                    total_cer += cer
+                    total_wer += wer
+                n += 1
+        n = max(n, 1)
+        out = {"val_loss": total_loss / n, **{k: v / n for k, v in totals.items()}}
+        if "recog" in self.loss:
+            out["val_CER"] = total_cer / n
+            out["val_WER"] = total_wer / n
+        return out

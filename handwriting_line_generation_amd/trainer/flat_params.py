@@ -193,14 +193,25 @@ FORCE_DP = bool(int(os.environ.get("HWG_FORCE_DP", "0") or 0))
 _CTL = [None]
 
 
+def _require_group():
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("data-parallel exchange requested (WORLD_SIZE > 1 or HWG_FORCE_DP=1) but torch.distributed is not initialised: "
+                           "launch through torch.distributed.run, or call dist.init_process_group first")
+
+
 def control_group():
     """gloo group for host-side decisions all ranks take together (which tensors received a gradient somewhere, whether to skip an
     iteration): CPU tensors, so the exchange never waits for a GPU stream. Created collectively on first use."""
     import torch.distributed as dist
+    _require_group()
     if _CTL[0] is None:
         # single-node jobs (all ranks local): pin gloo to the loopback interface - its default picks the interface by resolving the host
         # name, which containers do not always provide
-        if os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) == os.environ.get("WORLD_SIZE", "1"):
+        # (only when the launcher says so - LOCAL_WORLD_SIZE == WORLD_SIZE - or the rendezvous address is the loopback; a multi-node
+        # srun / mpirun launch that exports RANK / WORLD_SIZE / MASTER_ADDR only must keep gloo's own interface choice)
+        lws = os.environ.get("LOCAL_WORLD_SIZE")
+        if (lws is not None and lws == os.environ.get("WORLD_SIZE", "1")) or os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         _CTL[0] = dist.new_group(backend="gloo")
     return _CTL[0]
@@ -215,6 +226,7 @@ def start_stash_allreduce(stash, world, flat=None):
     import torch.distributed as dist
     st = [stash[0], stash[1], None, False]
     if world > 1 or FORCE_DP:
+        _require_group()
         if flat is None:
             _count(st[0])
             st[2] = [(dist.all_reduce(st[0], op=dist.ReduceOp.SUM, async_op=True), st[0])]
@@ -265,6 +277,7 @@ def allreduce_gradient_sets(flat, stashes, world, device):
     import torch.distributed as dist
     if world == 1 and not FORCE_DP:
         return
+    _require_group()
     ops.join_side_stream()
     # the None-masks are host state (set while the backward pass is being enqueued), so they are OR-ed over the gloo control group: no
     # device collective + read-back, the host keeps its run-ahead over the GPU (a device MAX all-reduce here cost 4 % of the step)
@@ -350,8 +363,14 @@ class HipAdam:
             sl = slice(int(f.offsets[k]), int(f.offsets[k] + f.numel[k]))
             state[j] = {"step": torch.tensor(float(self.steps[k])), "exp_avg": self.exp_avg[sl].view_as(p).clone(),
                         "exp_avg_sq": self.exp_avg_sq[sl].view_as(p).clone()}
-        return {"state": state, "param_groups": [{"lr": self.param_groups[0]["lr"], "betas": self.betas, "eps": self.eps, "weight_decay": 0,
-                                                  "amsgrad": False, "params": list(range(int(self.mask.sum())))}]}
+        n = int(self.mask.sum())
+        lr = self.param_groups[0]["lr"]
+        groups = [{"lr": lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False, "params": list(range(n))}]
+        if self.group == "main":
+            # the reference builds its main Adam with a second ("slow", lr x 0.1) group that the shipped configs leave empty
+            # (base/base_trainer.py:95-97); torch's load_state_dict insists on the same number of groups, so it is written here too
+            groups.append({"lr": 0.1 * lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False, "params": []})
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
         f = self.flat

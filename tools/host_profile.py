@@ -15,4 +15,4 @@ for it in range(14, 35): tr._train_iteration(it)
 pr.disable()
 tr.flush_log(); torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(32)
+st.sort_stats("tottime").print_stats(70); st.sort_stats("cumulative").print_stats(90)

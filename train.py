@@ -28,6 +28,9 @@ def main():
     ap.add_argument("-g", "--gpu", type=int, default=None)
     ap.add_argument("--synthetic", action="store_true", help="synthetic author batches instead of a dataset on disk")
     ap.add_argument("--iterations", type=int, default=None)
+    ap.add_argument("--random-init-aux", action="store_true",
+                    help="allow a RANDOM-INIT perceptual encoder / recogniser when trainer.encoder_weights / model.pretrained_hwr do not exist "
+                         "(the reference fails there); implied by --synthetic")
     args = ap.parse_args()
 
     resume = args.resume
@@ -78,6 +81,28 @@ def main():
     pkg_data = os.path.join(ROOT, "handwriting_line_generation_amd", "data")
     if not os.path.exists(dl["char_file"]):
         dl["char_file"] = os.path.join(pkg_data, os.path.basename(dl["char_file"]))
+    # The reference fails when the warm-start files are missing (model/hw_with_style.py:166-178 loads `pretrained_hwr`,
+    # trainer/hw_with_style_trainer.py:136-160 loads `encoder_weights`). A GAN trained against a random perceptual encoder or a random
+    # frozen recogniser is a different experiment, so stand-ins are written only on request and announced loudly.
+    tr = config["trainer"]
+    aux_ok = args.synthetic or args.random_init_aux
+    if "encoder_weights" in tr and not os.path.exists(tr["encoder_weights"]):
+        if not aux_ok:
+            raise SystemExit("trainer.encoder_weights %r does not exist (train the autoencoder config first; --random-init-aux substitutes a "
+                             "RANDOM-INIT encoder)" % tr["encoder_weights"])
+        logging.getLogger("train").warning("WARNING: %r missing -> the perceptual loss uses a RANDOM-INIT Encoder2 (--%s)",
+                                           tr["encoder_weights"], "synthetic" if args.synthetic else "random-init-aux")
+        os.makedirs(os.path.dirname(tr["encoder_weights"]) or ".", exist_ok=True)
+        if rank == 0:
+            torch.save({"state_dict": models.Autoencoder({"type": tr.get("encoder_type", "2tight"), "hwr": config["model"]["num_class"]}).state_dict()},
+                       tr["encoder_weights"])
+    if config["model"].get("pretrained_hwr") and not os.path.exists(config["model"]["pretrained_hwr"]):
+        if not aux_ok:
+            raise SystemExit("model.pretrained_hwr %r does not exist (train the recogniser config first; --random-init-aux keeps a RANDOM-INIT "
+                             "frozen recogniser)" % config["model"]["pretrained_hwr"])
+        logging.getLogger("train").warning("WARNING: %r missing -> the frozen recogniser stays RANDOM-INIT (--%s)",
+                                           config["model"]["pretrained_hwr"], "synthetic" if args.synthetic else "random-init-aux")
+        config["model"]["pretrained_hwr"] = None
     valid_loader = None
     if args.synthetic:
         ds = SyntheticAuthorDataset(dl["char_file"], dl["batch_size"], dl.get("a_batch_size", 1), width=512, label_len=30, num_batches=10 ** 9)
@@ -95,13 +120,6 @@ def main():
         tr["text_data"] = os.path.join(tr["save_dir"], "synthetic_corpus.txt")
         if rank == 0 and not os.path.exists(tr["text_data"]):
             write_synthetic_corpus(tr["text_data"], dl["char_file"])
-    if "encoder_weights" in tr and not os.path.exists(tr["encoder_weights"]):
-        os.makedirs(os.path.dirname(tr["encoder_weights"]) or ".", exist_ok=True)
-        if rank == 0:
-            torch.save({"state_dict": models.Autoencoder({"type": tr.get("encoder_type", "2tight"), "hwr": config["model"]["num_class"]}).state_dict()},
-                       tr["encoder_weights"])
-    if config["model"].get("pretrained_hwr") and not os.path.exists(config["model"]["pretrained_hwr"]):
-        config["model"]["pretrained_hwr"] = None
     if world > 1:
         torch.distributed.barrier()
 
@@ -113,11 +131,10 @@ def main():
         for p in list(trainer.model.parameters()) + list(trainer.model.buffers()):
             torch.distributed.broadcast(p.data, 0)
 
-    def on_sigint(sig, frame):
-        if rank == 0:
-            trainer.save()
-        sys.exit(0)
-    signal.signal(signal.SIGINT, on_sigint)
+    # SIGINT -> checkpoint (reference train.py:72-75). The handler only raises a flag; BaseTrainer.train() looks at it between iterations,
+    # ORs it over the ranks' control group and, when set anywhere, every rank calls save() at the same iteration and leaves. (Saving from
+    # inside the handler would put rank 0 into _save_checkpoint's barrier alone, possibly between two asynchronous gradient all-reduces.)
+    signal.signal(signal.SIGINT, lambda sig, frame: trainer.request_stop())
     trainer.train()
 
 
