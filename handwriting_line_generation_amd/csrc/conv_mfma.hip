@@ -769,7 +769,12 @@ static void wg_tile(WgPlan& p, int cfg, int K, int C) {
 // Schedule = (tile, number of pixel chunks) with the smallest modelled time; same quantum model as plan_conv (parameters fitted with
 // tools/wgrad_model_fit.py): ceil(blocks/256) workgroup quanta of (K steps + overhead) steps each, plus the pass that sums the per-chunk
 // partial weight images.
+static WgPlan plan_wgrad_model(const hwg_conv_desc* d);
 WgPlan plan_wgrad(const hwg_conv_desc* d) {
+  static thread_local HwgPlanCache<WgPlan> cache;
+  return cache.get(d, plan_wgrad_model);
+}
+static WgPlan plan_wgrad_model(const hwg_conv_desc* d) {
   WgPlan p;
   const int K = d->K, C = d->C;
   const long long Mtot = (long long)d->N * d->P * d->Q;
@@ -779,7 +784,7 @@ WgPlan plan_wgrad(const hwg_conv_desc* d) {
     wg_split(p, Mtot, (1024 + base - 1) / base);
     return p;
   }
-  if (const char* f = getenv("HWG_WGRAD_FORCE")) {  // tuning aid: "cfg,target_blocks"
+  if (const char* f = hwg_tune().wgrad_force; *f) {  // tuning aid: "cfg,target_blocks"
     int fc = -1, ft = 0;
     if (sscanf(f, "%d,%d", &fc, &ft) == 2 && ft > 0 && (fc == 1 || (fc == 0 && K >= 128 && C >= 128))) {
       wg_tile(p, fc, K, C);
@@ -867,7 +872,12 @@ struct ConvPlan {
   long long Mc;
   double model_s;   // modelled duration of the chosen schedule (seconds)
 };
+static ConvPlan plan_conv_model(const hwg_conv_desc* d);
 static ConvPlan plan_conv(const hwg_conv_desc* d) {
+  static thread_local HwgPlanCache<ConvPlan> cache;
+  return cache.get(d, plan_conv_model);
+}
+static ConvPlan plan_conv_model(const hwg_conv_desc* d) {
   ConvPlan p;
   p.mfma = !((!d->transposed) && (d->K <= 2 || d->C == 1));
   p.classes = d->transposed ? d->stride_h * d->stride_w : 1;
@@ -905,7 +915,7 @@ static ConvPlan plan_conv(const hwg_conv_desc* d) {
       if (tm < best) { best = tm; bm = t.bm; bn = t.bn; ns = n; }
     }
   }
-  if (const char* f = getenv("HWG_CONV_FORCE")) {  // tuning aid: "bm,bn,bk[,nsplit]" (ignored when the shape cannot use it)
+  if (const char* f = hwg_tune().conv_force; *f) {  // tuning aid: "bm,bn,bk[,nsplit]" (ignored when the shape cannot use it)
     int fm = 0, fn = 0, fk = 0, fs = 1;
     if (sscanf(f, "%d,%d,%d,%d", &fm, &fn, &fk, &fs) >= 3) {
       if ((fm == 128 && (fn == 128 || fn == 64 || fn == 32)) || (fm == 64 && fn == 64)) { bm = fm; bn = fn; }
@@ -990,6 +1000,7 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
   { hwg_set_error("conv_fwd: no tile config for bm=%d bn=%d", bm, bn); return HWG_ERR_ARG; }
 #undef HWG_CONV_CASE
   hwg_prof_close(prof, st);
+  hwg_note_plan(HWG_PROF_CONV, bm * 1000 + bn, p.nsplit);
   HWG_LAUNCH_CHECK("conv_fwd");
   if (p.nsplit > 1) {
     const long long total = (long long)d->N * d->P * d->Q * d->K;
@@ -1143,8 +1154,8 @@ __global__ __launch_bounds__(512) void wgrad_narrow_kernel(WgK a, int kbn, int c
   }
 }
 static bool wgrad_is_narrow(const hwg_conv_desc* d) {
-  const char* env = getenv("HWG_WGRAD_NARROW");          // 0: never, 2: also layers with 2 / 4 channel blocks (tests)
-  const bool off = env && atoi(env) == 0, all = env && atoi(env) == 2;
+  const int mode = hwg_tune().wgrad_narrow;               // 0: never, 2: also layers with 2 / 4 channel blocks (tests)
+  const bool off = mode == 0, all = mode == 2;
   const bool taps = (d->R == 3 && d->S == 3) || (d->R == 4 && d->S == 4);
   // LDS tree needs streams = 8 / blocks >= 1 and a power of two: 1, 2 or 4 blocks of 16 x 16
   const int kbn = hwg_cdiv(d->K, 16), cbn = hwg_cdiv(d->C, 16), nb = kbn * cbn;
@@ -1241,6 +1252,7 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
   else if (p.cfg == 3) hipLaunchKernelGGL((wgrad_mfma_kernel<64, 64, 32, 2, 2, 2, true>), grid, dim3(512), 0, st, k);
   else hipLaunchKernelGGL((wgrad_mfma_kernel<32, 32, 32, 1, 1, 4>), grid, dim3(256), 0, st, k);
   hwg_prof_close(prof, st);
+  hwg_note_plan(HWG_PROF_WGRAD, narrow ? 100 + d->R : (tapn ? 10 + p.cfg : p.cfg), p.nsplit);   // 103 / 104: all-taps narrow kernel, 1x: taps-as-N
   HWG_LAUNCH_CHECK("conv_wgrad");
   const int prof2 = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, 4.0 * ((double)d->R * d->S * d->K * d->C + (dbias ? d->K : 0)) * (p.nsplit + 1), st);
   rc = hwg_wgrad_reduce_launch((const float*)workspace, dw, p.nsplit, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias,

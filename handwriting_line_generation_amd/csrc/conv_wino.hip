@@ -1340,6 +1340,7 @@ struct WinoPlan {
   int cfg;      // 0: 64 tiles x 32 k, 1: 32 x 64, 2: 128 x 16 (all-purpose kernel); 4: 32 x 64 (wave-specialised kernel); 5: 64 x 64 (12 waves);
                 // 6: 64 x 64 with register-level operand reuse (wino_conv64_kernel); 3 unused
   int tm, tn, nsplit;
+  double model_s;   // modelled duration of the chosen schedule (seconds)
 };
 static void wino_cfg(WinoPlan& p, int cfg) {
   static const int tms[7] = {64, 32, 128, 64, 32, 64, 64}, tns[7] = {32, 64, 16, 32, 64, 64, 64};
@@ -1350,7 +1351,14 @@ static void wino_cfg(WinoPlan& p, int cfg) {
 // (fixed + rounds-of-the-channel-loop x step) microseconds; a channel split adds the pass that sums the partial outputs.
 struct WinoCost { int cfg; double fixed_us, step_us; };
 static const WinoCost kWinoCost[5] = {{1, 2.5, 1.17}, {5, 11.0, 2.09}, {0, 8.0, 1.2}, {2, 6.5, 1.5}, {6, 15.7, 1.04}};
+static WinoPlan plan_wino_model(const hwg_conv_desc* d);
 static WinoPlan plan_wino(const hwg_conv_desc* d, double* model_s = nullptr) {
+  static thread_local HwgPlanCache<WinoPlan> cache;
+  const WinoPlan p = cache.get(d, plan_wino_model);
+  if (model_s) *model_s = p.model_s;
+  return p;
+}
+static WinoPlan plan_wino_model(const hwg_conv_desc* d) {
   WinoPlan best;
   wino_cfg(best, d->K <= 16 ? 2 : d->K <= 48 ? 0 : 1);
   best.nsplit = 1;
@@ -1358,11 +1366,8 @@ static WinoPlan plan_wino(const hwg_conv_desc* d, double* model_s = nullptr) {
   const int chunks = d->C / 16;
   const double out_bytes = 4.0 * d->N * d->P * d->Q * d->K;
   double best_t = 1e30;
-  static const WinoCost cost6 = [] {         // tuning aid: HWG_WINO_COST6="fixed_us,step_us" overrides the 64x64 DMA kernel's model constants
-    WinoCost c = kWinoCost[4];
-    if (const char* e = getenv("HWG_WINO_COST6")) { double f = 0, s2 = 0; if (sscanf(e, "%lf,%lf", &f, &s2) == 2) { c.fixed_us = f; c.step_us = s2; } }
-    return c;
-  }();
+  WinoCost cost6 = kWinoCost[4];              // tuning aid: HWG_WINO_COST6="fixed_us,step_us" overrides the 64x64 DMA kernel's model constants
+  if (const char* e = hwg_tune().wino_cost6; *e) { double f = 0, s2 = 0; if (sscanf(e, "%lf,%lf", &f, &s2) == 2) { cost6.fixed_us = f; cost6.step_us = s2; } }
   for (int ci = 0; ci < 5; ++ci) {
     const WinoCost& wc = ci == 4 ? cost6 : kWinoCost[ci];
     if (wc.cfg == 2 && d->K > 16) continue;
@@ -1380,13 +1385,13 @@ static WinoPlan plan_wino(const hwg_conv_desc* d, double* model_s = nullptr) {
       if (t < best_t) { best_t = t; best = p; best.nsplit = ns; }
     }
   }
-  if (const char* f = getenv("HWG_WINO_FORCE")) {   // tuning aid: "cfg[,nsplit]"
+  if (const char* f = hwg_tune().wino_force; *f) {   // tuning aid: "cfg[,nsplit]"
     int fc = -1, fs = 0;
     const int n = sscanf(f, "%d,%d", &fc, &fs);
     if (n >= 1 && fc >= 0 && fc <= 6 && fc != 3 && fc != 4 && (fc == 2 || d->K > 16)) wino_cfg(best, fc);
     if (n >= 2 && fs >= 1) best.nsplit = fs > chunks ? chunks : fs;
   }
-  if (model_s) *model_s = best_t;
+  best.model_s = best_t;
   return best;
 }
 
@@ -1397,8 +1402,7 @@ extern "C" int hwg_wino_supported(const hwg_conv_desc* d) {
   if (d->R != 3 || d->S != 3 || d->stride_h != 1 || d->stride_w != 1 || d->dil_h != 1 || d->dil_w != 1) return 0;
   if (d->C % 16 != 0 || d->K < 16) return 0;
   if (d->P != d->H + 2 * d->pad_h - 2 || d->Q != d->W + 2 * d->pad_w - 2) return 0;
-  if (const char* f = getenv("HWG_WINO")) if (atoi(f) == 0) return 0;
-  return 1;
+  return hwg_tune().wino == 0 ? 0 : 1;
 }
 
 double hwg_conv_direct_model_seconds(const hwg_conv_desc* d);
@@ -1407,7 +1411,7 @@ double hwg_conv_direct_model_seconds(const hwg_conv_desc* d);
  * of the recogniser at 8 x 129 - stream 16 MB of transform-domain filters per 2000 tiles and stay on the direct kernels) */
 extern "C" int hwg_wino_preferred(const hwg_conv_desc* d) {
   if (!hwg_wino_supported(d)) return 0;
-  if (const char* f = getenv("HWG_WINO")) if (atoi(f) == 2) return 1;     // 2: always, 0: never (hwg_wino_supported), default: by model
+  if (hwg_tune().wino == 2) return 1;     // 2: always, 0: never (hwg_wino_supported), default: by model
   double tw = 0.0;
   (void)plan_wino(d, &tw);
   return tw < 0.97 * hwg_conv_direct_model_seconds(d) ? 1 : 0;
@@ -1458,18 +1462,18 @@ extern "C" int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const f
   k.nsplit = p.nsplit;
   k.part = (float*)workspace;
   k.mt = hwg_cdiv(k.M, p.tm); k.nt = hwg_cdiv(d->K, p.tn);
-  static const int order_env = [] { const char* e = getenv("HWG_WINO_ORDER"); return e ? atoi(e) : 1; }();
-  k.xcd_order = order_env;
+  k.xcd_order = hwg_tune().wino_order;
   dim3 grid((k.mt * k.nt * p.nsplit + 7) / 8 * 8);
   const int prof = hwg_prof_open(HWG_PROF_CONV_WINO, 2.0 * d->N * d->P * d->Q * (double)d->K * d->C * 9.0, st);
   if (p.cfg == 0) hipLaunchKernelGGL((wino_conv_kernel<4, 2>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 1) hipLaunchKernelGGL((wino_conv_kernel<2, 4>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 2) hipLaunchKernelGGL((wino_conv_kernel<8, 1>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 5) hipLaunchKernelGGL(wino_conv_big_kernel, grid, dim3(768), 0, st, k);
-  else if (p.cfg == 6 && !getenv("HWG_W64_NODMA")) hipLaunchKernelGGL(wino_conv64d_kernel, grid, dim3(512), 0, st, k);
+  else if (p.cfg == 6 && !hwg_tune().w64_nodma) hipLaunchKernelGGL(wino_conv64d_kernel, grid, dim3(512), 0, st, k);
   else if (p.cfg == 6) hipLaunchKernelGGL(wino_conv64_kernel, grid, dim3(512), 0, st, k);
   else hipLaunchKernelGGL((wino_conv_ws_kernel<1, 4>), grid, dim3(512), 0, st, k);
   hwg_prof_close(prof, st);
+  hwg_note_plan(HWG_PROF_CONV_WINO, p.cfg, p.nsplit);
   HWG_LAUNCH_CHECK("wino_conv_fwd");
   if (p.nsplit > 1) {
     const long long total = (long long)d->N * d->P * d->Q * d->K;

@@ -287,7 +287,7 @@ WgPlan plan_wino_wgrad(const hwg_conv_desc* d) {
   if (ns < 1) ns = 1;
   const int cap = rounds_all / 4 > 1 ? rounds_all / 4 : 1;
   if (ns > cap) ns = cap;
-  static const int force = [] { const char* e = getenv("HWG_WINO_WGRAD_SPLIT"); return e ? atoi(e) : 0; }();
+  const int force = hwg_tune().wino_wgrad_split;
   if (force > 0) ns = force < rounds_all ? force : rounds_all;
   p.nsplit = ns;
   return p;
@@ -303,8 +303,7 @@ extern "C" int hwg_wino_wgrad_supported(const hwg_conv_desc* d) {
 }
 
 extern "C" int hwg_wino_wgrad_preferred(const hwg_conv_desc* d) {
-  const char* e = getenv("HWG_WINO_WGRAD");      // 0 never, 2 always (tests), default: the rule below
-  const int mode = e ? atoi(e) : 1;
+  const int mode = hwg_tune().wino_wgrad;      // 0 never, 2 always (tests), default: the rule below
   if (mode == 0 || !hwg_wino_wgrad_supported(d)) return 0;
   if (mode == 2) return 1;
   // the 64 x 64 block wastes matrix-core work on narrower layers, and short pixel ranges cannot amortise the 16-position epilogue
@@ -338,11 +337,12 @@ extern "C" int hwg_wino_wgrad(const hwg_conv_desc* d, const float* dy, const flo
   k.pstride = 9ll * d->K * d->C + d->K;
   const int total = p.kt * p.ct * p.nsplit;
   int prof = hwg_prof_open(HWG_PROF_WGRAD_WINO, 2.0 * d->N * d->P * d->Q * (double)d->K * d->C * 9.0, st);
-  static const int dbg = [] { const char* e = getenv("HWG_WWG_DEBUG"); return e ? atoi(e) : 0; }();
+  const int dbg = hwg_tune().wwg_debug;
   if (dbg == 1) hipLaunchKernelGGL(wino_wgrad_kernel<1>, dim3((total + 7) / 8 * 8), dim3(512), 0, st, k);
   else if (dbg == 2) hipLaunchKernelGGL(wino_wgrad_kernel<2>, dim3((total + 7) / 8 * 8), dim3(512), 0, st, k);
   else hipLaunchKernelGGL(wino_wgrad_kernel<0>, dim3((total + 7) / 8 * 8), dim3(512), 0, st, k);
   hwg_prof_close(prof, st);
+  hwg_note_plan(HWG_PROF_WGRAD_WINO, 0, p.nsplit);
   HWG_LAUNCH_CHECK("wino_wgrad");
   // the partial images have the direct kernel's layout ([split][tap][K][C] + K bias sums): same fixed-order reduce into the weight's layout
   prof = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, (double)need, st);

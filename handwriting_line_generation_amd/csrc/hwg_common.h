@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include "../../include/hwg.h"
 
 #define HWG_WAVE 64
@@ -33,6 +34,57 @@ void hwg_prof_close(int rec, hipStream_t st);
 enum { HWG_PROF_CONV = 0, HWG_PROF_WGRAD = 1, HWG_PROF_CONV_REDUCE = 2, HWG_PROF_WGRAD_REDUCE = 3, HWG_PROF_CONV_DIRECT = 4, HWG_PROF_WGRAD_DIRECT = 5, HWG_PROF_CONV_WINO = 6, HWG_PROF_WGRAD_WINO = 7 };
 
 static inline int hwg_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- schedules are planned once per geometry ------------------------------------------------------------------------------
+// The cost models (and the environment knobs that override them: HWG_WINO, HWG_WINO_FORCE, HWG_CONV_FORCE, HWG_WGRAD_FORCE, ...) are
+// evaluated when a geometry is first seen; every later launch of that geometry is a lookup in a per-thread table. The knobs are
+// read at plan time only: a process that changes them afterwards (tests, sweeps) calls hwg_tuning_reload(), which starts a new epoch
+// and thereby drops every cached plan.
+unsigned hwg_tuning_epoch();
+// snapshot of the tuning knobs, taken on first use and after every hwg_tuning_reload() (strings: "" when unset)
+struct HwgTune {
+  unsigned epoch;
+  int wino;              // HWG_WINO: 0 never, 2 always, 1 (default) by cost model
+  int wino_wgrad;        // HWG_WINO_WGRAD: 0 never, 2 always, 1 (default) by rule
+  int wgrad_narrow;      // HWG_WGRAD_NARROW: 0 never, 2 also 2 / 4 channel blocks, 1 default
+  int w64_nodma;         // HWG_W64_NODMA: register-staged filter stream in the 64x64 Winograd kernel (A/B timing)
+  int wino_order;        // HWG_WINO_ORDER: 1 (default) XCD-contiguous work order
+  int wino_wgrad_split;  // HWG_WINO_WGRAD_SPLIT: forced pixel-range count of the Winograd weight gradient (0 = model)
+  int wwg_debug;         // HWG_WWG_DEBUG
+  int conv_lds;          // HWG_CONV_LDS: 0 keeps strided layers on the per-tap gather kernel (A/B timing), 1 default
+  int split_inkernel;    // HWG_SPLIT_INKERNEL: 0 = separate reduce launches for split partials, 1 default = last-arriver reduction
+  char wino_force[32];   // HWG_WINO_FORCE  "cfg[,nsplit]"
+  char conv_force[48];   // HWG_CONV_FORCE  "bm,bn,bk[,nsplit]"
+  char wgrad_force[32];  // HWG_WGRAD_FORCE "cfg,target_blocks"
+  char wino_cost6[48];   // HWG_WINO_COST6  "fixed_us,step_us"
+};
+const HwgTune& hwg_tune();
+// what the calling thread's last convolution-family launch ran: engine (HWG_PROF_* kind), schedule id, split factor
+void hwg_note_plan(int engine, int cfg, int nsplit);
+
+template <class Plan, int SLOTS = 256>
+struct HwgPlanCache {
+  struct Entry { hwg_conv_desc d; Plan p; unsigned epoch; };
+  Entry e[SLOTS];
+  HwgPlanCache() { for (int i = 0; i < SLOTS; ++i) e[i].epoch = 0; }
+  static unsigned slot(const hwg_conv_desc* d) {
+    const unsigned* w = (const unsigned*)d;
+    unsigned h = 2166136261u;
+    for (unsigned i = 0; i < sizeof(hwg_conv_desc) / sizeof(unsigned); ++i) h = (h ^ w[i]) * 16777619u;
+    return (h ^ (h >> 15)) % SLOTS;
+  }
+  template <class Make>
+  const Plan& get(const hwg_conv_desc* d, Make make) {
+    Entry& x = e[slot(d)];
+    const unsigned ep = hwg_tuning_epoch();
+    if (x.epoch != ep || memcmp(&x.d, d, sizeof(hwg_conv_desc)) != 0) {
+      x.p = make(d);
+      x.d = *d;
+      x.epoch = ep;
+    }
+    return x.p;
+  }
+};
 
 // cap grid for grid-stride streaming kernels: 256 CUs x 8 blocks
 static inline int hwg_stream_grid(long long work_items, int block) {

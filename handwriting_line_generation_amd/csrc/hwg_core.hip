@@ -12,7 +12,57 @@ void hwg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* hwg_last_error(void) { return g_err; }
-extern "C" int hwg_abi_version(void) { return 3; }
+extern "C" int hwg_abi_version(void) { return 4; }
+
+#include <atomic>
+static std::atomic<unsigned> g_tuning_epoch{1};
+unsigned hwg_tuning_epoch() { return g_tuning_epoch.load(std::memory_order_relaxed); }
+extern "C" int hwg_tuning_reload(void) { g_tuning_epoch.fetch_add(1); return HWG_OK; }
+#include <mutex>
+#include <stdlib.h>
+static void tune_str(char* dst, size_t cap, const char* name) {
+  const char* e = getenv(name);
+  snprintf(dst, cap, "%s", e ? e : "");
+}
+static int tune_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+const HwgTune& hwg_tune() {
+  static std::mutex mu;
+  static HwgTune* cur = nullptr;                      // snapshots are immutable once published; superseded ones are leaked (reloads are rare)
+  thread_local const HwgTune* mine = nullptr;
+  const unsigned ep = hwg_tuning_epoch();
+  if (mine && mine->epoch == ep) return *mine;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!cur || cur->epoch != ep) {
+    HwgTune* t = new HwgTune;
+    t->epoch = ep;
+    t->wino = tune_int("HWG_WINO", 1);
+    t->wino_wgrad = tune_int("HWG_WINO_WGRAD", 1);
+    t->wgrad_narrow = tune_int("HWG_WGRAD_NARROW", 1);
+    t->w64_nodma = tune_int("HWG_W64_NODMA", 0);
+    t->wino_order = tune_int("HWG_WINO_ORDER", 1);
+    t->wino_wgrad_split = tune_int("HWG_WINO_WGRAD_SPLIT", 0);
+    t->wwg_debug = tune_int("HWG_WWG_DEBUG", 0);
+    t->conv_lds = tune_int("HWG_CONV_LDS", 1);
+    t->split_inkernel = tune_int("HWG_SPLIT_INKERNEL", 1);
+    tune_str(t->wino_force, sizeof(t->wino_force), "HWG_WINO_FORCE");
+    tune_str(t->conv_force, sizeof(t->conv_force), "HWG_CONV_FORCE");
+    tune_str(t->wgrad_force, sizeof(t->wgrad_force), "HWG_WGRAD_FORCE");
+    tune_str(t->wino_cost6, sizeof(t->wino_cost6), "HWG_WINO_COST6");
+    cur = t;
+  }
+  mine = cur;
+  return *mine;
+}
+static int g_last_plan[3] = {-1, -1, -1};   // process-wide on purpose: backward passes launch from the autograd engine's thread
+void hwg_note_plan(int engine, int cfg, int nsplit) { g_last_plan[0] = engine; g_last_plan[1] = cfg; g_last_plan[2] = nsplit; }
+extern "C" int hwg_last_plan(int* engine_cfg_nsplit) {
+  HWG_REQUIRE(engine_cfg_nsplit, "last_plan: null pointer");
+  for (int i = 0; i < 3; ++i) engine_cfg_nsplit[i] = g_last_plan[i];
+  return HWG_OK;
+}
 extern "C" int hwg_device_ok(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -307,28 +307,73 @@ def _prof_tag(shape):
 _RUN_SCOPE = [None]     # scope of the conv op currently being executed (forward: SCOPE, backward: the scope saved at forward time)
 
 
+_conv_plans = {}    # geometry -> (descriptor, workspace bytes): descriptors are built (and the library's schedule queried) once per geometry
+
+
 def _run_conv(x, wp, bias, N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed, wino=False):
     y = torch.empty((N, P, Q, K), dtype=torch.float32, device=x.device)
-    d = _desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed)
+    key = (N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed, wino)
+    plan = _conv_plans.get(key)
+    if plan is None:
+        d = _desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed)
+        plan = _conv_plans[key] = (d, L.query("hwg_wino_conv_workspace" if wino else "hwg_conv_fwd_workspace", d.ptr), d.ptr)
+    d, need, dptr = plan
     if PROF_SHAPES is not None:
         _prof_tag((N, H, W, C, K, R, S, stride, pad, dil, transposed, _RUN_SCOPE[0]))
-    if wino:
-        need = L.query("hwg_wino_conv_workspace", ctypes.byref(d))
-        ws = workspace(need, x.device) if need else None
-        L.call("hwg_wino_conv_fwd", ctypes.byref(d), x, wp, bias, y, 0, ws, need, _stream())
-        return y
-    need = L.query("hwg_conv_fwd_workspace", ctypes.byref(d))
     ws = workspace(need, x.device) if need else None
-    L.call("hwg_conv_fwd", ctypes.byref(d), x, wp, bias, y, 0, ws, need, _stream())
+    L.call("hwg_wino_conv_fwd" if wino else "hwg_conv_fwd", dptr, x, wp, bias, y, 0, ws, need, _stream())
     return y
 
 
 # 3x3 / stride 1 / dilation 1 products with >= 16 output channels run as F(2x2,3x3) (csrc/conv_wino.hip); HWG_WINO=0 keeps them on the
 # direct implicit-GEMM kernels (A/B timing and numerics comparisons)
-WINOGRAD = bool(int(__import__("os").environ.get("HWG_WINO", "1") or 1))
+WINOGRAD = bool(int(os.environ.get("HWG_WINO", "1") or 1))
 
 
 _wino_choice = {}
+
+
+def tuning_reload():
+    """The library plans every geometry once and reads its tuning knobs (HWG_WINO, HWG_WINO_FORCE, HWG_CONV_FORCE, ...) at plan time; the
+    per-geometry choices are cached here as well. Call this after changing such a variable in a running process."""
+    global WINOGRAD
+    WINOGRAD = bool(int(os.environ.get("HWG_WINO", "1") or 1))
+    _wino_choice.clear(); _wino_wgrad_choice.clear(); _conv_plans.clear(); _wgrad_plans.clear()
+    L.call("hwg_tuning_reload")
+
+
+class tuning:
+    """`with ops.tuning(HWG_WINO="2", HWG_WINO_FORCE="6"):` - set tuning variables for a block (tests, sweeps) and restore them after"""
+
+    def __init__(self, **env):
+        self.env = {k: (None if v is None else str(v)) for k, v in env.items()}
+
+    def __enter__(self):
+        self.prev = {k: os.environ.get(k) for k in self.env}
+        for k, v in self.env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        tuning_reload()
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        tuning_reload()
+
+
+def last_plan():
+    """(engine, schedule id, split factor) of this thread's last convolution-family launch (engine: the profiler's kind codes - 0 direct
+    MFMA conv, 1 MFMA weight gradient, 6 Winograd conv, 7 Winograd weight gradient)"""
+    import numpy as np
+    out = np.full(3, -1, dtype=np.int32)
+    L.call("hwg_last_plan", out.ctypes.data)
+    return tuple(int(v) for v in out)
 
 
 def _wino_ok(N, H, W, C, K, R, S, stride, pad, dil, P, Q):
@@ -340,7 +385,7 @@ def _wino_ok(N, H, W, C, K, R, S, stride, pad, dil, P, Q):
     hit = _wino_choice.get(key)
     if hit is None:
         d = _desc(N, H, W, C, K, 3, 3, (1, 1), pad, (1, 1), P, Q, 0)
-        hit = _wino_choice[key] = bool(L.query("hwg_wino_preferred", ctypes.byref(d)))
+        hit = _wino_choice[key] = bool(L.query("hwg_wino_preferred", d.ptr))
     return hit
 
 
@@ -354,7 +399,7 @@ def _wino_wgrad_ok(d):
     key = (d.N, d.H, d.W, d.C, d.K, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.dil_h, d.dil_w, d.P, d.Q)
     hit = _wino_wgrad_choice.get(key)
     if hit is None:
-        hit = _wino_wgrad_choice[key] = bool(L.query("hwg_wino_wgrad_preferred", ctypes.byref(d)))
+        hit = _wino_wgrad_choice[key] = bool(L.query("hwg_wino_wgrad_preferred", d.ptr))
     return hit
 
 
@@ -380,6 +425,32 @@ def _taps(weight):
     if d == 2:
         return 1, 1
     raise L.HwgError("conv weight must have 2, 3 or 4 dimensions")
+
+
+_wgrad_plans = {}
+
+
+def _make_wgrad_plan(N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, P, Q, transposed):
+    """(descriptor, engine, workspace bytes, Kq, Cq, tiny_end, tap_gemm) of a weight gradient; engine 0 = Winograd F(3x3,2x2),
+    1 = MFMA kernel on channel-padded copies, 2 = MFMA / direct kernel on the tensors as they are"""
+    if not transposed:
+        d = _desc(N, H, W, C, K, R, S, (sh, sw), (ph, pw), (dh, dw), P, Q)
+    else:
+        d = _desc(N, P, Q, K, C, R, S, (sh, sw), (ph, pw), (dh, dw), H, W)
+    Kq, Cq = (d.K + 3) // 4 * 4, (d.C + 3) // 4 * 4
+    # single-channel ends (C == 1 first layers, K <= 2 heads) have a direct kernel; on large images the MFMA kernel on a
+    # 4-channel zero-padded copy is faster (measured 164 vs 390 us for the 7x7 first layer of D), so only small ones stay direct
+    # (the direct kernel runs a K<=2 head as ONE workgroup: 166 us for the discriminator's 256->1 3x3 head at 304 pixels, so heads
+    # with a wide gathered side go through the padded MFMA path as well; only narrow-and-small cases stay direct)
+    tiny_end = ((d.C == 1 and d.K % 4 == 0 and d.K > 2) or (d.K <= 2 and d.C % 4 == 0 and d.C < 16)) and d.N * d.P * d.Q < 8192
+    # single gathered channel (first layers): the library runs the taps as the GEMM's N dimension, no padding needed
+    tap_gemm = d.C == 1 and d.K > 2 and d.K % 4 == 0 and R * S <= 64
+    if _wino_wgrad_ok(d):
+        return d, 0, L.query("hwg_wino_wgrad_workspace", d.ptr), Kq, Cq, tiny_end, tap_gemm
+    if (Kq != d.K or Cq != d.C) and not tiny_end and not tap_gemm:
+        d.K, d.C = Kq, Cq
+        return d, 1, L.query("hwg_conv_wgrad_workspace", d.ptr), Kq, Cq, tiny_end, tap_gemm
+    return d, 2, L.query("hwg_conv_wgrad_workspace", d.ptr), Kq, Cq, tiny_end, tap_gemm
 
 
 class _Conv2d(Function):
@@ -470,24 +541,19 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[1]:
             direct = _direct(wref)
             dw_ = _grad_buffer(wref) if direct else torch.empty_like(weight)
+            # descriptor, engine choice and workspace size are fixed per geometry: built once (the library's cost models run there)
+            pkey = (N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, P, Q, transposed)
+            plan = _wgrad_plans.get(pkey)
+            if plan is None:
+                plan = _wgrad_plans[pkey] = _make_wgrad_plan(*pkey)
+            d, engine, need, Kq, Cq, tiny_end, tap_gemm = plan
             if not transposed:
-                d = _desc(N, H, W, C, K, R, S, (sh, sw), (ph, pw), (dh, dw), P, Q)
                 u, v = dy, x
                 sa, sb = C * R * S, R * S
             else:
-                d = _desc(N, P, Q, K, C, R, S, (sh, sw), (ph, pw), (dh, dw), H, W)
                 u, v = x, dy
                 sa, sb = K * R * S, R * S
-            Kq, Cq = (d.K + 3) // 4 * 4, (d.C + 3) // 4 * 4
-            # single-channel ends (C == 1 first layers, K <= 2 heads) have a direct kernel; on large images the MFMA kernel on a
-            # 4-channel zero-padded copy is faster (measured 164 vs 390 us for the 7x7 first layer of D), so only small ones stay direct
-            # (the direct kernel runs a K<=2 head as ONE workgroup: 166 us for the discriminator's 256->1 3x3 head at 304 pixels, so heads
-            # with a wide gathered side go through the padded MFMA path as well; only narrow-and-small cases stay direct)
-            tiny_end = ((d.C == 1 and d.K % 4 == 0 and d.K > 2) or (d.K <= 2 and d.C % 4 == 0 and d.C < 16)) and d.N * d.P * d.Q < 8192
-            # single gathered channel (first layers): the library runs the taps as the GEMM's N dimension, no padding needed
-            tap_gemm = d.C == 1 and d.K > 2 and d.K % 4 == 0 and R * S <= 64
-            if _wino_wgrad_ok(d):
-                need = L.query("hwg_wino_wgrad_workspace", ctypes.byref(d))
+            if engine == 0:
                 ws = workspace(need, x.device)
                 if PROF_SHAPES is not None:
                     _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad", ctx.scope))
@@ -499,22 +565,20 @@ class _Conv2d(Function):
                     bias_done = True
                     if not bdirect:
                         db = dbias
-                L.call("hwg_wino_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 1 if direct else 0, dbias, bacc or 0, ws, ws.numel(), st)
+                L.call("hwg_wino_wgrad", d.ptr, u, v, dw_, sa, sb, S, 1, 1 if direct else 0, dbias, bacc or 0, ws, ws.numel(), st)
                 if direct:
                     dw_ = None
-            elif (Kq != d.K or Cq != d.C) and not tiny_end and not tap_gemm:
+            elif engine == 1:
                 # channel counts that are not multiples of 4 (RIMES: 78 classes -> 206/334-channel inputs, 78 outputs): run the kernel
-                # on zero-padded copies and keep the valid block of the result
-                dK, dC = d.K, d.C
+                # on zero-padded copies and keep the valid block of the result (the plan's descriptor carries the padded counts)
+                dK, dC = (K, C) if not transposed else (C, K)
                 up = _pad_channels(u, Kq) if Kq != dK else u
                 vp = _pad_channels(v, Cq) if Cq != dC else v
-                d.K, d.C = Kq, Cq
                 tmp = torch.empty((Kq, Cq, R, S), dtype=torch.float32, device=x.device)
-                need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
                 ws = workspace(need, x.device)
                 if PROF_SHAPES is not None:
                     _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad", ctx.scope))
-                L.call("hwg_conv_wgrad", ctypes.byref(d), up, vp, tmp, Cq * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)
+                L.call("hwg_conv_wgrad", d.ptr, up, vp, tmp, Cq * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)
                 valid = tmp[:dK, :dC]
                 if direct:
                     dw_.add_(valid.reshape(dw_.shape))
@@ -522,7 +586,6 @@ class _Conv2d(Function):
                 else:
                     dw_ = valid.reshape(weight.shape).contiguous()
             else:
-                need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
                 ws = workspace(need, x.device)
                 if PROF_SHAPES is not None:
                     _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad", ctx.scope))
@@ -542,11 +605,11 @@ class _Conv2d(Function):
                     ev.record()                      # dy (and x) are complete on the main stream at this point
                     s2.wait_event(ev)
                     ws2 = _side_workspace(need, x.device, s2)
-                    L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 1, dbias, bacc or 0, ws2, ws2.numel(), raw2)
+                    L.call("hwg_conv_wgrad", d.ptr, u, v, dw_, sa, sb, S, 1, 1, dbias, bacc or 0, ws2, ws2.numel(), raw2)
                     u.record_stream(s2); v.record_stream(s2)
                     _side_dirty.add(skey)
                 else:
-                    L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw_, sa, sb, S, 1, 1 if direct else 0, dbias, bacc or 0, ws, ws.numel(), st)
+                    L.call("hwg_conv_wgrad", d.ptr, u, v, dw_, sa, sb, S, 1, 1 if direct else 0, dbias, bacc or 0, ws, ws.numel(), st)
                 if direct:
                     dw_ = None
         if ctx.has_bias and ctx.needs_input_grad[2] and not bias_done:

@@ -37,6 +37,13 @@ const char* hwg_last_error(void);
 int hwg_abi_version(void);
 /* 1 when a HIP device is present and usable */
 int hwg_device_ok(void);
+/* Schedules (tile, split factor, kernel variant) are planned once per geometry and cached per thread; the tuning knobs of the
+ * environment (HWG_WINO, HWG_WINO_FORCE, HWG_CONV_FORCE, HWG_WGRAD_FORCE, HWG_WINO_WGRAD, HWG_WGRAD_NARROW, ...) are read at plan time.
+ * A process that changes them afterwards calls hwg_tuning_reload() (drops every cached plan). hwg_last_plan() reports what the process's
+ * last convolution-family launch ran (any thread: backward passes launch from the autograd engine's thread): out[0] engine (the hwg_prof_stop kind codes), out[1] schedule id, out[2] split factor -
+ * how the parity tests assert that a forced schedule was the one launched. */
+int hwg_tuning_reload(void);
+int hwg_last_plan(int* engine_cfg_nsplit);
 
 /* Launch profiler for the matrix-core kernels (bench.py's roofline measurement): between hwg_prof_start() and hwg_prof_stop() every
  * MFMA convolution / weight-gradient launch (and their reduce passes) is bracketed by a HIP event pair on its stream. hwg_prof_tag()

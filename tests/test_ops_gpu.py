@@ -1,5 +1,6 @@
 """Per-kernel numerics: every HIP op (through the C-ABI) against a plain PyTorch fp32 CPU reference of the same op.
 Tolerance: 1e-4 of the reference's max magnitude (BASELINE.json north_star: fp32 1e-4); integer outputs exact."""
+import os
 import zlib
 
 import pytest
@@ -79,28 +80,18 @@ CONV_CASES = [
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv_fwd_bwd(cuda, case):
     from handwriting_line_generation_amd import ops
-    name, N, H, W, C, K, R, S, stride, pad, dil, transposed = case
+    name = case[0]
     if name.startswith("wino_"):
         # the library picks Winograd or the direct kernels per geometry from its cost models; these cases must run the Winograd kernels
-        import os
-        os.environ["HWG_WINO"] = "2"
-        ops._wino_choice.clear()
-        try:
-            return _conv_case(cuda, ops, case)
-        finally:
-            os.environ.pop("HWG_WINO", None)
-            ops._wino_choice.clear()
+        with ops.tuning(HWG_WINO="2"):
+            return _conv_case(cuda, ops, case, expect_fwd_engine=6)
     if name.startswith("narrow_"):
-        import os
-        os.environ["HWG_WGRAD_NARROW"] = "2"      # the all-taps narrow-layer weight-gradient kernel also for 2 / 4 channel blocks
-        try:
-            return _conv_case(cuda, ops, case)
-        finally:
-            os.environ.pop("HWG_WGRAD_NARROW", None)
+        with ops.tuning(HWG_WGRAD_NARROW="2"):      # the all-taps narrow-layer weight-gradient kernel also for 2 / 4 channel blocks
+            return _conv_case(cuda, ops, case, expect_wgrad_cfg=100 + case[6])
     return _conv_case(cuda, ops, case)
 
 
-def _conv_case(cuda, ops, case):
+def _conv_case(cuda, ops, case, expect_fwd_engine=None, expect_wgrad_cfg=None):
     name, N, H, W, C, K, R, S, stride, pad, dil, transposed = case
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)   # (hash() changes with PYTHONHASHSEED)
     x = torch.randn(N, C, H, W, generator=g)
@@ -126,8 +117,12 @@ def _conv_case(cuda, ops, case):
         yg = ops.conv_transpose2d(xg, wg, bg, stride=stride, padding=pad, dilation=dil)
     else:
         yg = ops.conv2d(xg, wg, bg, stride=stride, padding=pad, dilation=dil)
+    if expect_fwd_engine is not None:
+        assert ops.last_plan()[0] == expect_fwd_engine, "%s ran engine %s" % (name, ops.last_plan())
     _close(nchw(yg), yr, name + ".y")
     yg.backward(nhwc(gy).to(cuda))
+    if expect_wgrad_cfg is not None:      # the weight gradient is the last convolution-family launch of the backward pass
+        assert ops.last_plan()[:2] == (1, expect_wgrad_cfg), "%s: weight gradient ran %s" % (name, ops.last_plan())
     _close(nchw(xg.grad), xr.grad, name + ".dx")
     _close(wg.grad, wr.grad, name + ".dw")
     _close(bg.grad, br.grad, name + ".db")
@@ -141,20 +136,13 @@ def test_winograd_agrees_with_direct_engine(cuda):
     w = (torch.randn(96, 64, 3, 3, generator=g) / 24).to(cuda)
     gy = torch.randn(3, 11, 37, 96, generator=g).to(cuda)
     outs = []
-    import os
-    for flag in (True, False):
-        ops.WINOGRAD = flag
-        os.environ["HWG_WINO"] = "2"       # "always" when enabled (default: the library's cost models choose per geometry)
-        ops._wino_choice.clear()
-        try:
+    for mode, engine in (("2", 6), ("0", 0)):        # "2": always Winograd, "0": never (default: the library's cost models choose per geometry)
+        with ops.tuning(HWG_WINO=mode, HWG_WINO_WGRAD=mode):
             xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
             y = ops.conv2d(xg, wg, None, 1, 1)
+            assert ops.last_plan()[0] == engine
             y.backward(gy)
             outs.append((y.detach(), xg.grad, wg.grad))
-        finally:
-            ops.WINOGRAD = True
-            os.environ.pop("HWG_WINO", None)
-            ops._wino_choice.clear()
     for a, b, n in zip(outs[0], outs[1], ("y", "dx", "dw")):
         _close(a, b, "winograd vs direct " + n, tol=2e-5)
 
@@ -176,18 +164,13 @@ def test_winograd_weight_gradient(cuda, case):
     yr = F.conv2d(xr, wr, br, 1, (ph, pw))
     gy = torch.randn(yr.shape, generator=g)
     yr.backward(gy.double())
-    os.environ["HWG_WINO_WGRAD"] = "2"
-    ops._wino_wgrad_choice.clear()
-    try:
+    with ops.tuning(HWG_WINO_WGRAD="2"):
         xg = x.permute(0, 2, 3, 1).contiguous().to(cuda).requires_grad_(True)
         wg, bg = w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
         for rep in range(2):          # the second backward accumulates through autograd
             y = ops.conv2d(xg, wg, bg, 1, (ph, pw))
             y.backward(gy.permute(0, 2, 3, 1).contiguous().to(cuda))
-        assert any(ops._wino_wgrad_choice.values()), "the Winograd weight-gradient kernel was not selected"
-    finally:
-        os.environ.pop("HWG_WINO_WGRAD", None)
-        ops._wino_wgrad_choice.clear()
+            assert ops.last_plan()[0] == 7, "the Winograd weight-gradient kernel was not the one launched: %s" % (ops.last_plan(),)
     _close(wg.grad, 2 * wr.grad.float(), "wino wgrad dw", tol=2e-5)
     _close(bg.grad, 2 * br.grad.float(), "wino wgrad db", tol=2e-5)
     _close(xg.grad.permute(0, 3, 1, 2), 2 * xr.grad.float(), "wino wgrad dx", tol=2e-5)
@@ -207,18 +190,12 @@ def test_winograd_engines_agree_at_bench_sizes(cuda, shape):
     b = torch.randn(K, generator=g).to(cuda)
     outs = []
     for wino in ("2", "0"):
-        os.environ["HWG_WINO"] = wino
-        os.environ["HWG_WINO_WGRAD"] = wino
-        ops._wino_choice.clear(); ops._wino_wgrad_choice.clear()
-        try:
+        with ops.tuning(HWG_WINO=wino, HWG_WINO_WGRAD=wino):
             xg, wg, bg = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
             y = ops.conv2d(xg, wg, bg, 1, (ph, pw))
             gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(cuda)
             y.backward(gy)
             outs.append((y.detach(), xg.grad, wg.grad, bg.grad))
-        finally:
-            os.environ.pop("HWG_WINO", None); os.environ.pop("HWG_WINO_WGRAD", None)
-            ops._wino_choice.clear(); ops._wino_wgrad_choice.clear()
     for a, r, n in zip(outs[0], outs[1], ("y", "dx", "dw", "db")):
         err = float((a.double() - r.double()).norm() / r.double().norm())
         assert err < 1e-5, "winograd vs direct %s at %s: rel L2 %.2e" % (n, shape, err)
@@ -237,9 +214,7 @@ def test_winograd_dma_kernel_repeatable_under_contention(cuda, shape):
     w = (torch.randn(K, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(cuda)
     noise_a = torch.randn(1 << 22, device=cuda)
     side = torch.cuda.Stream()
-    os.environ["HWG_WINO"] = "2"; os.environ["HWG_WINO_FORCE"] = "6"
-    ops._wino_choice.clear()
-    try:
+    with ops.tuning(HWG_WINO="2", HWG_WINO_FORCE="6"):
         first = None
         for rep in range(60):
             with torch.cuda.stream(side):
@@ -247,13 +222,109 @@ def test_winograd_dma_kernel_repeatable_under_contention(cuda, shape):
                     noise_a = noise_a * 1.0000001 + 1e-9
             y = ops.conv2d(x, w, None, 1, (ph, pw))
             if first is None:
+                assert ops.last_plan()[:2] == (6, 6)
                 first = y.clone()
             else:
                 assert torch.equal(y, first), "launch %d differs from launch 0 in %d elements" % (rep, int((y != first).sum()))
         torch.cuda.synchronize()
-    finally:
-        os.environ.pop("HWG_WINO", None); os.environ.pop("HWG_WINO_FORCE", None)
-        ops._wino_choice.clear()
+
+
+# ---- every Winograd schedule, forced, against the CPU oracle -------------------------------------------------------------------------
+# The library picks one of five forward schedules (tile / kernel variant) and a channel-split factor per geometry from a cost model, so
+# which kernel a small test shape exercises is an accident of that model. Here each schedule x split factor is FORCED (HWG_WINO_FORCE)
+# onto ragged shapes - 80 / 208 output channels (partial 16-blocks), 48 input channels (3 chunks: uneven splits), odd tile counts,
+# padding 0 / 1 / 2 - and compared with torch's fp32 CPU convolution; hwg_last_plan() proves the forced schedule is what was launched.
+WINO_FORCED_SHAPES = [(2, 13, 37, 64, 80, 1, 1), (1, 9, 66, 48, 208, 0, 1), (3, 7, 21, 128, 32, 2, 2), (2, 5, 19, 96, 64, 0, 0), (1, 6, 10, 16, 16, 1, 0)]
+
+
+@pytest.mark.parametrize("nsplit", [1, 2, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 5, 6])
+def test_winograd_forced_schedules_vs_cpu(cuda, cfg, nsplit):
+    from handwriting_line_generation_amd import ops
+    ran = 0
+    for shape in WINO_FORCED_SHAPES:
+        N, H, W, C, K, ph, pw = shape
+        # the 12-wave producer / consumer kernel is only ever planned for >= 64 contraction channels (forward: C, data gradient: K);
+        # 16 output channels only have the 128 x 16 tile
+        if (cfg == 5 and min(C, K) < 64) or (cfg != 2 and min(C, K) <= 16):
+            continue
+        g = torch.Generator().manual_seed(31 + cfg)
+        x = torch.randn(N, C, H, W, generator=g); w = torch.randn(K, C, 3, 3, generator=g) / (3 * C ** 0.5); b = torch.randn(K, generator=g)
+        xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+        yr = F.conv2d(xr, wr, br, 1, (ph, pw))
+        gy = torch.randn(yr.shape, generator=g)
+        yr.backward(gy)
+        with ops.tuning(HWG_WINO="2", HWG_WINO_FORCE="%d,%d" % (cfg, nsplit), HWG_WINO_WGRAD="0"):
+            xg = nhwc(x).to(cuda).requires_grad_(True)
+            wg, bg = w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+            yg = ops.conv2d(xg, wg, bg, 1, (ph, pw))
+            want = (6, cfg, min(nsplit, C // 16))
+            assert ops.last_plan() == want, "forward of %s ran %s, forced %s" % (shape, ops.last_plan(), want)
+            dx = ops.conv2d(nhwc(gy).to(cuda), wg.detach().flip(2, 3).transpose(0, 1).contiguous(), None, 1, (2 - ph, 2 - pw)) if K % 16 == 0 else None
+            if dx is not None:      # the data gradient as its own forced Winograd launch (correlation with the mirrored, transposed filter)
+                assert ops.last_plan() == (6, cfg, min(nsplit, K // 16)), ops.last_plan()
+                _close(nchw(dx), xr.grad, "forced %d,%d %s dx(direct call)" % (cfg, nsplit, shape), tol=2e-5)
+            yg.backward(nhwc(gy).to(cuda))
+        name = "forced cfg %d split %d %s" % (cfg, nsplit, shape)
+        _close(nchw(yg), yr, name + ".y", tol=2e-5)
+        _close(nchw(xg.grad), xr.grad, name + ".dx", tol=2e-5)
+        _close(wg.grad, wr.grad, name + ".dw", tol=2e-5)
+        _close(bg.grad, br.grad, name + ".db", tol=2e-5)
+        ran += 1
+    assert ran >= 2
+
+
+# One full-size layer per network (the bench step's own geometries), every engine, against torch's CPU convolution in fp64: the kernels that
+# carry the headline number are compared with the oracle directly, not only with each other.
+FULL_SIZE_LAYERS = [("D convs1.0", (16, 58, 512, 64, 64, 0, 1)), ("HWR conv5", (8, 8, 129, 512, 512, 0, 0)), ("style down.2", (4, 32, 514, 128, 128, 0, 0))]
+
+
+@pytest.mark.parametrize("engine", ["model", "wino6", "wino1", "wino5", "direct"])
+@pytest.mark.parametrize("layer", FULL_SIZE_LAYERS, ids=[l[0].replace(" ", "_") for l in FULL_SIZE_LAYERS])
+def test_full_size_layers_vs_fp64(cuda, layer, engine):
+    from handwriting_line_generation_amd import ops
+    N, H, W, C, K, ph, pw = layer[1]
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(N, C, H, W, generator=g); w = torch.randn(K, C, 3, 3, generator=g) / (3 * C ** 0.5); b = torch.randn(K, generator=g)
+    ref = _full_size_reference(layer[1], x, w, b)
+    env = {"model": {}, "direct": dict(HWG_WINO="0", HWG_WINO_WGRAD="0"), "wino6": dict(HWG_WINO="2", HWG_WINO_FORCE="6", HWG_WINO_WGRAD="2"),
+           "wino1": dict(HWG_WINO="2", HWG_WINO_FORCE="1", HWG_WINO_WGRAD="2"), "wino5": dict(HWG_WINO="2", HWG_WINO_FORCE="5", HWG_WINO_WGRAD="2")}[engine]
+    with ops.tuning(**env):
+        xg = nhwc(x).to(cuda).requires_grad_(True)
+        wg, bg = w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+        y = ops.conv2d(xg, wg, bg, 1, (ph, pw))
+        fwd_plan = ops.last_plan()
+        y.backward(nhwc(ref["gy"]).to(cuda))
+        wgrad_plan = ops.last_plan()
+    if engine.startswith("wino"):
+        assert fwd_plan[:2] == (6, int(engine[4:])) and wgrad_plan[0] == 7, (fwd_plan, wgrad_plan)
+    elif engine == "direct":
+        assert fwd_plan[0] == 0 and wgrad_plan[0] == 1, (fwd_plan, wgrad_plan)
+    worst = 0.0
+    for got, key in ((nchw(y), "y"), (nchw(xg.grad), "dx"), (wg.grad, "dw"), (bg.grad, "db")):
+        want = ref[key]
+        rel = float((got.detach().cpu().double() - want).norm() / want.norm())
+        mx = float((got.detach().cpu().double() - want).abs().max() / want.abs().max())
+        worst = max(worst, mx)
+        assert rel < 3e-6 and mx < 1e-4, "%s [%s, forward %s, weight gradient %s] %s: rel L2 %.2e, max/max %.2e vs fp64" % (
+            layer[0], engine, fwd_plan, wgrad_plan, key, rel, mx)
+    print("\n%s [%s]: forward plan %s, weight-gradient plan %s, worst max-norm error vs fp64 %.2e" % (layer[0], engine, fwd_plan, wgrad_plan, worst))
+
+
+_FULL_REF = {}
+
+
+def _full_size_reference(shape, x, w, b):
+    """fp64 CPU autograd reference of a layer, computed once per layer (a few seconds each) and shared by the engine variants"""
+    if shape not in _FULL_REF:
+        ph, pw = shape[5], shape[6]
+        xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+        torch.set_num_threads(max(torch.get_num_threads(), min(16, os.cpu_count() or 1)))
+        yr = F.conv2d(xr, wr, br, 1, (ph, pw))
+        gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(43))
+        yr.backward(gy.double())
+        _FULL_REF[shape] = {"y": yr.detach(), "dx": xr.grad, "dw": wr.grad, "db": br.grad, "gy": gy}
+    return _FULL_REF[shape]
 
 
 def test_linear(cuda):

@@ -58,7 +58,7 @@ for (name, N, H, W, C, K, R, S, stride, pad, tr) in SHAPES:
     x = torch.randn(N, H, W, C, device=dev); wp = torch.randn(R * S, K, C, device=dev) * 0.05
     y = torch.empty(N, P, Q, K, device=dev)
     d = ops._desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q, tr)
-    t = bench(lambda: L.call("hwg_conv_fwd", ctypes.byref(d), x, wp, None, y, 0, None, 0, st))
+    t = bench(lambda: L.call("hwg_conv_fwd", d.ptr, x, wp, None, y, 0, None, 0, st))
     # weight gradient of the same layer: anchor = output side
     if tr:
         dw_desc = ops._desc(N, P, Q, K, C, R, S, stride, pad, dil, H, W); u, v = x, y
@@ -66,8 +66,8 @@ for (name, N, H, W, C, K, R, S, stride, pad, tr) in SHAPES:
     else:
         dw_desc = ops._desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q); u, v = y, x
         dwt = torch.empty(K, C, R, S, device=dev); sa, sb = C * R * S, R * S
-    need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(dw_desc)); ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
-    tw = bench(lambda: L.call("hwg_conv_wgrad", ctypes.byref(dw_desc), u, v, dwt, sa, sb, S, 1, 0, None, 0, ws, ws.numel(), st))
+    need = L.query("hwg_conv_wgrad_workspace", dw_desc.ptr); ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    tw = bench(lambda: L.call("hwg_conv_wgrad", dw_desc.ptr, u, v, dwt, sa, sb, S, 1, 0, None, 0, ws, ws.numel(), st))
     tot["fwd"][0] += fl; tot["fwd"][1] += t; tot["wgrad"][0] += fl; tot["wgrad"][1] += tw
     print("%-26s %9d %8.2f | %7.1f %5.1f | %7.1f %5.1f" % (name, pix, fl / 1e9, t * 1e6, fl / t / 1e12, tw * 1e6, fl / tw / 1e12))
 for k, (f, t) in tot.items():

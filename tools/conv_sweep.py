@@ -51,13 +51,13 @@ for (N, H, W, C, K, R, S, stride, pad, dil, tr), n, avg_in_step in shapes:
     d = ops._desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q, tr)
 
     def run():
-        need = L.query("hwg_conv_fwd_workspace", ctypes.byref(d))
+        need = L.query("hwg_conv_fwd_workspace", d.ptr)
         ws = ops.workspace(need, dev) if need else None
-        L.call("hwg_conv_fwd", ctypes.byref(d), x, wp, None, y, 0, ws, need, st)
+        L.call("hwg_conv_fwd", d.ptr, x, wp, None, y, 0, ws, need, st)
 
-    os.environ["HWG_CONV_FORCE"] = "64,64,16,1"
+    os.environ["HWG_CONV_FORCE"] = "64,64,16,1"; ops.tuning_reload()
     run(); y_ref = y.clone()
-    os.environ.pop("HWG_CONV_FORCE", None)
+    os.environ.pop("HWG_CONV_FORCE", None); ops.tuning_reload()
     t_def = bench(run)
     worst = float((y - y_ref).abs().max())
     best = (t_def, "default")
@@ -66,12 +66,12 @@ for (N, H, W, C, K, R, S, stride, pad, dil, tr), n, avg_in_step in shapes:
         if bn > 32 and K <= 32: continue
         for ns in SPLITS:
             if ns > 1 and pix * K * ns * 4 > (1 << 30): continue
-            os.environ["HWG_CONV_FORCE"] = "%d,%d,%d,%d" % (bm, bn, 32 if C % 32 == 0 else 16, ns)
+            os.environ["HWG_CONV_FORCE"] = "%d,%d,%d,%d" % (bm, bn, 32 if C % 32 == 0 else 16, ns); ops.tuning_reload()
             t = bench(run, 6)
             worst = max(worst, float((y - y_ref).abs().max()))
             res[(bm, bn, ns)] = t
             if t < best[0]: best = (t, "%dx%d/%d" % (bm, bn, ns))
-    os.environ.pop("HWG_CONV_FORCE", None)
+    os.environ.pop("HWG_CONV_FORCE", None); ops.tuning_reload()
     tot_def += t_def * n / steps; tot_best += best[0] * n / steps
     top = sorted(res.items(), key=lambda kv: kv[1])[:4]
     ALL.append({"shape": [N, H, W, C, K, R, S, list(stride), list(pad), list(dil), tr], "P": P, "Q": Q, "launches_per_step": n / steps, "default_us": t_def * 1e6,

@@ -1,5 +1,6 @@
-"""Host side of the step: wall time per step, process CPU time per step (GIL-bound Python: CPU time ~ host critical path) and, per lesson,
-the host time spent enqueueing (time until `_train_iteration` returns) against the GPU time of the lesson (HIP events)."""
+"""Host side of the step: wall time per step, process CPU time per step and, per lesson, the host time spent ENQUEUEING (time until
+`_train_iteration` returns minus the time the host spent blocked on the GPU inside it: event waits and device->host reads) against the GPU
+time of the lesson (HIP events). The step is host-bound where enqueue time exceeds GPU time."""
 import sys, time, torch, numpy as np, random
 sys.path.insert(0, '.')
 torch.set_num_threads(1)
@@ -8,17 +9,36 @@ from handwriting_line_generation_amd import rng
 rng.set_mode('device', seed=3); torch.manual_seed(0); np.random.seed(0); random.seed(0)
 tr, cfg = build_gan_trainer('iam_gan', 4, 2, width=512, label_len=30)
 tr.data_loader.make_resident(80, tr.gpu); tr.data_loader_iter = iter(tr.data_loader); tr.async_log = True
+blocked = [0.0]
+
+
+def timed(fn):
+    def wrapper(*a, **k):
+        t0 = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            blocked[0] += time.perf_counter() - t0
+    return wrapper
+
+
+torch.cuda.Event.synchronize = timed(torch.cuda.Event.synchronize)
+_cpu = torch.Tensor.cpu
+torch.Tensor.cpu = lambda self, *a, **k: (timed(_cpu)(self, *a, **k) if self.is_cuda else _cpu(self, *a, **k))
+torch.Tensor.item = timed(torch.Tensor.item)
 for it in range(14): tr._train_iteration(it)
 torch.cuda.synchronize()
 w0, c0 = time.perf_counter(), time.process_time()
 N = 42
 host = [0.0] * 7
+wait = [0.0] * 7
 evs = [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
 evs[0].record()
 for i, it in enumerate(range(14, 14 + N)):
-    t0 = time.perf_counter()
+    t0 = time.perf_counter(); blocked[0] = 0.0
     tr._train_iteration(it)
-    host[it % 7] += time.perf_counter() - t0
+    host[it % 7] += time.perf_counter() - t0 - blocked[0]
+    wait[it % 7] += blocked[0]
     evs[i + 1].record()
 tr.flush_log(); torch.cuda.synchronize()
 w1, c1 = time.perf_counter(), time.process_time()
@@ -27,4 +47,5 @@ gpu = [0.0] * 7
 for i in range(N):
     gpu[(14 + i) % 7] += evs[i].elapsed_time(evs[i + 1])
 for l in range(7):
-    print("lesson %d: host enqueue %.2f ms, GPU (event to event) %.2f ms" % (l, host[l] / (N / 7) * 1e3, gpu[l] / (N / 7)))
+    print("lesson %d: host enqueue %.2f ms (+ %.2f ms blocked on the GPU), GPU (event to event) %.2f ms" % (l, host[l] / (N / 7) * 1e3, wait[l] / (N / 7) * 1e3, gpu[l] / (N / 7)))
+print("host enqueue %.2f ms/step, blocked %.2f ms/step" % (sum(host) / N * 1e3, sum(wait) / N * 1e3))

@@ -82,27 +82,27 @@ def run(path, timing=False):
         if wgrad:
             u = torch.randn(N, P, Q, K, generator=g).to(dev)
             dw = torch.empty(K, C, R, S, dtype=torch.float32, device=dev)
-            if L.query("hwg_wino_wgrad_preferred", ctypes.byref(d)):      # as ops.py chooses
-                need = L.query("hwg_wino_wgrad_workspace", ctypes.byref(d))
+            if L.query("hwg_wino_wgrad_preferred", d.ptr):      # as ops.py chooses
+                need = L.query("hwg_wino_wgrad_workspace", d.ptr)
                 ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
-                call = lambda: L.call("hwg_wino_wgrad", ctypes.byref(d), u, x, dw, C * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)  # noqa: E731
+                call = lambda: L.call("hwg_wino_wgrad", d.ptr, u, x, dw, C * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)  # noqa: E731
             else:
-                need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
+                need = L.query("hwg_conv_wgrad_workspace", d.ptr)
                 ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
-                call = lambda: L.call("hwg_conv_wgrad", ctypes.byref(d), u, x, dw, C * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)  # noqa: E731
+                call = lambda: L.call("hwg_conv_wgrad", d.ptr, u, x, dw, C * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)  # noqa: E731
         elif (kind == "wino_conv_kernel" if not os.environ.get("PMC_FREE_CHOICE") else
-              (not transposed and L.query("hwg_wino_supported", ctypes.byref(d)) and L.query("hwg_wino_preferred", ctypes.byref(d)))):
+              (not transposed and L.query("hwg_wino_supported", d.ptr) and L.query("hwg_wino_preferred", d.ptr))):
             w = torch.randn(L.query("hwg_wino_weight_floats", K, C), generator=g).to(dev)
             y = torch.empty(N, P, Q, K, dtype=torch.float32, device=dev)
-            need = L.query("hwg_wino_conv_workspace", ctypes.byref(d))
+            need = L.query("hwg_wino_conv_workspace", d.ptr)
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
-            call = lambda: L.call("hwg_wino_conv_fwd", ctypes.byref(d), x, w, None, y, 0, ws, ws.numel(), st)  # noqa: E731
+            call = lambda: L.call("hwg_wino_conv_fwd", d.ptr, x, w, None, y, 0, ws, ws.numel(), st)  # noqa: E731
         else:
             w = torch.randn(R * S, K, C, generator=g).to(dev)
             y = torch.empty(N, P, Q, K, dtype=torch.float32, device=dev)
-            need = L.query("hwg_conv_fwd_workspace", ctypes.byref(d))
+            need = L.query("hwg_conv_fwd_workspace", d.ptr)
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
-            call = lambda: L.call("hwg_conv_fwd", ctypes.byref(d), x, w, None, y, 0, ws, ws.numel(), st)  # noqa: E731
+            call = lambda: L.call("hwg_conv_fwd", d.ptr, x, w, None, y, 0, ws, ws.numel(), st)  # noqa: E731
         if timing:
             for _ in range(3):
                 call()

@@ -37,11 +37,11 @@ for (N, H, W, C, K, R, S, stride, pad, dil, _), n, avg in shapes:
     d = ops._desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q)
 
     def run():
-        need = L.query("hwg_conv_wgrad_workspace", ctypes.byref(d))
+        need = L.query("hwg_conv_wgrad_workspace", d.ptr)
         ws = ops.workspace(need, dev)
-        L.call("hwg_conv_wgrad", ctypes.byref(d), u, v, dw, C * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)
+        L.call("hwg_conv_wgrad", d.ptr, u, v, dw, C * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)
 
-    os.environ.pop("HWG_WGRAD_FORCE", None)
+    os.environ.pop("HWG_WGRAD_FORCE", None); ops.tuning_reload()
     t_def = bench(run)
     ref = dw.clone()
     res = {}
@@ -50,11 +50,11 @@ for (N, H, W, C, K, R, S, stride, pad, dil, _), n, avg in shapes:
         if cfg == 0 and not (K >= 128 and C >= 128): continue
         if cfg == 1 and not (K > 32 or C > 32): continue
         for tg in TARGETS:
-            os.environ["HWG_WGRAD_FORCE"] = "%d,%d" % (cfg, tg)
-            if L.query("hwg_conv_wgrad_workspace", ctypes.byref(d)) > (3 << 30): continue
+            os.environ["HWG_WGRAD_FORCE"] = "%d,%d" % (cfg, tg); ops.tuning_reload()
+            if L.query("hwg_conv_wgrad_workspace", d.ptr) > (3 << 30): continue
             res["%d,%d" % (cfg, tg)] = bench(run, 6)
             worst = max(worst, float((dw - ref).abs().max() / ref.abs().max()))
-    os.environ.pop("HWG_WGRAD_FORCE", None)
+    os.environ.pop("HWG_WGRAD_FORCE", None); ops.tuning_reload()
     if not res: res = {"default": t_def}
     bk = min(res, key=res.get)
     tot_def += t_def * n / steps; tot_best += min(res[bk], t_def) * n / steps

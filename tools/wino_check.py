@@ -68,15 +68,15 @@ def main():
         b = torch.randn(K, generator=g)
         xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
         d = ops._desc(N, H, W, C, K, 3, 3, (1, 1), (ph, pw), (1, 1), P, Q, 0)
-        assert L.query("hwg_wino_supported", ctypes.byref(d)), tag
+        assert L.query("hwg_wino_supported", d.ptr), tag
         u = torch.empty(L.query("hwg_wino_weight_floats", K, C), dtype=torch.float32, device=dev)
         L.call("hwg_wino_pack_weight", wd, u, K, C, C * 9, 9, 3, 1, 0, st)
         y = torch.empty(N, P, Q, K, dtype=torch.float32, device=dev)
-        need = L.query("hwg_wino_conv_workspace", ctypes.byref(d))
+        need = L.query("hwg_wino_conv_workspace", d.ptr)
         ws = ops.workspace(max(need, 16), dev)
 
         def run_wino():
-            L.call("hwg_wino_conv_fwd", ctypes.byref(d), xd, u, bd, y, 0, ws, ws.numel(), st)
+            L.call("hwg_wino_conv_fwd", d.ptr, xd, u, bd, y, 0, ws, ws.numel(), st)
 
         def run_direct():
             ops.WINOGRAD = False
@@ -105,17 +105,17 @@ def main():
         res = []
         for force in CONFIGS:
             if force is None:
-                os.environ.pop("HWG_WINO_FORCE", None)
+                os.environ.pop("HWG_WINO_FORCE", None); ops.tuning_reload()
             else:
-                os.environ["HWG_WINO_FORCE"] = force
-            need2 = L.query("hwg_wino_conv_workspace", ctypes.byref(d))
+                os.environ["HWG_WINO_FORCE"] = force; ops.tuning_reload()
+            need2 = L.query("hwg_wino_conv_workspace", d.ptr)
             ws = ops.workspace(max(need2, 16), dev)
             y.zero_()
             run_wino()
             e2 = float((yd.double() - y.double()).abs().max() / yd.abs().max())
             worst = max(worst, e2 if not os.environ.get('HWG_WINO_DBG') else 0.0)
             res.append("%s:%6.1fus/%5.1fTF" % (force or "plan", time_it(run_wino), fl / time_it(run_wino) * 1e-6))
-        os.environ.pop("HWG_WINO_FORCE", None)
+        os.environ.pop("HWG_WINO_FORCE", None); ops.tuning_reload()
         print("%-22s N%d %dx%d C%d K%d err64 %.1e |w-d| %.1e direct %6.1fus/%5.1fTF  %s" %
               (tag, N, H, W, C, K, err, errd, td, fl / td * 1e-6, "  ".join(res)), flush=True)
     print("worst relative error %.2e" % worst)
