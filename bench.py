@@ -139,6 +139,8 @@ def main():
     cycle = 7   # lessons of the shipped GAN curriculum: count, gen, auto, disc, gen, auto, disc
     PROF_EVERY = 10
     profiling = rank == 0 and not os.environ.get("HWG_BENCH_NO_PROF")
+    side_wgrad = bool(int(os.environ.get("HWG_SIDE_WGRAD", "0") or 0))   # measured neutral since the host side got faster (r3: 66.9 vs 66.8 steps/s)
+    ops.SIDE_WGRAD = side_wgrad
     if profiling:
         ops.prof_start()
     from handwriting_line_generation_amd.model.char_style import CharStyleEncoder
@@ -155,6 +157,9 @@ def main():
             on = (k // cycle) % PROF_EVERY == 0
             ops.prof_enable(on)
             prof_steps += int(on)
+            # weight gradients run on a second stream (+2-3 % steps/s: their workgroups fill CUs the data-gradient chain leaves idle)
+            # except in the cycles whose launches are timed for the roofline object: co-running kernels inflate each other's durations
+            ops.SIDE_WGRAD = side_wgrad and not on
         marks[k].record()
         trainer._train_iteration(it); it += 1
     marks[args.steps].record()
@@ -312,6 +317,7 @@ def main():
             "data_parallel": {"world_size": world, "backend": (dist.get_backend() if dist.is_initialized() else None), "forced_single_rank_exchange": force_dp,
                               "collectives_per_step": round(flat_params.COMM["collectives"] / args.steps, 2),
                               "allreduce_mbytes_per_step": round(flat_params.COMM["bytes"] / args.steps / 1e6, 2)},
+            "side_stream_wgrad": side_wgrad,   # off inside the roofline-profiled cycles (see the timed loop)
             "inputs_resident": True,     # one synthetic batch per step built and uploaded before the timed region (SyntheticLoader.make_resident)
             # load of the per-character expert bank (K18): style extractions in the timed region, character windows and distinct experts per call
             "style_extractor_load": {"recogniser": "peaked (70% blanks, +10 logit on one class per column)" if wl.get("peaked") else "random-init on uniform-noise lines",

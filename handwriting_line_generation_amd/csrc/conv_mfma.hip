@@ -29,7 +29,12 @@ struct ConvK {
   float* part;     // nsplit > 1: partial outputs [nsplit][N*P*Q*K] in y's layout, summed (+bias) by conv_split_reduce_kernel
 };
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+// PF = register prefetch depth in K steps. 1: the loads of step t+1 are issued before the MFMAs of step t and consumed right after them
+// (their latency has ONE step of matrix-core work to hide behind: enough for the 16-wave 128x128 tile, whose co-resident waves cover
+// for each other). 2: the loads of step t+2 are issued before the MFMAs of step t (two register sets): small layers run one 4-wave
+// workgroup per CU, a step is ~1000 matrix-core cycles and an L2 / HBM round trip 2000-4000, so with depth 1 such a workgroup sits in
+// s_waitcnt for most of every step.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int PF = 1>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK a) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;  // 4 or 8 wavefronts per workgroup
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -125,8 +130,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  float4 ra[A_IT], rb[B_IT];
-  bool ma[A_IT];   // validity of the A loads in flight (applied when the tile is stored, so the wait for the loads sits after the MFMAs)
+  float4 ra[PF][A_IT], rb[PF][B_IT];
+  bool ma[PF][A_IT];   // validity of the A loads in flight (applied when the tile is stored, so the wait for the loads sits after the MFMAs)
   // coordinates of the tile being LOADED (this workgroup's K range starts at step t_begin)
   int c0 = (t_begin % csteps) * BK;
   int js = (t_begin / csteps) % (ns > 0 ? ns : 1);
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
   const float* __restrict__ xg = a.x;
   const float* __restrict__ wg = a.w;
 
-  auto load_tile = [&]() {
+  auto load_tile = [&](float4* ra, float4* rb, bool* ma) {
     const int r = r0 + tr * jr, s = s0 + ts * js;
     const int tap = r * a.S + s;
 #pragma unroll
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
       if (++js >= ns) { js = 0; ++jr; }
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const float4* ra, const float4* rb, const bool* ma) {
     float* Ab = As + buf * BM * LD;
     float* Bb = Bs + buf * BN * LD;
 #pragma unroll
@@ -182,15 +187,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
   const int l31 = lane & 31;
   const int lhi = lane >> 5;
 
-  if (T > 0) {
-    load_tile();
-    store_tile(0);
-  }
-  __syncthreads();
-
-  for (int t = 0; t < T; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < T) load_tile();  // global loads in flight during the MFMAs below
+  // one K step: fragment reads + MFMAs on LDS buffer `buf`
+  auto compute = [&](int buf) {
     const float* Ab = As + buf * BM * LD;
     const float* Bb = Bs + buf * BN * LD;
     // lane (i = lane&31, half = lane>>5) reads 4 consecutive k values starting at 4*(2*sg+half); the j-th of them
@@ -227,8 +225,38 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (t + 1 < T) store_tile(buf ^ 1);
+  };
+  if constexpr (PF == 1) {
+    if (T > 0) {
+      load_tile(ra[0], rb[0], ma[0]);
+      store_tile(0, ra[0], rb[0], ma[0]);
+    }
     __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      const int buf = t & 1;
+      if (t + 1 < T) load_tile(ra[0], rb[0], ma[0]);  // global loads in flight during the MFMAs below
+      compute(buf);
+      if (t + 1 < T) store_tile(buf ^ 1, ra[0], rb[0], ma[0]);
+      __syncthreads();
+    }
+  } else {
+    // register set (t & 1) carries tile t between its loads (issued during step t-2) and its LDS store (after the MFMAs of step t-1);
+    // the loop is unrolled by two so that the sets are addressed with constants (they must stay in registers)
+    if (T > 0) load_tile(ra[0], rb[0], ma[0]);
+    if (T > 1) load_tile(ra[1], rb[1], ma[1]);
+    if (T > 0) store_tile(0, ra[0], rb[0], ma[0]);
+    __syncthreads();
+    for (int t = 0; t < T; t += 2) {
+      if (t + 2 < T) load_tile(ra[0], rb[0], ma[0]);
+      compute(0);
+      if (t + 1 < T) store_tile(1, ra[1], rb[1], ma[1]);
+      __syncthreads();
+      if (t + 1 >= T) break;
+      if (t + 3 < T) load_tile(ra[1], rb[1], ma[1]);
+      compute(1);
+      if (t + 2 < T) store_tile(0, ra[0], rb[0], ma[0]);
+      __syncthreads();
+    }
   }
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -738,8 +766,9 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, in
 }
 
 template <int BM, int BN, int BK, int WM_, int WN_>
-void launch_conv(const ConvK& k, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, st, k);
+void launch_conv(const ConvK& k, dim3 grid, hipStream_t st, int pf) {
+  if (pf >= 2) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 2>), grid, dim3(64 * WM_ * WN_), 0, st, k);
+  else hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 1>), grid, dim3(64 * WM_ * WN_), 0, st, k);
 }
 
 struct WgPlan {
@@ -911,6 +940,10 @@ static ConvPlan plan_conv_model(const hwg_conv_desc* d) {
       const double q = per_xcd * n / 32.0;
       const double quanta = q <= 8.0 ? ceil(q) : q + 0.5;
       double tm = quanta * (T_total / n + t.overhead) * step_s;
+      // the 4-wave 64x64 workgroup is rated for a CU that holds several of them (they cover each other's barrier / LDS phases);
+      // alone on its CU it measures 1.0 us per 32-channel step instead of 0.65 (tools/conv_probe.py: 8x8x122x128->128 3x3 44 us at
+      // 244 workgroups, 27 us per 244 at 976)
+      if (t.bm == 64 && q < 2.0) tm /= (q <= 1.0 ? 0.65 : 0.65 + 0.35 * (q - 1.0));
       if (n > 1) tm += (n + 1) * out_bytes / 8.0e12 + 6e-6;
       if (tm < best) { best = tm; bm = t.bm; bn = t.bn; ns = n; }
     }
@@ -986,10 +1019,11 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
   // algorithmic work: every output pixel x K x C x taps (transposed: every input pixel feeds RxS outputs)
   const double pix = d->transposed ? (double)d->N * d->H * d->W : (double)d->N * d->P * d->Q;
   const int prof = hwg_prof_open(HWG_PROF_CONV, 2.0 * pix * d->K * d->C * d->R * d->S, st);
+  const int pf = hwg_tune().conv_pf;
 #define HWG_CONV_CASE(BM_, BN_, WMW, WNW)                                   \
   if (bm == BM_ && bn == BN_) {                                             \
-    if (bk == 32) launch_conv<BM_, BN_, 32, WMW, WNW>(k, grid, st);         \
-    else launch_conv<BM_, BN_, 16, WMW, WNW>(k, grid, st);                  \
+    if (bk == 32) launch_conv<BM_, BN_, 32, WMW, WNW>(k, grid, st, pf);     \
+    else launch_conv<BM_, BN_, 16, WMW, WNW>(k, grid, st, pf);              \
   } else
   // 16 / 8 wavefronts per workgroup on the big tiles: same LDS footprint, twice / four times the resident waves per SIMD to overlap
   // the gather phase of one wave with the MFMA phase of another (measured +8..15 % over 4-wave workgroups)

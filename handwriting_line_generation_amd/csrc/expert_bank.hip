@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512) void gmm_wgrad_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int co = blockIdx.y * 32 + l31;         // A operand column of this lane
   const int ci = blockIdx.z * 256 + wid * 32 + l31;
-  const bool ci_ok = ci < Cin;
+  const bool ci_ok = ci < Cin, co_ok = co < Cout;   // ragged channel blocks: operands outside are fed as zeros, results outside are not stored
   if (blockIdx.z * 256 + wid * 32 >= Cin) return;   // whole wave outside (no barriers in this kernel)
   const float* dyb = dy + (long long)i0 * R * Cout + co;
   const float* xb = x + (long long)i0 * R * Cin + (ci_ok ? ci : 0);
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512) void gmm_wgrad_kernel(const float* __restrict_
       int pu = p + 2 * u;
       pu %= R;
       const bool rok = rw < rend;
-      av[u] = rok ? dyb[(long long)rw * Cout] : 0.f;
+      av[u] = (rok && co_ok) ? dyb[(long long)rw * Cout] : 0.f;
 #pragma unroll
       for (int sft = 0; sft < S; ++sft) {
         const int q = pu + sft - pad;
@@ -213,12 +213,12 @@ __global__ __launch_bounds__(512) void gmm_wgrad_kernel(const float* __restrict_
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int cr = blockIdx.y * 32 + (t & 3) + 8 * (t >> 2) + 4 * lhi;
-        pw[((long long)cr * Cin + ci) * S + sft] = acc[sft][t];
+        if (cr < Cout) pw[((long long)cr * Cin + ci) * S + sft] = acc[sft][t];
       }
   }
   if (blockIdx.z == 0 && wid == 0) {
     const float tot = bsum + __shfl_xor(bsum, 32, 64);
-    if (lhi == 0) pw[(long long)Cout * Cin * S + co] = tot;
+    if (lhi == 0 && co_ok) pw[(long long)Cout * Cin * S + co] = tot;
   }
 }
 // dW[e(g)] += sum_{tiles of run g} part[tile]   (and db)
@@ -300,13 +300,12 @@ extern "C" int hwg_grouped_conv1d_wgrad(const float* dy, const float* x, const i
   HWG_REQUIRE(dy && x && seg_start && seg_eid && tile_seg && tile_row0 && run_tile0 && gwptr && G > 0 && ntiles >= G && tile_rows > 0 && R > 0 && R <= MAXR && Cin > 0 &&
                   Cout > 0, "grouped_conv1d_wgrad: bad arguments");
   HWG_REQUIRE((S == 1 && pad == 0) || (S == 3 && pad == 1), "grouped_conv1d_wgrad: only S=1/pad=0 and S=3/pad=1 are built (got S=%d pad=%d)", S, pad);
-  HWG_REQUIRE(Cout % 32 == 0, "grouped_conv1d_wgrad: Cout must be a multiple of 32 (got %d)", Cout);
   const size_t need = hwg_grouped_conv1d_wgrad_workspace(ntiles, Cin, Cout, S);
   if (!workspace || workspace_bytes < need) {
     hwg_set_error("grouped_conv1d_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     return HWG_ERR_WORKSPACE;
   }
-  dim3 grid(ntiles, Cout / 32, hwg_cdiv(Cin, 256));
+  dim3 grid(ntiles, hwg_cdiv(Cout, 32), hwg_cdiv(Cin, 256));
   hipStream_t st = (hipStream_t)stream;
   if (S == 1)
     hipLaunchKernelGGL(gmm_wgrad_kernel<1>, grid, dim3(512), 0, st, dy, x, seg_start, tile_seg, tile_row0, tile_rows, (float*)workspace, R, Cin, Cout,

@@ -51,6 +51,7 @@ struct HwgTune {
   int wino_order;        // HWG_WINO_ORDER: 1 (default) XCD-contiguous work order
   int wino_wgrad_split;  // HWG_WINO_WGRAD_SPLIT: forced pixel-range count of the Winograd weight gradient (0 = model)
   int wwg_debug;         // HWG_WWG_DEBUG
+  int conv_pf;           // HWG_CONV_PF: register prefetch depth of the implicit-GEMM conv kernel (1 or 2)
   int conv_lds;          // HWG_CONV_LDS: 0 keeps strided layers on the per-tap gather kernel (A/B timing), 1 default
   int split_inkernel;    // HWG_SPLIT_INKERNEL: 0 = separate reduce launches for split partials, 1 default = last-arriver reduction
   char wino_force[32];   // HWG_WINO_FORCE  "cfg[,nsplit]"

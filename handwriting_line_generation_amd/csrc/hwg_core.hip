@@ -45,6 +45,7 @@ const HwgTune& hwg_tune() {
     t->wino_order = tune_int("HWG_WINO_ORDER", 1);
     t->wino_wgrad_split = tune_int("HWG_WINO_WGRAD_SPLIT", 0);
     t->wwg_debug = tune_int("HWG_WWG_DEBUG", 0);
+    t->conv_pf = tune_int("HWG_CONV_PF", 2);
     t->conv_lds = tune_int("HWG_CONV_LDS", 1);
     t->split_inkernel = tune_int("HWG_SPLIT_INKERNEL", 1);
     tune_str(t->wino_force, sizeof(t->wino_force), "HWG_WINO_FORCE");

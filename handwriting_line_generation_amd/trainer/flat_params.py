@@ -372,8 +372,15 @@ class HipAdam:
             groups.append({"lr": 0.1 * lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False, "params": []})
         return {"state": state, "param_groups": groups}
 
+    def reset_state(self):
+        """forget every moment and step count (what a freshly constructed torch.optim.Adam holds)"""
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.steps[:] = 0
+
     def load_state_dict(self, sd):
         f = self.flat
+        self.reset_state()        # tensors absent from the loaded state have no state, as in torch.optim.Adam.load_state_dict
         ks = np.nonzero(self.mask)[0]
         for j, st in sd["state"].items():
             k = ks[int(j)]

@@ -646,7 +646,7 @@ def test_style_helpers_rng(cuda):
     assert torch.equal(am.cpu().long(), x.view(60, 16).argmax(1))
 
 
-@pytest.mark.parametrize("R,Cin,Cout,S", [(5, 256, 128, 3), (5, 128, 256, 3), (5, 256, 256, 1), (1, 256, 128, 1), (3, 64, 96, 3)])
+@pytest.mark.parametrize("R,Cin,Cout,S", [(5, 256, 128, 3), (5, 128, 256, 3), (5, 256, 256, 1), (1, 256, 128, 1), (3, 64, 96, 3), (5, 32, 16, 3), (1, 16, 48, 1)])
 def test_grouped_expert_layers(cuda, R, Cin, Cout, S):
     """grouped per-expert Conv1d (hwg_grouped_conv1d_*) against torch conv1d run expert by expert; one long run spans several row tiles"""
     import numpy as np

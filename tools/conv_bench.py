@@ -42,6 +42,8 @@ def bench(fn, iters=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e-3
 
+import os
+AB = dict(kv.split("=") for kv in os.environ.get("CONV_BENCH_AB", "").split(";") if kv)     # e.g. CONV_BENCH_AB="HWG_CONV_PF=1": second fwd timing under these knobs
 dev = torch.device('cuda:0')
 st = torch.cuda.current_stream().cuda_stream
 tot = {"fwd": [0, 0], "wgrad": [0, 0]}
@@ -58,7 +60,15 @@ for (name, N, H, W, C, K, R, S, stride, pad, tr) in SHAPES:
     x = torch.randn(N, H, W, C, device=dev); wp = torch.randn(R * S, K, C, device=dev) * 0.05
     y = torch.empty(N, P, Q, K, device=dev)
     d = ops._desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q, tr)
-    t = bench(lambda: L.call("hwg_conv_fwd", d.ptr, x, wp, None, y, 0, None, 0, st))
+    needf = L.query("hwg_conv_fwd_workspace", d.ptr); wsf = torch.empty(max(needf, 16), dtype=torch.uint8, device=dev)
+    t = bench(lambda: L.call("hwg_conv_fwd", d.ptr, x, wp, None, y, 0, wsf, wsf.numel(), st))
+    alt = ""
+    if AB:
+        with ops.tuning(**AB):
+            needf = L.query("hwg_conv_fwd_workspace", d.ptr); wsf = torch.empty(max(needf, 16), dtype=torch.uint8, device=dev)
+            t2 = bench(lambda: L.call("hwg_conv_fwd", d.ptr, x, wp, None, y, 0, wsf, wsf.numel(), st))
+            alt = " | %s: %7.1f us %5.1f TF plan %s" % (AB, t2 * 1e6, fl / t2 / 1e12, ops.last_plan())
+        L.call("hwg_conv_fwd", d.ptr, x, wp, None, y, 0, wsf if needf else None, needf, st) if False else None
     # weight gradient of the same layer: anchor = output side
     if tr:
         dw_desc = ops._desc(N, P, Q, K, C, R, S, stride, pad, dil, H, W); u, v = x, y
@@ -69,6 +79,6 @@ for (name, N, H, W, C, K, R, S, stride, pad, tr) in SHAPES:
     need = L.query("hwg_conv_wgrad_workspace", dw_desc.ptr); ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
     tw = bench(lambda: L.call("hwg_conv_wgrad", dw_desc.ptr, u, v, dwt, sa, sb, S, 1, 0, None, 0, ws, ws.numel(), st))
     tot["fwd"][0] += fl; tot["fwd"][1] += t; tot["wgrad"][0] += fl; tot["wgrad"][1] += tw
-    print("%-26s %9d %8.2f | %7.1f %5.1f | %7.1f %5.1f" % (name, pix, fl / 1e9, t * 1e6, fl / t / 1e12, tw * 1e6, fl / tw / 1e12))
+    print("%-26s %9d %8.2f | %7.1f %5.1f | %7.1f %5.1f%s" % (name, pix, fl / 1e9, t * 1e6, fl / t / 1e12, tw * 1e6, fl / tw / 1e12, alt))
 for k, (f, t) in tot.items():
     print("TOTAL %-6s %.1f GFLOP in %.2f ms = %.1f TFLOP/s (%.1f%% of 157.3)" % (k, f / 1e9, t * 1e3, f / t / 1e12, f / t / 1e12 / 157.3 * 100))

@@ -1,0 +1,45 @@
+"""Timing probe for single conv launches: each line of PROBE (or argv) is  N,H,W,C,K,R,S,ph,pw[,sh,sw,transposed]  optionally followed by
+KEY=VALUE tuning knobs (HWG_CONV_FORCE=64,64,32,1 ...). Prints event-timed microseconds per launch (hwg_conv_fwd only)."""
+import os, sys, torch
+sys.path.insert(0, '.')
+from handwriting_line_generation_amd import _lib as L, ops
+
+dev = torch.device('cuda:0')
+st = torch.cuda.current_stream().cuda_stream
+
+
+def bench(fn, iters=30):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+lines = [l for l in (sys.argv[1:] or os.environ.get("PROBE", "").split(";")) if l.strip()]
+for line in lines:
+    parts = line.split()
+    v = [int(t) for t in parts[0].split(",")]
+    N, H, W, C, K, R, S, ph, pw = v[:9]
+    sh, sw, tr = (v[9:12] + [1, 1, 0][len(v[9:12]):])
+    env = dict(kv.split("=", 1) for kv in parts[1:])
+    wino = env.pop("WINO", None)
+    if tr:
+        P = (H - 1) * sh - 2 * ph + R; Q = (W - 1) * sw - 2 * pw + S; pix = N * H * W
+    else:
+        P = (H + 2 * ph - R) // sh + 1; Q = (W + 2 * pw - S) // sw + 1; pix = N * P * Q
+    fl = 2.0 * pix * K * C * R * S
+    x = torch.randn(N, H, W, C, device=dev); y = torch.empty(N, P, Q, K, device=dev)
+    with ops.tuning(**env):
+        d = ops._desc(N, H, W, C, K, R, S, (sh, sw), (ph, pw), (1, 1), P, Q, tr)
+        if wino:
+            wp = torch.randn((C + 15) // 16, 16, (K + 15) // 16 * 16, 16, device=dev) * 0.05
+            need = L.query("hwg_wino_conv_workspace", d.ptr); ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+            t = bench(lambda: L.call("hwg_wino_conv_fwd", d.ptr, x, wp, None, y, 0, ws, ws.numel(), st))
+        else:
+            wp = torch.randn(R * S, K, C, device=dev) * 0.05
+            need = L.query("hwg_conv_fwd_workspace", d.ptr); ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+            t = bench(lambda: L.call("hwg_conv_fwd", d.ptr, x, wp, None, y, 0, ws, ws.numel(), st))
+        print("%-44s %-40s %8.1f us %6.1f TF  plan %s" % (parts[0], " ".join(parts[1:]), t * 1e6, fl / t / 1e12, ops.last_plan()), flush=True)

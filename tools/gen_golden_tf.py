@@ -1,0 +1,270 @@
+"""Teacher-forced trainer goldens: every lesson kind of the GAN curriculum, each run by the UNMODIFIED reference trainer
+(trainer/hw_with_style_trainer.py:207-418, CPU) from a fully specified training state that the HIP trainer is put into as well
+(oracle/tf_state.py), instead of from the end of a chain of earlier iterations.
+
+Units = groups of consecutive curriculum positions that belong together: [count], [gen, auto] (the auto lesson balances the two
+gradient sets the no-step gen lesson stashed), [disc], [gen, auto], [disc]. Before every unit both sides load: weights and buffers
+(BN running statistics, spectral-norm u / v), empty Adam states, the style bank, no stashed sets, the unit's data position and RNG seeds.
+At the point where the reference clips the gradients (trainer :381) the Adam moments of every tensor that has a gradient are set to
+seeded draws scaled by that gradient's RMS (recorded here, replayed on the GPU side), so the compared parameter update is the smooth
+mid-run Adam update, not the sign-like first step after initialisation.
+
+Cases
+  tf_full     shipped IAM GAN config at full size, seeded weights (different seeds per unit)
+  tf_trained  the same config at reduced widths, state taken from the reference's own trajectory: WARM iterations of the reference
+              from seeded weights, snapshot stored as int8 deltas per tensor (tests/golden/tf_trained_state.npz, a few MB); every unit
+              starts from that snapshot
+
+Recorded per iteration (fp32 run and fp64 run with identical draws, as tools/gen_golden_lessons.py): losses, fingerprints of every
+pre-clip gradient / stashed set / parameter update, the discriminator's inputs, and the per-tensor gradient RMS used for the moments.
+
+Build container only:   python tools/gen_golden_tf.py [case ...]
+"""
+import json
+import os
+import random
+import subprocess
+import sys
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+WSEED_MODEL, WSEED_ENC = 21, 32
+# Seeded spacer weights predict arbitrary character widths; with some seeds the text lessons generate lines narrower than the recogniser's
+# receptive field (the reference fails in its Conv1d there). These seeds give 280 - 460 px lines for each unit's text draw (probed; below ~200 px the CTC loss of a 38-character text is infeasible).
+UNIT_SEEDS = [21, 71, 131, 121, 61]
+REDUCED = {"gen_dim": 64, "disc_dim": 16, "style_extractor_dim": 8, "char_style_extractor_dim": 16}
+CASES = {
+    "tf_full": dict(config="iam_gan", reduced=None, B=2, A=2, W=256, L=12, warm=0),
+    "tf_trained": dict(config="iam_gan", reduced=REDUCED, B=2, A=2, W=256, L=12, warm=147),
+}
+UNITS = [[0], [1, 2], [3], [4, 5], [6]]      # curriculum positions (count | gen auto | disc | gen auto | disc)
+N_PREV_STYLES = 20
+
+
+def build_reference(case, wide, workdir):
+    """the unmodified reference trainer on seeded weights and synthetic author batches (fp64-widened when `wide`)"""
+    import ref_bootstrap
+    ref_bootstrap.bootstrap()
+    import torch
+    torch.set_num_threads(8)
+    from gen_golden_lessons import _Loader
+    from handwriting_line_generation_amd.harness import synthetic_gan_config
+    from handwriting_line_generation_amd.data.synthetic import SyntheticAuthorDataset
+    from oracle import torch_ref
+    c = CASES[case]
+    os.makedirs(workdir, exist_ok=True)
+    cfg, _ = synthetic_gan_config(c["config"], c["B"], c["A"], workdir=workdir)
+    cfg["cuda"] = False
+    if c["reduced"]:
+        cfg["model"].update(c["reduced"])
+    from model import HWWithStyle, Autoencoder
+    import model.loss as ref_loss
+    from trainer import HWWithStyleTrainer
+    ae = Autoencoder({"type": "2tight", "hwr": cfg["model"]["num_class"]})
+    torch.save({"state_dict": torch_ref.seeded_state_dict(ae, WSEED_ENC)}, cfg["trainer"]["encoder_weights"])
+    cast = (lambda t: t)
+    if wide:
+        torch.set_default_dtype(torch.float64)
+        cast = (lambda t: t.double())
+
+        class _Wide(torch.Tensor):
+            def normal_(self, *a, **k):
+                r = torch.empty(self.shape, dtype=torch.float32).normal_(*a, **k)
+                return self.as_subclass(torch.Tensor).copy_(r)
+
+        torch.FloatTensor = lambda *a: torch.DoubleTensor(*a).as_subclass(_Wide)
+        _rl = torch.randn_like
+        torch.randn_like = lambda t, **k: _rl(t.to(torch.float32), **k).double()
+        torch.Tensor.float = lambda self, *a, **k: self.double()
+    model = HWWithStyle(cfg["model"])
+    if wide:
+        model = model.double()
+    ds = SyntheticAuthorDataset(cfg["data_loader"]["char_file"], c["B"], c["A"], width=c["W"], label_len=c["L"])
+    losses = {n: getattr(ref_loss, f) for n, f in cfg["loss"].items()}
+    trainer = HWWithStyleTrainer(model, losses, [], None, cfg, _Loader(ds, cast), None, None)
+    if wide:
+        trainer.encoder = trainer.encoder.double()
+    return trainer, model, cfg, cast
+
+
+def seeded_sd(model, seed, wide):
+    from oracle import torch_ref
+    import torch
+    dt = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float32)          # the weights are drawn in fp32 in both runs and widened afterwards
+    sd = torch_ref.seeded_state_dict(model, seed)
+    torch.set_default_dtype(dt)
+    return {k: (v.double() if wide and v.dtype.is_floating_point else v) for k, v in sd.items()}
+
+
+def warm_run(case, out_path):
+    """the reference's own trajectory: WARM iterations from seeded weights (fp32), state stored as int8 deltas"""
+    warnings.filterwarnings("ignore")
+    trainer, model, cfg, _ = build_reference(case, False, "/tmp/hwg_tf_%s_warm" % case)
+    import torch
+    from oracle import tf_state
+    sd0 = seeded_sd(model, WSEED_MODEL, False)
+    model.load_state_dict(sd0)
+    torch.manual_seed(0); np.random.seed(0); random.seed(0)
+    warm = CASES[case]["warm"]
+    for it in range(warm):
+        log = trainer._train_iteration(it)
+        if it % 7 == 6:
+            print("warm", it, {k: round(float(v), 4) for k, v in log.items()}, flush=True)
+    sd = model.state_dict()
+    params = dict(model.named_parameters())
+    out = {}
+    moved = 0
+    for k, v in sd.items():
+        if not v.dtype.is_floating_point:
+            out["raw:" + k] = v.numpy()
+            continue
+        if k in params and params[k].requires_grad and not k.startswith("hwr."):
+            q, scale = tf_state.quantize_delta(v, sd0[k])
+            out["q:" + k] = q.numpy(); out["s:" + k] = np.float32(scale)
+            moved += int(scale != 0)
+        elif torch.equal(v, sd0[k]):
+            continue                                   # untouched (frozen recogniser weights, constant blur kernels): the seeded value
+        else:
+            out["raw:" + k] = v.numpy()                # BN running statistics, spectral-norm u / v: exact
+    out["prev_styles"] = torch.stack(trainer.prev_styles).numpy()
+    np.savez_compressed(out_path, **out)
+    print("warm state: %d tensors moved, %s: %.2f MB" % (moved, out_path, os.path.getsize(out_path) / 1e6))
+
+
+def trained_sd(model, path, wide):
+    """seeded weights + the stored deltas / exact buffers -> the state every unit of a trained-regime case starts from"""
+    import torch
+    from oracle import tf_state
+    sd = seeded_sd(model, WSEED_MODEL, False)
+    z = np.load(path)
+    for key in z.files:
+        if key.startswith("q:"):
+            k = key[2:]
+            sd[k] = tf_state.apply_delta(sd[k], torch.from_numpy(z[key]), float(z["s:" + k]))
+        elif key.startswith("raw:"):
+            sd[key[4:]] = torch.from_numpy(z[key])
+    prev = [t.clone() for t in torch.from_numpy(z["prev_styles"])]
+    if wide:
+        sd = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    return sd, prev
+
+
+def run_units(case, wide, out_path, rms_path):
+    warnings.filterwarnings("ignore")
+    trainer, model, cfg, cast = build_reference(case, wide, "/tmp/hwg_tf_%s_%d" % (case, int(wide)))
+    import torch
+    import torch.nn.utils as nnu
+    from gen_golden_lessons import fingerprint
+    from oracle import tf_state
+    c = CASES[case]
+    names = [k for k, _ in model.named_parameters()]
+    plist = [p for _, p in model.named_parameters()]
+    rms_in = json.load(open(rms_path)) if wide else None      # the fp64 run uses the moments of the fp32 run
+    orig_clip = nnu.clip_grad_value_
+    cur = {"key": None}
+    grads_at_clip, rms_at_clip = {}, {}
+
+    def spy_clip(params, value):
+        key = cur["key"]
+        grads_at_clip[key] = [fingerprint(p.grad, k) if p.grad is not None else None for k, p in enumerate(plist)]
+        rms = rms_in[key] if wide else [float(p.grad.float().pow(2).mean().sqrt()) if p.grad is not None else None for p in plist]
+        rms_at_clip[key] = rms
+        uit = int(key.split(":")[1])
+        for opt in (trainer.optimizer, trainer.optimizer_discriminator):
+            for group in opt.param_groups:
+                for p in group["params"]:
+                    k = index_of[id(p)]
+                    if p.grad is None:
+                        continue
+                    m, v = tf_state.seeded_moments(p.shape, rms[k], tf_state.moment_key(uit, k))
+                    opt.state[p] = {"step": torch.tensor(float(tf_state.ADAM_STEP)), "exp_avg": m.to(p.dtype), "exp_avg_sq": v.to(p.dtype)}
+        return orig_clip(model.parameters(), value)
+    index_of = {id(p): k for k, p in enumerate(plist)}
+    nnu.clip_grad_value_ = spy_clip
+    torch.nn.utils.clip_grad_value_ = spy_clip
+    d_calls = []
+    model.discriminator.register_forward_pre_hook(lambda mod, args: d_calls.append([list(args[0].shape)] + fingerprint(args[0], 0)))
+    if c["warm"]:
+        base_sd, base_prev = trained_sd(model, os.path.join(GOLD, "%s_state.npz" % case), wide)
+    units = []
+    for u, positions in enumerate(UNITS):
+        if c["warm"]:
+            sd, prev = base_sd, [t.clone() for t in base_prev]
+        else:
+            sd = seeded_sd(model, UNIT_SEEDS[u], wide)
+            prev = tf_state.seeded_prev_styles(N_PREV_STYLES, cfg["model"]["style_dim"], 900 + u)
+        model.load_state_dict(sd)
+        for opt in (trainer.optimizer, trainer.optimizer_discriminator):
+            opt.state.clear()
+        trainer.prev_styles = [cast(t) for t in prev]
+        trainer.saved_grads = []
+        for p in plist:
+            p.grad = None
+        trainer.data_loader_iter.i = 10 * u
+        torch.manual_seed(500 + u); np.random.seed(500 + u); random.seed(500 + u)
+        its = []
+        for pos in positions:
+            it = c["warm"] + pos
+            cur["key"] = "%d:%d" % (u, pos)
+            snap = [p.detach().clone() for p in plist]
+            del d_calls[:]
+            log = trainer._train_iteration(it)
+            upd = [fingerprint(p.detach() - s, k) for k, (p, s) in enumerate(zip(plist, snap))]
+            stashes = [[fingerprint(R, k) if R is not None else None for k, R in enumerate(sg)] for sg in getattr(trainer, "saved_grads", [])]
+            its.append({"iteration": it, "position": pos, "lesson": trainer.curriculum.getLesson(it), "log": {k: float(v) for k, v in log.items()},
+                        "grads": grads_at_clip.get(cur["key"]), "rms": rms_at_clip.get(cur["key"]),
+                        "update": [x if x[1] != 0.0 else None for x in upd], "stashes": stashes, "d_inputs": [list(x) for x in d_calls]})
+            print(case, "fp64" if wide else "fp32", "unit", u, "it", it, its[-1]["lesson"], its[-1]["log"], flush=True)
+        units.append(its)
+    if not wide:
+        with open(rms_path, "w") as f:
+            json.dump(rms_at_clip, f)
+    with open(out_path, "w") as f:
+        json.dump({"names": names, "units": units}, f)
+
+
+def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--warm":
+        return warm_run(sys.argv[2], sys.argv[3])
+    if len(sys.argv) >= 3 and sys.argv[1] == "--units":
+        return run_units(sys.argv[2], sys.argv[3] == "1", sys.argv[4], sys.argv[5])
+    for case in (sys.argv[1:] or list(CASES)):
+        c = CASES[case]
+        if c["warm"]:
+            state = os.path.join(GOLD, "%s_state.npz" % case)
+            if not (os.environ.get("HWG_GOLDEN_REUSE") and os.path.exists(state)):
+                subprocess.check_call([sys.executable, os.path.abspath(__file__), "--warm", case, state])
+        res = {}
+        rms_path = "/tmp/hwg_tf_%s_rms.json" % case
+        for wide in (0, 1):
+            tmp = "/tmp/hwg_tf_%s_%d.json" % (case, wide)
+            if not (os.environ.get("HWG_GOLDEN_REUSE") and os.path.exists(tmp)):
+                subprocess.check_call([sys.executable, os.path.abspath(__file__), "--units", case, str(wide), tmp, rms_path])
+            res[wide] = json.load(open(tmp))
+        out = {"case": case, "config": c["config"], "reduced": c["reduced"], "batch_size": c["B"], "a_batch_size": c["A"], "W": c["W"], "label_len": c["L"],
+               "warm": c["warm"], "wseed_model": WSEED_MODEL, "wseed_enc": WSEED_ENC, "n_prev_styles": N_PREV_STYLES, "unit_seeds": UNIT_SEEDS, "names": res[0]["names"], "units": []}
+        for u32, u64 in zip(res[0]["units"], res[1]["units"]):
+            unit = []
+            for a, b in zip(u32, u64):
+                assert a["lesson"] == b["lesson"]
+                for k in a["log"]:      # same draws in both precisions (a different noise tensor / dropout mask moves a loss by percents)
+                    assert abs(a["log"][k] - b["log"][k]) <= 2e-3 * max(abs(b["log"][k]), 1e-2), (case, k, a["log"][k], b["log"][k])
+                unit.append({"iteration": a["iteration"], "position": a["position"], "lesson": a["lesson"], "log": a["log"], "log64": b["log"],
+                             "grads": a["grads"], "grads64": b["grads"], "rms": a["rms"], "update": a["update"], "update64": b["update"],
+                             "stashes": a["stashes"], "stashes64": b["stashes"], "d_inputs": a["d_inputs"], "d_inputs64": b["d_inputs"]})
+            out["units"].append(unit)
+        path = os.path.join(GOLD, "%s.json" % case)
+        with open(path, "w") as f:
+            json.dump(out, f, separators=(",", ":"))
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
