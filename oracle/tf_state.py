@@ -24,8 +24,9 @@ def seeded_moments(shape, rms, key):
     """(exp_avg, exp_avg_sq) for one tensor; fp32 CPU, a pure function of (shape, rms, key)"""
     g = torch.Generator().manual_seed(int(key))
     rms = float(np.float32(rms))
-    m = torch.randn(shape, generator=g) * (0.5 * rms)
-    v = (torch.rand(shape, generator=g) + 0.25) * (rms * rms)
+    # explicit fp32 draws: the reference's fp64-widened run sets torch's default dtype to float64, and a float64 draw is a different stream
+    m = torch.randn(shape, generator=g, dtype=torch.float32) * (0.5 * rms)
+    v = (torch.rand(shape, generator=g, dtype=torch.float32) + 0.25) * (rms * rms)
     return m, v
 
 
@@ -35,12 +36,12 @@ def moment_key(unit_iteration, tensor_index):
 
 def seeded_prev_styles(n, dim, seed):
     g = torch.Generator().manual_seed(int(seed))
-    return [torch.randn(dim, generator=g) for _ in range(n)]
+    return [torch.randn(dim, generator=g, dtype=torch.float32) for _ in range(n)]
 
 
 def quantize_delta(w, w0):
     """int8 image of (w - w0) with one fp32 scale per tensor -> (q int8, scale float32)"""
-    d = (w - w0).float()
+    d = (w - w0).to(torch.float32)
     amax = float(d.abs().max()) if d.numel() else 0.0
     scale = np.float32(amax / 127.0) if amax > 0 else np.float32(0.0)
     q = torch.zeros(d.shape, dtype=torch.int8) if scale == 0 else torch.clamp(torch.round(d / float(scale)), -127, 127).to(torch.int8)
@@ -49,4 +50,5 @@ def quantize_delta(w, w0):
 
 def apply_delta(w0, q, scale):
     """the fp32 tensor both sides load: w0 + q * scale, evaluated in fp32 on the CPU (bit-identical wherever it runs)"""
-    return (w0.float() + q.float() * torch.tensor(float(scale), dtype=torch.float32)).to(torch.float32)
+    # (.to(torch.float32), not .float(): the reference's widened run patches Tensor.float to return float64)
+    return (w0.to(torch.float32) + q.to(torch.float32) * torch.tensor(float(scale), dtype=torch.float32)).to(torch.float32)

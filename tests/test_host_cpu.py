@@ -88,3 +88,27 @@ def test_flat_params_bookkeeping_on_cpu():
     f.zero_grad("main")
     assert f.touched.tolist() == [False, False, True, True]
     assert ps[0].grad.data_ptr() == f.flat_grad.data_ptr()
+
+
+def test_getcer_known_answers_from_the_reference():
+    """getCER = greedy CTC decode + CER / WER (reference: trainer/hw_with_style_trainer.py:894-914, utils/error_rates.py:2-26): the answers of
+    the unmodified reference on oracle/cer_kats.py's inputs (tests/golden/valid_gan.json), case sensitive and insensitive"""
+    import json
+    from oracle import cer_kats
+    from handwriting_line_generation_amd.trainer.hw_with_style_trainer import HWWithStyleTrainer
+    from handwriting_line_generation_amd.trainer.auto_trainer import AutoTrainer
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "valid_gan.json")))
+    pkg = os.path.join(os.path.dirname(os.path.dirname(__file__)), "handwriting_line_generation_amd", "data", "IAM_char_set.json")
+    idx_to_char = {int(k): v for k, v in json.load(open(pkg))["idx_to_char"].items()}
+    stub = type("T", (), {"idx_to_char": idx_to_char, "casesensitive": True})()
+    cases = cer_kats.cases(idx_to_char, len(idx_to_char) + 1)
+    assert len(cases) == len(gold["cer_kats"]) == 6
+    for (pred, texts, casesens), ref in zip(cases, gold["cer_kats"]):
+        stub.casesensitive = casesens
+        cer, wer, strs = HWWithStyleTrainer.getCER(stub, texts, pred)
+        assert strs == ref["strs"]
+        assert abs(cer - ref["cer"]) < 1e-12 and abs(wer - ref["wer"]) < 1e-12, (cer, ref["cer"], wer, ref["wer"])
+        if casesens:      # the autoencoder trainer's getCER has no case switch (trainer/auto_trainer.py:321-342)
+            cer2, wer2, strs2 = AutoTrainer.getCER(stub, texts, pred)
+            assert strs2 == strs and abs(cer2 - ref["cer"]) < 1e-12 and abs(wer2 - ref["wer"]) < 1e-12
+    assert any(r["cer"] > 0 for r in gold["cer_kats"])       # the corrupted trials really have errors
