@@ -136,6 +136,17 @@ class AuthorHWDataset(torch.utils.data.Dataset):
     def max_len(self):
         return self.max_char_len
 
+    def estimated_width(self, idx):
+        """width (px) of item `idx` after height normalisation, from the line boxes alone (no image is read): what width bucketing sorts by"""
+        author, lines = self.lineIndex[idx]
+        w = 0
+        for line in lines:
+            if line >= len(self.authors[author]):
+                line = (line + 37) % len(self.authors[author])
+            lb = self.authors[author][line][1]
+            w = max(w, min((lb[3] - lb[2]) * self.img_height / max(lb[1] - lb[0], 1), self.max_width))
+        return w
+
     def _page(self, path):
         if path not in self._pages:
             if len(self._pages) > 8:
@@ -198,64 +209,137 @@ class AuthorHWDataset(torch.utils.data.Dataset):
 
 
 def collate(batch):
-    """items -> instance dict (author_hw_dataset.py:27-112): images padded with -1 to the widest item, labels with 0 to the longest"""
+    """items -> instance dict (author_hw_dataset.py:27-112; the RIMES copy author_rimeslines_dataset.py:27-112 is the same function):
+    images / masks padded with -1 to the widest item, labels with 0 to the longest, foreground masks and per-column line geometry
+    (top_and_bottom 0, center_line H/2) padded likewise when the items carry them. One item is handed through as the batch."""
     if len(batch) == 1:
         batch[0]["a_batch_size"] = batch[0]["image"].size(0)
         return batch[0]
     batch = [b for b in batch if b is not None]
     A = len(batch[0]["gt"])
+    n = len(batch) * A
     dim1, dim2 = batch[0]["image"].shape[1], batch[0]["image"].shape[2]
     dim3 = max(b["image"].shape[3] for b in batch)
     max_label = max(b["label"].size(0) for b in batch)
-    images = torch.full((len(batch) * A, dim1, dim2, dim3), float(PADDING_CONSTANT))
-    labels = torch.zeros((max_label, len(batch) * A), dtype=torch.int32)
+    images = torch.full((n, dim1, dim2, dim3), float(PADDING_CONSTANT))
+    labels = torch.zeros((max_label, n), dtype=torch.int32)
+    has = lambda key: batch[0].get(key) is not None          # noqa: E731
+    masks = torch.full((n, dim1, dim2, dim3), float(PADDING_CONSTANT)) if has("mask") else None
+    tab = torch.zeros((n, 2, dim3)) if has("top_and_bottom") else None
+    centre = torch.full((n, dim3), dim2 / 2) if has("center_line") else None
+    fg = torch.zeros((n, 1, dim2, dim3)) if "fg_mask" in batch[0] else None
+    changed = torch.full((n, dim1, dim2, dim3), float(PADDING_CONSTANT)) if "changed_image" in batch[0] else None
+    spaced = None
+    if has("spaced_label"):
+        spaced = torch.zeros((max(b["spaced_label"].size(0) for b in batch), n), dtype=torch.int32)
     for i, b in enumerate(batch):
-        images[i * A:(i + 1) * A, :, :, :b["image"].shape[3]] = b["image"]
-        labels[:b["label"].size(0), i * A:(i + 1) * A] = b["label"]
-    return {"image": images, "mask": None, "top_and_bottom": None, "center_line": None, "label": labels, "style": None,
-            "label_lengths": torch.cat([b["label_lengths"] for b in batch], dim=0), "gt": [l for b in batch for l in b["gt"]], "spaced_label": None,
-            "author": [l for b in batch for l in b["author"]], "author_idx": [l for b in batch for l in b["author_idx"]],
-            "name": [l for b in batch for l in b["name"]], "a_batch_size": A}
+        rows, w = slice(i * A, (i + 1) * A), b["image"].shape[3]
+        images[rows, :, :, :w] = b["image"]
+        labels[:b["label"].size(0), rows] = b["label"]
+        if masks is not None:
+            masks[rows, :, :, :w] = b["mask"]
+        if tab is not None:
+            tab[rows, :, :w] = b["top_and_bottom"]
+        if centre is not None:
+            centre[rows, :w] = b["center_line"]
+        if fg is not None:
+            fg[rows, :, :, :w] = b["fg_mask"]
+        if changed is not None:
+            changed[rows, :, :, :w] = b["changed_image"]
+        if spaced is not None:
+            spaced[:b["spaced_label"].size(0), rows] = b["spaced_label"]
+    out = {"image": images, "mask": masks, "top_and_bottom": tab, "center_line": centre, "label": labels,
+           "style": None if batch[0].get("style") is None else torch.cat([b["style"] for b in batch], dim=0),
+           "label_lengths": torch.cat([b["label_lengths"] for b in batch], dim=0), "gt": [l for b in batch for l in b["gt"]], "spaced_label": spaced,
+           "author": [l for b in batch for l in b["author"]], "author_idx": [l for b in batch for l in b["author_idx"]],
+           "name": [l for b in batch for l in b["name"]], "a_batch_size": A}
+    if fg is not None:
+        out["fg_mask"] = fg
+    if changed is not None:
+        out["changed_image"] = changed
+    return out
+
+
+def pad_width(instance, multiple):
+    """Width bucketing (not in the reference; off unless data_loader.width_bucket is set): widen the batch image with padding columns (-1,
+    what collate pads with anyway) to the next multiple of `multiple`. Real line widths take hundreds of distinct values; every distinct
+    padded width is a new set of layer geometries (conv plans, workspaces, Winograd / direct choice) for the kernels, so a training run
+    would keep planning. With buckets the number of distinct widths is max_width / multiple. The extra columns are seen by the networks
+    exactly like the reference's own padding columns (they take part in GroupNorm / InstanceNorm statistics, as padding does there)."""
+    img = instance["image"]
+    w = img.shape[3]
+    target = -(-w // multiple) * multiple
+    if target != w:
+        for key, fill in (("image", float(PADDING_CONSTANT)), ("mask", float(PADDING_CONSTANT)), ("fg_mask", 0.0), ("changed_image", float(PADDING_CONSTANT))):
+            t = instance.get(key)
+            if t is not None:
+                instance[key] = torch.nn.functional.pad(t, (0, target - w), value=fill)
+    return instance
 
 
 class ShardedLoader:
     """DataLoader over the items of one data-parallel rank: the epoch's (seeded) item order is cut into batches of `batch_size` items and
     rank r takes batches r, r + N, ... - every rank sees different authors, all ranks take the same number of steps per epoch. Batches are
-    prefetched by `num_workers` torch DataLoader workers; `.batch_size` / `.dataset` as the trainer expects."""
+    prefetched by `num_workers` torch DataLoader workers; `.batch_size` / `.dataset` as the trainer expects.
 
-    def __init__(self, dataset, batch_size, shuffle, num_workers, rank=0, world=1, seed=0):
+    `width_bucket` (pixels, 0 = off = the reference's behaviour): items are grouped by estimated line width before they are cut into
+    batches - inside windows of `bucket_window` batches of the shuffled order, so the epoch stays shuffled - and the collated image is
+    padded to a multiple of `width_bucket` (pad_width). Less padding per batch (an item of 300 px no longer shares a batch with one of
+    1200 px) and a bounded number of distinct widths for the kernels' plan caches."""
+
+    def __init__(self, dataset, batch_size, shuffle, num_workers, rank=0, world=1, seed=0, width_bucket=0, bucket_window=16):
         self.dataset, self.batch_size, self.shuffle, self.num_workers = dataset, batch_size, shuffle, num_workers
         self.rank, self.world, self.seed, self.epoch = rank, world, seed, 0
+        self.width_bucket, self.bucket_window = int(width_bucket or 0), bucket_window
 
     def _batches(self):
         n = len(self.dataset)
         order = np.random.RandomState(self.seed + self.epoch).permutation(n) if self.shuffle else np.arange(n)
+        if self.width_bucket and hasattr(self.dataset, "estimated_width"):
+            span = self.batch_size * self.bucket_window
+            widths = np.array([self.dataset.estimated_width(int(i)) for i in order])
+            order = np.concatenate([order[a:a + span][np.argsort(widths[a:a + span], kind="stable")] for a in range(0, n, span)])
         full = [order[i:i + self.batch_size].tolist() for i in range(0, n - self.batch_size + 1, self.batch_size)] or [order.tolist()]
+        if self.width_bucket and self.shuffle:      # the batches of a window come out narrow-to-wide: shuffle the batches, not their contents
+            full = [full[i] for i in np.random.RandomState(self.seed + self.epoch + 7919).permutation(len(full))]
         usable = len(full) // self.world * self.world or len(full)
         return full[:usable][self.rank::self.world] or full[:1]
 
     def __len__(self):
         return len(self._batches())
 
+    def _collate(self, items):
+        inst = collate(items)
+        return pad_width(inst, self.width_bucket) if self.width_bucket else inst
+
     def __iter__(self):
         batches = self._batches()
         self.epoch += 1
-        return iter(torch.utils.data.DataLoader(self.dataset, batch_sampler=batches, num_workers=self.num_workers, collate_fn=collate))
+        return iter(torch.utils.data.DataLoader(self.dataset, batch_sampler=batches, num_workers=self.num_workers, collate_fn=self._collate))
+
+
+DATASETS = {}
 
 
 def getDataLoader(config, split, rank=0, world=1):
-    """data_loader.getDataLoader of the reference (data_loader/data_loaders.py:11-75) for the author-grouped IAM dataset -> (train, valid)"""
+    """data_loader.getDataLoader of the reference (data_loader/data_loaders.py:11-75) for the author-grouped line datasets -> (train, valid).
+    `data_loader.width_bucket` (pixels, optional, not in the reference) switches width bucketing on, see ShardedLoader."""
     dl = config["data_loader"]
-    if dl["data_set_name"] != "AuthorHWDataset":
-        raise NotImplementedError("dataset %r: only the author-grouped IAM line dataset has a loader here" % dl["data_set_name"])
+    if not DATASETS:
+        from .author_rimeslines_dataset import AuthorRIMESLinesDataset
+        DATASETS.update(AuthorHWDataset=AuthorHWDataset, AuthorRIMESLinesDataset=AuthorRIMESLinesDataset)
+    if dl["data_set_name"] not in DATASETS:
+        raise NotImplementedError("dataset %r: only the author-grouped IAM / RIMES line datasets have a loader here" % dl["data_set_name"])
+    cls = DATASETS[dl["data_set_name"]]
     val = dict(config.get("validation", {}))
     for k, v in dl.items():
         val.setdefault(k, v)
+    wb = dl.get("width_bucket", 0)
     if split == "train":
-        train = AuthorHWDataset(dl["data_dir"], "train", dl)
-        valid = AuthorHWDataset(dl["data_dir"], "valid", val)
-        tl = ShardedLoader(train, dl["batch_size"], dl.get("shuffle", True), dl.get("num_workers", 1), rank, world)
-        vl = ShardedLoader(valid, val.get("batch_size", dl["batch_size"]), val.get("shuffle", False), val.get("num_workers", 1)) if len(valid) else None
+        train = cls(dl["data_dir"], "train", dl)
+        valid = cls(dl["data_dir"], "valid", val)
+        tl = ShardedLoader(train, dl["batch_size"], dl.get("shuffle", True), dl.get("num_workers", 1), rank, world, width_bucket=wb)
+        vl = ShardedLoader(valid, val.get("batch_size", dl["batch_size"]), val.get("shuffle", False), val.get("num_workers", 1), width_bucket=wb) if len(valid) else None
         return tl, vl
-    test = AuthorHWDataset(dl["data_dir"], split, val)
-    return ShardedLoader(test, val.get("batch_size", dl["batch_size"]), False, val.get("num_workers", 1)), None
+    test = cls(dl["data_dir"], split, val)
+    return ShardedLoader(test, val.get("batch_size", dl["batch_size"]), False, val.get("num_workers", 1), width_bucket=wb), None

@@ -1,0 +1,60 @@
+"""Test infrastructure: fabricated dataset items (what AuthorHWDataset / AuthorRIMESLinesDataset.__getitem__ return, reference:
+datasets/author_hw_dataset.py:546-571) for the collate known-answer test, and a fabricated RIMES annotation file for the parser / item
+index known-answer test. tools/gen_golden_collate.py feeds them to the reference's own collate / parser / dataset constructor."""
+import numpy as np
+import torch
+
+
+def items(seed=3, widths=(37, 52, 44), A=2, H=8, extras=False, spaced=False):
+    """one item per entry of `widths`: A lines of one author, image [A,1,H,W] in [-1,1], labels of ragged length (0-padded per item)"""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i, W in enumerate(widths):
+        L = 3 + 2 * i
+        lens = [L - (a % 2) for a in range(A)]
+        label = torch.zeros(L, A, dtype=torch.int32)
+        for a, n in enumerate(lens):
+            label[:n, a] = torch.randint(1, 80, (n,), generator=g, dtype=torch.int32)
+        it = {"image": torch.rand(A, 1, H, W, generator=g) * 2 - 1,
+              "mask": torch.rand(A, 1, H, W, generator=g).round() * 2 - 1,
+              "top_and_bottom": torch.rand(A, 2, W, generator=g) * H,
+              "center_line": torch.rand(A, W, generator=g) * H,
+              "label": label, "style": None, "label_lengths": torch.IntTensor(lens),
+              "gt": ["item%d line%d" % (i, a) for a in range(A)], "spaced_label": None,
+              "author": ["w%02d" % i] * A, "author_idx": [i] * A, "name": ["w%02d_%d" % (i, a) for a in range(A)]}
+        if spaced:
+            S = L + 4
+            it["spaced_label"] = torch.randint(0, 80, (S, A), generator=g, dtype=torch.int32)
+        if extras:
+            it["fg_mask"] = torch.rand(A, 1, H, W, generator=g).round()
+            it["changed_image"] = torch.rand(A, 1, H, W, generator=g) * 2 - 1
+            it["style"] = torch.randn(A, 16, generator=g)
+        out.append(it)
+    return out
+
+
+RIMES_XML = """<?xml version="1.0" encoding="UTF-8"?>
+<DocumentList>
+%s
+</DocumentList>
+"""
+
+
+def rimes_xml(n_pages=4, seed=9):
+    """annotation file in the layout of RIMES' lines_training_2011.xml: pages with 1-6 lines of ragged heights and widths; includes
+    escaped characters and a page with a single line"""
+    rs = np.random.RandomState(seed)
+    pages = []
+    for p in range(n_pages):
+        n_lines = [5, 1, 3, 6, 2, 4][p % 6]
+        lines = []
+        top = 40
+        for l in range(n_lines):
+            h = int(rs.randint(28, 60))
+            left = int(rs.randint(10, 60))
+            w = int(rs.randint(200, 900))
+            text = ["Bonjour Monsieur,", "je vous &amp; &quot;prie&quot;", "d&apos;agr&#233;er", "mes salutations", "distingu&#233;es.", "A+"][(p + l) % 6]
+            lines.append('      <Line Value="%s" Top="%d" Bottom="%d" Left="%d" Right="%d"/>' % (text, top, top + h, left, left + w))
+            top += h + int(rs.randint(5, 25))
+        pages.append('  <SinglePage FileName="images_gray/page%03d.png">\n    <Paragraph>\n%s\n    </Paragraph>\n  </SinglePage>' % (p, "\n".join(lines)))
+    return RIMES_XML % "\n".join(pages)

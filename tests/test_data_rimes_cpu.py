@@ -1,0 +1,93 @@
+"""CPU: data-side code against known answers from the reference's own pure-Python data code (tools/gen_golden_collate.py):
+collate (datasets/author_hw_dataset.py:27-112, author_rimeslines_dataset.py:27-112), the RIMES annotation parser
+(utils/parseRIMESlines.py:14-47) and the item index of AuthorRIMESLinesDataset (:142-185); plus width bucketing of the sharded loader."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import collate_items
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CHAR_FILE = os.path.join(os.path.dirname(os.path.dirname(__file__)), "handwriting_line_generation_amd", "data", "RIMES_characterset_lines.json")
+
+
+@pytest.mark.parametrize("case,kw", [("iam_plain", {}), ("iam_extras", dict(extras=True, spaced=True, widths=(41, 33))),
+                                     ("rimes_plain", dict(seed=4, widths=(29, 64, 30, 47))), ("single", dict(widths=(25,)))])
+def test_collate_equals_the_references(case, kw):
+    from handwriting_line_generation_amd.data.author_hw_dataset import collate
+    z = np.load(os.path.join(GOLD, "collate.npz"))
+    want = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(case + "/")}
+    got = collate(collate_items.items(**kw))
+    assert set(got) == set(want), (sorted(got), sorted(want))
+    for k, w in want.items():
+        g = got[k]
+        if w.dtype.kind in "US":                      # json-encoded lists / ints / None
+            assert g == json.loads(str(w)), k
+        else:
+            assert torch.is_tensor(g) and tuple(g.shape) == w.shape, (k, None if g is None else g.shape, w.shape)
+            assert np.array_equal(g.numpy().astype(w.dtype), w), k
+            assert g.dtype == torch.from_numpy(w).dtype, (k, g.dtype, w.dtype)
+
+
+@pytest.fixture()
+def rimes_dir(tmp_path):
+    from PIL import Image
+    text = collate_items.rimes_xml()
+    for fn in ("lines_training_2011.xml", "lines_eval_2011_annotated.xml"):
+        (tmp_path / fn).write_text(text)
+    os.makedirs(tmp_path / "images_gray")
+    rs = np.random.RandomState(1)
+    for p in range(4):
+        Image.fromarray((rs.rand(420, 1000) * 255).astype(np.uint8)).save(str(tmp_path / "images_gray" / ("page%03d.png" % p)))
+    return str(tmp_path)
+
+
+def test_rimes_parser_and_item_index_equal_the_references(rimes_dir):
+    from handwriting_line_generation_amd.data.author_rimeslines_dataset import AuthorRIMESLinesDataset, parse_rimes_xml
+    gold = json.load(open(os.path.join(GOLD, "rimes_index.json")))
+    pages = parse_rimes_xml(os.path.join(rimes_dir, "lines_training_2011.xml"))
+    assert {k: [[i, list(b), t] for i, b, t in v] for k, v in pages.items()} == gold["pages"]
+    for key, ref in gold["index"].items():
+        split, A = key.split("_a")
+        ds = AuthorRIMESLinesDataset(rimes_dir, split, {"img_height": 64, "a_batch_size": int(A), "char_file": CHAR_FILE, "max_width": 1300})
+        assert [[a, list(l)] for a, l in ds.lineIndex] == ref["lineIndex"], key
+        assert ds.max_char_len == ref["max_char_len"] and ds.author_list == ref["author_list"] and len(ds) == ref["len"]
+
+
+def test_rimes_items_and_bucketed_loader(rimes_dir):
+    """items decode to 64-px-high lines with the label of their transcription; with width bucketing the loader's batches hold items of
+    similar width, are padded to multiples of the bucket, visit every item once per epoch, and are the plain loader's batches when off"""
+    from handwriting_line_generation_amd.data.author_hw_dataset import ShardedLoader, getDataLoader
+    from handwriting_line_generation_amd.data.author_rimeslines_dataset import AuthorRIMESLinesDataset
+    cfg = {"img_height": 64, "a_batch_size": 2, "char_file": CHAR_FILE, "max_width": 1300, "augmentation": None}
+    ds = AuthorRIMESLinesDataset(rimes_dir, "train", cfg)
+    item = ds[0]
+    assert item["image"].shape[:3] == (2, 1, 64) and item["label"].shape[1] == 2 and len(item["gt"]) == 2
+    assert float(item["image"].max()) <= 1.0 and float(item["image"].min()) >= -1.0
+    for a in range(2):
+        n = int(item["label_lengths"][a])
+        assert n == len([c for c in item["gt"][a] if c in ds.char_to_idx])
+    est = ds.estimated_width(0)
+    assert abs(est - item["image"].shape[3]) <= 0.05 * est + 2, (est, item["image"].shape)
+    plain = ShardedLoader(ds, 2, True, 0, seed=3)
+    bucketed = ShardedLoader(ds, 2, True, 0, seed=3, width_bucket=64, bucket_window=4)
+    seen = sorted(i for b in bucketed._batches() for i in b)
+    assert seen == sorted(i for b in plain._batches() for i in b) == list(range(len(ds) // 2 * 2))
+    spread_b = np.mean([abs(ds.estimated_width(b[0]) - ds.estimated_width(b[1])) for b in bucketed._batches()])
+    spread_p = np.mean([abs(ds.estimated_width(b[0]) - ds.estimated_width(b[1])) for b in plain._batches()])
+    assert spread_b < 0.6 * spread_p, (spread_b, spread_p)
+    widths = set()
+    for k, inst in enumerate(bucketed):
+        assert inst["image"].shape[3] % 64 == 0 and inst["image"].shape[0] == 4
+        widths.add(inst["image"].shape[3])
+        if k >= 5:
+            break
+    assert len(widths) <= 6
+    config = {"data_loader": dict(cfg, data_set_name="AuthorRIMESLinesDataset", data_dir=rimes_dir, batch_size=2, shuffle=True, num_workers=0, width_bucket=128),
+              "validation": {"shuffle": False, "batch_size": 2, "a_batch_size": 2, "augmentation": None}}
+    tl, vl = getDataLoader(config, "train")
+    inst = next(iter(tl))
+    assert inst["image"].shape[3] % 128 == 0 and inst["a_batch_size"] == 2 and vl is not None and len(vl) > 0

@@ -107,12 +107,13 @@ def main():
     if args.synthetic:
         ds = SyntheticAuthorDataset(dl["char_file"], dl["batch_size"], dl.get("a_batch_size", 1), width=512, label_len=30, num_batches=10 ** 9)
         loader = SyntheticLoader(ds, rank, world)
-    elif os.path.isdir(os.path.join(dl["data_dir"], "xmls")):
-        # a dataset on disk in the reference's layout: author-grouped batches, every rank its own authors (data/author_hw_dataset.py)
+    elif os.path.isdir(os.path.join(dl["data_dir"], "xmls")) or os.path.exists(os.path.join(dl["data_dir"], "lines_training_2011.xml")):
+        # a dataset on disk in the reference's layout (IAM: forms/ + xmls/ + sets.json; RIMES: images_gray/ + lines_*_2011*.xml):
+        # author-grouped batches, every rank its own authors (data/author_hw_dataset.py, data/author_rimeslines_dataset.py)
         from handwriting_line_generation_amd.data.author_hw_dataset import getDataLoader
         loader, valid_loader = getDataLoader(config, "train", rank, world)
     else:
-        raise SystemExit("no dataset at %r (expected the reference's layout: forms/, xmls/, data/sets.json); pass --synthetic to train on "
+        raise SystemExit("no dataset at %r (expected the reference's layout: IAM forms/ xmls/ data/sets.json, or RIMES images_gray/ lines_training_2011.xml); pass --synthetic to train on "
                          "synthetic author batches of the configured shape" % dl["data_dir"])
     tr = config["trainer"]
     if "text_data" in tr and not os.path.exists(tr["text_data"]):
