@@ -60,6 +60,29 @@ def peaked_offset_fn(num_class, seed=5, blank_frac=0.7, gain=10.0):
     return fn
 
 
+def rccl_summary(path):
+    """what RCCL reported at communicator init (NCCL_DEBUG=INFO, INIT + GRAPH subsystems, written to `path`): rank count, library version,
+    number of channels, the transports of the ring / tree connections - enough to see from the JSON line whether an N-GPU run really ran
+    N ranks over xGMI P2P"""
+    if not path or not os.path.exists(path):
+        return None
+    import re
+    text = open(path, errors="replace").read()
+    out = {"log": path}
+    m = re.search(r"nranks (\d+)", text)
+    if m:
+        out["nranks"] = int(m.group(1))
+    m = re.search(r"(RCCL|NCCL) version ([\w.+-]+)", text)
+    if m:
+        out["version"] = m.group(1) + " " + m.group(2)
+    ch = re.findall(r"(\d+) coll channels", text)
+    if ch:
+        out["coll_channels"] = int(ch[-1])
+    out["via"] = sorted(set(re.findall(r"via (P2P/[\w/]+|SHM[\w/]*|NET/[\w/]+|direct[\w/]*)", text)))[:6]
+    out["rings_trees"] = {"ring_lines": len(re.findall(r"Ring \d+ :", text)), "tree_lines": len(re.findall(r"Trees? ", text))}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,8 +106,15 @@ def main():
     local = local % ndev
     torch.cuda.set_device(local)
     force_dp = bool(int(os.environ.get("HWG_FORCE_DP", "0") or 0))     # one-rank process group with the data-parallel exchange switched on
+    rccl_log = None
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl" and "NCCL_DEBUG" not in os.environ:
+            # self-diagnosing multi-GPU runs: RCCL's init / topology report goes to a per-rank file (stdout must stay one JSON line) and
+            # rank 0 folds its summary (ranks, channels, transports) into the JSON's data_parallel.rccl
+            import tempfile
+            rccl_log = os.path.join(tempfile.gettempdir(), "hwg_rccl_rank%d_%d.log" % (rank, os.getpid()))
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH", NCCL_DEBUG_FILE=rccl_log)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local), rank=rank, world_size=world)
         else:
@@ -315,6 +345,7 @@ def main():
             "per_lesson_ms": per_lesson_ms,
             # data parallel: ranks in the process group and this rank's all-reduce traffic (gradient sets + None-masks) per step
             "data_parallel": {"world_size": world, "backend": (dist.get_backend() if dist.is_initialized() else None), "forced_single_rank_exchange": force_dp,
+                              "rccl": rccl_summary(rccl_log),
                               "collectives_per_step": round(flat_params.COMM["collectives"] / args.steps, 2),
                               "allreduce_mbytes_per_step": round(flat_params.COMM["bytes"] / args.steps / 1e6, 2)},
             "side_stream_wgrad": side_wgrad,   # off inside the roofline-profiled cycles (see the timed loop)

@@ -122,7 +122,7 @@ class BaseTrainer:
             groups = {"main": main}
             if disc:
                 groups["disc"] = disc
-            self.flat = FlatParams(list(self.model.parameters()), groups)
+            self.flat = FlatParams(list(self.model.parameters()), groups, names=[n for n, _ in self.model.named_parameters()])
             self.optimizer = HipAdam(self.flat, "main", **config["optimizer"])
             self.optimizer_discriminator = HipAdam(self.flat, "disc", **config["optimizer_discriminator"]) if disc else None
         else:

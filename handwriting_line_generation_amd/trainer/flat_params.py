@@ -27,9 +27,10 @@ CHUNK = 65536
 
 
 class FlatParams:
-    def __init__(self, params, groups):
+    def __init__(self, params, groups, names=None):
         """params: list of all model parameters (model.parameters() order); groups: dict name -> list of params (disjoint).
-        Parameters in no group form the group 'rest'."""
+        Parameters in no group form the group 'rest'. names (optional, parallel to params): dotted parameter names; their first component
+        (the sub-network) defines the `segments` that data-parallel stash reductions travel in."""
         self.params = list(params)
         self.device = self.params[0].device
         ids = {id(p): i for i, p in enumerate(self.params)}
@@ -78,6 +79,19 @@ class FlatParams:
         self.d_param_ptrs = torch.from_numpy(self._param_ptrs).to(self.device)
         self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._stash_pool = []
+        # segments: maximal runs of flat positions that belong to one sub-network (or, without names, one optimizer group)
+        label = [(names[pi].split(".")[0] if names is not None else None) for pi in order]
+        gname = [None] * self.nt
+        for name, (a, b) in self.group_range.items():
+            for k in range(a, b):
+                gname[k] = name
+        self.segment_of = np.zeros(self.nt, dtype=np.int64)
+        self.segments = []          # [(first float, one past the last float)]
+        for k in range(self.nt):
+            if k == 0 or (label[k], gname[k]) != (label[k - 1], gname[k - 1]):
+                self.segments.append([int(self.offsets[k]), 0])
+            self.segments[-1][1] = int(self.offsets[k] + padded[k])
+            self.segment_of[k] = len(self.segments) - 1
 
     def _make_touch(self, k):
         def touch():
@@ -217,27 +231,52 @@ def control_group():
     return _CTL[0]
 
 
-def start_stash_allreduce(stash, world, flat=None):
+_SPAN_CACHE = {}     # (id(flat), key) -> sorted list of segment indices every rank reduces for that (lesson, stash position)
+
+
+def segment_spans(flat, segs):
+    """float ranges of a set of segments, adjacent ones merged"""
+    spans = []
+    for i in sorted(segs):
+        a, b = flat.segments[i]
+        if spans and spans[-1][1] == a:
+            spans[-1][1] = b
+        else:
+            spans.append([a, b])
+    return [(a, b) for a, b in spans]
+
+
+def start_stash_allreduce(stash, world, flat=None, key=None):
     """Data parallel: begin the SUM all-reduce of a freshly stashed gradient set without waiting for it. The collectives run on the
     communicator's stream behind the stash copy, so they overlap the backward passes that follow (an `auto` lesson stashes four sets
-    before it balances them). With `flat` given the set's None-mask is OR-ed over the control group first (host only) and just the ranges
-    that hold touched tensors travel (a text lesson's recogniser-loss set touches a quarter of the buffer); `allreduce_gradient_sets`
-    collects the handles. Returns the stash as a list [buffer, mask, pending work(s), mask already exchanged]."""
+    before it balances them). Every rank must reduce the SAME ranges, and which tensors a set touches differs between ranks (a character
+    expert is touched only where that character occurs), so the ranges are whole sub-network segments, agreed once: the first time a
+    (lesson, stash position) `key` occurs the None-masks are OR-ed over the control group right here (a blocking host exchange) and the
+    segments the OR-ed mask touches are remembered; every later occurrence starts its reductions at once from the remembered segments, and
+    the masks travel with the ONE exchange `allreduce_gradient_sets` makes per lesson anyway (which also verifies the remembered
+    segments still cover the set, and widens them - on every rank alike - if they do not). Without `flat` the whole buffer travels.
+    Returns the stash as a list [buffer, mask, pending work(s), mask already exchanged, segments reduced]."""
     import torch.distributed as dist
-    st = [stash[0], stash[1], None, False]
+    st = [stash[0], stash[1], None, False, None]
     if world > 1 or FORCE_DP:
         _require_group()
         if flat is None:
             _count(st[0])
             st[2] = [(dist.all_reduce(st[0], op=dist.ReduceOp.SUM, async_op=True), st[0])]
         else:
-            m = torch.from_numpy(np.asarray(st[1]).astype(np.int32))
-            _count(m)
-            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=control_group())
-            st[1][:] = m.numpy().astype(bool)
-            st[3] = True
+            segs = _SPAN_CACHE.get((id(flat), key)) if key is not None else None
+            if segs is None:
+                m = torch.from_numpy(np.asarray(st[1]).astype(np.int32))
+                _count(m)
+                dist.all_reduce(m, op=dist.ReduceOp.MAX, group=control_group())
+                st[1][:] = m.numpy().astype(bool)
+                st[3] = True
+                segs = sorted(set(flat.segment_of[np.nonzero(st[1])[0]].tolist()))
+                if key is not None:
+                    _SPAN_CACHE[(id(flat), key)] = segs
+            st[4] = list(segs)
             st[2] = []
-            for a, b in touched_spans(flat, st[1]):
+            for a, b in segment_spans(flat, segs):
                 view = st[0][a:b]
                 _count(view)
                 st[2].append((dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True), view))
@@ -295,6 +334,20 @@ def allreduce_gradient_sets(flat, stashes, world, device):
         works = s[2] if len(s) > 2 else None
         if works is not None:
             pending.extend(works)
+            if len(s) > 4 and s[4] is not None:
+                # started from remembered segments: the OR-ed mask (identical on every rank) must lie inside them; a tensor outside means
+                # some rank touched a sub-network this (lesson, stash position) never touched before - reduce those segments now, on every
+                # rank alike, and remember them
+                need = set(flat.segment_of[np.nonzero(s[1])[0]].tolist()) - set(s[4])
+                if need:
+                    for a, b in segment_spans(flat, need):
+                        view = s[0][a:b]
+                        _count(view)
+                        pending.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True), view))
+                    for ck, segs in _SPAN_CACHE.items():
+                        if segs is not None and ck[0] == id(flat) and sorted(segs) == sorted(s[4]):
+                            _SPAN_CACHE[ck] = sorted(set(segs) | need)
+                    s[4] = sorted(set(s[4]) | need)
         else:
             for a, b in touched_spans(flat, s[1]):
                 view = s[0][a:b]

@@ -146,9 +146,10 @@ class HWWithStyleTrainer(BaseTrainer):
     def _allreduce_grads(self, stashes=()):
         allreduce_gradient_sets(self.flat, stashes, self.world, self.gpu)
 
-    def _stash(self):
-        """clone-and-zero the current gradients (trainer :305-338); data parallel: their all-reduce starts right away"""
-        return start_stash_allreduce(self.flat.stash(), self.world, self.flat)
+    def _stash(self, key=None):
+        """clone-and-zero the current gradients (trainer :305-338); data parallel: their all-reduce starts right away (`key` = (lesson,
+        position of the set in the lesson): the ranges to reduce are agreed between the ranks once per key, see start_stash_allreduce)"""
+        return start_stash_allreduce(self.flat.stash(), self.world, self.flat, key=key)
 
     def _train_iteration(self, iteration):
         if not self.model.training:   # nn.Module.train() walks all ~3000 sub-modules; only do it when the mode actually changes
@@ -193,12 +194,13 @@ class HWWithStyleTrainer(BaseTrainer):
             else:
                 loss = v if isinstance(loss, int) else ops.add(loss, v)
 
+        lkey = tuple(lesson) if lesson else ()
         if self.balance_loss:
-            for part in (autoGenLoss, recogLoss):
+            for pos, part in enumerate((autoGenLoss, recogLoss)):
                 if not isinstance(part, int):
                     part.backward(retain_graph=True)
                     ops.join_side_stream()
-                    self.saved_grads.append(self._stash())
+                    self.saved_grads.append(self._stash((lkey, pos)))
         else:
             for part in (recogLoss, autoGenLoss):
                 if not isinstance(part, int):
@@ -207,7 +209,7 @@ class HWWithStyleTrainer(BaseTrainer):
             loss.backward()
             ops.join_side_stream()
         if self.balance_loss and "no-step" in lesson:
-            self.saved_grads.append(self._stash())
+            self.saved_grads.append(self._stash((lkey, 2)))
         return scaled, pred
 
     def _apply_step(self, lesson, iteration, instance, scaled, pred):

@@ -20,14 +20,15 @@ def _worker(rank, world, port, out):
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3), torch.nn.Linear(3, 2))
     params = list(net.parameters())
-    flat = FlatParams(params, {"main": params[:4], "disc": params[4:]})
+    flat = FlatParams(params, {"main": params[:4], "disc": params[4:]}, names=[n for n, _ in net.named_parameters()])
+    assert len(flat.segments) == 3 and flat.segment_of.tolist() == [0, 0, 1, 1, 2, 2]      # one segment per sub-network ("0", "1", "2")
     g = torch.Generator().manual_seed(10 + rank)
     # rank 0 touches tensors {0,1,2}, rank 1 touches {1,2,5}, rank 2 only {2}; one stash each with different masks
-    touch = [{0, 1, 2}, {1, 2, 5}, {2}][rank]
+    touch = [{0, 1, 2}, {1, 2, 5}, {2}][min(rank, 2)]
     for k in touch:
         params[flat.order[k]].grad.copy_(torch.randn(params[flat.order[k]].shape, generator=g))
         flat.touched[k] = True
-    stash_mask = np.zeros(flat.nt, dtype=bool); stash_mask[[3, 4, 3][rank]] = True
+    stash_mask = np.zeros(flat.nt, dtype=bool); stash_mask[[3, 4, 3][min(rank, 2)]] = True
 
     def masked_randn():   # a gradient set holds values only inside tensors whose mask bit is set (everything else is zero on every rank)
         buf = torch.zeros(flat.total)
@@ -41,15 +42,32 @@ def _worker(rank, world, port, out):
     # ... and one whose mask is exchanged at stash time so that only the touched ranges travel (what the trainer does)
     span_buf = masked_randn()
     span = start_stash_allreduce((span_buf.clone(), stash_mask.copy()), world, flat)
-    stashes = [(stash_buf.clone(), stash_mask.copy()), early, span]
+    # ... and the trainer's steady state: ranges agreed once per (lesson, stash position) key, later occurrences start without any exchange
+    from handwriting_line_generation_amd.trainer import flat_params as fp
+    key_buf = masked_randn()
+    first = start_stash_allreduce((key_buf.clone(), stash_mask.copy()), world, flat, key=("auto", 0))
+    assert first[3] and first[4] == [1, 2][: 1 + (world >= 2)]          # masks OR-ed right away: tensors 3 (segment 1) / 4 (segment 2)
+    allreduce_gradient_sets(flat, [first], world, torch.device("cpu"))
+    before = fp.COMM["collectives"]
+    again_buf = masked_randn()
+    wide_mask = stash_mask.copy()
+    if rank == 0:
+        wide_mask[0] = True            # rank 0 alone touches a sub-network (segment 0) this key never touched: must still be averaged
+        again_buf[int(flat.offsets[0]): int(flat.offsets[0]) + int(flat.numel[0])] = 1.0 + torch.arange(int(flat.numel[0]), dtype=torch.float32)
+    again = start_stash_allreduce((again_buf.clone(), wide_mask), world, flat, key=("auto", 0))
+    assert not again[3] and fp.COMM["collectives"] - before == len(fp.segment_spans(flat, again[4]))     # reductions only, no mask exchange
+    stashes = [(stash_buf.clone(), stash_mask.copy()), early, span, again]
     mine = flat.flat_grad.clone()
     allreduce_gradient_sets(flat, stashes, world, torch.device("cpu"))
+    al = [torch.zeros_like(again_buf) for _ in range(world)]; dist.all_gather(al, again_buf)
+    ok_again = torch.allclose(again[0], sum(al) / world) and again[1][0] and 0 in fp._SPAN_CACHE[(id(flat), ("auto", 0))]
+    stashes = stashes[:3]
     # gather every rank's original sets to rank-independent expectation
     gl = [torch.zeros_like(mine) for _ in range(world)]; dist.all_gather(gl, mine)
     sl = [torch.zeros_like(stash_buf) for _ in range(world)]; dist.all_gather(sl, stash_buf)
     el = [torch.zeros_like(early_buf) for _ in range(world)]; dist.all_gather(el, early_buf)
     pl = [torch.zeros_like(span_buf) for _ in range(world)]; dist.all_gather(pl, span_buf)
-    ok = torch.allclose(flat.flat_grad, sum(gl) / world) and torch.allclose(stashes[0][0], sum(sl) / world)
+    ok = ok_again and torch.allclose(flat.flat_grad, sum(gl) / world) and torch.allclose(stashes[0][0], sum(sl) / world)
     ok = ok and torch.allclose(early[0], sum(el) / world) and early[2] is None
     ok = ok and torch.allclose(span[0], sum(pl) / world) and span[2] is None and span[1].tolist() == stashes[0][1].tolist()
     ok = ok and flat.touched.tolist() == [True, True, True, False, False, True]
@@ -63,10 +81,12 @@ def _worker(rank, world, port, out):
 import pytest
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_gradient_exchange_equals_average_of_all_ranks(world):
-    """2 and 3 ranks (an odd world: the average is not a power-of-two division, ranks touch different tensor sets, one rank touches a single
-    tensor so that its span list differs from the others' before the masks are OR-ed)"""
+    """2, 3 and 8 ranks (an odd world: the average is not a power-of-two division; the node size; ranks touch different tensor sets, one rank
+    touches a single tensor so that its span list differs from the others' before the masks are OR-ed). Covers the order of the
+    exchanges - early whole-buffer reduction, keyed segment reductions with and without their one-time mask exchange, the widening of
+    remembered segments, then the per-lesson exchange - which must be the same sequence of collectives on every rank."""
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     out = mgr.dict()
