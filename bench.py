@@ -35,6 +35,9 @@ WORKLOADS = {
     # SURVEY 8d "peaked recogniser": the default workload with a trained-looking recogniser output (70 % blanks, confident characters), so
     # that the per-character expert bank of the style extractor runs a realistic number of windows / experts
     "iam_gan_b4a2_w512_peaked": dict(which="iam_gan", batch_size=4, a_batch_size=2, width=512, label_len=30, peaked=True),
+    # BASELINE.json configs[1]: the style autoencoder's pre-training step (AutoTrainer: Encoder2 -> DecoderNoSkip + E_HWR, L1 + CTC), the
+    # shipped batch of 28 lines of 64x512. Not a GAN curriculum: every step is the same lesson; reported as "AE train steps/sec"
+    "iam_auto_b28_w512": dict(which="iam_auto", batch_size=28, a_batch_size=1, width=512, label_len=30),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 256 CU x 2.4 GHz
 LESSONS = ("count", "gen", "auto", "disc", "gen", "auto", "disc")   # the shipped GAN curriculum
@@ -138,8 +141,16 @@ def main():
     rng.set_mode("device", seed=99 + rank)
     # identical initial weights on every rank (seeded init before the rank-dependent seeds matter): build under a fixed seed
     torch.manual_seed(0)
-    trainer, cfg = build_gan_trainer(wl["which"], wl["batch_size"], wl["a_batch_size"], width=wl["width"], label_len=wl["label_len"],
-                                     min_width=wl.get("min_width"), gpu=local, rank=rank, world=world)
+    gan = wl["which"].endswith("_gan")
+    if gan:
+        trainer, cfg = build_gan_trainer(wl["which"], wl["batch_size"], wl["a_batch_size"], width=wl["width"], label_len=wl["label_len"],
+                                         min_width=wl.get("min_width"), gpu=local, rank=rank, world=world)
+    else:
+        from handwriting_line_generation_amd.harness import build_simple_trainer
+        trainer, cfg = build_simple_trainer(wl["which"], batch_size=wl["batch_size"], width=wl["width"], label_len=wl["label_len"], gpu=local,
+                                            rank=rank, world=world)
+        trainer.flush_log = lambda: {}
+        args.no_gen = True
     torch.manual_seed(1234 + rank)
     if wl.get("peaked"):
         trainer.model.hwr.logit_offset = peaked_offset_fn(cfg["model"]["num_class"])
@@ -166,11 +177,15 @@ def main():
     # ~10 % of a step (each one is an extra packet between two kernels that also keeps the next kernel from starting under the tail of the
     # previous one), so they are recorded on a sample of the timed region: the first whole curriculum cycle of every PROF_EVERY cycles
     # (2 of the default run's 20 cycles; `profiled_steps` in the JSON).
-    cycle = 7   # lessons of the shipped GAN curriculum: count, gen, auto, disc, gen, auto, disc
+    cycle = 7 if gan else 1   # lessons of the shipped GAN curriculum: count, gen, auto, disc, gen, auto, disc
     PROF_EVERY = 10
     profiling = rank == 0 and not os.environ.get("HWG_BENCH_NO_PROF")
-    side_wgrad = bool(int(os.environ.get("HWG_SIDE_WGRAD", "0") or 0))   # measured neutral since the host side got faster (r3: 66.9 vs 66.8 steps/s)
-    ops.SIDE_WGRAD = side_wgrad
+    # weight gradients on a second stream: "auto" = in the auto lessons only (GPU-bound: three backward passes over every network), 1 = in
+    # every lesson, 0 = never
+    sw = os.environ.get("HWG_SIDE_WGRAD", "auto")
+    side_wgrad = "auto" if sw == "auto" else bool(int(sw or 0))
+    if not gan:
+        side_wgrad = False
     if profiling:
         ops.prof_start()
     from handwriting_line_generation_amd.model.char_style import CharStyleEncoder
@@ -189,7 +204,8 @@ def main():
             prof_steps += int(on)
             # weight gradients run on a second stream (+2-3 % steps/s: their workgroups fill CUs the data-gradient chain leaves idle)
             # except in the cycles whose launches are timed for the roofline object: co-running kernels inflate each other's durations
-            ops.SIDE_WGRAD = side_wgrad and not on
+            trainer._side_wgrad = False if on else side_wgrad
+            ops.SIDE_WGRAD = side_wgrad is True and not on
         marks[k].record()
         trainer._train_iteration(it); it += 1
     marks[args.steps].record()
@@ -198,7 +214,7 @@ def main():
     elapsed = time.perf_counter() - t0
     lesson_ms = {}
     for k in range(args.steps):
-        name = "%d:%s" % ((first_lesson + k) % cycle, LESSONS[(first_lesson + k) % cycle])
+        name = "%d:%s" % ((first_lesson + k) % cycle, LESSONS[(first_lesson + k) % cycle] if gan else "auto-pretrain")
         lesson_ms.setdefault(name, []).append(marks[k].elapsed_time(marks[k + 1]))
     per_lesson_ms = {n: round(sum(v) / len(v), 3) for n, v in sorted(lesson_ms.items())}
     st = dict(CharStyleEncoder.stats)
@@ -320,7 +336,7 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and gan:
             # the oracle's CPU cycle runs in a child process (it never touches the GPU) under a hard timeout
             import subprocess
             B = wl["batch_size"] * wl["a_batch_size"]
@@ -334,12 +350,12 @@ def main():
             except Exception as e:  # noqa: BLE001 - the baseline is a reported extra, never a reason to lose the GPU number
                 cpu = {"value": None, "unit": "steps/s", "cores": None, "kind": "port", "sample": "cpu baseline failed: %r" % (e,)}
         out = {
-            "metric": "G+D train steps/sec", "value": round(world * args.steps / elapsed, 4), "unit": "steps/s", "n_gpus": world,
+            "metric": "G+D train steps/sec" if gan else "AE train steps/sec", "value": round(world * args.steps / elapsed, 4), "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "steps_requested": steps_req, "warmup_requested": warm_req, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "config_file": cfg["name"], "lines_per_gpu_step": wl["batch_size"] * wl["a_batch_size"],
                        "authors_per_gpu": wl["batch_size"], "a_batch_size": wl["a_batch_size"], "line_px": "64x%d" % wl["width"],
-                       "curriculum": "count,gen,auto,disc,gen,auto,disc", "parallelism": "dp%d" % world},
+                       "curriculum": "count,gen,auto,disc,gen,auto,disc" if gan else None, "parallelism": "dp%d" % world},
             "roofline": roofline, "gen_lines_per_sec": gen, "cpu_baseline": cpu,
             # GPU time between the starts of consecutive steps (HIP events on the step stream), averaged per lesson of the curriculum
             "per_lesson_ms": per_lesson_ms,

@@ -130,8 +130,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  float4 ra[PF][A_IT], rb[PF][B_IT];
-  bool ma[PF][A_IT];   // validity of the A loads in flight (applied when the tile is stored, so the wait for the loads sits after the MFMAs)
+  constexpr int NSET = PF == 2 ? 2 : 1;
+  float4 ra[NSET][A_IT], rb[NSET][B_IT];
+  bool ma[NSET][A_IT];   // validity of the A loads in flight (applied when the tile is stored, so the wait for the loads sits after the MFMAs)
   // coordinates of the tile being LOADED (this workgroup's K range starts at step t_begin)
   int c0 = (t_begin % csteps) * BK;
   int js = (t_begin / csteps) % (ns > 0 ? ns : 1);
@@ -237,6 +238,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
       if (t + 1 < T) load_tile(ra[0], rb[0], ma[0]);  // global loads in flight during the MFMAs below
       compute(buf);
       if (t + 1 < T) store_tile(buf ^ 1, ra[0], rb[0], ma[0]);
+      __syncthreads();
+    }
+  } else if constexpr (PF == 3) {
+    // "store first": tile t+1 goes to LDS at the START of step t (its loads were issued at the start of step t-1), then the loads of tile
+    // t+2 are issued, then the MFMAs of tile t run. The LDS-store latency sits under the MFMAs instead of between them and the barrier,
+    // and right after the barrier the next step's fragments are already in LDS (one register set, two LDS buffers as before).
+    if (T > 0) {
+      load_tile(ra[0], rb[0], ma[0]);
+      store_tile(0, ra[0], rb[0], ma[0]);
+    }
+    if (T > 1) load_tile(ra[0], rb[0], ma[0]);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T) store_tile((t + 1) & 1, ra[0], rb[0], ma[0]);
+      if (t + 2 < T) load_tile(ra[0], rb[0], ma[0]);
+      compute(t & 1);
       __syncthreads();
     }
   } else {
@@ -767,7 +784,8 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, in
 
 template <int BM, int BN, int BK, int WM_, int WN_>
 void launch_conv(const ConvK& k, dim3 grid, hipStream_t st, int pf) {
-  if (pf >= 2) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 2>), grid, dim3(64 * WM_ * WN_), 0, st, k);
+  if (pf == 3) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 3>), grid, dim3(64 * WM_ * WN_), 0, st, k);
+  else if (pf == 2) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 2>), grid, dim3(64 * WM_ * WN_), 0, st, k);
   else hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 1>), grid, dim3(64 * WM_ * WN_), 0, st, k);
 }
 

@@ -68,9 +68,8 @@ __device__ __forceinline__ float quad_partner(float v) {
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 16 + 4 * (chunk ^ ((row >> 1) & 3)); }
 
 template <int WGM, int WGN>
-__global__ __launch_bounds__(512) void wino_conv_kernel(WinoK a) {
-  constexpr int NT = 512;
-  static_assert(WGM * WGN == 8, "8 wavefronts per workgroup");
+__global__ __launch_bounds__(64 * WGM * WGN) void wino_conv_kernel(WinoK a) {
+  constexpr int NT = 64 * WGM * WGN;      // 8 wavefronts (64 x 32 / 32 x 64 / 128 x 16 tiles) or 4 (32 x 32: twice the workgroups for small layers)
   constexpr int TM = 16 * WGM, TN = 16 * WGN;
   constexpr int PSV = TM * 16 + 8, PSU = TN * 16 + 8;
   constexpr int XI = (TM * 16 + NT - 1) / NT;        // x work items per thread: (tile, 4-channel group, patch column)
@@ -1343,14 +1342,14 @@ struct WinoPlan {
   double model_s;   // modelled duration of the chosen schedule (seconds)
 };
 static void wino_cfg(WinoPlan& p, int cfg) {
-  static const int tms[7] = {64, 32, 128, 64, 32, 64, 64}, tns[7] = {32, 64, 16, 32, 64, 64, 64};
+  static const int tms[8] = {64, 32, 128, 64, 32, 64, 64, 32}, tns[8] = {32, 64, 16, 32, 64, 64, 64, 32};
   p.cfg = cfg; p.tm = tms[cfg]; p.tn = tns[cfg];
 }
 // Schedule = (kernel variant, channel split) with the smallest modelled time. Model (fitted to tools/wino_check.py sweeps on MI355X,
 // profiles/r02_wino_shapes.txt): one workgroup per CU at a time, so the launch takes ceil(workgroups / 256) rounds of
 // (fixed + rounds-of-the-channel-loop x step) microseconds; a channel split adds the pass that sums the partial outputs.
 struct WinoCost { int cfg; double fixed_us, step_us; };
-static const WinoCost kWinoCost[5] = {{1, 2.5, 1.17}, {5, 11.0, 2.09}, {0, 8.0, 1.2}, {2, 6.5, 1.5}, {6, 15.7, 1.04}};
+static const WinoCost kWinoCost[6] = {{1, 2.5, 1.17}, {5, 11.0, 2.09}, {0, 8.0, 1.2}, {2, 6.5, 1.5}, {6, 15.7, 1.04}, {7, 2.0, 1.0}};
 static WinoPlan plan_wino_model(const hwg_conv_desc* d);
 static WinoPlan plan_wino(const hwg_conv_desc* d, double* model_s = nullptr) {
   static thread_local HwgPlanCache<WinoPlan> cache;
@@ -1368,8 +1367,9 @@ static WinoPlan plan_wino_model(const hwg_conv_desc* d) {
   double best_t = 1e30;
   WinoCost cost6 = kWinoCost[4];              // tuning aid: HWG_WINO_COST6="fixed_us,step_us" overrides the 64x64 DMA kernel's model constants
   if (const char* e = hwg_tune().wino_cost6; *e) { double f = 0, s2 = 0; if (sscanf(e, "%lf,%lf", &f, &s2) == 2) { cost6.fixed_us = f; cost6.step_us = s2; } }
-  for (int ci = 0; ci < 5; ++ci) {
+  for (int ci = 0; ci < 6; ++ci) {
     const WinoCost& wc = ci == 4 ? cost6 : kWinoCost[ci];
+    if (wc.cfg == 7 && (d->K <= 16 || d->K > 64)) continue;     // 32 x 32 tiles (4 waves): pays on 32..64-channel layers with few tiles
     if (wc.cfg == 2 && d->K > 16) continue;
     if (wc.cfg == 0 && d->K > 48) continue;
     if ((wc.cfg == 1 || wc.cfg == 5 || wc.cfg == 6) && d->K <= 48) continue;
@@ -1388,7 +1388,7 @@ static WinoPlan plan_wino_model(const hwg_conv_desc* d) {
   if (const char* f = hwg_tune().wino_force; *f) {   // tuning aid: "cfg[,nsplit]"
     int fc = -1, fs = 0;
     const int n = sscanf(f, "%d,%d", &fc, &fs);
-    if (n >= 1 && fc >= 0 && fc <= 6 && fc != 3 && fc != 4 && (fc == 2 || d->K > 16)) wino_cfg(best, fc);
+    if (n >= 1 && fc >= 0 && fc <= 7 && fc != 3 && fc != 4 && (fc == 2 || d->K > 16)) wino_cfg(best, fc);
     if (n >= 2 && fs >= 1) best.nsplit = fs > chunks ? chunks : fs;
   }
   best.model_s = best_t;
@@ -1468,6 +1468,7 @@ extern "C" int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const f
   if (p.cfg == 0) hipLaunchKernelGGL((wino_conv_kernel<4, 2>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 1) hipLaunchKernelGGL((wino_conv_kernel<2, 4>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 2) hipLaunchKernelGGL((wino_conv_kernel<8, 1>), grid, dim3(512), 0, st, k);
+  else if (p.cfg == 7) hipLaunchKernelGGL((wino_conv_kernel<2, 2>), grid, dim3(256), 0, st, k);
   else if (p.cfg == 5) hipLaunchKernelGGL(wino_conv_big_kernel, grid, dim3(768), 0, st, k);
   else if (p.cfg == 6 && !hwg_tune().w64_nodma) hipLaunchKernelGGL(wino_conv64d_kernel, grid, dim3(512), 0, st, k);
   else if (p.cfg == 6) hipLaunchKernelGGL(wino_conv64_kernel, grid, dim3(512), 0, st, k);

@@ -307,8 +307,12 @@ extern "C" int hwg_wino_wgrad_preferred(const hwg_conv_desc* d) {
   if (mode == 0 || !hwg_wino_wgrad_supported(d)) return 0;
   if (mode == 2) return 1;
   // the 64 x 64 block wastes matrix-core work on narrower layers, and short pixel ranges cannot amortise the 16-position epilogue
+  // (tools/conv_probe.py WGRAD=1, round 3: 8x8x122x128->128 39.5 vs 45.1 us and 8x16x122x128->64 37.2 vs 43.4 us in favour of this kernel
+  //  at 7808 tile-blocks; 16x5x64x128->256, three output rows, 46.8 vs 36.0 us against it)
   const long long tiles = (long long)d->N * hwg_cdiv(d->P, 2) * hwg_cdiv(d->Q, 2);
-  return d->K >= 48 && d->C >= 48 && tiles * hwg_cdiv(d->K, 64) * hwg_cdiv(d->C, 64) >= 256 * 32;
+  const int blocks = hwg_cdiv(d->K, 64) * hwg_cdiv(d->C, 64);
+  if (d->P <= 3 && blocks <= 8) return 0;
+  return d->K >= 48 && d->C >= 48 && tiles * blocks >= 256 * 28;
 }
 
 extern "C" size_t hwg_wino_wgrad_workspace(const hwg_conv_desc* d) {

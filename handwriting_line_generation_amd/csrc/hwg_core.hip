@@ -45,7 +45,7 @@ const HwgTune& hwg_tune() {
     t->wino_order = tune_int("HWG_WINO_ORDER", 1);
     t->wino_wgrad_split = tune_int("HWG_WINO_WGRAD_SPLIT", 0);
     t->wwg_debug = tune_int("HWG_WWG_DEBUG", 0);
-    t->conv_pf = tune_int("HWG_CONV_PF", 2);
+    t->conv_pf = tune_int("HWG_CONV_PF", 3);
     t->conv_lds = tune_int("HWG_CONV_LDS", 1);
     t->split_inkernel = tune_int("HWG_SPLIT_INKERNEL", 1);
     tune_str(t->wino_force, sizeof(t->wino_force), "HWG_WINO_FORCE");
@@ -57,6 +57,26 @@ const HwgTune& hwg_tune() {
   mine = cur;
   return *mine;
 }
+// ---- stream fork / join (weight gradients on a side stream): side waits for main's queue as it stands / main waits for side's ----------
+// One library call each (hipEventRecord + hipStreamWaitEvent on a ring of reusable events) instead of creating, recording and waiting on
+// a framework event object per weight gradient.
+namespace {
+thread_local hipEvent_t g_fork_ev[64];
+thread_local int g_fork_n = 0, g_fork_i = 0;
+int stream_dep(hipStream_t from, hipStream_t to, const char* what) {
+  if (g_fork_n < 64) {
+    if (hipEventCreateWithFlags(&g_fork_ev[g_fork_n], hipEventDisableTiming) != hipSuccess) { hwg_set_error("%s: hipEventCreate failed", what); return HWG_ERR_LAUNCH; }
+    ++g_fork_n;
+  }
+  hipEvent_t ev = g_fork_ev[g_fork_i];
+  g_fork_i = (g_fork_i + 1) % g_fork_n;
+  if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) { hwg_set_error("%s: event record / wait failed", what); return HWG_ERR_LAUNCH; }
+  return HWG_OK;
+}
+}  // namespace
+extern "C" int hwg_stream_fork(void* main_stream, void* side_stream) { return stream_dep((hipStream_t)main_stream, (hipStream_t)side_stream, "stream_fork"); }
+extern "C" int hwg_stream_join(void* side_stream, void* main_stream) { return stream_dep((hipStream_t)side_stream, (hipStream_t)main_stream, "stream_join"); }
+
 static int g_last_plan[3] = {-1, -1, -1};   // process-wide on purpose: backward passes launch from the autograd engine's thread
 void hwg_note_plan(int engine, int cfg, int nsplit) { g_last_plan[0] = engine; g_last_plan[1] = cfg; g_last_plan[2] = nsplit; }
 extern "C" int hwg_last_plan(int* engine_cfg_nsplit) {
@@ -76,7 +96,7 @@ extern "C" int hwg_device_ok(void) {
 // out of the measured duration. Off by default; never synchronises except in hwg_prof_stop().
 #include <atomic>
 namespace {
-struct ProfRec { hipEvent_t e0, e1; int kind, tag; double work; };
+struct ProfRec { hipEvent_t e0, e1; int kind, tag, launched; double work; };
 ProfRec* g_prof = nullptr;
 int g_prof_cap = 0;
 std::atomic<int> g_prof_n{0};
@@ -84,16 +104,29 @@ std::atomic<int> g_prof_on{0};
 thread_local int g_prof_tag = -1;
 }  // namespace
 
+namespace {
+thread_local int g_prof_cur = -1;       // record opened by this thread and not closed yet
+thread_local int g_prof_cur_launches = 0;
+}
 int hwg_prof_open(int kind, double work, hipStream_t st) {
+  (void)st;
   if (!g_prof_on.load(std::memory_order_relaxed)) return -1;
   const int i = g_prof_n.fetch_add(1);
   if (i >= g_prof_cap) return -1;
-  g_prof[i].kind = kind; g_prof[i].tag = g_prof_tag; g_prof[i].work = work;
-  (void)hipEventRecord(g_prof[i].e0, st);
+  g_prof[i].kind = kind; g_prof[i].tag = g_prof_tag; g_prof[i].work = work; g_prof[i].launched = 0;
+  g_prof_cur = i; g_prof_cur_launches = 0;
   return i;
 }
 void hwg_prof_close(int i, hipStream_t st) {
-  if (i >= 0) (void)hipEventRecord(g_prof[i].e1, st);
+  (void)st;
+  if (i >= 0 && g_prof_cur == i) { g_prof[i].launched = g_prof_cur_launches; g_prof_cur = -1; }
+}
+HwgProfEv hwg_prof_launch_events() {
+  HwgProfEv ev = {nullptr, nullptr};
+  if (g_prof_cur < 0 || !g_prof) return ev;
+  if (g_prof_cur_launches++ == 0) ev.e0 = g_prof[g_prof_cur].e0;
+  ev.e1 = g_prof[g_prof_cur].e1;
+  return ev;
 }
 
 extern "C" int hwg_prof_start(int max_records) {
@@ -124,6 +157,7 @@ extern "C" int hwg_prof_stop(int* kinds, int* tags, double* work, float* ms, int
   int out = 0;
   for (int i = 0; i < n; ++i) {
     float t = 0.f;
+    if (g_prof[i].launched <= 0) continue;      // bracket opened, nothing launched (an error path)
     (void)hipEventSynchronize(g_prof[i].e1);
     if (hipEventElapsedTime(&t, g_prof[i].e0, g_prof[i].e1) != hipSuccess) continue;
     if (out < capacity && kinds && tags && work && ms) {

@@ -109,14 +109,15 @@ def _side_workspace(nbytes, device, stream):
     return buf
 
 
+_side_hold = []      # operands of side-stream launches: kept alive until the join so that the allocator cannot hand their memory to a main-stream kernel
+
+
 def join_side_stream():
     """make torch's current stream wait for every weight gradient enqueued on the side stream so far"""
     for key in list(_side_dirty):
-        st = _side_streams[key][0]
-        ev = torch.cuda.Event()
-        ev.record(st)
-        torch.cuda.current_stream().wait_event(ev)
+        L.call("hwg_stream_join", _side_streams[key][1], _stream())
     _side_dirty.clear()
+    del _side_hold[:]
 
 
 def _chk(t, name, dtype=torch.float32):
@@ -601,12 +602,10 @@ class _Conv2d(Function):
                         db = dbias
                 if SIDE_WGRAD and direct and (dbias is None or bacc):
                     s2, raw2, skey = _side_stream(x.device)
-                    ev = torch.cuda.Event()
-                    ev.record()                      # dy (and x) are complete on the main stream at this point
-                    s2.wait_event(ev)
+                    L.call("hwg_stream_fork", st, raw2)      # dy (and x) are complete on the main stream at this point
                     ws2 = _side_workspace(need, x.device, s2)
                     L.call("hwg_conv_wgrad", d.ptr, u, v, dw_, sa, sb, S, 1, 1, dbias, bacc or 0, ws2, ws2.numel(), raw2)
-                    u.record_stream(s2); v.record_stream(s2)
+                    _side_hold.append((u, v))
                     _side_dirty.add(skey)
                 else:
                     L.call("hwg_conv_wgrad", d.ptr, u, v, dw_, sa, sb, S, 1, 1 if direct else 0, dbias, bacc or 0, ws, ws.numel(), st)

@@ -114,7 +114,11 @@ class HWWithStyleTrainer(BaseTrainer):
         self.async_log = tr.get("async_log", False)
         # optional: weight-gradient kernels on a second HIP stream (fills the CUs the data-gradient chain leaves idle: +2.7 % steps/s);
         # off by default because co-running kernels inflate the per-kernel durations the roofline measurement relies on
-        ops.SIDE_WGRAD = bool(tr.get("side_stream_wgrad", False) or int(os.environ.get("HWG_SIDE_WGRAD", "0") or 0))
+        # "auto": only in the lessons with the long backward passes (auto / auto-gen: three passes over every network), where the GPU is
+        # the bottleneck; the short lessons are bound by the host's enqueue rate and every extra call costs there
+        side = tr.get("side_stream_wgrad", os.environ.get("HWG_SIDE_WGRAD", "0"))
+        self._side_wgrad = "auto" if side == "auto" else bool(int(side or 0)) if isinstance(side, str) else bool(side)
+        ops.SIDE_WGRAD = self._side_wgrad is True
         self._pending_log = None
         self.pre_clip_hook = None
 
@@ -155,6 +159,8 @@ class HWWithStyleTrainer(BaseTrainer):
         if not self.model.training:   # nn.Module.train() walks all ~3000 sub-modules; only do it when the mode actually changes
             self.model.train()
         lesson = self.curriculum.getLesson(iteration) if self.curriculum else None
+        if self._side_wgrad == "auto":
+            ops.SIDE_WGRAD = bool(lesson) and "auto" in lesson
         instance = self._next_instance(lesson or [])
         produced = self._forward_backward(instance, lesson)
         if produced is None:

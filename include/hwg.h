@@ -44,6 +44,11 @@ int hwg_device_ok(void);
  * how the parity tests assert that a forced schedule was the one launched. */
 int hwg_tuning_reload(void);
 int hwg_last_plan(int* engine_cfg_nsplit);
+/* Stream dependencies for kernels launched off the caller's main stream (weight gradients on a side stream: nothing in a backward pass
+ * waits for them, only the optimizer does). fork: `side_stream` waits for everything enqueued on `main_stream` so far; join: `main_stream`
+ * waits for everything enqueued on `side_stream` so far. Host cost: one event record + one stream wait on a reused event. */
+int hwg_stream_fork(void* main_stream, void* side_stream);
+int hwg_stream_join(void* side_stream, void* main_stream);
 
 /* Launch profiler for the matrix-core kernels (bench.py's roofline measurement): between hwg_prof_start() and hwg_prof_stop() every
  * MFMA convolution / weight-gradient launch (and their reduce passes) is bracketed by a HIP event pair on its stream. hwg_prof_tag()

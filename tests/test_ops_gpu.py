@@ -238,7 +238,7 @@ WINO_FORCED_SHAPES = [(2, 13, 37, 64, 80, 1, 1), (1, 9, 66, 48, 208, 0, 1), (3, 
 
 
 @pytest.mark.parametrize("nsplit", [1, 2, 4])
-@pytest.mark.parametrize("cfg", [0, 1, 2, 5, 6])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 5, 6, 7])
 def test_winograd_forced_schedules_vs_cpu(cuda, cfg, nsplit):
     from handwriting_line_generation_amd import ops
     ran = 0

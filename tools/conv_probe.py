@@ -26,6 +26,7 @@ for line in lines:
     sh, sw, tr = (v[9:12] + [1, 1, 0][len(v[9:12]):])
     env = dict(kv.split("=", 1) for kv in parts[1:])
     wino = env.pop("WINO", None)
+    wgrad = env.pop("WGRAD", None)
     if tr:
         P = (H - 1) * sh - 2 * ph + R; Q = (W - 1) * sw - 2 * pw + S; pix = N * H * W
     else:
@@ -34,7 +35,13 @@ for line in lines:
     x = torch.randn(N, H, W, C, device=dev); y = torch.empty(N, P, Q, K, device=dev)
     with ops.tuning(**env):
         d = ops._desc(N, H, W, C, K, R, S, (sh, sw), (ph, pw), (1, 1), P, Q, tr)
-        if wino:
+        if wgrad:          # weight gradient of the (non-transposed) layer: engine chosen like ops._make_wgrad_plan does
+            dy = torch.randn(N, P, Q, K, device=dev); dw = torch.empty(K, C, R, S, device=dev); db = torch.empty(K, device=dev)
+            use_wino = R == 3 and S == 3 and bool(L.query("hwg_wino_wgrad_preferred", d.ptr))
+            fn = "hwg_wino_wgrad" if use_wino else "hwg_conv_wgrad"
+            need = L.query(fn + "_workspace", d.ptr); ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+            t = bench(lambda: L.call(fn, d.ptr, dy, x, dw, C * R * S, R * S, S, 1, 0, db, 0, ws, ws.numel(), st))
+        elif wino:
             wp = torch.randn((C + 15) // 16, 16, (K + 15) // 16 * 16, 16, device=dev) * 0.05
             need = L.query("hwg_wino_conv_workspace", d.ptr); ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
             t = bench(lambda: L.call("hwg_wino_conv_fwd", d.ptr, x, wp, None, y, 0, ws, ws.numel(), st))
