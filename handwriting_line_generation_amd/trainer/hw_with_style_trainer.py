@@ -121,6 +121,13 @@ class HWWithStyleTrainer(BaseTrainer):
         ops.SIDE_WGRAD = self._side_wgrad is True
         self._pending_log = None
         self.pre_clip_hook = None
+        # Dead-gradient elimination (off by default = the reference's launches). The reference computes two families of parameter gradients
+        # that nothing ever reads: the frozen recogniser's (it is in no optimizer; 11 backward traversals per cycle) and the
+        # discriminator's in gen / auto lessons (optimizer_discriminator.zero_grad() drops them before the next disc lesson reads any).
+        # With the switch on those weight-gradient kernels are not launched: losses, every optimizer update and all weights stay
+        # bit-identical (tests/test_trainer_gpu.py), only `.grad` of those never-stepped tensors stays None.
+        self.skip_unused_grads = bool(tr.get("skip_unused_grads", int(os.environ.get("HWG_SKIP_UNUSED_GRADS", "0") or 0)))
+        self._grad_switch = None
 
     # ------------------------------------------------------------------------------------------
     def _to_tensor(self, instance):
@@ -167,6 +174,22 @@ class HWWithStyleTrainer(BaseTrainer):
             return {}
         return self._apply_step(lesson, iteration, instance, *produced)
 
+    def _set_unused_grads(self, lesson):
+        """skip_unused_grads: the recogniser's parameters never require a gradient (when it is frozen), the discriminator's only in the
+        lessons that step it; restored to the reference's behaviour when the switch is off"""
+        if not self.curriculum:
+            return
+        want_d = (not self.skip_unused_grads) or any("disc" in l for l in lesson)
+        want_h = not (self.skip_unused_grads and self.hwr_frozen)
+        if self._grad_switch == (want_d, want_h):
+            return
+        self._grad_switch = (want_d, want_h)
+        for name, p in self.model.named_parameters():
+            if name.startswith("discriminator.") and not name.endswith(("weight_u", "weight_v")):
+                p.requires_grad_(want_d)
+            elif name.startswith("hwr."):
+                p.requires_grad_(want_h)
+
     def _forward_backward(self, instance, lesson):
         """Gradient production of one iteration (trainer :236-338): zero the gradients of the optimizer(s) in play, run the lesson's forward
         graph, weight the losses and run the up-to-three backward passes of the balancing scheme; every separately balanced gradient set is
@@ -175,6 +198,7 @@ class HWWithStyleTrainer(BaseTrainer):
         self.optimizer.zero_grad()
         if self.curriculum and any("disc" in l for l in lesson):
             self.optimizer_discriminator.zero_grad()
+        self._set_unused_grads(lesson)
 
         if self.curriculum:
             # the reference skips a batch without any text; data parallel: if one rank has to skip, all do (a rank that returned

@@ -56,3 +56,29 @@ def test_curriculum_cycle_matches_reference(cuda, tmp_path):
         assert not bad, "; ".join(bad)
     finally:
         rng.set_mode("device")
+
+
+def test_skip_unused_grads_changes_no_weight_and_no_loss(cuda, tmp_path):
+    """trainer.skip_unused_grads drops the weight-gradient kernels of parameters whose gradients nothing reads (frozen recogniser; discriminator
+    outside disc lessons). Two curriculum cycles with the switch on and off from the same seeds (device Philox noise, same stream): every
+    logged loss and every parameter / buffer after the run must be BIT-identical, and the skipped tensors must really be untouched."""
+    from handwriting_line_generation_amd import rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    outs = []
+    for skip in (False, True):
+        rng.set_mode("device", seed=11)
+        torch.manual_seed(3); np.random.seed(3); random.seed(3)
+        trainer, _ = build_gan_trainer("iam_gan", 2, 2, width=256, label_len=12, workdir=str(tmp_path / ("s%d" % skip)))
+        trainer.skip_unused_grads = skip
+        torch.manual_seed(5); np.random.seed(5); random.seed(5)
+        logs = [trainer._train_iteration(it) for it in range(14)]
+        f = trainer.flat
+        names = [n for n, _ in trainer.model.named_parameters()]
+        touched = {names[pi]: bool(f.touched[k]) for k, pi in enumerate(f.order)}
+        outs.append((logs, {k: v.detach().clone() for k, v in trainer.model.state_dict().items()}, touched))
+    (la, sa, ta), (lb, sb, tb) = outs
+    for it, (a, b) in enumerate(zip(la, lb)):
+        assert a == b, "iteration %d: %s vs %s" % (it, a, b)
+    for k, v in sa.items():
+        assert torch.equal(v, sb[k]), "%s differs with skip_unused_grads" % k
+    assert any(ta[k] for k in ta if k.startswith("hwr.")) and not any(tb[k] for k in tb if k.startswith("hwr."))
