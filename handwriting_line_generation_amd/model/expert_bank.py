@@ -7,7 +7,7 @@ without a window in the batch are never touched, which preserves the reference's
 """
 import numpy as np
 import torch
-from torch.autograd import Function
+from ..ops import Function
 
 from .. import _lib as L
 from .. import ops
