@@ -322,6 +322,14 @@ def main():
                                           for k, v in fam.items() if k != dom},
                         "time_frac_of_step": round(sec / (elapsed * prof_steps / args.steps), 3),
                         "profiled_steps": prof_steps}
+            if dom.startswith("wino"):
+                # Winograd F(2x2,3x3) / F(3x3,2x2) kernels are credited with the layer's direct-form FLOPs (FLOPs = 2 MAC of the
+                # convolution) but issue 16 instead of 36 multiplies per 2x2 tile and channel pair: the matrix cores are busy for 1/2.25 of it
+                roofline["flops_counted"] = "direct-form (2 x MACs of the convolution); the kernel issues 1/2.25 of them on the matrix cores"
+                roofline["mfma_issued_frac"] = round(ach / 2.25 / PEAK_FP32_MFMA_TFLOPS, 4)
+            for k, v in roofline["other_kernels"].items():
+                if k.startswith("wino") and "achieved" in v:
+                    v["mfma_issued_frac"] = round(v["achieved"] / 2.25 / PEAK_FP32_MFMA_TFLOPS, 4)
             gfl, gsec = gd["G"][0] + gd["D"][0], gd["G"][1] + gd["D"][1]
             if gsec > 0:
                 # FLOPs are those of the launches this implementation makes ("minimum-necessary": the discriminator's weight gradients are not
@@ -337,7 +345,7 @@ def main():
         if roofline:
             # HBM bytes per launch of the dominant kernel: PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately with rocprofv3 on this
             # same command and corrected per MI355X_MICROARCH.md) are committed under profiles/; they cannot be collected from inside bench.py
-            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", name)))
                     if pm.get("workload") == args.workload and dom in pm["kernels"]:
@@ -350,14 +358,15 @@ def main():
             # ... and per layer shape (tools/pmc_shapes.py replays the step's top conv shapes under the same counters): measured HBM bytes against
             # the one-pass operand bytes 4*(input + weights + output), weighted by this run's launch counts
             try:
-                ps = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_shapes.json")))
+                shapes_file = "r03_pmc_shapes.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_shapes.json")) else "r02_pmc_shapes.json"
+                ps = json.load(open(os.path.join(ROOT, "profiles", shapes_file)))
                 launches = {(k, repr(sh)): v[2] for (k, sh), v in by_shape.items()}
                 tot = {}
                 for row in ps["shapes"]:
                     n_here = launches.get((row["kind"], row["shape"]), 0)
                     t = tot.setdefault(row["kind"], [0.0, 0.0, 0])
                     t[0] += n_here * (row["hbm_fetch_bytes"] + row["hbm_write_bytes"]); t[1] += n_here * row["algorithmic_bytes"]; t[2] += n_here
-                roofline["traffic_by_shape"] = {"source": "profiles/r02_pmc_shapes.json",
+                roofline["traffic_by_shape"] = {"source": "profiles/" + shapes_file,
                                                 "kernels": {k: {"launches_covered": t[2], "launches": fam[k][2], "hbm_bytes_per_launch": round(t[0] / t[2]),
                                                                 "operand_bytes_per_launch": round(t[1] / t[2]), "ratio": round(t[0] / t[1], 2)}
                                                             for k, t in tot.items() if t[2] > 0 and k in fam}}

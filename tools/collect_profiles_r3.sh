@@ -8,18 +8,31 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 STEPS="--steps 28 --warmup 7"
 timeout 600 python bench.py --steps 70 --warmup 14 > $OUT/bench_line.json 2> $OUT/bench_err.log
-HWG_CONV_DUMP=$OUT/conv_shapes.txt timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -f csv -- python3 bench.py $STEPS --no-cpu-baseline --no-gen > $OUT/kt.log 2>&1
+HWG_BENCH_NO_MINNEC=1 HWG_CONV_DUMP=$OUT/conv_shapes.txt timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -f csv -- python3 bench.py $STEPS --no-cpu-baseline --no-gen > $OUT/kt.log 2>&1
 cp $OUT/kt/*kernel_stats.csv $OUT/kernel_stats_b4a2_w512.csv 2>/dev/null || find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_b4a2_w512.csv \;
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $c | cut -d' ' -f1)
-  timeout 400 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$tag -o p -- python3 bench.py --steps 7 --warmup 7 --no-cpu-baseline --no-gen > $OUT/pmc_$tag.log 2>&1
+  HWG_BENCH_NO_MINNEC=1 timeout 400 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$tag -o p -- python3 bench.py --steps 7 --warmup 7 --no-cpu-baseline --no-gen > $OUT/pmc_$tag.log 2>&1
 done
 python tools/prof_families.py $OUT/kernel_stats_b4a2_w512.csv $(find $OUT/pmc_FETCH_SIZE -name "*.db" | head -1) $(find $OUT/pmc_WRITE_SIZE -name "*.db" | head -1) $(find $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*.db" | head -1) $OUT/families.json $OUT/families.txt > $OUT/families.log 2>&1
 python tools/pmc_traffic.py $(find $OUT/pmc_FETCH_SIZE -name "*.db" | head -1) $(find $OUT/pmc_WRITE_SIZE -name "*.db" | head -1) > $OUT/pmc_traffic.jsonl 2>&1
+python - <<PY
+import json
+rows = [json.loads(l) for l in open("$OUT/pmc_traffic.jsonl") if l.startswith("{")]
+json.dump({"workload": "iam_gan_b4a2_w512",
+           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 7 --warmup 7 --no-cpu-baseline --no-gen",
+           "correction": "gfx950: bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports half of wide coalesced reads)",
+           "kernels": {r["kernel"]: r for r in rows}}, open("$OUT/pmc_traffic.json", "w"), indent=1)
+PY
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES
+# per-shape traffic of the conv kernels: the bench run's top shapes replayed one by one under the same two counters
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/shapes/fetch -o sf -- python3 tools/pmc_shapes.py run $OUT/conv_shapes.txt > $OUT/shapes_fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/shapes/write -o sw -- python3 tools/pmc_shapes.py run $OUT/conv_shapes.txt > $OUT/shapes_write.log 2>&1
+python tools/pmc_shapes.py parse $OUT/conv_shapes.txt $OUT/shapes $OUT/pmc_shapes.json > $OUT/shapes_parse.log 2>&1
+rm -rf $OUT/shapes
 for wl in iam_gan_b1a1_w512 rimes_gan_b4a2_w256_1024 iam_auto_b28_w512; do
   timeout 400 python bench.py --workload $wl $STEPS --no-cpu-baseline > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
-  timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt_$wl -o kt -f csv -- python3 bench.py --workload $wl --steps 14 --warmup 7 --no-cpu-baseline --no-gen > $OUT/kt_$wl.log 2>&1
+  HWG_BENCH_NO_MINNEC=1 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt_$wl -o kt -f csv -- python3 bench.py --workload $wl --steps 14 --warmup 7 --no-cpu-baseline --no-gen > $OUT/kt_$wl.log 2>&1
   find $OUT/kt_$wl -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$wl.csv \;
   rm -rf $OUT/kt_$wl
 done

@@ -48,7 +48,11 @@ for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ns"]):
         r["frac_of_8TBps"] = r["achieved_GBps"] / 8000.0
     m = mfma.get(k)
     if m and m.get("GRBM_GUI_ACTIVE"):
-        r["mfma_busy_frac"] = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (m["GRBM_GUI_ACTIVE"] * 1024.0)
+        # GRBM_GUI_ACTIVE comes back as ONE value per dispatch that is the SUM over the 8 XCDs' GRBMs (calibrated on kernels whose issued
+        # matrix-core work is known from their FLOP count: the Winograd weight gradient issues 80 TFLOP/s = 0.51 of peak and reads 0.51
+        # with this normalisation, 0.064 without): active cycles of the launch = value / 8; 1024 SIMDs each retire at most one MFMA pass
+        # per SQ_VALU_MFMA_BUSY cycle
+        r["mfma_busy_frac"] = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (m["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
     rows.append(r)
 json.dump({"total_gpu_ms": total_ns / 1e6, "kernels": rows}, open(out_json, "w"), indent=0)
 with open(out_txt, "w") as fh:
