@@ -675,6 +675,65 @@ __global__ __launch_bounds__(256) void wgrad_reduce_lanes_kernel(const float* pa
   }
 }
 
+// Tap-contiguous weights (ss == 1, sr == S, sb == R*S - every weight this package owns): the sums of 256 / SL neighbouring (k, c) pairs go
+// through LDS and leave as whole runs of R*S*(256/SL) consecutive floats. The plain kernel above writes a tap at a time, 4 bytes every
+// R*S*4, and was bound by those scattered stores (27 us for 512x512x3x3 with 4 partial images, 38 MB read + 9 MB written).
+// Thread t: pair t % KC, partial images t / KC, t / KC + SL, ... (combined through LDS in lane order: a fixed order, deterministic).
+template <int SL, int RSC>
+__global__ __launch_bounds__(256) void wgrad_reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int RS_rt, int K, int C,
+                                                                long long sa, int accumulate, long long pstride, float* dbias, int bias_accumulate,
+                                                                int main_blocks) {
+  constexpr int KC = 256 / SL;
+  const int RS = RSC ? RSC : RS_rt;
+  extern __shared__ float red[];          // [SL][KC][RS] (+1 float of padding per pair)
+  const int ldp = RS | 1;
+  const long long KCtot = (long long)K * C;
+  if ((int)blockIdx.x >= main_blocks) {    // the K bias sums behind every partial image
+    const int k = ((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[(long long)sp * pstride + RS * KCtot + k];
+    dbias[k] = bias_accumulate ? dbias[k] + s : s;
+    return;
+  }
+  const int pl = threadIdx.x % KC, sl = threadIdx.x / KC;
+  const long long base = (long long)blockIdx.x * KC;
+  const long long kc = base + pl;
+  if (kc < KCtot) {
+    if (RSC) {
+      float acc[RSC ? RSC : 1];
+#pragma unroll
+      for (int t = 0; t < RSC; ++t) acc[t] = 0.f;
+      for (int sp = sl; sp < nsplit; sp += SL) {
+        const float* src = part + (long long)sp * pstride + kc;
+#pragma unroll
+        for (int t = 0; t < RSC; ++t) acc[t] += src[t * KCtot];
+      }
+#pragma unroll
+      for (int t = 0; t < RSC; ++t) red[(sl * KC + pl) * ldp + t] = acc[t];
+    } else {
+      for (int t = 0; t < RS; ++t) {
+        float a = 0.f;
+        for (int sp = sl; sp < nsplit; sp += SL) a += part[(long long)sp * pstride + t * KCtot + kc];
+        red[(sl * KC + pl) * ldp + t] = a;
+      }
+    }
+  }
+  __syncthreads();
+  const int n_out = KC * RS;
+  for (int j = threadIdx.x; j < n_out; j += 256) {
+    const int p = j / RS, t = j - p * RS;
+    const long long q = base + p;
+    if (q >= KCtot) break;
+    float s = red[p * ldp + t];
+#pragma unroll
+    for (int l = 1; l < SL; ++l) s += red[(l * KC + p) * ldp + t];
+    const long long k = q / C;
+    const long long o = k * sa + (q - k * C) * RS + t;
+    dw[o] = accumulate ? dw[o] + s : s;
+  }
+}
+
 __global__ void pack_weight_kernel(const float* src, float* dst, int A, int B, int Bpad, int R, int S,
                                    long long sa, long long sb, long long sr, long long ss, int flip) {
   const long long total = (long long)R * S * A * Bpad;
@@ -1238,6 +1297,27 @@ static WgPlan plan_wgrad_tapn(const hwg_conv_desc* d) {
 int hwg_wgrad_reduce_launch(const float* part, float* dw, int nsplit, int RS, int S, int K, int C, long long sa, long long sb, long long sr,
                             long long ss, int accumulate, long long pstride, float* dbias, int bias_accumulate, hipStream_t st) {
   const long long total = (long long)RS * K * C + (dbias ? K : 0);
+  // large filters cut into few ranges (the 256..512-channel layers): row-contiguous stores. Measured (tools/probe_r3_reduce.txt, whole weight
+  // gradient): 512x512x3x3 / 4 images 144 -> 138 us, 256x256x3x3 / 16 images 48.7 -> 45.0 us, 512x512x1x3 / 4 images 32.6 -> 31.0 us; with many
+  // images of a small filter the lane-split kernels below stay ahead (128x128x3x3 / 62 images 38 vs 44 us).
+  const long long pairs = (long long)K * C;
+  if (ss == 1 && sr == S && sb == RS && hwg_tune().wgrad_reduce_rows && RS <= 49 && pairs >= 65536 && nsplit <= 16) {
+    const int sl = nsplit >= 8 && pairs <= 65536 ? 4 : 1;
+    const int kc = 256 / sl;
+    const int main_blocks = (int)hwg_cdiv(pairs, kc);
+    const int blocks = main_blocks + (dbias ? hwg_cdiv(K, 256) : 0);
+    const size_t lds = (size_t)256 * (RS | 1) * sizeof(float);
+#define HWG_ROWS(SL, RSC)                                                                                                                       \
+  hipLaunchKernelGGL((wgrad_reduce_rows_kernel<SL, RSC>), dim3(blocks), dim3(256), lds, st, part, dw, nsplit, RS, K, C, sa, accumulate, pstride, \
+                     dbias, bias_accumulate, main_blocks)
+    if (RS == 9) { if (sl == 4) HWG_ROWS(4, 9); else HWG_ROWS(1, 9); }
+    else if (RS == 16) { if (sl == 4) HWG_ROWS(4, 16); else HWG_ROWS(1, 16); }
+    else if (RS == 3) { if (sl == 4) HWG_ROWS(4, 3); else HWG_ROWS(1, 3); }
+    else { if (sl == 4) HWG_ROWS(4, 0); else HWG_ROWS(1, 0); }
+#undef HWG_ROWS
+    HWG_LAUNCH_CHECK("conv_wgrad_reduce");
+    return HWG_OK;
+  }
   if (nsplit >= 64 && total <= 65536)
     hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<32>, dim3(hwg_cdiv(total, 8)), dim3(256), 0, st, part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss,
                        accumulate, pstride, dbias, bias_accumulate);

@@ -67,7 +67,7 @@ struct HwgTune {
   int wwg_debug;         // HWG_WWG_DEBUG
   int conv_pf;           // HWG_CONV_PF: register prefetch depth of the implicit-GEMM conv kernel (1 or 2)
   int conv_lds;          // HWG_CONV_LDS: 0 keeps strided layers on the per-tap gather kernel (A/B timing), 1 default
-  int split_inkernel;    // HWG_SPLIT_INKERNEL: 0 = separate reduce launches for split partials, 1 default = last-arriver reduction
+  int wgrad_reduce_rows; // HWG_WGRAD_REDUCE_ROWS: 0 = tap-at-a-time partial-image reduce (A/B timing), 1 default = row-contiguous stores
   char wino_force[32];   // HWG_WINO_FORCE  "cfg[,nsplit]"
   char conv_force[48];   // HWG_CONV_FORCE  "bm,bn,bk[,nsplit]"
   char wgrad_force[32];  // HWG_WGRAD_FORCE "cfg,target_blocks"

@@ -176,6 +176,37 @@ def test_winograd_weight_gradient(cuda, case):
     _close(xg.grad.permute(0, 3, 1, 2), 2 * xr.grad.float(), "wino wgrad dx", tol=2e-5)
 
 
+REDUCE_CASES = [  # N, H, W, C, K, R, S, stride, pad, wino-wgrad mode; the row kernel takes filters of >= 65536 (k, c) pairs cut into <= 16 ranges
+    (2, 12, 40, 256, 256, 3, 3, 1, 1, "2"), (2, 12, 40, 256, 256, 3, 3, 1, 1, "0"), (2, 5, 40, 512, 512, 3, 3, 1, 1, "1"), (1, 9, 33, 272, 304, 3, 3, 1, 0, "2"),
+    (2, 20, 66, 256, 256, 4, 4, 2, 0, "0"), (2, 1, 127, 512, 512, 1, 3, 1, (0, 1), "0"), (1, 12, 30, 256, 256, 5, 5, 1, 2, "0"),
+    (2, 12, 40, 64, 64, 3, 3, 1, 1, "2"), (3, 7, 19, 20, 36, 3, 3, 1, 1, "0")]
+
+
+@pytest.mark.parametrize("case", REDUCE_CASES, ids=lambda c: "x".join(str(v) for v in c[:7]))
+def test_weight_gradient_partial_image_reduce_variants(cuda, case):
+    """the row-contiguous reduce of the split weight-gradient partials (wgrad_reduce_rows_kernel) against the tap-at-a-time one it
+    replaces: same sums (the lane-split variants add in another fixed order: 1e-6), first launch and accumulating launch, with the bias sums"""
+    from handwriting_line_generation_amd import ops
+    N, H, W, C, K, R, S, stride, pad, wmode = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, H, W, C, generator=g).to(cuda)
+    w = (torch.randn(K, C, R, S, generator=g) / (R * S * C) ** 0.5).to(cuda)
+    b = torch.randn(K, generator=g).to(cuda)
+    outs = []
+    for rows in ("0", "1"):
+        with ops.tuning(HWG_WGRAD_REDUCE_ROWS=rows, HWG_WINO_WGRAD=wmode):
+            wg, bg = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            for rep in range(2):
+                y = ops.conv2d(x, wg, bg, stride, pad)
+                gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(9 + rep)).to(cuda)
+                y.backward(gy)
+                if rep == 0:
+                    first = (wg.grad.clone(), bg.grad.clone())
+            outs.append((first[0], first[1], wg.grad.clone(), bg.grad.clone()))
+    for a, r_, name in zip(outs[1], outs[0], ("dw", "db", "dw accumulated", "db accumulated")):
+        _close(a, r_, "reduce variants " + name, tol=2e-6)
+
+
 @pytest.mark.parametrize("shape", [(16, 58, 512, 64, 64, 0, 1), (8, 8, 129, 512, 512, 0, 0), (4, 32, 514, 128, 128, 0, 0)], ids=lambda c: "x".join(map(str, c)))
 def test_winograd_engines_agree_at_bench_sizes(cuda, shape):
     """full-size layers of the bench step (discriminator 64 ch at 58x512, recogniser 512 ch, style extractor 128 ch): the Winograd forward,
