@@ -56,9 +56,62 @@ __global__ void segment_weighted_mean_kernel(const float* v, const float* wgt, c
   const int b = i / C, c = i % C;
   float tot = 0.f, ws = 0.f;
   for (int k = 0; k < n; ++k)
-    if (seg[k] == b) { tot += wgt[k] * v[(long long)k * C + c]; ws += wgt[k]; }
+    if (seg[k] == b) { tot = fmaf(wgt[k], v[(long long)k * C + c], tot); ws += wgt[k]; }
   out[i] = ws != 0.f ? tot / ws : tot;
   if (c == 0) wsum_out[b] = ws;
+}
+// Same sums, one workgroup per segment: the first wavefront compacts the segment's members (ascending k: the order of the loop above) into
+// LDS, then every thread adds only those, eight independent loads at a time. The kernel above walks all n items per output with a
+// dependent load chain (120 us for 970 windows x 8 lines); this one takes the time of n / B loads.
+__global__ __launch_bounds__(256) void segment_weighted_mean_list_kernel(const float* __restrict__ v, const float* __restrict__ wgt,
+                                                                         const int* __restrict__ seg, int n, int C, float* out, float* wsum_out) {
+  extern __shared__ int seg_list[];                 // [n] member indices, then [n] their weights, then the member count
+  float* lw = reinterpret_cast<float*>(seg_list + n);
+  int* count = seg_list + 2 * n;
+  const int b = blockIdx.x, lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    int base = 0;
+    for (int k0 = 0; k0 < n; k0 += 256) {
+      int sg[4];
+      float w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {               // four groups of 64 items in flight
+        const int k = k0 + 64 * u + lane;
+        sg[u] = k < n ? seg[k] : -1;
+        w[u] = k < n ? wgt[k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool m = sg[u] == b;
+        const unsigned long long mask = __ballot(m);
+        if (m) {
+          const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+          seg_list[pos] = k0 + 64 * u + lane;
+          lw[pos] = w[u];
+        }
+        base += __popcll(mask);
+      }
+    }
+    if (lane == 0) *count = base;
+  }
+  __syncthreads();
+  const int cnt = *count;
+  float ws = 0.f;
+  for (int i = 0; i < cnt; ++i) ws += lw[i];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float tot = 0.f;
+    int i = 0;
+    for (; i + 8 <= cnt; i += 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = v[(long long)seg_list[i + u] * C + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tot = fmaf(lw[i + u], x[u], tot);
+    }
+    for (; i < cnt; ++i) tot = fmaf(lw[i], v[(long long)seg_list[i] * C + c], tot);
+    out[(long long)b * C + c] = ws != 0.f ? tot / ws : tot;
+  }
+  if (threadIdx.x == 0) wsum_out[b] = ws;
 }
 // dv[i][c] = wgt_i / wsum[seg_i] * dout[seg_i][c]
 __global__ void segment_weighted_mean_bwd_kernel(const float* dout, const float* wgt, const int* seg, const float* wsum, int n, int C, float* dv) {
@@ -335,7 +388,11 @@ extern "C" int hwg_scatter_windows(const float* dpatches, int B, int Wx, int C, 
 }
 extern "C" int hwg_segment_weighted_mean(const float* v, const float* wgt, const int* seg, int n, int C, int B, float* out, float* wsum, void* stream) {
   HWG_REQUIRE(v && wgt && seg && out && wsum && n > 0 && C > 0 && B > 0, "segment_weighted_mean: bad arguments");
-  hipLaunchKernelGGL(segment_weighted_mean_kernel, dim3(hwg_cdiv(B * C, 128)), dim3(128), 0, (hipStream_t)stream, v, wgt, seg, n, C, B, out, wsum);
+  const size_t lds = ((size_t)2 * n + 1) * sizeof(int);
+  if (lds <= 60 * 1024)
+    hipLaunchKernelGGL(segment_weighted_mean_list_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, v, wgt, seg, n, C, out, wsum);
+  else
+    hipLaunchKernelGGL(segment_weighted_mean_kernel, dim3(hwg_cdiv(B * C, 128)), dim3(128), 0, (hipStream_t)stream, v, wgt, seg, n, C, B, out, wsum);
   HWG_LAUNCH_CHECK("segment_weighted_mean");
   return HWG_OK;
 }

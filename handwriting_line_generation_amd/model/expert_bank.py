@@ -178,8 +178,8 @@ class _GroupedGN(Function):
         return dx, None, None, None, None, None, None
 
 
-TILE_ROWS = 64          # GT_ROWS of csrc/expert_bank.hip (forward / data gradient)
-WGRAD_TILE_ROWS = 256   # rows per weight-gradient work tile
+TILE_ROWS = 32          # GT_ROWS of csrc/expert_bank.hip (forward / data gradient)
+WGRAD_TILE_ROWS = 64    # rows per weight-gradient work tile (tools/expert_probe.py: 64 beats 128 / 256 - the row loop is a latency chain)
 
 
 def _tiles_host(starts, R, tile_rows):
