@@ -12,7 +12,7 @@ void hwg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* hwg_last_error(void) { return g_err; }
-extern "C" int hwg_abi_version(void) { return 4; }
+extern "C" int hwg_abi_version(void) { return 5; }
 
 #include <atomic>
 static std::atomic<unsigned> g_tuning_epoch{1};

@@ -173,6 +173,13 @@ __device__ __forceinline__ void sample_stats(const InlineStats& is, const Geo& g
   }
 }
 
+// pre-activation value of the forward pass, z = mask * (gamma * xhat + beta), as one fixed sequence of rounded operations: the backward
+// kernels recompute it from x (which they read anyway) to get the activation's gate instead of reading y - relu / leaky relu only need
+// the sign of z - and for that the two sides must agree to the last bit, whatever the compiler would contract where.
+__device__ __forceinline__ float norm_pre(float v, float m, float r, float g, float b, float k) {
+  return __fmul_rn(k, __fmaf_rn(g, __fmul_rn(__fsub_rn(v, m), r), b));
+}
+
 // ---------------- forward stage 3: y = act(mask * (gamma * xhat + beta)) -----------------------------------------------
 __global__ __launch_bounds__(256) void apply_fwd_kernel(const float* x, float* y, Geo g, const float* mean, const float* rstd,
                                                         const float* gamma, const float* beta, int per_sample,
@@ -206,18 +213,20 @@ __global__ __launch_bounds__(256) void apply_fwd_kernel(const float* x, float* y
     const float4 v = *reinterpret_cast<const float4*>(x + off);
     float4 o;
     // keep the reference's operation order (normalise, then affine) for rounding parity
-    o.x = act_apply(k4.x * (g4.x * ((v.x - m4.x) * r4.x) + b4.x), act, slope);
-    o.y = act_apply(k4.y * (g4.y * ((v.y - m4.y) * r4.y) + b4.y), act, slope);
-    o.z = act_apply(k4.z * (g4.z * ((v.z - m4.z) * r4.z) + b4.z), act, slope);
-    o.w = act_apply(k4.w * (g4.w * ((v.w - m4.w) * r4.w) + b4.w), act, slope);
+    o.x = act_apply(norm_pre(v.x, m4.x, r4.x, g4.x, b4.x, k4.x), act, slope);
+    o.y = act_apply(norm_pre(v.y, m4.y, r4.y, g4.y, b4.y, k4.y), act, slope);
+    o.z = act_apply(norm_pre(v.z, m4.z, r4.z, g4.z, b4.z, k4.z), act, slope);
+    o.w = act_apply(norm_pre(v.w, m4.w, r4.w, g4.w, b4.w, k4.w), act, slope);
     (void)sc; (void)sh;
     *reinterpret_cast<float4*>(y + off) = o;
   }
 }
 
 // ---------------- backward stage 1: partial sums of g and g*xhat, g = dy * act'(y) * mask ---------------------------------
+// `y` == null with act = relu / leaky relu: the gate comes from the recomputed pre-activation (gamma, beta as in the forward call)
 __global__ __launch_bounds__(256) void moments_bwd_kernel(const float* dy, const float* x, const float* y, Geo g, double* part,
-                                                          const float* mean, const float* rstd, const float* mask, int act, float slope) {
+                                                          const float* mean, const float* rstd, const float* mask, int act, float slope,
+                                                          const float* gamma, const float* beta, int per_sample) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x;
   const int cl = tid % g.L, pl = tid / g.L;
@@ -232,12 +241,21 @@ __global__ __launch_bounds__(256) void moments_bwd_kernel(const float* dy, const
     const float4 r4 = *reinterpret_cast<const float4*>(rstd + n * g.C + c);
     float4 k4 = make_float4(1.f, 1.f, 1.f, 1.f);
     if (mask) k4 = *reinterpret_cast<const float4*>(mask + n * g.C + c);
+    float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gamma) g4 = *reinterpret_cast<const float4*>(gamma + (per_sample ? n * g.C + c : c));
+    if (beta) b4 = *reinterpret_cast<const float4*>(beta + (per_sample ? n * g.C + c : c));
     for (int p = p0 + pl; p < p1; p += g.PP) {
       const size_t off = ((size_t)n * g.HW + p) * g.C + c;
       float4 d = *reinterpret_cast<const float4*>(dy + off);
       const float4 v = *reinterpret_cast<const float4*>(x + off);
       if (act != 0) {
-        const float4 o = *reinterpret_cast<const float4*>(y + off);
+        float4 o;
+        if (y) {
+          o = *reinterpret_cast<const float4*>(y + off);
+        } else {
+          o.x = norm_pre(v.x, m4.x, r4.x, g4.x, b4.x, k4.x); o.y = norm_pre(v.y, m4.y, r4.y, g4.y, b4.y, k4.y);
+          o.z = norm_pre(v.z, m4.z, r4.z, g4.z, b4.z, k4.z); o.w = norm_pre(v.w, m4.w, r4.w, g4.w, b4.w, k4.w);
+        }
         d.x *= act_grad_from_out(o.x, act, slope); d.y *= act_grad_from_out(o.y, act, slope);
         d.z *= act_grad_from_out(o.z, act, slope); d.w *= act_grad_from_out(o.w, act, slope);
       }
@@ -298,7 +316,7 @@ template <bool PRE>
 __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* dy, const float* x, const float* y, float* dx, Geo g,
                                                         const float* mean, const float* rstd, const float* gamma, int per_sample,
                                                         const float* c1, const float* c2, const float* mask, int act, float slope,
-                                                        const float* noise, float pre_slope, double* part2, InlineStats is) {
+                                                        const float* noise, float pre_slope, double* part2, InlineStats is, const float* beta) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ __attribute__((aligned(16))) float s_a[NS_MAXC];
   __shared__ __attribute__((aligned(16))) float s_b[NS_MAXC];
@@ -321,14 +339,22 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* dy, const f
     if (gamma) g4 = *reinterpret_cast<const float4*>(gamma + (per_sample ? n * g.C + c : c));
     float4 k4 = make_float4(1.f, 1.f, 1.f, 1.f);
     if (mask) k4 = *reinterpret_cast<const float4*>(mask + n * g.C + c);
+    float4 be4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (beta) be4 = *reinterpret_cast<const float4*>(beta + (per_sample ? n * g.C + c : c));
     for (int p = p0 + pl; p < p1; p += g.PP) {
       const size_t off = ((size_t)n * g.HW + p) * g.C + c;
       float4 d = *reinterpret_cast<const float4*>(dy + off);
       const float4 v = *reinterpret_cast<const float4*>(x + off);
       if (act != 0) {
-        const float4 o = *reinterpret_cast<const float4*>(y + off);
-        d.x *= act_grad_from_out(o.x, act, slope); d.y *= act_grad_from_out(o.y, act, slope);
-        d.z *= act_grad_from_out(o.z, act, slope); d.w *= act_grad_from_out(o.w, act, slope);
+        float4 z;
+        if (y) {
+          z = *reinterpret_cast<const float4*>(y + off);
+        } else {     // gate from the recomputed pre-activation (see norm_pre)
+          z.x = norm_pre(v.x, m4.x, r4.x, g4.x, be4.x, k4.x); z.y = norm_pre(v.y, m4.y, r4.y, g4.y, be4.y, k4.y);
+          z.z = norm_pre(v.z, m4.z, r4.z, g4.z, be4.z, k4.z); z.w = norm_pre(v.w, m4.w, r4.w, g4.w, be4.w, k4.w);
+        }
+        d.x *= act_grad_from_out(z.x, act, slope); d.y *= act_grad_from_out(z.y, act, slope);
+        d.z *= act_grad_from_out(z.z, act, slope); d.w *= act_grad_from_out(z.w, act, slope);
       }
       float4 o;
       o.x = r4.x * (d.x * k4.x * g4.x - a4.x - ((v.x - m4.x) * r4.x) * b4.x);
@@ -489,13 +515,16 @@ extern "C" int hwg_norm_fwd(const float* x, float* y, int N, int HW, int C, int 
 }
 
 extern "C" int hwg_norm_bwd(const float* dy, const float* x, const float* y, float* dx, int N, int HW, int C, int mode, int groups,
-                            const float* gamma, int affine_per_sample, const float* chan_mask, int act, float slope,
+                            const float* gamma, const float* beta, int affine_per_sample, const float* chan_mask, int act, float slope,
                             const float* mean, const float* rstd, float* dgamma, float* dbeta, int accumulate,
                             void* ws, size_t ws_bytes, void* stream) {
   int rc = check_geo(N, HW, C, "norm_bwd");
   if (rc) return rc;
   HWG_REQUIRE(dy && x && dx && mean && rstd, "norm_bwd: null pointer");
-  HWG_REQUIRE(act == 0 || y, "norm_bwd: y required when an activation is fused");
+  HWG_REQUIRE(act == 0 || act == HWG_ACT_RELU || act == HWG_ACT_LRELU || y, "norm_bwd: y required when tanh is fused");
+  // relu / leaky relu: the gate is the sign of the forward pre-activation, recomputed from x, the statistics and the affine of the forward
+  // call - two of the seven passes over the tensor (y in both sweeps) are not made
+  if (act == HWG_ACT_RELU || act == HWG_ACT_LRELU) y = nullptr;
   Geo g = make_geo(N, HW, C);
   if (!ws || ws_bytes < hwg_norm_workspace(N, HW, C)) { hwg_set_error("norm_bwd: workspace too small"); return HWG_ERR_WORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
@@ -503,7 +532,8 @@ extern "C" int hwg_norm_bwd(const float* dy, const float* x, const float* y, flo
   float* c1 = (float*)((char*)ws + 2 * part_bytes(g));
   float* c2 = c1 + (size_t)N * C;
   dim3 grid(g.chunks, N);
-  hipLaunchKernelGGL(moments_bwd_kernel, grid, dim3(256), red_smem(g), st, dy, x, y, g, part, mean, rstd, chan_mask, act, slope);
+  hipLaunchKernelGGL(moments_bwd_kernel, grid, dim3(256), red_smem(g), st, dy, x, y, g, part, mean, rstd, chan_mask, act, slope, gamma, beta,
+                     affine_per_sample);
   HWG_LAUNCH_CHECK("norm_bwd.moments");
   InlineStats is = {};
   if (mode == MODE_BN) {
@@ -519,7 +549,7 @@ extern "C" int hwg_norm_bwd(const float* dy, const float* x, const float* y, flo
     HWG_LAUNCH_CHECK("norm_bwd.param_grad");
   }
   hipLaunchKernelGGL(apply_bwd_kernel<false>, grid, dim3(256), 0, st, dy, x, y, dx, g, mean, rstd, gamma, affine_per_sample,
-                     (const float*)c1, (const float*)c2, chan_mask, act, slope, nullptr, 0.f, nullptr, is);
+                     (const float*)c1, (const float*)c2, chan_mask, act, slope, nullptr, 0.f, nullptr, is, beta);
   HWG_LAUNCH_CHECK("norm_bwd.apply");
   return HWG_OK;
 }
@@ -561,13 +591,13 @@ extern "C" int hwg_adain_bwd(const float* dy, const float* u, const float* noise
   float* c2 = c1 + (size_t)N * C;
   dim3 grid(g.chunks, N);
   hipLaunchKernelGGL(moments_bwd_kernel, grid, dim3(256), red_smem(g), st, dy, u, (const float*)nullptr, g, part, mean, rstd,
-                     (const float*)nullptr, 0, 0.f);
+                     (const float*)nullptr, 0, 0.f, (const float*)nullptr, (const float*)nullptr, 0);
   HWG_LAUNCH_CHECK("adain_bwd.moments");
   // dgamma/dbeta are per (n,c) and are NOT accumulated (they feed the style Linear's backward); c1/c2 are formed inside the apply pass
   InlineStats is = {};
   is.part = part; is.cpg = 1; is.gamma = gamma; is.per_sample = 1; is.out_a = dgamma; is.out_b = dbeta; is.accumulate = 0;
   hipLaunchKernelGGL(apply_bwd_kernel<true>, grid, dim3(256), red_smem(g), st, dy, u, (const float*)nullptr, dx, g, mean, rstd, gamma, 1,
-                     (const float*)c1, (const float*)c2, (const float*)nullptr, 0, 0.f, noise, slope, part2, is);
+                     (const float*)c1, (const float*)c2, (const float*)nullptr, 0, 0.f, noise, slope, part2, is, (const float*)nullptr);
   HWG_LAUNCH_CHECK("adain_bwd.apply");
   if (dnoise_w || dbias) {
     hipLaunchKernelGGL(adain_param_grad_kernel, dim3(hwg_cdiv(C, 4)), dim3(256), 0, st, (const double*)part2, g, noise_scale, dbias, dnoise_w,

@@ -156,13 +156,13 @@ class _GroupedGN(Function):
         ws = ops.workspace(L.query("hwg_norm_workspace", n, R, C), x.device)
         L.call("hwg_norm_fwd", x, y, n, R, C, ops.NORM_GN, groups, eps, gamma, beta, 1, None, ops.ACT_RELU, 0.0, mean, rstd, None, None, 0.0,
                ws, ws.numel(), st)
-        ctx.save_for_backward(x, y, gamma, mean, rstd)
+        ctx.save_for_backward(x, y, gamma, beta, mean, rstd)
         ctx.cfg = (bank, gk, bk, plan, groups, n, R, C)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, mean, rstd = ctx.saved_tensors
+        x, y, gamma, beta, mean, rstd = ctx.saved_tensors
         bank, gk, bk, plan, groups, n, R, C = ctx.cfg
         dy = dy.contiguous()
         st = _st()
@@ -170,7 +170,7 @@ class _GroupedGN(Function):
         dgamma = torch.empty((n, C), dtype=torch.float32, device=x.device)
         dbeta = torch.empty_like(dgamma)
         ws = ops.workspace(L.query("hwg_norm_workspace", n, R, C), x.device)
-        L.call("hwg_norm_bwd", dy, x, y, dx, n, R, C, ops.NORM_GN, groups, gamma, 1, None, ops.ACT_RELU, 0.0, mean, rstd, dgamma, dbeta, 0,
+        L.call("hwg_norm_bwd", dy, x, y, dx, n, R, C, ops.NORM_GN, groups, gamma, beta, 1, None, ops.ACT_RELU, 0.0, mean, rstd, dgamma, dbeta, 0,
                ws, ws.numel(), st)
         gp = bank.grad_ptrs(plan, x.device)
         L.call("hwg_segment_accumulate_ptr", dgamma, plan["seg_start"], plan["seg_eid"], plan["G"], gp[gk], C, st)

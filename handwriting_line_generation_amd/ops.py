@@ -694,7 +694,8 @@ class _Norm(Function):
             dgamma = torch.empty((C,), dtype=torch.float32, device=x.device) if gamma is not None else None
             dbeta = torch.empty((C,), dtype=torch.float32, device=x.device) if has_beta else None
         ws = workspace(L.query("hwg_norm_workspace", N, HW, C), x.device)
-        L.call("hwg_norm_bwd", dy, x, y, dx, N, HW, C, mode, groups, gamma, 0, mask, act, slope, mean, rstd, dgamma, dbeta, 1 if direct else 0,
+        # beta: relu / leaky relu gates are recomputed from x and the forward call's affine instead of being read from y (csrc/norm_act.hip)
+        L.call("hwg_norm_bwd", dy, x, y, dx, N, HW, C, mode, groups, gamma, bref if has_beta else None, 0, mask, act, slope, mean, rstd, dgamma, dbeta, 1 if direct else 0,
                ws, ws.numel(), _stream())
         if direct:
             dgamma = dbeta = None

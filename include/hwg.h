@@ -160,6 +160,8 @@ int hwg_colsum(const float* x, long long rows, int C, float* out, int accumulate
  * model/autoencoder.py:346-395,307-330, model/char_style.py:41,91,100,166, model/count_cnn.py:13-21;
  * nn.BatchNorm2d/1d at model/cnn_only_hwr.py:36,80-89; nn.InstanceNorm2d at model/pure_gen.py:56.
  * mean/rstd are [N][C] outputs kept for the backward pass.
+ * hwg_norm_bwd takes the forward call's gamma / beta: with relu / leaky relu fused it recomputes the activation gate (the sign of the
+ * pre-activation, bit-identical to the forward pass) from x instead of reading y - `y` may be NULL then; tanh needs y.
  * ------------------------------------------------------------------------------------------ */
 size_t hwg_norm_workspace(int N, int HW, int C);
 int hwg_norm_fwd(const float* x, float* y, int N, int HW, int C, int mode, int groups, float eps,
@@ -167,7 +169,7 @@ int hwg_norm_fwd(const float* x, float* y, int N, int HW, int C, int mode, int g
                  int act, float slope, float* mean, float* rstd, float* running_mean, float* running_var,
                  float momentum, void* ws, size_t ws_bytes, void* stream);
 int hwg_norm_bwd(const float* dy, const float* x, const float* y, float* dx, int N, int HW, int C, int mode, int groups,
-                 const float* gamma, int affine_per_sample, const float* chan_mask, int act, float slope,
+                 const float* gamma, const float* beta, int affine_per_sample, const float* chan_mask, int act, float slope,
                  const float* mean, const float* rstd, float* dgamma, float* dbeta, int accumulate,
                  void* ws, size_t ws_bytes, void* stream);
 
