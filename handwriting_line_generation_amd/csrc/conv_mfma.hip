@@ -823,6 +823,37 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, lon
     }
   }
 }
+// C <= 8 (bias gradients of the 1- and 2-channel heads): the kernel above would keep 4 of its 256 threads busy. Here every thread owns whole
+// rows (C consecutive floats, neighbouring lanes neighbouring rows), the block combines its 256 row lanes in a fixed tree.
+template <int CC>
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const float* __restrict__ x, long long rows, float* part, long long rows_per_chunk,
+                                                            float* direct_out, int accumulate) {
+  __shared__ double red[256][CC];
+  const long long rb = blockIdx.x * rows_per_chunk;
+  const long long re = min(rb + rows_per_chunk, rows);
+  double s[CC];
+#pragma unroll
+  for (int c = 0; c < CC; ++c) s[c] = 0.0;
+  for (long long r = rb + threadIdx.x; r < re; r += 256) {
+#pragma unroll
+    for (int c = 0; c < CC; ++c) s[c] += (double)x[r * CC + c];
+  }
+#pragma unroll
+  for (int c = 0; c < CC; ++c) red[threadIdx.x][c] = s[c];
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+#pragma unroll
+      for (int c = 0; c < CC; ++c) red[threadIdx.x][c] += red[threadIdx.x + w][c];
+    }
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < CC) {
+    const float v = (float)red[0][threadIdx.x];
+    if (direct_out) direct_out[threadIdx.x] = accumulate ? direct_out[threadIdx.x] + v : v;
+    else part[(long long)blockIdx.x * CC + threadIdx.x] = v;
+  }
+}
 // second stage: 16 columns x 16 chunk lanes per workgroup (fixed combination order -> deterministic)
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, int chunks, int C, float* out, int accumulate) {
   __shared__ float red[16][17];
@@ -1414,7 +1445,14 @@ extern "C" int hwg_colsum(const float* x, long long rows, int C, float* out, int
   hipStream_t st = (hipStream_t)stream;
   const long long chunks = colsum_chunks(rows);
   const long long rpc = (rows + chunks - 1) / chunks;
-  if (C % 4 == 0)
+  float* direct = chunks == 1 ? out : (float*)nullptr;
+  if (C == 1)
+    hipLaunchKernelGGL(colsum_narrow_kernel<1>, dim3((unsigned)chunks), dim3(256), 0, st, x, rows, (float*)workspace, rpc, direct, accumulate);
+  else if (C == 2)
+    hipLaunchKernelGGL(colsum_narrow_kernel<2>, dim3((unsigned)chunks), dim3(256), 0, st, x, rows, (float*)workspace, rpc, direct, accumulate);
+  else if (C == 3)
+    hipLaunchKernelGGL(colsum_narrow_kernel<3>, dim3((unsigned)chunks), dim3(256), 0, st, x, rows, (float*)workspace, rpc, direct, accumulate);
+  else if (C % 4 == 0)
     hipLaunchKernelGGL(colsum_partial_kernel<4>, dim3((unsigned)chunks, hwg_cdiv(C, 64)), dim3(256), 0, st, x, rows, C, (float*)workspace, rpc,
                        chunks == 1 ? out : (float*)nullptr, accumulate);
   else

@@ -358,6 +358,22 @@ def _full_size_reference(shape, x, w, b):
     return _FULL_REF[shape]
 
 
+@pytest.mark.parametrize("rows,C", [(1, 1), (300, 1), (262144, 1), (70000, 2), (1000, 3), (5000, 5), (4097, 49), (30000, 64)])
+def test_colsum(cuda, rows, C):
+    """column sums (bias gradients outside the fused paths): narrow (C <= 3), scalar and float4 kernels, one and many chunks, accumulate"""
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g)
+    ref = x.double().sum(0)
+    xd = x.to(cuda)
+    out = ops.colsum(xd)
+    tol = 1e-6 * max(1.0, float(x.abs().double().sum(0).max()))
+    assert float((out.cpu().double() - ref).abs().max()) <= tol
+    base = torch.randn(C, generator=g)
+    out2 = ops.colsum(xd, out=base.to(cuda), accumulate=True)
+    assert float((out2.cpu().double() - (ref + base.double())).abs().max()) <= tol + 1e-6 * float(base.abs().max())
+
+
 def test_linear(cuda):
     from handwriting_line_generation_amd import ops
     g = torch.Generator().manual_seed(3)
