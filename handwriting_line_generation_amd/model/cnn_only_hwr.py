@@ -51,14 +51,22 @@ class CNNOnlyHWR(nn.Module):
         layers += [Conv1d(size1d, nclass, 3, 1, 0, 1), Marker("log softmax")]
         self.cnn1d = nn.Sequential(*layers)
 
-    def _conv_block(self, i, x):
+    def _conv_block(self, i, x, pool=None):
+        """conv (+norm) + ReLU, followed by the max-pool `pool` = (kernel, stride, padding) of the reference's Sequential when there is one"""
         conv = getattr(self.cnn, "conv%d" % i)
         if i in self.NORMED and self.norm_kind is not None:
             h = conv(x)
             norm = getattr(self.cnn, ("groupnorm%d" if self.norm_kind == "group" else "batchnorm%d") % i)
-            return norm(h, "relu")
+            h = norm(h, "relu")
+            return ops.max_pool2d(h, *pool) if pool else h
         # the bias is added in the conv epilogue (its gradient then rides along in the weight-gradient kernel); ReLU is one elementwise pass
-        return ops.bias_act(ops.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation), None, None, ops.ACT_RELU)
+        h = ops.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation)
+        if pool:
+            # ReLU after the pool instead of before it: max and ReLU are both monotone, relu(max(w)) == max(relu(w)) exactly, and the two
+            # orders route the gradient to the same window element wherever it is not zero anyway (a window whose maximum is <= 0 passes
+            # nothing back in either order) - same bits forward and backward, with the ReLU passes over a half / quarter of the pixels
+            h = ops.max_pool2d(h, *pool)
+        return ops.bias_act(h, None, None, ops.ACT_RELU)
 
     logit_offset = None
 
@@ -71,16 +79,12 @@ class CNNOnlyHWR(nn.Module):
         x = ops.to_nhwc(input)
         if self.pad_cols:
             x = ops.pad2d(x, self.pad_cols, self.pad_cols, 0, 0, "constant", 0.0)
-        x = self._conv_block(0, x)
-        x = ops.max_pool2d(x, 2, 2)
-        x = self._conv_block(1, x)
-        x = ops.max_pool2d(x, 2, 2)
+        x = self._conv_block(0, x, (2, 2))
+        x = self._conv_block(1, x, (2, 2))
         x = self._conv_block(2, x)
-        x = self._conv_block(3, x)
-        x = ops.max_pool2d(x, (2, 2), (2, 1), (0, 1))
+        x = self._conv_block(3, x, ((2, 2), (2, 1), (0, 1)))
         x = self._conv_block(4, x)
-        x = self._conv_block(5, x)
-        x = ops.max_pool2d(x, (2, 2), (2, 1), (0, 1))
+        x = self._conv_block(5, x, ((2, 2), (2, 1), (0, 1)))
         x = self._conv_block(6, x)
         B, H, W, C = x.shape
         if H != 1:
