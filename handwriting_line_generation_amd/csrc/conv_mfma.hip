@@ -34,9 +34,11 @@ struct ConvK {
 // for each other). 2: the loads of step t+2 are issued before the MFMAs of step t (two register sets): small layers run one 4-wave
 // workgroup per CU, a step is ~1000 matrix-core cycles and an L2 / HBM round trip 2000-4000, so with depth 1 such a workgroup sits in
 // s_waitcnt for most of every step.
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int PF = 1>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK a) {
-  constexpr int NT = 64 * WAVES_M * WAVES_N;  // 4 or 8 wavefronts per workgroup
+// WK > 1: WK wavefronts share every (M, N) sub-tile and split each K step between them (their partial sums meet in LDS once, at the end):
+// a second wavefront per SIMD for layers whose grid is one small workgroup per CU, without a second launch to add partial images.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int PF = 1, int WK = 1>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(ConvK a) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N * WK;  // 4, 8 or 16 wavefronts per workgroup
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MI = WM / 32, NI = WN / 32;
   static_assert(MI >= 1 && NI >= 1, "wave tile must be at least 32x32");
@@ -183,8 +185,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
     }
   };
 
-  const int wm0 = (wid / WAVES_N) * WM;
-  const int wn0 = (wid % WAVES_N) * WN;
+  constexpr int WMN = WAVES_M * WAVES_N;
+  const int wk = wid / WMN, wmn = wid % WMN;
+  const int wm0 = (wmn / WAVES_N) * WM;
+  const int wn0 = (wmn % WAVES_N) * WN;
   const int l31 = lane & 31;
   const int lhi = lane >> 5;
 
@@ -196,10 +200,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
     // is the operand of the j-th MFMA of this group. A and B use the same mapping, so MFMA j contracts
     // k = {8sg+j, 8sg+4+j}: a permutation of the K order, which the sum does not care about.
     // Software pipeline: the fragment reads of group sg+1 are issued before the MFMAs of group sg.
-    constexpr int NSG = BK / 8;
+    constexpr int NSG = BK / 8 / WK;        // groups of 8 k values of this wavefront's share of the step
+    static_assert(NSG >= 1, "K step too short for the K-split wavefronts");
     float4 af[2][MI], bf[2][NI];
     auto frag = [&](int sg, int slot) {
-      const int koff = 4 * (2 * sg + lhi);
+      const int koff = 4 * (2 * (wk * NSG + sg) + lhi);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) af[slot][mi] = *reinterpret_cast<const float4*>(Ab + (wm0 + mi * 32 + l31) * LD + koff);
 #pragma unroll
@@ -276,6 +281,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_kernel(ConvK
     }
   }
 
+  if constexpr (WK > 1) {
+    // the K-split wavefronts' partial sums meet in LDS (the tile buffers are free after the loop's last barrier); wavefront group 0 adds
+    // them in group order and writes the output
+    float* red = smem;
+    if (wk > 0) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) red[((((wk - 1) * WMN + wmn) * MI * NI + mi * NI + ni) * 16 + e) * 64 + lane] = acc[mi][ni][e];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int w = 1; w < WK; ++w)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[mi][ni][e] += red[((((w - 1) * WMN + wmn) * MI * NI + mi * NI + ni) * 16 + e) * 64 + lane];
+  }
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   float bv[NI];
 #pragma unroll
@@ -874,6 +902,12 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, in
 
 template <int BM, int BN, int BK, int WM_, int WN_>
 void launch_conv(const ConvK& k, dim3 grid, hipStream_t st, int pf) {
+  if constexpr (BM == 64 && BN == 64) {
+    if (hwg_tune().conv_wk == 2) {       // K-split wavefront pairs (8 wavefronts on the 64 x 64 tile)
+      hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 3, 2>), grid, dim3(128 * WM_ * WN_), 0, st, k);
+      return;
+    }
+  }
   if (pf == 3) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 3>), grid, dim3(64 * WM_ * WN_), 0, st, k);
   else if (pf == 2) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 2>), grid, dim3(64 * WM_ * WN_), 0, st, k);
   else hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 1>), grid, dim3(64 * WM_ * WN_), 0, st, k);
