@@ -903,7 +903,10 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* part, in
 template <int BM, int BN, int BK, int WM_, int WN_>
 void launch_conv(const ConvK& k, dim3 grid, hipStream_t st, int pf) {
   if constexpr (BM == 64 && BN == 64) {
-    if (hwg_tune().conv_wk == 2) {       // K-split wavefront pairs (8 wavefronts on the 64 x 64 tile)
+    // K-split wavefront pairs on the 4-wavefront 64 x 64 tile (8 wavefronts): 42.2 -> 37.6 us on 8x8x122x128->128, 32.8 -> 29.4 us on
+    // the recogniser's 1x3 layers, 20.9 -> 19.2 us on the generator's 4x4 stride-2 layer (tools/probe_r3_wk.txt); four-way splits and
+    // the 128 x 32 tile measured no better (HWG_CONV_WK=1 restores the 4-wavefront kernel for A/B runs)
+    if (hwg_tune().conv_wk >= 2) {
       hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 3, 2>), grid, dim3(128 * WM_ * WN_), 0, st, k);
       return;
     }
