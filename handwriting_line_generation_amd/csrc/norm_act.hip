@@ -9,6 +9,7 @@
 namespace {
 
 enum { MODE_IN = 0, MODE_GN = 1, MODE_BN = 2 };
+constexpr int NU = 4;   // pixels in flight per thread in the streaming loops
 
 struct Geo {
   int N, HW, C, C4, L, PP, chunks, cs;
@@ -70,18 +71,33 @@ __global__ __launch_bounds__(256) void moments_fwd_kernel(const float* x, Geo g,
     w4.x *= nscale; w4.y *= nscale; w4.z *= nscale; w4.w *= nscale;
   }
   if (pl < g.PP) {
-    for (int p = p0 + pl; p < p1; p += g.PP) {
-      const size_t off = ((size_t)n * g.HW + p) * g.C + cl * 4;
-      float4 v = *reinterpret_cast<const float4*>(x + off);
-      if (NOISE) {
-        const float4 nz = *reinterpret_cast<const float4*>(noise + off);
-        v.x += w4.x * nz.x; v.y += w4.y * nz.y; v.z += w4.z * nz.z; v.w += w4.w * nz.w;
-        v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
-        v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
-        *reinterpret_cast<float4*>(u + off) = v;
+    // NU pixels per trip, all their loads issued before the first is used: a workgroup makes only ~8 passes over its chunk, so with one
+    // pixel per trip the kernel's time is 8 exposed memory latencies (the tensors of an 8-line batch are too small to hide them behind
+    // other workgroups); pixels past the chunk re-read pixel p and are skipped. Same accumulation order as the one-pixel loop.
+    for (int p = p0 + pl; p < p1; p += NU * g.PP) {
+      float4 vv[NU], nn[NU];
+      size_t offs[NU];
+#pragma unroll
+      for (int q = 0; q < NU; ++q) {
+        const int pp = p + q * g.PP;
+        offs[q] = ((size_t)n * g.HW + (pp < p1 ? pp : p)) * g.C + cl * 4;
+        vv[q] = *reinterpret_cast<const float4*>(x + offs[q]);
+        if (NOISE) nn[q] = *reinterpret_cast<const float4*>(noise + offs[q]);
       }
-      acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
-      acc[1].x += v.x * v.x; acc[1].y += v.y * v.y; acc[1].z += v.z * v.z; acc[1].w += v.w * v.w;
+#pragma unroll
+      for (int q = 0; q < NU; ++q) {
+        if (p + q * g.PP >= p1) break;
+        float4 v = vv[q];
+        if (NOISE) {
+          const float4 nz = nn[q];
+          v.x += w4.x * nz.x; v.y += w4.y * nz.y; v.z += w4.z * nz.z; v.w += w4.w * nz.w;
+          v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+          v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+          *reinterpret_cast<float4*>(u + offs[q]) = v;
+        }
+        acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+        acc[1].x += v.x * v.x; acc[1].y += v.y * v.y; acc[1].z += v.z * v.z; acc[1].w += v.w * v.w;
+      }
     }
   }
   block_reduce_store<2>(acc, g, part, sm);
@@ -208,17 +224,28 @@ __global__ __launch_bounds__(256) void apply_fwd_kernel(const float* x, float* y
   sc.y = k4.y * g4.y * r4.y; sh.y = k4.y * (b4.y - g4.y * r4.y * m4.y);
   sc.z = k4.z * g4.z * r4.z; sh.z = k4.z * (b4.z - g4.z * r4.z * m4.z);
   sc.w = k4.w * g4.w * r4.w; sh.w = k4.w * (b4.w - g4.w * r4.w * m4.w);
-  for (int p = p0 + pl; p < p1; p += g.PP) {
-    const size_t off = ((size_t)n * g.HW + p) * g.C + c;
-    const float4 v = *reinterpret_cast<const float4*>(x + off);
-    float4 o;
-    // keep the reference's operation order (normalise, then affine) for rounding parity
-    o.x = act_apply(norm_pre(v.x, m4.x, r4.x, g4.x, b4.x, k4.x), act, slope);
-    o.y = act_apply(norm_pre(v.y, m4.y, r4.y, g4.y, b4.y, k4.y), act, slope);
-    o.z = act_apply(norm_pre(v.z, m4.z, r4.z, g4.z, b4.z, k4.z), act, slope);
-    o.w = act_apply(norm_pre(v.w, m4.w, r4.w, g4.w, b4.w, k4.w), act, slope);
+  for (int p = p0 + pl; p < p1; p += NU * g.PP) {
+    float4 vv[NU];
+    size_t offs[NU];
+#pragma unroll
+    for (int q = 0; q < NU; ++q) {
+      const int pp = p + q * g.PP;
+      offs[q] = ((size_t)n * g.HW + (pp < p1 ? pp : p)) * g.C + c;
+      vv[q] = *reinterpret_cast<const float4*>(x + offs[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NU; ++q) {
+      if (p + q * g.PP >= p1) break;
+      const float4 v = vv[q];
+      float4 o;
+      // keep the reference's operation order (normalise, then affine) for rounding parity
+      o.x = act_apply(norm_pre(v.x, m4.x, r4.x, g4.x, b4.x, k4.x), act, slope);
+      o.y = act_apply(norm_pre(v.y, m4.y, r4.y, g4.y, b4.y, k4.y), act, slope);
+      o.z = act_apply(norm_pre(v.z, m4.z, r4.z, g4.z, b4.z, k4.z), act, slope);
+      o.w = act_apply(norm_pre(v.w, m4.w, r4.w, g4.w, b4.w, k4.w), act, slope);
+      *reinterpret_cast<float4*>(y + offs[q]) = o;
+    }
     (void)sc; (void)sh;
-    *reinterpret_cast<float4*>(y + off) = o;
   }
 }
 
@@ -244,14 +271,25 @@ __global__ __launch_bounds__(256) void moments_bwd_kernel(const float* dy, const
     float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (gamma) g4 = *reinterpret_cast<const float4*>(gamma + (per_sample ? n * g.C + c : c));
     if (beta) b4 = *reinterpret_cast<const float4*>(beta + (per_sample ? n * g.C + c : c));
-    for (int p = p0 + pl; p < p1; p += g.PP) {
-      const size_t off = ((size_t)n * g.HW + p) * g.C + c;
-      float4 d = *reinterpret_cast<const float4*>(dy + off);
-      const float4 v = *reinterpret_cast<const float4*>(x + off);
+    for (int p = p0 + pl; p < p1; p += NU * g.PP) {
+     float4 dd[NU], vv[NU], yy[NU];
+#pragma unroll
+     for (int q = 0; q < NU; ++q) {
+       const int pp = p + q * g.PP;
+       const size_t off = ((size_t)n * g.HW + (pp < p1 ? pp : p)) * g.C + c;
+       dd[q] = *reinterpret_cast<const float4*>(dy + off);
+       vv[q] = *reinterpret_cast<const float4*>(x + off);
+       if (act != 0 && y) yy[q] = *reinterpret_cast<const float4*>(y + off);
+     }
+#pragma unroll
+     for (int q = 0; q < NU; ++q) {
+      if (p + q * g.PP >= p1) break;
+      float4 d = dd[q];
+      const float4 v = vv[q];
       if (act != 0) {
         float4 o;
         if (y) {
-          o = *reinterpret_cast<const float4*>(y + off);
+          o = yy[q];
         } else {
           o.x = norm_pre(v.x, m4.x, r4.x, g4.x, b4.x, k4.x); o.y = norm_pre(v.y, m4.y, r4.y, g4.y, b4.y, k4.y);
           o.z = norm_pre(v.z, m4.z, r4.z, g4.z, b4.z, k4.z); o.w = norm_pre(v.w, m4.w, r4.w, g4.w, b4.w, k4.w);
@@ -263,6 +301,7 @@ __global__ __launch_bounds__(256) void moments_bwd_kernel(const float* dy, const
       acc[0].x += d.x; acc[0].y += d.y; acc[0].z += d.z; acc[0].w += d.w;
       acc[1].x += d.x * ((v.x - m4.x) * r4.x); acc[1].y += d.y * ((v.y - m4.y) * r4.y);
       acc[1].z += d.z * ((v.z - m4.z) * r4.z); acc[1].w += d.w * ((v.w - m4.w) * r4.w);
+     }
     }
   }
   block_reduce_store<2>(acc, g, part, sm);
@@ -341,14 +380,28 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* dy, const f
     if (mask) k4 = *reinterpret_cast<const float4*>(mask + n * g.C + c);
     float4 be4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (beta) be4 = *reinterpret_cast<const float4*>(beta + (per_sample ? n * g.C + c : c));
-    for (int p = p0 + pl; p < p1; p += g.PP) {
-      const size_t off = ((size_t)n * g.HW + p) * g.C + c;
-      float4 d = *reinterpret_cast<const float4*>(dy + off);
-      const float4 v = *reinterpret_cast<const float4*>(x + off);
+    for (int p = p0 + pl; p < p1; p += NU * g.PP) {
+     float4 dd[NU], vv[NU], yy[NU], nn[NU];
+     size_t offs[NU];
+#pragma unroll
+     for (int q = 0; q < NU; ++q) {
+       const int pp = p + q * g.PP;
+       offs[q] = ((size_t)n * g.HW + (pp < p1 ? pp : p)) * g.C + c;
+       dd[q] = *reinterpret_cast<const float4*>(dy + offs[q]);
+       vv[q] = *reinterpret_cast<const float4*>(x + offs[q]);
+       if (act != 0 && y) yy[q] = *reinterpret_cast<const float4*>(y + offs[q]);
+       if (PRE) nn[q] = *reinterpret_cast<const float4*>(noise + offs[q]);
+     }
+#pragma unroll
+     for (int q = 0; q < NU; ++q) {
+      if (p + q * g.PP >= p1) break;
+      const size_t off = offs[q];
+      float4 d = dd[q];
+      const float4 v = vv[q];
       if (act != 0) {
         float4 z;
         if (y) {
-          z = *reinterpret_cast<const float4*>(y + off);
+          z = yy[q];
         } else {     // gate from the recomputed pre-activation (see norm_pre)
           z.x = norm_pre(v.x, m4.x, r4.x, g4.x, be4.x, k4.x); z.y = norm_pre(v.y, m4.y, r4.y, g4.y, be4.y, k4.y);
           z.z = norm_pre(v.z, m4.z, r4.z, g4.z, be4.z, k4.z); z.w = norm_pre(v.w, m4.w, r4.w, g4.w, be4.w, k4.w);
@@ -365,11 +418,12 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* dy, const f
         // x here is u (the lrelu output that was normalised)
         o.x *= v.x > 0.f ? 1.f : pre_slope; o.y *= v.y > 0.f ? 1.f : pre_slope;
         o.z *= v.z > 0.f ? 1.f : pre_slope; o.w *= v.w > 0.f ? 1.f : pre_slope;
-        const float4 nz = *reinterpret_cast<const float4*>(noise + off);
+        const float4 nz = nn[q];
         acc[0].x += o.x; acc[0].y += o.y; acc[0].z += o.z; acc[0].w += o.w;
         acc[1].x += o.x * nz.x; acc[1].y += o.y * nz.y; acc[1].z += o.z * nz.z; acc[1].w += o.w * nz.w;
       }
       *reinterpret_cast<float4*>(dx + off) = o;
+     }
     }
   }
   if (PRE) block_reduce_store<2>(acc, g, part2, sm);
