@@ -9,6 +9,8 @@
 
 namespace {
 
+constexpr int MT_U = 4;   // 16-byte pieces per stream in flight per thread in the multi-tensor streaming loops
+
 struct MtArgs {
   const long long* pa;
   const long long* pb;
@@ -102,12 +104,22 @@ __global__ __launch_bounds__(256) void mt_axpy_kernel(MtArgs a, const float* coe
   const long long n4 = al ? (end - off) >> 2 : 0;
   float4* d4 = reinterpret_cast<float4*>(dst + off);
   const float4* s4 = reinterpret_cast<const float4*>(src + off);
-#pragma unroll 4
-  for (long long j = threadIdx.x; j < n4; j += 256) {
-    float4 d = d4[j];
-    const float4 v = s4[j];
-    d.x += c * v.x; d.y += c * v.y; d.z += c * v.z; d.w += c * v.w;
-    d4[j] = d;
+  // MT_U 16-byte pieces per stream in flight per thread: the loads of a trip are issued before its first store (the compiler may not move a
+  // load across a store through a pointer that could alias it, so the plain loop ran one piece at a time)
+  for (long long j = threadIdx.x; j < n4; j += MT_U * 256) {
+    float4 d[MT_U], v[MT_U];
+#pragma unroll
+    for (int u = 0; u < MT_U; ++u) {
+      const long long ju = j + u * 256 < n4 ? j + u * 256 : j;
+      d[u] = d4[ju];
+      v[u] = s4[ju];
+    }
+#pragma unroll
+    for (int u = 0; u < MT_U; ++u) {
+      if (j + u * 256 >= n4) break;
+      d[u].x += c * v[u].x; d[u].y += c * v[u].y; d[u].z += c * v[u].z; d[u].w += c * v[u].w;
+      d4[j + u * 256] = d[u];
+    }
   }
   for (long long i = off + 4 * n4 + threadIdx.x; i < end; i += 256) dst[i] += c * src[i];
 }
@@ -126,14 +138,23 @@ __global__ __launch_bounds__(256) void mt_unary_kernel(MtArgs a, int op, float c
   float4* x4 = reinterpret_cast<float4*>(x + off);
   float4* y4 = y ? reinterpret_cast<float4*>(y + off) : nullptr;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-  for (long long j = threadIdx.x; j < n4; j += 256) {
-    const float4 v = x4[j];
-    if (op == 0) x4[j] = zero4;
-    else if (op == 1) x4[j] = make_float4(fminf(fmaxf(v.x, -c), c), fminf(fmaxf(v.y, -c), c), fminf(fmaxf(v.z, -c), c), fminf(fmaxf(v.w, -c), c));
-    else if (op == 2) bad |= !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
-    else if (op == 3) { if (y4) y4[j] = v; }
-    else { if (y4) y4[j] = v; x4[j] = zero4; }
+  for (long long j0 = threadIdx.x; j0 < n4; j0 += MT_U * 256) {
+    float4 vv[MT_U];
+    if (op != 0) {
+#pragma unroll
+      for (int u = 0; u < MT_U; ++u) vv[u] = x4[j0 + u * 256 < n4 ? j0 + u * 256 : j0];
+    }
+#pragma unroll
+    for (int u = 0; u < MT_U; ++u) {
+      const long long j = j0 + u * 256;
+      if (j >= n4) break;
+      const float4 v = vv[u];
+      if (op == 0) x4[j] = zero4;
+      else if (op == 1) x4[j] = make_float4(fminf(fmaxf(v.x, -c), c), fminf(fmaxf(v.y, -c), c), fminf(fmaxf(v.z, -c), c), fminf(fmaxf(v.w, -c), c));
+      else if (op == 2) bad |= !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+      else if (op == 3) { if (y4) y4[j] = v; }
+      else { if (y4) y4[j] = v; x4[j] = zero4; }
+    }
   }
   for (long long i = off + 4 * n4 + threadIdx.x; i < end; i += 256) {
     const float v = x[i];
@@ -165,24 +186,34 @@ __global__ __launch_bounds__(256) void mt_adam_kernel(MtArgs a, const float* ste
   float4* g4 = reinterpret_cast<float4*>(g + off);
   float4* m4 = reinterpret_cast<float4*>(m + off);
   float4* v4 = reinterpret_cast<float4*>(v + off);
-#pragma unroll 2
-  for (long long j = threadIdx.x; j < n4; j += 256) {
-    float4 gq = g4[j], mq = m4[j], vq = v4[j], pq = p4[j];
-    float* gp = reinterpret_cast<float*>(&gq); float* mp = reinterpret_cast<float*>(&mq);
-    float* vp = reinterpret_cast<float*>(&vq); float* pp = reinterpret_cast<float*>(&pq);
+  constexpr int AU = 2;     // two pieces of each of the four streams in flight per thread
+  for (long long j0 = threadIdx.x; j0 < n4; j0 += AU * 256) {
+    float4 gq[AU], mq[AU], vq[AU], pq[AU];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float gi = gp[e];
-      if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
-      gp[e] = gi;
-      const float mi = mp[e] + (gi - mp[e]) * (1.f - beta1);
-      const float vi = vp[e] * beta2 + (1.f - beta2) * gi * gi;
-      mp[e] = mi; vp[e] = vi;
-      const float denom = sqrtf(vi) / b2 + eps;
-      pp[e] = pp[e] - ss * (mi / denom);
+    for (int u = 0; u < AU; ++u) {
+      const long long ju = j0 + u * 256 < n4 ? j0 + u * 256 : j0;
+      gq[u] = g4[ju]; mq[u] = m4[ju]; vq[u] = v4[ju]; pq[u] = p4[ju];
     }
-    if (clip > 0.f) g4[j] = gq;
-    m4[j] = mq; v4[j] = vq; p4[j] = pq;
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+      const long long j = j0 + u * 256;
+      if (j >= n4) break;
+      float* gp = reinterpret_cast<float*>(&gq[u]); float* mp = reinterpret_cast<float*>(&mq[u]);
+      float* vp = reinterpret_cast<float*>(&vq[u]); float* pp = reinterpret_cast<float*>(&pq[u]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float gi = gp[e];
+        if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+        gp[e] = gi;
+        const float mi = mp[e] + (gi - mp[e]) * (1.f - beta1);
+        const float vi = vp[e] * beta2 + (1.f - beta2) * gi * gi;
+        mp[e] = mi; vp[e] = vi;
+        const float denom = sqrtf(vi) / b2 + eps;
+        pp[e] = pp[e] - ss * (mi / denom);
+      }
+      if (clip > 0.f) g4[j] = gq[u];
+      m4[j] = mq[u]; v4[j] = vq[u]; p4[j] = pq[u];
+    }
   }
   for (long long i = off + 4 * n4 + threadIdx.x; i < end; i += 256) {
     float gi = g[i];
