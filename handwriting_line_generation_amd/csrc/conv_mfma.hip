@@ -355,7 +355,8 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const float* par
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
       if (bias) {
-        const float4 b = *reinterpret_cast<const float4*>(bias + (int)((4 * i) % K));
+        const int kb = total < (1ll << 32) ? (int)((unsigned)(4 * i) % (unsigned)K) : (int)((4 * i) % K);   // 64-bit division: ~40 VALU instructions
+        const float4 b = *reinterpret_cast<const float4*>(bias + kb);
         s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
       }
       if (accumulate) {
@@ -636,10 +637,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       for (int u = 0; u < 4; ++u) dbias[k + u] = bias_accumulate ? dbias[k + u] + e[u] : e[u];
       continue;
     }
-    const int c = (int)(i % C);
-    const long long t = i / C;
-    const int k = (int)(t % K);
-    const int tap = (int)(t / K);
+    const unsigned iu = (unsigned)i, t = iu / (unsigned)C;       // 32-bit: a weight image has far fewer than 2^31 elements
+    const int c = (int)(iu - t * C);
+    const int tap = (int)(t / (unsigned)K);
+    const int k = (int)(t - (unsigned)tap * K);
     const long long o = k * sa + c * sb + (tap / S) * sr + (tap % S) * ss;
 #pragma unroll
     for (int u = 0; u < 4; ++u) dw[o + u * sb] = accumulate ? dw[o + u * sb] + e[u] : e[u];
@@ -659,10 +660,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* _
       dbias[k] = bias_accumulate ? dbias[k] + sum : sum;
       continue;
     }
-    const int c = (int)(i % C);
-    const long long t = i / C;
-    const int k = (int)(t % K);
-    const int tap = (int)(t / K);
+    const unsigned iu = (unsigned)i, t = iu / (unsigned)C;
+    const int c = (int)(iu - t * C);
+    const int tap = (int)(t / (unsigned)K);
+    const int k = (int)(t - (unsigned)tap * K);
     const long long o = k * sa + c * sb + (tap / S) * sr + (tap % S) * ss;
     dw[o] = accumulate ? dw[o] + sum : sum;
   }
@@ -694,10 +695,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_lanes_kernel(const float* pa
       dbias[kb] = bias_accumulate ? dbias[kb] + t : t;
       return;
     }
-    const int c = (int)(i % C);
-    const long long q = i / C;
-    const int k = (int)(q % K);
-    const int tap = (int)(q / K);
+    const unsigned iu = (unsigned)i, q = iu / (unsigned)C;
+    const int c = (int)(iu - q * C);
+    const int tap = (int)(q / (unsigned)K);
+    const int k = (int)(q - (unsigned)tap * K);
     const long long o = k * sa + c * sb + (tap / S) * sr + (tap % S) * ss;
     dw[o] = accumulate ? dw[o] + t : t;
   }
@@ -1365,6 +1366,7 @@ static WgPlan plan_wgrad_tapn(const hwg_conv_desc* d) {
 int hwg_wgrad_reduce_launch(const float* part, float* dw, int nsplit, int RS, int S, int K, int C, long long sa, long long sb, long long sr,
                             long long ss, int accumulate, long long pstride, float* dbias, int bias_accumulate, hipStream_t st) {
   const long long total = (long long)RS * K * C + (dbias ? K : 0);
+  if (total >= (1ll << 31)) { hwg_set_error("wgrad_reduce: weight image too large for 32-bit element indices"); return HWG_ERR_ARG; }
   // large filters cut into few ranges (the 256..512-channel layers): row-contiguous stores. Measured (tools/probe_r3_reduce.txt, whole weight
   // gradient): 512x512x3x3 / 4 images 144 -> 138 us, 256x256x3x3 / 16 images 48.7 -> 45.0 us, 512x512x1x3 / 4 images 32.6 -> 31.0 us; with many
   // images of a small filter the lane-split kernels below stay ahead (128x128x3x3 / 62 images 38 vs 44 us).

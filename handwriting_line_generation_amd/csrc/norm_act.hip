@@ -448,42 +448,59 @@ __global__ __launch_bounds__(256) void adain_param_grad_kernel(const double* par
 }
 
 // ---------------- plain elementwise: y = act(mask * (x + bias)) and its backward ----------------------------------------------
-__global__ void bias_act_fwd_kernel(const float* x, const float* bias, const float* mask, float* y, long long rows, int HW, int C,
-                                    int act, float slope) {
-  const long long total4 = rows * C / 4;
-  const int C4 = C / 4;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    const long long row = i / C4;
-    float4 v = reinterpret_cast<const float4*>(x)[i];
-    if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-    if (mask) {
-      const float4 k = *reinterpret_cast<const float4*>(mask + (row / HW) * C + c);
-      v.x *= k.x; v.y *= k.y; v.z *= k.z; v.w *= k.w;
+// IDX: the element needs its channel (bias) / sample (mask) coordinates; without either (the ReLU-only passes) no index arithmetic at all.
+// 32-bit indices (the entry points check the size), two 16-byte pieces per stream in flight per thread.
+template <bool IDX>
+__global__ __launch_bounds__(256) void bias_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ mask,
+                                                           float* __restrict__ y, unsigned total4, int HW, int C, int act, float slope) {
+  const unsigned C4 = C / 4, stride = gridDim.x * blockDim.x;
+  for (unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < total4; i0 += 2 * stride) {
+    const unsigned i1 = i0 + stride < total4 ? i0 + stride : i0;
+    float4 v[2] = {reinterpret_cast<const float4*>(x)[i0], reinterpret_cast<const float4*>(x)[i1]};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const unsigned i = u ? i1 : i0;
+      if (u && i1 == i0) break;
+      float4 w = v[u];
+      if (IDX) {
+        const unsigned row = i / C4, c = (i - row * C4) * 4;
+        if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + c); w.x += b.x; w.y += b.y; w.z += b.z; w.w += b.w; }
+        if (mask) {
+          const float4 k = *reinterpret_cast<const float4*>(mask + (size_t)(row / HW) * C + c);
+          w.x *= k.x; w.y *= k.y; w.z *= k.z; w.w *= k.w;
+        }
+      }
+      w.x = act_apply(w.x, act, slope); w.y = act_apply(w.y, act, slope);
+      w.z = act_apply(w.z, act, slope); w.w = act_apply(w.w, act, slope);
+      reinterpret_cast<float4*>(y)[i] = w;
     }
-    v.x = act_apply(v.x, act, slope); v.y = act_apply(v.y, act, slope);
-    v.z = act_apply(v.z, act, slope); v.w = act_apply(v.w, act, slope);
-    reinterpret_cast<float4*>(y)[i] = v;
   }
 }
-__global__ void bias_act_bwd_kernel(const float* dy, const float* y, const float* mask, float* dx, long long rows, int HW, int C,
-                                    int act, float slope) {
-  const long long total4 = rows * C / 4;
-  const int C4 = C / 4;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    const long long row = i / C4;
-    float4 d = reinterpret_cast<const float4*>(dy)[i];
-    if (act != 0) {
-      const float4 o = reinterpret_cast<const float4*>(y)[i];
-      d.x *= act_grad_from_out(o.x, act, slope); d.y *= act_grad_from_out(o.y, act, slope);
-      d.z *= act_grad_from_out(o.z, act, slope); d.w *= act_grad_from_out(o.w, act, slope);
+template <bool IDX>
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ mask,
+                                                           float* __restrict__ dx, unsigned total4, int HW, int C, int act, float slope) {
+  const unsigned C4 = C / 4, stride = gridDim.x * blockDim.x;
+  for (unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < total4; i0 += 2 * stride) {
+    const unsigned i1 = i0 + stride < total4 ? i0 + stride : i0;
+    float4 d[2] = {reinterpret_cast<const float4*>(dy)[i0], reinterpret_cast<const float4*>(dy)[i1]};
+    float4 o[2];
+    if (act != 0) { o[0] = reinterpret_cast<const float4*>(y)[i0]; o[1] = reinterpret_cast<const float4*>(y)[i1]; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const unsigned i = u ? i1 : i0;
+      if (u && i1 == i0) break;
+      float4 w = d[u];
+      if (act != 0) {
+        w.x *= act_grad_from_out(o[u].x, act, slope); w.y *= act_grad_from_out(o[u].y, act, slope);
+        w.z *= act_grad_from_out(o[u].z, act, slope); w.w *= act_grad_from_out(o[u].w, act, slope);
+      }
+      if (IDX) {
+        const unsigned row = i / C4, c = (i - row * C4) * 4;
+        const float4 k = *reinterpret_cast<const float4*>(mask + (size_t)(row / HW) * C + c);
+        w.x *= k.x; w.y *= k.y; w.z *= k.z; w.w *= k.w;
+      }
+      reinterpret_cast<float4*>(dx)[i] = w;
     }
-    if (mask) {
-      const float4 k = *reinterpret_cast<const float4*>(mask + (row / HW) * C + c);
-      d.x *= k.x; d.y *= k.y; d.z *= k.z; d.w *= k.w;
-    }
-    reinterpret_cast<float4*>(dx)[i] = d;
   }
 }
 // scalar-tail versions for C % 4 != 0 (tiny tensors only)
@@ -666,7 +683,11 @@ extern "C" int hwg_bias_act_fwd(const float* x, const float* bias, const float* 
   HWG_REQUIRE(x && y && rows > 0 && C > 0 && HW > 0, "bias_act_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (C % 4 == 0) {
-    hipLaunchKernelGGL(bias_act_fwd_kernel, dim3(hwg_stream_grid(rows * C / 4, 256)), dim3(256), 0, st, x, bias, chan_mask, y, rows, HW, C, act, slope);
+    HWG_REQUIRE(rows * C / 4 < (1ll << 31), "bias_act_fwd: tensor too large for 32-bit indexing");
+    const unsigned total4 = (unsigned)(rows * C / 4);
+    const dim3 grid(hwg_stream_grid((total4 + 1) / 2, 256));
+    if (bias || chan_mask) hipLaunchKernelGGL(bias_act_fwd_kernel<true>, grid, dim3(256), 0, st, x, bias, chan_mask, y, total4, HW, C, act, slope);
+    else hipLaunchKernelGGL(bias_act_fwd_kernel<false>, grid, dim3(256), 0, st, x, bias, chan_mask, y, total4, HW, C, act, slope);
   } else {
     hipLaunchKernelGGL(bias_act_fwd_scalar_kernel, dim3(hwg_stream_grid(rows * C, 256)), dim3(256), 0, st, x, bias, chan_mask, y, rows, HW, C, act, slope);
   }
@@ -680,7 +701,11 @@ extern "C" int hwg_bias_act_bwd(const float* dy, const float* y, const float* ch
   HWG_REQUIRE(act == 0 || y, "bias_act_bwd: y required when an activation is fused");
   hipStream_t st = (hipStream_t)stream;
   if (C % 4 == 0) {
-    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(hwg_stream_grid(rows * C / 4, 256)), dim3(256), 0, st, dy, y, chan_mask, dx, rows, HW, C, act, slope);
+    HWG_REQUIRE(rows * C / 4 < (1ll << 31), "bias_act_bwd: tensor too large for 32-bit indexing");
+    const unsigned total4 = (unsigned)(rows * C / 4);
+    const dim3 grid(hwg_stream_grid((total4 + 1) / 2, 256));
+    if (chan_mask) hipLaunchKernelGGL(bias_act_bwd_kernel<true>, grid, dim3(256), 0, st, dy, y, chan_mask, dx, total4, HW, C, act, slope);
+    else hipLaunchKernelGGL(bias_act_bwd_kernel<false>, grid, dim3(256), 0, st, dy, y, chan_mask, dx, total4, HW, C, act, slope);
   } else {
     hipLaunchKernelGGL(bias_act_bwd_scalar_kernel, dim3(hwg_stream_grid(rows * C, 256)), dim3(256), 0, st, dy, y, chan_mask, dx, rows, HW, C, act, slope);
   }

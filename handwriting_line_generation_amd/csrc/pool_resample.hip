@@ -17,8 +17,11 @@ template <int V> __device__ __forceinline__ void vstore(float* p, const VecT<V>&
 }
 template <int V> __device__ __forceinline__ VecT<V> vzero() { VecT<V> r; for (int i = 0; i < V; ++i) r.v[i] = 0.f; return r; }
 
+// 32-bit element indices: a 64-bit division costs ~40 VALU instructions on this ISA and every kernel here splits its index three or four
+// times per 16 bytes moved - with 64-bit indices these "HBM-bound" kernels were VALU-bound at ~3 TB/s. LAUNCH_V refuses tensors of 2^31
+// vectors or more.
 #define GRID_STRIDE(i, total) \
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (total); i += (long long)gridDim.x * blockDim.x)
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)(total); i += gridDim.x * blockDim.x)
 
 // ---------------- average pooling (kernel == stride, no padding, floor) ----------------
 template <int V>
@@ -27,7 +30,7 @@ __global__ void avgpool_fwd_kernel(const float* x, float* y, int N, int H, int W
   const long long total = (long long)N * P * Q * CV;
   const float inv = 1.f / (kh * kw);
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int c = (int)(i % CV) * V; unsigned t = i / CV;
     const int q = (int)(t % Q); t /= Q;
     const int p = (int)(t % P); const int n = (int)(t / P);
     VecT<V> acc = vzero<V>();
@@ -37,7 +40,7 @@ __global__ void avgpool_fwd_kernel(const float* x, float* y, int N, int H, int W
         for (int e = 0; e < V; ++e) acc.v[e] += v.v[e];
       }
     for (int e = 0; e < V; ++e) acc.v[e] *= inv;
-    vstore<V>(y + i * V, acc);
+    vstore<V>(y + (size_t)i * V, acc);
   }
 }
 template <int V>
@@ -46,7 +49,7 @@ __global__ void avgpool_bwd_kernel(const float* dy, float* dx, int N, int H, int
   const long long total = (long long)N * H * W * CV;
   const float inv = 1.f / (kh * kw);
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int c = (int)(i % CV) * V; unsigned t = i / CV;
     const int w = (int)(t % W); t /= W;
     const int h = (int)(t % H); const int n = (int)(t / H);
     const int p = h / kh, q = w / kw;
@@ -55,7 +58,7 @@ __global__ void avgpool_bwd_kernel(const float* dy, float* dx, int N, int H, int
       r = vload<V>(dy + (((long long)n * P + p) * Q + q) * C + c);
       for (int e = 0; e < V; ++e) r.v[e] *= inv;
     }
-    vstore<V>(dx + i * V, r);
+    vstore<V>(dx + (size_t)i * V, r);
   }
 }
 
@@ -66,7 +69,7 @@ __global__ void maxpool_fwd_kernel(const float* x, float* y, int* idx, int N, in
   const int CV = C / V;
   const long long total = (long long)N * P * Q * CV;
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int c = (int)(i % CV) * V; unsigned t = i / CV;
     const int q = (int)(t % Q); t /= Q;
     const int p = (int)(t % P); const int n = (int)(t / P);
     VecT<V> best; int bi[V];
@@ -83,8 +86,8 @@ __global__ void maxpool_fwd_kernel(const float* x, float* y, int* idx, int N, in
           if (v.v[e] > best.v[e] || v.v[e] != v.v[e] || bi[e] < 0) { best.v[e] = v.v[e]; bi[e] = h * W + w; }
       }
     }
-    vstore<V>(y + i * V, best);
-    for (int e = 0; e < V; ++e) idx[i * V + e] = bi[e];
+    vstore<V>(y + (size_t)i * V, best);
+    for (int e = 0; e < V; ++e) idx[(size_t)i * V + e] = bi[e];
   }
 }
 template <int V>
@@ -93,7 +96,7 @@ __global__ void maxpool_bwd_kernel(const float* dy, const int* idx, float* dx, i
   const int CV = C / V;
   const long long total = (long long)N * H * W * CV;
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int c = (int)(i % CV) * V; unsigned t = i / CV;
     const int w = (int)(t % W); t /= W;
     const int h = (int)(t % H); const int n = (int)(t / H);
     const int me = h * W + w;
@@ -109,7 +112,7 @@ __global__ void maxpool_bwd_kernel(const float* dy, const int* idx, float* dx, i
         for (int e = 0; e < V; ++e)
           if (idx[o + e] == me) acc.v[e] += dy[o + e];
       }
-    vstore<V>(dx + i * V, acc);
+    vstore<V>(dx + (size_t)i * V, acc);
   }
 }
 
@@ -120,10 +123,10 @@ __global__ void upsample_fwd_kernel(const float* x, float* y, int N, int H, int 
   const int P = H * fh, Q = W * fw;
   const long long total = (long long)N * P * Q * CV;
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int c = (int)(i % CV) * V; unsigned t = i / CV;
     const int q = (int)(t % Q); t /= Q;
     const int p = (int)(t % P); const int n = (int)(t / P);
-    vstore<V>(y + i * V, vload<V>(x + (((long long)n * H + p / fh) * W + q / fw) * C + c));
+    vstore<V>(y + (size_t)i * V, vload<V>(x + (((long long)n * H + p / fh) * W + q / fw) * C + c));
   }
 }
 template <int V>
@@ -132,7 +135,7 @@ __global__ void upsample_bwd_kernel(const float* dy, float* dx, int N, int H, in
   const int P = H * fh, Q = W * fw;
   const long long total = (long long)N * H * W * CV;
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int c = (int)(i % CV) * V; unsigned t = i / CV;
     const int w = (int)(t % W); t /= W;
     const int h = (int)(t % H); const int n = (int)(t / H);
     VecT<V> acc = vzero<V>();
@@ -141,7 +144,7 @@ __global__ void upsample_bwd_kernel(const float* dy, float* dx, int N, int H, in
         const VecT<V> v = vload<V>(dy + (((long long)n * P + h * fh + a) * Q + w * fw + b) * C + c);
         for (int e = 0; e < V; ++e) acc.v[e] += v.v[e];
       }
-    vstore<V>(dx + i * V, acc);
+    vstore<V>(dx + (size_t)i * V, acc);
   }
 }
 
@@ -151,7 +154,7 @@ __global__ void blur3_kernel(const float* x, float* y, int N, int H, int W, int 
   const int CV = C / V;
   const long long total = (long long)N * H * W * CV;
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int c = (int)(i % CV) * V; unsigned t = i / CV;
     const int w = (int)(t % W); t /= W;
     const int h = (int)(t % H); const int n = (int)(t / H);
     VecT<V> acc = vzero<V>();
@@ -167,7 +170,7 @@ __global__ void blur3_kernel(const float* x, float* y, int N, int H, int W, int 
         for (int e = 0; e < V; ++e) acc.v[e] += k * v.v[e];
       }
     }
-    vstore<V>(y + i * V, acc);
+    vstore<V>(y + (size_t)i * V, acc);
   }
 }
 
@@ -178,7 +181,7 @@ __global__ void pad2d_fwd_kernel(const float* x, float* y, int N, int H, int W, 
   const int P = H + pt + pb, Q = W + pl + pr;
   const long long total = (long long)N * P * Q * CV;
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int c = (int)(i % CV) * V; unsigned t = i / CV;
     const int q = (int)(t % Q); t /= Q;
     const int p = (int)(t % P); const int n = (int)(t / P);
     int h = p - pt, w = q - pl;
@@ -192,7 +195,7 @@ __global__ void pad2d_fwd_kernel(const float* x, float* y, int N, int H, int W, 
     } else {
       for (int e = 0; e < V; ++e) r.v[e] = value;
     }
-    vstore<V>(y + i * V, r);
+    vstore<V>(y + (size_t)i * V, r);
   }
 }
 template <int V>
@@ -201,7 +204,7 @@ __global__ void pad2d_bwd_kernel(const float* dy, float* dx, int N, int H, int W
   const int P = H + pt + pb, Q = W + pl + pr;
   const long long total = (long long)N * H * W * CV;
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % CV) * V; long long t = i / CV;
+    const int c = (int)(i % CV) * V; unsigned t = i / CV;
     const int w = (int)(t % W); t /= W;
     const int h = (int)(t % H); const int n = (int)(t / H);
     int p0 = h + pt, p1 = h + pt, q0 = w + pl, q1 = w + pl;
@@ -218,7 +221,7 @@ __global__ void pad2d_bwd_kernel(const float* dy, float* dx, int N, int H, int W
         const VecT<V> v = vload<V>(dy + (((long long)n * P + p) * Q + q) * C + c);
         for (int e = 0; e < V; ++e) acc.v[e] += v.v[e];
       }
-    vstore<V>(dx + i * V, acc);
+    vstore<V>(dx + (size_t)i * V, acc);
   }
 }
 
@@ -228,11 +231,11 @@ __global__ void copy_channels_kernel(const float* src, int Cs, int soff, float* 
                                      int accumulate) {
   const long long total = rows * Cn;
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % Cn);
-    const long long row = i / Cn;
-    const long long srow = bcast ? row / HW : row;
-    const float v = src[srow * Cs + soff + c];
-    float* d = dst + row * Cd + doff + c;
+    const unsigned row = i / Cn;
+    const int c = (int)(i - row * Cn);
+    const unsigned srow = bcast ? row / HW : row;
+    const float v = src[(size_t)srow * Cs + soff + c];
+    float* d = dst + (size_t)row * Cd + doff + c;
     *d = accumulate ? *d + v : v;
   }
 }
@@ -257,7 +260,7 @@ __global__ void onehot_kernel(const int* label, float* out, int L, int B, int nc
   const long long total = (long long)B * L * ncls;
   GRID_STRIDE(i, total) {
     const int c = (int)(i % ncls);
-    const long long t = i / ncls;
+    const unsigned t = i / ncls;
     const int l = (int)(t % L), b = (int)(t / L);
     out[((long long)b * L + l) * Cd + doff + c] = (label[l * B + b] == c) ? 1.f : 0.f;
   }
@@ -267,7 +270,7 @@ __global__ void onehot_kernel(const int* label, float* out, int L, int B, int nc
 __global__ void permute4_kernel(const float* in, float* out, int d0, int d1, int d2, int d3, long long s0, long long s1, long long s2, long long s3) {
   const long long total = (long long)d0 * d1 * d2 * d3;
   GRID_STRIDE(i, total) {
-    const int i3 = (int)(i % d3); long long t = i / d3;
+    const int i3 = (int)(i % d3); unsigned t = i / d3;
     const int i2 = (int)(t % d2); t /= d2;
     const int i1 = (int)(t % d1); const int i0 = (int)(t / d1);
     out[i] = in[i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3];
@@ -305,6 +308,7 @@ __global__ void fused_up_weight_bwd_kernel(const float* dw4, float* dw3, long lo
 
 #define LAUNCH_V(kern, total_of_v, C, ...)                                                                         \
   do {                                                                                                               \
+    HWG_REQUIRE((long long)(total_of_v) < (1ll << 31), "tensor too large for the 32-bit indices of the resampling kernels"); \
     if ((C) % 4 == 0) hipLaunchKernelGGL(kern<4>, dim3(hwg_stream_grid((total_of_v) / 4, 256)), dim3(256), 0, st, __VA_ARGS__); \
     else hipLaunchKernelGGL(kern<1>, dim3(hwg_stream_grid((total_of_v), 256)), dim3(256), 0, st, __VA_ARGS__);           \
   } while (0)
@@ -416,6 +420,7 @@ extern "C" int hwg_copy_channels(const float* src, int Cs, int soff, float* dst,
   HWG_REQUIRE(src && dst && rows > 0 && Cn > 0 && soff >= 0 && doff >= 0 && soff + Cn <= Cs && doff + Cn <= Cd && HW > 0,
               "copy_channels: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  HWG_REQUIRE((long long)(rows * Cn) < (1ll << 31), "tensor too large for 32-bit element indices");
   hipLaunchKernelGGL(copy_channels_kernel, dim3(hwg_stream_grid(rows * Cn, 256)), dim3(256), 0, st, src, Cs, soff, dst, Cd, doff, Cn, rows, HW,
                      bcast, accumulate);
   HWG_LAUNCH_CHECK("copy_channels");
@@ -431,6 +436,7 @@ extern "C" int hwg_reduce_rows(const float* src, int Cs, int soff, float* out, i
 extern "C" int hwg_onehot(const int* label, float* out, int L, int B, int ncls, int Cd, int doff, void* stream) {
   HWG_REQUIRE(label && out && L > 0 && B > 0 && ncls > 0 && doff >= 0 && doff + ncls <= Cd, "onehot: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  HWG_REQUIRE((long long)((long long)B * L * ncls) < (1ll << 31), "tensor too large for 32-bit element indices");
   hipLaunchKernelGGL(onehot_kernel, dim3(hwg_stream_grid((long long)B * L * ncls, 256)), dim3(256), 0, st, label, out, L, B, ncls, Cd, doff);
   HWG_LAUNCH_CHECK("onehot");
   return HWG_OK;
@@ -439,6 +445,7 @@ extern "C" int hwg_permute4(const float* in, float* out, int d0, int d1, int d2,
                             void* stream) {
   HWG_REQUIRE(in && out && d0 > 0 && d1 > 0 && d2 > 0 && d3 > 0, "permute4: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  HWG_REQUIRE((long long)((long long)d0 * d1 * d2 * d3) < (1ll << 31), "tensor too large for 32-bit element indices");
   hipLaunchKernelGGL(permute4_kernel, dim3(hwg_stream_grid((long long)d0 * d1 * d2 * d3, 256)), dim3(256), 0, st, in, out, d0, d1, d2, d3, s0, s1,
                      s2, s3);
   HWG_LAUNCH_CHECK("permute4");
@@ -447,12 +454,14 @@ extern "C" int hwg_permute4(const float* in, float* out, int d0, int d1, int d2,
 
 extern "C" int hwg_fused_upsample_weight_fwd(const float* w3, float* w4, long long AB, float mult, void* stream) {
   HWG_REQUIRE(w3 && w4 && AB > 0, "fused_upsample_weight_fwd: bad arguments");
+  HWG_REQUIRE((long long)(AB * 16) < (1ll << 31), "tensor too large for 32-bit element indices");
   hipLaunchKernelGGL(fused_up_weight_fwd_kernel, dim3(hwg_stream_grid(AB * 16, 256)), dim3(256), 0, (hipStream_t)stream, w3, w4, AB, mult);
   HWG_LAUNCH_CHECK("fused_upsample_weight_fwd");
   return HWG_OK;
 }
 extern "C" int hwg_fused_upsample_weight_bwd(const float* dw4, float* dw3, long long AB, float mult, void* stream) {
   HWG_REQUIRE(dw4 && dw3 && AB > 0, "fused_upsample_weight_bwd: bad arguments");
+  HWG_REQUIRE((long long)(AB * 9) < (1ll << 31), "tensor too large for 32-bit element indices");
   hipLaunchKernelGGL(fused_up_weight_bwd_kernel, dim3(hwg_stream_grid(AB * 9, 256)), dim3(256), 0, (hipStream_t)stream, dw4, dw3, AB, mult);
   HWG_LAUNCH_CHECK("fused_upsample_weight_bwd");
   return HWG_OK;
