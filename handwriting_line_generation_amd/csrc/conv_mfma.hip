@@ -350,7 +350,15 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const float* par
     const long long n4 = total >> 2;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
       float4 s = *reinterpret_cast<const float4*>(part + 4 * i);
-      for (int sp = 1; sp < nsplit; ++sp) {
+      int sp = 1;
+      for (; sp + 2 < nsplit; sp += 3) {               // splits are 2, 4 or 8: the first image plus groups of three, all loads of a group in flight
+        float4 v[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) v[u] = *reinterpret_cast<const float4*>(part + (sp + u) * total + 4 * i);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+      }
+      for (; sp < nsplit; ++sp) {
         const float4 v = *reinterpret_cast<const float4*>(part + sp * total + 4 * i);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
@@ -626,7 +634,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < n4; j += (long long)gridDim.x * blockDim.x) {
     const long long i = j << 2;
     float4 sum = *reinterpret_cast<const float4*>(part + i);
-    for (int sp = 1; sp < nsplit; ++sp) {
+    int sp = 1;
+    for (; sp + 3 < nsplit; sp += 4) {                 // four partial images in flight, added in image order
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(part + (long long)(sp + u) * pstride + i);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w; }
+    }
+    for (; sp < nsplit; ++sp) {
       const float4 v = *reinterpret_cast<const float4*>(part + (long long)sp * pstride + i);
       sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
     }
@@ -682,8 +698,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_lanes_kernel(const float* pa
   const int ol = threadIdx.x % OUT, lane = threadIdx.x / OUT;
   const long long i = (long long)blockIdx.x * OUT + ol;
   float sum = 0.f;
-  if (i < all)
-    for (int sp = lane; sp < nsplit; sp += SL) sum += part[(long long)sp * pstride + i];
+  if (i < all) {
+    int sp = lane;
+    for (; sp + 3 * SL < nsplit; sp += 4 * SL) {      // four partial images in flight, added in image order
+      const float v0 = part[(long long)sp * pstride + i], v1 = part[(long long)(sp + SL) * pstride + i];
+      const float v2 = part[(long long)(sp + 2 * SL) * pstride + i], v3 = part[(long long)(sp + 3 * SL) * pstride + i];
+      sum += v0; sum += v1; sum += v2; sum += v3;
+    }
+    for (; sp < nsplit; sp += SL) sum += part[(long long)sp * pstride + i];
+  }
   red[lane][ol] = sum;
   __syncthreads();
   if (lane == 0 && i < all) {
