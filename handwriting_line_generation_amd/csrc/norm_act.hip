@@ -151,10 +151,18 @@ __device__ __forceinline__ void sample_stats(const InlineStats& is, const Geo& g
   const int tid = threadIdx.x;
   for (int c = tid; c < g.C; c += 256) {
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < g.chunks; ++k) {
-      const double* p = is.part + (((size_t)n * g.chunks + k) * g.C + c) * 2;
-      s1 += p[0]; s2 += p[1];
+    // every workgroup of the apply pass starts here: up to 64 chunk partials per channel, eight loads in flight (one at a time this chain
+    // was a third of the kernel on the step's 5-50 MB tensors), added in chunk order
+    const double2* pp = reinterpret_cast<const double2*>(is.part) + (size_t)n * g.chunks * g.C + c;
+    int k = 0;
+    for (; k + 8 <= g.chunks; k += 8) {
+      double2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(k + u) * g.C];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s1 += v[u].x; s2 += v[u].y; }
     }
+    for (; k < g.chunks; ++k) { const double2 v = pp[(size_t)k * g.C]; s1 += v.x; s2 += v.y; }
     if (BWD) {
       if (blockIdx.x == 0 && is.per_sample) {
         const int idx = n * g.C + c;
