@@ -10,6 +10,9 @@ namespace {
 
 enum { MODE_IN = 0, MODE_GN = 1, MODE_BN = 2 };
 constexpr int NU = 4;   // pixels in flight per thread in the streaming loops
+#ifndef NORM_PASSES
+#define NORM_PASSES 4   // sweeps of PP pixels per workgroup = one trip of the NU-deep loops (tools/ab_kernels.sh: 4 / 8 / 16 / 32 -> 1.46 / 1.51 / 1.67 / 2.13 ms of norm kernels per step)
+#endif
 
 struct Geo {
   int N, HW, C, C4, L, PP, chunks, cs;
@@ -19,9 +22,9 @@ Geo make_geo(int N, int HW, int C) {
   g.N = N; g.HW = HW; g.C = C; g.C4 = C / 4;
   g.L = g.C4;                 // float4 lanes per pixel (<= 256)
   g.PP = 256 / g.L;           // pixels per pass
-  // a workgroup sweeps PP pixels per pass; aim at ~8 passes per workgroup so that narrow-and-deep tensors (HWR tail: 126 pixels x 512
+  // a workgroup sweeps PP pixels per pass; aim at NORM_PASSES passes per workgroup so that narrow-and-deep tensors (HWR tail: 126 pixels x 512
   // channels) still spread over the chip instead of 8 workgroups running 63 dependent passes each (37 us -> latency bound)
-  int chunks = (HW + g.PP * 8 - 1) / (g.PP * 8);
+  int chunks = (HW + g.PP * NORM_PASSES - 1) / (g.PP * NORM_PASSES);
   if (chunks > 64) chunks = 64;
   while (chunks > 1 && (long long)chunks * N > 4096) chunks >>= 1;
   if (chunks < 1) chunks = 1;
