@@ -928,7 +928,7 @@ template <int BM, int BN, int BK, int WM_, int WN_>
 void launch_conv(const ConvK& k, dim3 grid, hipStream_t st, int pf) {
   if constexpr (BM == 64 && BN == 64) {
     // K-split wavefront pairs on the 4-wavefront 64 x 64 tile (8 wavefronts): 42.2 -> 37.6 us on 8x8x122x128->128, 32.8 -> 29.4 us on
-    // the recogniser's 1x3 layers, 20.9 -> 19.2 us on the generator's 4x4 stride-2 layer (tools/probe_r3_wk.txt); four-way splits and
+    // the recogniser's 1x3 layers, 20.9 -> 19.2 us on the generator's 4x4 stride-2 layer (tools/probes/probe_r3_wk.txt); four-way splits and
     // the 128 x 32 tile measured no better (HWG_CONV_WK=1 restores the 4-wavefront kernel for A/B runs)
     if (hwg_tune().conv_wk >= 2) {
       hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 3, 2>), grid, dim3(128 * WM_ * WN_), 0, st, k);
@@ -1390,7 +1390,7 @@ int hwg_wgrad_reduce_launch(const float* part, float* dw, int nsplit, int RS, in
                             long long ss, int accumulate, long long pstride, float* dbias, int bias_accumulate, hipStream_t st) {
   const long long total = (long long)RS * K * C + (dbias ? K : 0);
   if (total >= (1ll << 31)) { hwg_set_error("wgrad_reduce: weight image too large for 32-bit element indices"); return HWG_ERR_ARG; }
-  // large filters cut into few ranges (the 256..512-channel layers): row-contiguous stores. Measured (tools/probe_r3_reduce.txt, whole weight
+  // large filters cut into few ranges (the 256..512-channel layers): row-contiguous stores. Measured (tools/probes/probe_r3_reduce.txt, whole weight
   // gradient): 512x512x3x3 / 4 images 144 -> 138 us, 256x256x3x3 / 16 images 48.7 -> 45.0 us, 512x512x1x3 / 4 images 32.6 -> 31.0 us; with many
   // images of a small filter the lane-split kernels below stay ahead (128x128x3x3 / 62 images 38 vs 44 us).
   const long long pairs = (long long)K * C;
