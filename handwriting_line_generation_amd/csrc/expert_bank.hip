@@ -20,9 +20,11 @@ constexpr int MT = GT_ROWS / 32;
 constexpr int GT_CK = 256;   // channels of the LDS-staged operand per step (the experts' 128 / 256-channel layers: one step, 68 KB of LDS)
 
 // ---- forward: D[m = row][n = co]; A = shifted x rows from LDS, B = W rows straight from global (16-byte loads along (ci,s)) ----
-// block = 4 waves, wave w owns output channels [co_blk + 32 w, +32) and both 32-row tiles of the work tile.
+// block = 8 waves: wave (wk, wq) owns output channels [co_blk + 32 wq, +32) of the work tile and half wk of every staged K range (the two
+// halves' sums meet in LDS at the end): two wavefronts per SIMD, so one's weight / LDS latencies hide behind the other's MFMAs. Pays on long
+// contractions (Cin*S >= 768: 31 -> 28 us); shorter ones are launched with 4 waves and no split (28 -> 33 us with it). tools/expert_probe.py
 template <int S>
-__global__ __launch_bounds__(256) void gmm_fwd_kernel(const float* __restrict__ x, const int* seg_start, const int* seg_eid, const int* tile_seg,
+__global__ __launch_bounds__(512) void gmm_fwd_kernel(const float* __restrict__ x, const int* seg_start, const int* seg_eid, const int* tile_seg,
                                                       const int* tile_row0, const long long* wptr, const long long* bptr, float* __restrict__ y,
                                                       int R, int Cin, int Cout, int pad) {
   constexpr int LD = GT_CK + 1;
@@ -34,7 +36,8 @@ __global__ __launch_bounds__(256) void gmm_fwd_kernel(const float* __restrict__ 
   const float* __restrict__ W = reinterpret_cast<const float*>(wptr[e]);
   const float* bias = bptr ? reinterpret_cast<const float*>(bptr[e]) : nullptr;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const int co = blockIdx.y * 128 + wid * 32 + l31;
+  const int wk = wid >> 2, wq = wid & 3;
+  const int co = blockIdx.y * 128 + wq * 32 + l31;
   const bool co_ok = co < Cout;
   const long long xbase = (long long)i0 * R * Cin;
   const int KS = Cin * S;
@@ -70,20 +73,22 @@ __global__ __launch_bounds__(256) void gmm_fwd_kernel(const float* __restrict__ 
 
   for (int ci0 = 0; ci0 < Cin; ci0 += GT_CK) {
     const int ngroups = min(GT_CK, Cin - ci0) / 8;
+    const int ghalf = blockDim.x == 512 ? (ngroups + 1) / 2 : ngroups;     // launched with 256 threads: one wavefront per 32 channels, no K split
+    const int gbeg = wk ? ghalf : 0, gend = wk ? ngroups : ghalf;     // this wavefront's groups
     const float* wr = W + (long long)(co_ok ? co : 0) * KS + ci0 * S + 4 * lhi;
     auto load_w = [&](int g0, float4 (&w)[NP]) {
 #pragma unroll
       for (int gi = 0; gi < GP; ++gi)
 #pragma unroll
         for (int u = 0; u < S; ++u)
-          w[gi * S + u] = (co_ok && g0 + gi < ngroups) ? *reinterpret_cast<const float4*>(wr + 8 * (S * (g0 + gi) + u)) : make_float4(0.f, 0.f, 0.f, 0.f);
+          w[gi * S + u] = (co_ok && g0 + gi < gend) ? *reinterpret_cast<const float4*>(wr + 8 * (S * (g0 + gi) + u)) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     float4 wa[NP], wb[NP];
-    load_w(0, wa);                 // in flight while the x tile is staged
+    load_w(gbeg, wa);              // in flight while the x tile is staged
     __syncthreads();
     // stage rows [rc0 - pad, rc0 + GT_ROWS + pad) x channels [ci0, ci0 + GT_CK)
     const int cw4 = (min(GT_CK, Cin - ci0) + 3) / 4;      // 16-byte column groups of this step
-    for (int t = threadIdx.x; t < (GT_ROWS + 2 * pad) * cw4; t += 256) {
+    for (int t = threadIdx.x; t < (GT_ROWS + 2 * pad) * cw4; t += blockDim.x) {
       const int rl = t / cw4, c4 = t - rl * cw4;
       const int row = rc0 - pad + rl;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void gmm_fwd_kernel(const float* __restrict__ 
     auto run_w = [&](int g0, const float4 (&w)[NP], const float (&a)[GP][S][4][MT]) {
 #pragma unroll
       for (int gi = 0; gi < GP; ++gi) {
-        if (g0 + gi >= ngroups) break;
+        if (g0 + gi >= gend) break;
 #pragma unroll
         for (int u = 0; u < S; ++u)
 #pragma unroll
@@ -122,8 +127,8 @@ __global__ __launch_bounds__(256) void gmm_fwd_kernel(const float* __restrict__ 
       }
     };
     float aa[GP][S][4][MT], ab[GP][S][4][MT];
-    load_a(0, aa);
-    for (int g = 0; g < ngroups; g += 2 * GP) {
+    load_a(gbeg, aa);
+    for (int g = gbeg; g < gend; g += 2 * GP) {
       load_w(g + GP, wb);
       load_a(g + GP, ab);
       __builtin_amdgcn_sched_barrier(0);
@@ -135,6 +140,22 @@ __global__ __launch_bounds__(256) void gmm_fwd_kernel(const float* __restrict__ 
       run_w(g + GP, wb, ab);
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
+  // the second K half hands its sums to the first through LDS (the tile buffer is free now)
+  if (blockDim.x == 512) {
+  __syncthreads();
+  if (wk) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) xs[((wq * MT + mt) * 16 + t) * 64 + lane] = acc[mt][t];
+  }
+  __syncthreads();
+  if (wk || !co_ok) return;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[mt][t] += xs[((wq * MT + mt) * 16 + t) * 64 + lane];
   }
   if (!co_ok) return;
   const float bv = bias ? bias[co] : 0.f;
@@ -149,7 +170,7 @@ __global__ __launch_bounds__(256) void gmm_fwd_kernel(const float* __restrict__ 
 
 // ---- data gradient: D[m = row][n = ci]; A = shifted dy rows from LDS, B = W[co][ci][0..S) (one S-float load per lane) ----
 template <int S>
-__global__ __launch_bounds__(256) void gmm_dgrad_kernel(const float* __restrict__ dy, const int* seg_start, const int* seg_eid, const int* tile_seg,
+__global__ __launch_bounds__(512) void gmm_dgrad_kernel(const float* __restrict__ dy, const int* seg_start, const int* seg_eid, const int* tile_seg,
                                                         const int* tile_row0, const long long* wptr, float* __restrict__ dx, int R, int Cin,
                                                         int Cout, int pad) {
   constexpr int LD = GT_CK + 1;
@@ -159,7 +180,8 @@ __global__ __launch_bounds__(256) void gmm_dgrad_kernel(const float* __restrict_
   const int nrows = (seg_start[g + 1] - i0) * R;
   const float* __restrict__ W = reinterpret_cast<const float*>(wptr[seg_eid[g]]);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const int ci = blockIdx.y * 128 + wid * 32 + l31;
+  const int wk = wid >> 2, wq = wid & 3;     // K-split wavefront pairs as in gmm_fwd_kernel
+  const int ci = blockIdx.y * 128 + wq * 32 + l31;
   const bool ci_ok = ci < Cin;
   const long long ybase = (long long)i0 * R * Cout;
   // offsets / window masks of the A operand per (row tile, tap): unconditional LDS reads, see gmm_fwd_kernel
@@ -183,23 +205,25 @@ __global__ __launch_bounds__(256) void gmm_dgrad_kernel(const float* __restrict_
 
   for (int co0 = 0; co0 < Cout; co0 += GT_CK) {
     const int cn = min(GT_CK, Cout - co0);
+    const int chalf = ((cn + 1) / 2 + 1) & ~1;
+    const int cbeg = wk ? chalf : 0, cend = wk ? cn : chalf;     // this wavefront's output channels of the contraction
     // DU k pairs (2 output channels each) of weights in flight, the next group's loads issued before this group's MFMAs (see gmm_fwd_kernel)
     constexpr int DU = 8;
     auto load_w = [&](int cp0, float (&w)[DU][S]) {
 #pragma unroll
       for (int u = 0; u < DU; ++u) {
         const int col = cp0 + 2 * u + lhi;  // this half's output channel of the k pair
-        const bool ok = ci_ok && col < cn;
+        const bool ok = ci_ok && col < cend;
         const float* wr = W + ((long long)(co0 + (ok ? col : 0)) * Cin + (ci_ok ? ci : 0)) * S;
 #pragma unroll
         for (int sft = 0; sft < S; ++sft) w[u][sft] = ok ? wr[sft] : 0.f;
       }
     };
     float wa[DU][S], wb[DU][S];
-    load_w(0, wa);                 // in flight while the dy tile is staged
+    load_w(cbeg, wa);              // in flight while the dy tile is staged
     __syncthreads();
     const int cw4 = (cn + 3) / 4;                          // 16-byte column groups of this step
-    for (int t = threadIdx.x; t < (GT_ROWS + 2 * pad) * cw4; t += 256) {
+    for (int t = threadIdx.x; t < (GT_ROWS + 2 * pad) * cw4; t += 512) {
       const int rl = t / cw4, c4 = t - rl * cw4;
       const int row = rc0 - pad + rl;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -221,7 +245,7 @@ __global__ __launch_bounds__(256) void gmm_dgrad_kernel(const float* __restrict_
     auto run_w = [&](int cp0, const float (&w)[DU][S], const float (&a)[DU][S][MT]) {
 #pragma unroll
       for (int u = 0; u < DU; ++u) {
-        if (cp0 + 2 * u >= cn) break;
+        if (cp0 + 2 * u >= cend) break;
 #pragma unroll
         for (int sft = 0; sft < S; ++sft)
 #pragma unroll
@@ -229,8 +253,8 @@ __global__ __launch_bounds__(256) void gmm_dgrad_kernel(const float* __restrict_
       }
     };
     float aa[DU][S][MT], ab[DU][S][MT];
-    load_a(0, aa);
-    for (int cp = 0; cp < cn; cp += 4 * DU) {
+    load_a(cbeg, aa);
+    for (int cp = cbeg; cp < cend; cp += 4 * DU) {
       load_w(cp + 2 * DU, wb);
       load_a(cp + 2 * DU, ab);
       __builtin_amdgcn_sched_barrier(0);
@@ -243,7 +267,19 @@ __global__ __launch_bounds__(256) void gmm_dgrad_kernel(const float* __restrict_
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if (!ci_ok) return;
+  __syncthreads();
+  if (wk) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) dys[((wq * MT + mt) * 16 + t) * 64 + lane] = acc[mt][t];
+  }
+  __syncthreads();
+  if (wk || !ci_ok) return;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[mt][t] += dys[((wq * MT + mt) * 16 + t) * 64 + lane];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -433,11 +469,12 @@ extern "C" int hwg_grouped_conv1d_fwd(const float* x, const int* seg_start, cons
   HWG_REQUIRE(Cin % 8 == 0, "grouped_conv1d_fwd: Cin must be a multiple of 8 (got %d)", Cin);
   dim3 grid(ntiles, hwg_cdiv(Cout, 128));
   hipStream_t st = (hipStream_t)stream;
+  const dim3 blk(Cin * S >= 768 ? 512 : 256);      // K-split wavefront pairs on long contractions only
   if (S == 1)
-    hipLaunchKernelGGL(gmm_fwd_kernel<1>, grid, dim3(256), 0, st, x, seg_start, seg_eid, tile_seg, tile_row0, (const long long*)wptr, (const long long*)bptr, y,
+    hipLaunchKernelGGL(gmm_fwd_kernel<1>, grid, blk, 0, st, x, seg_start, seg_eid, tile_seg, tile_row0, (const long long*)wptr, (const long long*)bptr, y,
                        R, Cin, Cout, pad);
   else
-    hipLaunchKernelGGL(gmm_fwd_kernel<3>, grid, dim3(256), 0, st, x, seg_start, seg_eid, tile_seg, tile_row0, (const long long*)wptr, (const long long*)bptr, y,
+    hipLaunchKernelGGL(gmm_fwd_kernel<3>, grid, blk, 0, st, x, seg_start, seg_eid, tile_seg, tile_row0, (const long long*)wptr, (const long long*)bptr, y,
                        R, Cin, Cout, pad);
   HWG_LAUNCH_CHECK("grouped_conv1d_fwd");
   return HWG_OK;
@@ -451,9 +488,9 @@ extern "C" int hwg_grouped_conv1d_dgrad(const float* dy, const int* seg_start, c
   dim3 grid(ntiles, hwg_cdiv(Cin, 128));
   hipStream_t st = (hipStream_t)stream;
   if (S == 1)
-    hipLaunchKernelGGL(gmm_dgrad_kernel<1>, grid, dim3(256), 0, st, dy, seg_start, seg_eid, tile_seg, tile_row0, (const long long*)wptr, dx, R, Cin, Cout, pad);
+    hipLaunchKernelGGL(gmm_dgrad_kernel<1>, grid, dim3(512), 0, st, dy, seg_start, seg_eid, tile_seg, tile_row0, (const long long*)wptr, dx, R, Cin, Cout, pad);
   else
-    hipLaunchKernelGGL(gmm_dgrad_kernel<3>, grid, dim3(256), 0, st, dy, seg_start, seg_eid, tile_seg, tile_row0, (const long long*)wptr, dx, R, Cin, Cout, pad);
+    hipLaunchKernelGGL(gmm_dgrad_kernel<3>, grid, dim3(512), 0, st, dy, seg_start, seg_eid, tile_seg, tile_row0, (const long long*)wptr, dx, R, Cin, Cout, pad);
   HWG_LAUNCH_CHECK("grouped_conv1d_dgrad");
   return HWG_OK;
 }
