@@ -693,6 +693,32 @@ def test_style_helpers_rng(cuda):
     assert torch.equal(am.cpu().long(), x.view(60, 16).argmax(1))
 
 
+@pytest.mark.parametrize("n,B,C", [(970, 8, 128), (3, 8, 16), (9000, 4, 64)])
+def test_segment_weighted_mean_at_scale(cuda, n, B, C):
+    """per-line score-weighted mean of the window styles: the list kernel (members of a line compacted in LDS, in order) at the bench step's
+    load, a tiny call with empty lines, and a call too long for LDS (the walk-all-items kernel); forward and backward against the
+    reference's accumulation loop in fp64"""
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(n + C)
+    v = torch.randn(n, C, generator=g)
+    wgt = torch.rand(n, generator=g)
+    seg = torch.randint(0, B, (n,), generator=g, dtype=torch.int32)
+    if n == 3:
+        seg = torch.tensor([1, 1, 5], dtype=torch.int32)
+    vr = v.double().requires_grad_(True)
+    tot = torch.zeros(B, C, dtype=torch.float64)
+    tot = tot.index_add(0, seg.long(), wgt.double()[:, None] * vr)
+    ws = torch.zeros(B, dtype=torch.float64).index_add(0, seg.long(), wgt.double())
+    ref = torch.where(ws[:, None] != 0, tot / ws[:, None].clamp_min(1e-300), tot)
+    gy = torch.randn(B, C, generator=g)
+    ref.backward(gy.double())
+    vg = v.to(cuda).requires_grad_(True)
+    out = ops.segment_weighted_mean(vg, wgt.to(cuda), seg.to(cuda), B)
+    _close(out, ref.float(), "segment mean", tol=5e-6)
+    out.backward(gy.to(cuda))
+    _close(vg.grad, vr.grad.float(), "segment mean dv", tol=5e-6)
+
+
 @pytest.mark.parametrize("R,Cin,Cout,S", [(5, 256, 128, 3), (5, 128, 256, 3), (5, 256, 256, 1), (1, 256, 128, 1), (3, 64, 96, 3), (5, 32, 16, 3), (1, 16, 48, 1)])
 def test_grouped_expert_layers(cuda, R, Cin, Cout, S):
     """grouped per-expert Conv1d (hwg_grouped_conv1d_*) against torch conv1d run expert by expert; one long run spans several row tiles"""
