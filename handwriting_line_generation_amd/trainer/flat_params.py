@@ -136,13 +136,32 @@ class FlatParams:
     def stash(self):
         """clone every non-None gradient and zero it in place (trainer :305-311, :316-322, :331-338)"""
         ops.join_side_stream()   # weight gradients enqueued on the side stream must have landed before the buffer is read
-        buf = self._stash_pool.pop() if self._stash_pool else torch.empty_like(self.flat_grad)
-        buf.copy_(self.flat_grad)
-        self.flat_grad.zero_()
-        return (buf, self.touched.copy())
+        if self._stash_pool:
+            buf, dirty = self._stash_pool.pop()
+        else:
+            buf, dirty = torch.zeros_like(self.flat_grad), np.zeros(self.nt, dtype=bool)
+        if not self.flat_grad.is_cuda:
+            buf.copy_(self.flat_grad)
+            self.flat_grad.zero_()
+            return (buf, self.touched.copy())
+        # One pass over the tensors that HAVE a gradient (buf = grad, grad = 0) instead of a copy and a fill of the whole 190 MB buffer - a gen
+        # lesson touches a third of it. A stash must hold zeros where there is no gradient (a tensor another rank or shard touched is summed
+        # into it), so the slots an earlier use of `buf` left non-zero (`dirty`, kept with the pooled buffer) and that are not overwritten
+        # now are cleared first; the gradient buffer's other slots are zero already (zero_grad / the previous stash left them so).
+        tm = self.touched
+        stale = dirty & ~tm
+        rows = [self.base_ptrs(self.flat_grad) * tm.astype(np.int64), self.base_ptrs(buf) * tm.astype(np.int64)]
+        if stale.any():
+            rows.append(self.base_ptrs(buf) * stale.astype(np.int64))
+        tab = ops.h2d(np.stack(rows), self.device)
+        if stale.any():
+            L.call("hwg_mt_unary", tab[2], None, 0, 0.0, None, self.d_numel, self.d_chunk_tensor, self.d_chunk_off, self.nchunks, CHUNK, self._st())
+        L.call("hwg_mt_unary", tab[0], tab[1], 4, 0.0, None, self.d_numel, self.d_chunk_tensor, self.d_chunk_off, self.nchunks, CHUNK, self._st())
+        return (buf, tm.copy())
 
     def release(self, stash):
-        self._stash_pool.append(stash[0])
+        """back to the pool, with the mask of the slots that may be non-zero now (the stash's own mask: an all-reduce widens it to the union)"""
+        self._stash_pool.append((stash[0], np.array(stash[1], dtype=bool, copy=True)))
 
     def abs_sums(self, flat, mask):
         out = torch.empty(self.nt, dtype=torch.float64, device=self.device)
