@@ -17,6 +17,73 @@ struct DirK {
   int accumulate;
 };
 
+// ---- C == 1 on the matrix cores: the taps are the contraction (im2col tile built on the fly, like the TAPN weight gradient) ----
+// D[m = pixel][n = k] = sum_t A[m][t] * w[t][k]: a workgroup (4 wavefronts, one 32-pixel row block each) stages the filter once and walks
+// 128-pixel tiles; per tile every thread gathers TP / 2 input values (neighbouring lanes = neighbouring pixels: coalesced, masked after an
+// unconditional clamped load), then TP / 2 v_mfma_f32_32x32x2_f32 per 32 output channels. The VALU kernel below spends 16 FMAs per
+// 4-byte weight read and runs at a third of the vector rate (23 TFLOP/s on the discriminator's 7x7 first layer, 34 here). K = 32 or 64,
+// 36..64 taps (smaller filters stay on the VALU kernel: the gather phase dominates there).
+template <int BN>
+__global__ __launch_bounds__(256) void conv_c1_mfma_kernel(DirK a, int TP, int ntiles) {
+  constexpr int BM = 128, NI = BN / 32;
+  __shared__ __attribute__((aligned(16))) float As[64 * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[64 * BN];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int RS = a.R * a.S;
+  for (int i = tid; i < TP * BN; i += 256) {
+    const int t = i / BN, k = i - t * BN;
+    Bs[i] = (t < RS && k < a.K) ? a.w[t * a.K + k] : 0.f;
+  }
+  const int px = tid & (BM - 1), thalf = tid >> 7;      // this thread gathers pixel px for the taps thalf, thalf + 2, ...
+  const long long Mtot = (long long)a.N * a.P * a.Q;
+  float bv[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) bv[ni] = (a.bias && ni * 32 + l31 < a.K) ? a.bias[ni * 32 + l31] : 0.f;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long m = (long long)tile * BM + px;
+    const bool mok = m < Mtot;
+    const long long mm = mok ? m : 0;
+    const int q = (int)(mm % a.Q);
+    const long long t2 = mm / a.Q;
+    const int p = (int)(t2 % a.P), n = (int)(t2 / a.P);
+    const int ih0 = p * a.sh - a.ph, iw0 = q * a.sw - a.pw;
+    const float* xn = a.x + (long long)n * a.H * a.W;
+    __syncthreads();                                    // the previous tile's fragment reads are done (and Bs is staged)
+    for (int t = thalf; t < TP; t += 2) {
+      const int r = t / a.S, sx = t - r * a.S;
+      const int ih = ih0 + r * a.dh, iw = iw0 + sx * a.dw;
+      const bool ok = mok && t < RS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+      const float v = xn[(long long)min(max(ih, 0), a.H - 1) * a.W + min(max(iw, 0), a.W - 1)];
+      As[t * BM + px] = ok ? v : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ni][e] = 0.f;
+    for (int kk = 0; kk < TP; kk += 2) {
+      const float af = As[(kk + lhi) * BM + wid * 32 + l31];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, Bs[(kk + lhi) * BN + ni * 32 + l31], acc[ni], 0, 0, 0);
+    }
+    // C/D layout of the 32x32 MFMA: col (k) = lane & 31, row (pixel) = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const long long mo = (long long)tile * BM + wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+      if (mo >= Mtot) continue;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int k = ni * 32 + l31;
+        if (k >= a.K) continue;
+        float* yo = a.y + mo * a.K + k;
+        const float v = acc[ni][e] + bv[ni];
+        *yo = a.accumulate ? *yo + v : v;
+      }
+    }
+  }
+}
+
 // ---- C == 1 : each thread computes 4 consecutive q pixels x 4 channels; weights [R*S][K] staged in LDS ----
 __global__ __launch_bounds__(256) void conv_c1_kernel(DirK a, int KG, int PG) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];  // [R*S][KG*4]
@@ -279,6 +346,24 @@ bool plan_wd(const hwg_conv_desc* d, WdPlan* p) {
 
 int hwg_conv_c1_fwd_impl(const hwg_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int accumulate, hipStream_t st) {
   HWG_REQUIRE(d->C == 1, "conv_c1: C must be 1");
+  // the matrix-core kernel pays from ~36 taps (7x7: 128 -> 88 us on 16x64x512; 5x5 and 3x3 layers are no faster or slower: tools/probes/probe_r3_c1.txt)
+  if (hwg_tune().c1_mfma && (d->K == 32 || d->K == 64) && d->R * d->S <= 64 && d->R * d->S >= 36) {
+    DirK k;
+    k.x = x; k.w = w; k.bias = bias; k.y = y;
+    k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.R = d->R; k.S = d->S;
+    k.sh = d->stride_h; k.sw = d->stride_w; k.ph = d->pad_h; k.pw = d->pad_w; k.dh = d->dil_h; k.dw = d->dil_w;
+    k.P = d->P; k.Q = d->Q; k.accumulate = accumulate;
+    const int TP = (d->R * d->S + 1) & ~1;
+    const long long M = (long long)d->N * d->P * d->Q;
+    const int ntiles = (int)((M + 127) / 128);
+    const int grid = ntiles < 768 ? ntiles : 768;       // three workgroups per CU (48 KB of LDS each) walk the tiles
+    const int prof = hwg_prof_open(HWG_PROF_CONV_DIRECT, 2.0 * d->N * d->P * d->Q * d->K * d->C * d->R * d->S, st);
+    if (d->K == 64) hipLaunchKernelGGL(conv_c1_mfma_kernel<64>, dim3(grid), dim3(256), 0, st, k, TP, ntiles);
+    else hipLaunchKernelGGL(conv_c1_mfma_kernel<32>, dim3(grid), dim3(256), 0, st, k, TP, ntiles);
+    hwg_prof_close(prof, st);
+    HWG_LAUNCH_CHECK("conv_c1_mfma");
+    return HWG_OK;
+  }
   const int KG = (d->K + 3) / 4;
   HWG_REQUIRE(KG <= 256, "conv_c1: K=%d too large", d->K);
   const int PG = 256 / KG;
