@@ -63,6 +63,102 @@ def peaked_offset_fn(num_class, seed=5, blank_frac=0.7, gain=10.0):
     return fn
 
 
+class ClockSampler:
+    """GPU clock / power state during the timed region, so that a box-to-box difference can be read from the record: a thread samples the
+    amdgpu sysfs files of the device (current sclk / mclk level, hwmon power) every 100 ms - file reads, no GPU calls, no subprocess inside
+    the timed region."""
+
+    def __init__(self, index):
+        import glob
+        self.files = {}
+        self.samples = {}
+        self.note = None
+        try:
+            bus = torch.cuda.get_device_properties(index)
+            want = None
+            for attr in ("pci_bus_id", "pci_device_id", "pci_domain_id"):
+                if not hasattr(bus, attr):
+                    want = None
+                    break
+            else:
+                want = "%04x:%02x:%02x.0" % (bus.pci_domain_id, bus.pci_bus_id, bus.pci_device_id)
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+            cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
+            pick = None
+            for c in cards:
+                if want and os.path.realpath(c).endswith(want):
+                    pick = c
+            if pick is None and cards:
+                pick = cards[min(index, len(cards) - 1)]
+                self.note = "device matched by index, not by PCI address"
+            if pick:
+                self.files["sclk_mhz"] = os.path.join(pick, "pp_dpm_sclk")
+                self.files["mclk_mhz"] = os.path.join(pick, "pp_dpm_mclk")
+                for h in glob.glob(os.path.join(pick, "hwmon", "hwmon*")):
+                    for name in ("power1_average", "power1_input"):
+                        if os.path.exists(os.path.join(h, name)):
+                            self.files["power_w"] = os.path.join(h, name)
+                            break
+                    if os.path.exists(os.path.join(h, "freq1_input")):
+                        self.files["sclk_mhz"] = os.path.join(h, "freq1_input")
+                self.card = pick
+        except Exception as e:  # noqa: BLE001 - a missing sysfs node must never cost the bench line
+            self.note = "sysfs probe failed: %r" % (e,)
+        self._stop = False
+        self._thread = None
+
+    @staticmethod
+    def _read(key, path):
+        txt = open(path).read()
+        if path.endswith(("pp_dpm_sclk", "pp_dpm_mclk")):
+            for line in txt.splitlines():          # "1: 2100Mhz *"
+                if line.rstrip().endswith("*"):
+                    return float(line.split(":")[1].strip().split("M")[0])
+            return None
+        v = float(txt.strip())
+        if key == "power_w":
+            return v / 1e6
+        if path.endswith("freq1_input"):
+            return v / 1e6
+        return v
+
+    def _run(self):
+        while not self._stop:
+            for k, p in self.files.items():
+                try:
+                    v = self._read(k, p)
+                    if v is not None:
+                        self.samples.setdefault(k, []).append(v)
+                except Exception:  # noqa: BLE001
+                    pass
+            time.sleep(0.1)
+
+    def start(self):
+        import threading
+        if self.files:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+        out = {"source": "amdgpu sysfs, sampled every 100 ms inside the timed region" if self.files else None, "note": self.note}
+        for k, v in self.samples.items():
+            if v:
+                out[k] = {"min": round(min(v), 1), "mean": round(sum(v) / len(v), 1), "max": round(max(v), 1), "samples": len(v)}
+        if not self.samples:
+            # no readable sysfs nodes for this user: fall back to one rocm-smi query right after the timed region (the GPU is idle by then,
+            # so this is the idle state - said so in the record)
+            try:
+                import subprocess
+                r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20)
+                out["rocm_smi_after_timed_region_idle"] = json.loads(r.stdout) if r.stdout.strip().startswith("{") else r.stdout[-400:]
+            except Exception as e:  # noqa: BLE001
+                out["rocm_smi_after_timed_region_idle"] = "unavailable: %r" % (e,)
+        return out
+
+
 def rccl_summary(path):
     """what RCCL reported at communicator init (NCCL_DEBUG=INFO, INIT + GRAPH subsystems, written to `path`): rank count, library version,
     number of channels, the transports of the ring / tree connections - enough to see from the JSON line whether an N-GPU run really ran
@@ -160,97 +256,143 @@ def main():
         for b in trainer.model.buffers():
             dist.broadcast(b.data, 0)
 
-    # inputs resident in HBM before the timed region (the contract's "inputs already resident"): one batch per step, built up front
-    trainer.data_loader.make_resident(args.warmup + args.steps + 21, trainer.gpu)
+    # inputs resident in HBM before the timed region (the contract's "inputs already resident"): a ring of synthetic batches built up
+    # front (the loader wraps around; the text lessons draw from the corpus on the host as the reference does)
+    trainer.data_loader.make_resident(min(args.warmup + args.steps + 21, 192), trainer.gpu)
     trainer.data_loader_iter = iter(trainer.data_loader)
     trainer.async_log = True   # losses of step i are read back while step i+1 runs (flushed inside the timed region)
-    it = 0
-    for _ in range(args.warmup):
-        trainer._train_iteration(it); it += 1
+    cycle = 7 if gan else 1   # lessons of the shipped GAN curriculum: count, gen, auto, disc, gen, auto, disc
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Roofline measurement: HIP event pairs around every MFMA launch, recorded inside the library on the launch stream. The pairs cost
-    # ~10 % of a step (each one is an extra packet between two kernels that also keeps the next kernel from starting under the tail of the
-    # previous one), so they are recorded on a sample of the timed region: the first whole curriculum cycle of every PROF_EVERY cycles
-    # (2 of the default run's 20 cycles; `profiled_steps` in the JSON).
-    cycle = 7 if gan else 1   # lessons of the shipped GAN curriculum: count, gen, auto, disc, gen, auto, disc
-    PROF_EVERY = 10
-    profiling = rank == 0 and not os.environ.get("HWG_BENCH_NO_PROF")
+    def agree_max(v):
+        """the same number on every rank (loop counts must agree: every rank runs the same lessons)"""
+        if world > 1:
+            t = torch.tensor([v], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return v
+
     # weight gradients on a second stream: "auto" = in the auto lessons only (GPU-bound: three backward passes over every network), 1 = in
     # every lesson, 0 = never
     sw = os.environ.get("HWG_SIDE_WGRAD", "auto")
     side_wgrad = "auto" if sw == "auto" else bool(int(sw or 0))
     if not gan:
         side_wgrad = False
-    if profiling:
-        ops.prof_start()
+    trainer._side_wgrad = side_wgrad
+    ops.SIDE_WGRAD = side_wgrad is True
+
+    # Warm-up: the requested steps rounded up to whole cycles AND at least WARM_SECONDS of wall time (round 3 warmed up for 0.1 s and timed
+    # 0.3 s: the box's clock / power state was still moving, the driver's line came out 10 % under the builder's). Still whole cycles.
+    WARM_SECONDS, TIMED_SECONDS, MIN_CYCLES = 1.5, 1.5, 10
+    it = 0
+    barrier()
+    tw = time.perf_counter()
+    warm_done = 0
+    while True:
+        for _ in range(cycle):
+            trainer._train_iteration(it); it += 1
+        warm_done += cycle
+        if warm_done < args.warmup:
+            continue
+        torch.cuda.synchronize()
+        if agree_max(time.perf_counter() - tw) >= WARM_SECONDS or warm_done >= 100 * cycle:
+            break
+    # one more cycle, timed on its own, to size the timed region: at least the requested steps, MIN_CYCLES cycles and TIMED_SECONDS
+    barrier()
+    tc = time.perf_counter()
+    for _ in range(cycle):
+        trainer._train_iteration(it); it += 1
+    barrier()
+    cyc_s = agree_max(time.perf_counter() - tc)
+    warm_done += cycle
+    args.warmup = warm_done
+    want = max(args.steps, (MIN_CYCLES * cycle) if gan else 20, int(TIMED_SECONDS / max(cyc_s, 1e-6)) * cycle + cycle)
+    args.steps = min(-(-want // cycle) * cycle, max(args.steps, 2000))
+
     from handwriting_line_generation_amd.model.char_style import CharStyleEncoder
     from handwriting_line_generation_amd.trainer import flat_params
     CharStyleEncoder.stats.update(calls=0, windows=0, experts=0)
     flat_params.COMM.update(collectives=0, bytes=0)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-lesson GPU time: one event between steps
     first_lesson = it % cycle
+    clocks = ClockSampler(local)
+    clocks.start()
     barrier()
     t0 = time.perf_counter()
-    prof_steps = 0
     for k in range(args.steps):
-        if profiling:
-            on = (k // cycle) % PROF_EVERY == 0
-            ops.prof_enable(on)
-            prof_steps += int(on)
-            # weight gradients run on a second stream (+2-3 % steps/s: their workgroups fill CUs the data-gradient chain leaves idle)
-            # except in the cycles whose launches are timed for the roofline object: co-running kernels inflate each other's durations
-            trainer._side_wgrad = False if on else side_wgrad
-            ops.SIDE_WGRAD = side_wgrad is True and not on
         marks[k].record()
         trainer._train_iteration(it); it += 1
     marks[args.steps].record()
     trainer.flush_log()
     barrier()
     elapsed = time.perf_counter() - t0
+    clock_report = clocks.stop()
+    st = dict(CharStyleEncoder.stats)
+    comm = dict(flat_params.COMM)
+
+    # Roofline measurement, AFTER the timed region (round 3 profiled cycles inside it: `value` carried the event packets and the
+    # side-stream-off mode on a third of the driver's steps). The library records every MFMA launch's own begin / end timestamps
+    # (hwg_prof_*); the weight-gradient side stream is off here because co-running kernels inflate each other's durations.
+    profiling = rank == 0 and not os.environ.get("HWG_BENCH_NO_PROF")
+    PROF_CYCLES = int(os.environ.get("HWG_BENCH_PROF_CYCLES", "2"))
+    prof_steps = 0
+    prof_elapsed = 0.0
+    if world > 1:
+        profiling_any = True   # every rank runs the same lessons (collectives inside); only rank 0 records
+    else:
+        profiling_any = profiling
+    prof = []
+    if profiling_any and not os.environ.get("HWG_BENCH_NO_PROF"):
+        if profiling:
+            ops.prof_start()
+            ops.prof_enable(True)
+        trainer._side_wgrad = False
+        ops.SIDE_WGRAD = False
+        barrier()
+        tp = time.perf_counter()
+        for _ in range(PROF_CYCLES * cycle):
+            trainer._train_iteration(it); it += 1
+            prof_steps += 1
+        trainer.flush_log()
+        barrier()
+        prof_elapsed = time.perf_counter() - tp
+        if profiling:
+            ops.prof_enable(False)
+            prof = ops.prof_stop()
+        trainer._side_wgrad = side_wgrad
+        ops.SIDE_WGRAD = side_wgrad is True
+
     # Secondary figure, AFTER the timed region that `value` reports: the same loop with dead-gradient elimination on (trainer.skip_unused_grads:
     # no weight-gradient kernels for the frozen recogniser and for the discriminator outside disc lessons - SURVEY 8d's "minimum necessary"
     # variant; weights and losses are bit-identical, tests/test_trainer_gpu.py). `value` itself is the reference's launches, as executed.
     min_nec = None
     if gan and not os.environ.get("HWG_BENCH_NO_MINNEC"):
-        if profiling:
-            ops.prof_enable(False)
         trainer.skip_unused_grads = True
-        n2 = 2 * cycle
+        n2 = 3 * cycle
         for _ in range(cycle):                       # one cycle to switch the gradient requirements / plans over, untimed
             trainer._train_iteration(it); it += 1
         trainer.flush_log()
         barrier()
         t1 = time.perf_counter()
         for _ in range(n2):
-            trainer._side_wgrad = side_wgrad
             trainer._train_iteration(it); it += 1
         trainer.flush_log()
         barrier()
-        e2 = time.perf_counter() - t1
+        e2 = agree_max(time.perf_counter() - t1)
         trainer.skip_unused_grads = False
-        if world > 1:
-            t = torch.tensor([e2], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e2 = float(t.item())
         min_nec = {"value": round(world * n2 / e2, 4), "unit": "steps/s", "steps": n2, "ms_per_step": round(e2 / n2 * 1e3, 3),
                    "what": "same loop with trainer.skip_unused_grads (no weight gradients for the frozen recogniser / for the discriminator outside disc "
                            "lessons); measured after the timed region, not part of `value`"}
+    elapsed = agree_max(elapsed)
     lesson_ms = {}
     for k in range(args.steps):
         name = "%d:%s" % ((first_lesson + k) % cycle, LESSONS[(first_lesson + k) % cycle] if gan else "auto-pretrain")
         lesson_ms.setdefault(name, []).append(marks[k].elapsed_time(marks[k + 1]))
     per_lesson_ms = {n: round(sum(v) / len(v), 3) for n, v in sorted(lesson_ms.items())}
-    st = dict(CharStyleEncoder.stats)
-    prof = ops.prof_stop() if (rank == 0 and ops.PROF_SHAPES is not None) else []
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # secondary metric of BASELINE.json ("and gen lines/sec"): HWWithStyle.forward(label, lengths, style) -> images, inference only,
     # measured AFTER the timed training region on the same weights (spacer -> host insert_spaces -> generator; one line = 64 x ~4T px)
@@ -291,7 +433,7 @@ def main():
             g[0] += flops; g[1] += dt; g[2] += 1
         if os.environ.get("HWG_CONV_DUMP"):
             with open(os.environ["HWG_CONV_DUMP"], "w") as fh:
-                fh.write("# per-shape MFMA conv launches inside the timed region (%d steps): time_ms  launches  avg_us  TFLOP/s  kind  shape(N,H,W,C,K,R,S,stride,pad,dil,mode)\n" % args.steps)
+                fh.write("# per-shape MFMA conv launches in the profiled cycles after the timed region (%d steps): time_ms  launches  avg_us  TFLOP/s  kind  shape(N,H,W,C,K,R,S,stride,pad,dil,mode)\n" % prof_steps)
                 for (kind, shape), (fl, sec, n) in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
                     fh.write("%9.3f %6d %9.1f %7.1f  %s %s\n" % (sec * 1e3, n, sec / n * 1e6, fl / sec / 1e12 if sec > 0 else 0, kind, shape))
         # the north-star target is stated on the G+D conv stack: every conv kernel (MFMA, direct, their reduce passes) launched by the
@@ -318,10 +460,11 @@ def main():
                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "launches": n, "avg_launch_us": round(sec / n * 1e6, 2),
                         "gflop_per_launch": round(fl / n / 1e9, 4),
                         "other_kernels": {k: {("achieved_GBps" if k.endswith("reduce_kernel") else "achieved"): round(v[0] / v[1] / (1e9 if k.endswith("reduce_kernel") else 1e12), 3),
-                                              "launches": v[2], "time_frac_of_step": round(v[1] / (elapsed * prof_steps / args.steps), 3)}
+                                              "launches": v[2], "time_frac_of_step": round(v[1] / max(prof_elapsed, 1e-9), 3)}
                                           for k, v in fam.items() if k != dom},
-                        "time_frac_of_step": round(sec / (elapsed * prof_steps / args.steps), 3),
-                        "profiled_steps": prof_steps}
+                        "time_frac_of_step": round(sec / max(prof_elapsed, 1e-9), 3),
+                        "profiled_steps": prof_steps, "profiled_where": "whole curriculum cycles run after the timed region (kernel begin / end timestamps "
+                                                                          "of every launch; weight-gradient side stream off)"}
             if dom.startswith("wino"):
                 # Winograd F(2x2,3x3) / F(3x3,2x2) kernels are credited with the layer's direct-form FLOPs (FLOPs = 2 MAC of the
                 # convolution) but issue 16 instead of 36 multiplies per 2x2 tile and channel pair: the matrix cores are busy for 1/2.25 of it
@@ -399,9 +542,11 @@ def main():
             # data parallel: ranks in the process group and this rank's all-reduce traffic (gradient sets + None-masks) per step
             "data_parallel": {"world_size": world, "backend": (dist.get_backend() if dist.is_initialized() else None), "forced_single_rank_exchange": force_dp,
                               "rccl": rccl_summary(rccl_log),
-                              "collectives_per_step": round(flat_params.COMM["collectives"] / args.steps, 2),
-                              "allreduce_mbytes_per_step": round(flat_params.COMM["bytes"] / args.steps / 1e6, 2)},
-            "side_stream_wgrad": side_wgrad,   # off inside the roofline-profiled cycles (see the timed loop)
+                              "collectives_per_step": round(comm["collectives"] / args.steps, 2),
+                              "allreduce_mbytes_per_step": round(comm["bytes"] / args.steps / 1e6, 2)},
+            "side_stream_wgrad": side_wgrad,   # off in the roofline-profiled cycles, which run after the timed region
+            # sclk / mclk / socket power sampled from sysfs every 100 ms during the timed region (min / mean / max), and rocm-smi's view
+            "clocks": clock_report,
             "inputs_resident": True,     # one synthetic batch per step built and uploaded before the timed region (SyntheticLoader.make_resident)
             # load of the per-character expert bank (K18): style extractions in the timed region, character windows and distinct experts per call
             "style_extractor_load": {"recogniser": "peaked (70% blanks, +10 logit on one class per column)" if wl.get("peaked") else "random-init on uniform-noise lines",

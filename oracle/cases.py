@@ -42,6 +42,10 @@ CASES = {
                                                                      activ="relu", pad_type="replicate", n_class=78, global_pool=True,
                                                                      average_found_char_style=1.0, window=2),
                                   wseed=25, B=2, W=192, widths=(192, 140), n_class=78),
+    # one 64x512 line through the FULL-WIDTH generator (dim 256) and discriminator (dim 64) of the shipped IAM GAN config
+    "generator_full": dict(kind="generator", ctor=dict(n_class=80, style_size=128, dim=256, n_style_trans=6, append_style=True), wseed=31,
+                           T=128, B=1, n_class=80, style=128),
+    "discriminator_full": dict(kind="discriminator", ctor=dict(dim=64, use_low=True, use_med=True), wseed=32, N=1, W=512),
 }
 
 
