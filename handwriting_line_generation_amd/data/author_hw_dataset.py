@@ -108,19 +108,28 @@ class AuthorHWDataset(torch.utils.data.Dataset):
         # items: consecutive groups of a_batch_size lines of one author; the left-over lines are topped up with the author's first ones
         self.lineIndex = []
         short = config.get("short", False)
+        # `short` (debug option): the reference tests its loop variable `i` AFTER the loop (author_hw_dataset.py:176-180), where it still holds
+        # whatever the last loop that ran left in it - this author's group loop, or, for an author with fewer than a_batch_size lines, the
+        # previous author's top-up loops. Kept: the item index is part of the drop-in surface (tests/golden/iam_index.json).
+        i = None
         for author, lines in self.authors.items():
-            n_full = len(lines) // self.batch_size
-            stop = False
-            for i in range(n_full):
+            for i in range(len(lines) // self.batch_size):
                 self.lineIndex.append((author, [self.batch_size * i + n for n in range(self.batch_size)]))
                 if short and i >= short:
-                    stop = True
                     break
-            if stop:
-                continue
+            if short:
+                if i is None:
+                    raise NameError("name 'i' is not defined (the reference fails the same way: `short` with a first author of fewer than a_batch_size lines)")
+                if i >= short:
+                    continue
             leftover = len(lines) % self.batch_size
             fill = self.batch_size - leftover
-            self.lineIndex.append((author, list(range(fill)) + [len(lines) - (1 + i) for i in range(leftover)]))
+            last = []
+            for i in range(fill):
+                last.append(i)
+            for i in range(leftover):
+                last.append(len(lines) - (1 + i))
+            self.lineIndex.append((author, last))
         if config.get("overfit"):
             self.lineIndex = self.lineIndex[:10]
         with open(config["char_file"]) as f:

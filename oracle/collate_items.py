@@ -58,3 +58,58 @@ def rimes_xml(n_pages=4, seed=9):
             top += h + int(rs.randint(5, 25))
         pages.append('  <SinglePage FileName="images_gray/page%03d.png">\n    <Paragraph>\n%s\n    </Paragraph>\n  </SinglePage>' % (p, "\n".join(lines)))
     return RIMES_XML % "\n".join(pages)
+
+
+IAM_TEXTS = ["the quick brown", "fox jumps", "over a lazy dog", "pack my box", "with five dozen", "liquor jugs", "sphinx of black quartz",
+             "he said &quot;no&quot;", "Tom &amp; Co.", "a", "judge my vow", "it&apos;s 4 o&apos;clock"]
+
+
+def fake_iam(root, n_pages=6, seed=5, with_images=True):
+    """fabricated IAM directory in the reference's layout (`forms/<page>.png`, `xmls/<page>.xml` with writer-id / line / word / cmp boxes,
+    `sets.json`): pages of 1-6 lines with ragged line heights (so that both branches of the mean-height growth run), several cmp boxes per
+    word, escaped characters, three writers of which one has a single line (the left-over-item quirk), pages shared between splits"""
+    import json
+    import os
+    rs = np.random.RandomState(seed)
+    os.makedirs(os.path.join(root, "forms"), exist_ok=True); os.makedirs(os.path.join(root, "xmls"), exist_ok=True)
+    lines_per_page = [3, 1, 5, 4, 6, 2][:n_pages] + [3] * max(0, n_pages - 6)
+    writers = ["000", "017", "000", "230", "017", "000"][:n_pages] + ["230"] * max(0, n_pages - 6)
+    pages, t = [], 0
+    for p in range(n_pages):
+        name = "p%02d-%03d" % (p, 7 * p)
+        pages.append(name)
+        boxes = []
+        xml = ['<form id="%s" writer-id="%s"><machine-printed-part/><handwritten-part>' % (name, writers[p])]
+        y0 = 30
+        for l in range(lines_per_page[p]):
+            text = IAM_TEXTS[t % len(IAM_TEXTS)]; t += 1
+            h = int(rs.randint(34, 78))
+            xml.append('<line id="%s-%02d" text="%s">' % (name, l, text))
+            x = int(rs.randint(20, 70))
+            plain = text.replace("&quot;", '"').replace("&amp;", "&").replace("&apos;", "'")
+            for w in plain.split(" "):
+                xml.append('<word id="w" text="%s">' % w.replace("&", "&amp;").replace('"', "&quot;"))
+                for c in range(1 + len(w) // 4):                 # several component boxes per word, ragged tops / heights
+                    cw = int(rs.randint(14, 40)); dy = int(rs.randint(0, 9)); ch = h - dy - int(rs.randint(0, 7))
+                    xml.append('<cmp x="%d" y="%d" width="%d" height="%d"/>' % (x, y0 + dy, cw, ch))
+                    boxes.append((x, y0 + dy, cw, ch))
+                    x += cw + int(rs.randint(1, 5))
+                xml.append("</word>")
+                x += int(rs.randint(12, 30))
+            xml.append("</line>")
+            y0 += h + int(rs.randint(18, 50))
+        xml.append("</handwritten-part></form>")
+        with open(os.path.join(root, "xmls", name + ".xml"), "w") as f:
+            f.write("".join(xml))
+        if with_images:
+            from PIL import Image, ImageDraw
+            W = max(b[0] + b[2] for b in boxes) + 80
+            img = Image.new("L", (W, y0 + 40), 255)
+            dr = ImageDraw.Draw(img)
+            for (x, y, w, h) in boxes:
+                dr.rectangle([x, y, x + w, y + h], fill=int(rs.randint(20, 110)))
+            img.save(os.path.join(root, "forms", name + ".png"))
+    sets = {"train": pages[:4], "valid": pages[4:], "test": pages[3:]}
+    with open(os.path.join(root, "sets.json"), "w") as f:
+        json.dump(sets, f)
+    return pages, sets

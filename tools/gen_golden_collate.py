@@ -6,7 +6,10 @@
   * utils/parseRIMESlines.getLineBoundaries on a fabricated annotation file, and the item index (`lineIndex`, `max_char_len`, `author_list`)
     the unmodified AuthorRIMESLinesDataset constructor builds from it (train: all pairs of an author's lines at a_batch_size 2, otherwise
     consecutive groups + a topped-up remainder).
--> tests/golden/collate.npz, tests/golden/rimes_index.json
+  * utils/parseIAM.getLineBoundaries (:88-135) on every form XML of the fabricated IAM directory of oracle/collate_items.fake_iam, and the
+    item index (`lineIndex`, `max_char_len`, `author_list`, per-author line lists) the unmodified AuthorHWDataset constructor
+    (datasets/author_hw_dataset.py:115-297) builds from it for train / valid / test at a_batch_size 2 and 3 and with `short`.
+-> tests/golden/collate.npz, tests/golden/rimes_index.json, tests/golden/iam_index.json
 """
 import json
 import os
@@ -64,6 +67,36 @@ def main():
     with open(os.path.join(GOLD, "rimes_index.json"), "w") as f:
         json.dump(idx, f, separators=(",", ":"))
     print("rimes_index.json", {k: v["len"] for k, v in idx["index"].items()})
+
+    # IAM: the reference opens data/sets.json relative to the working directory, so it is run from a scratch directory holding one
+    import shutil
+    work = "/tmp/hwg_golden_iam"
+    shutil.rmtree(work, ignore_errors=True)
+    root = os.path.join(work, "iam")
+    os.makedirs(os.path.join(work, "data"))
+    pages, sets = collate_items.fake_iam(root, with_images=False)
+    shutil.copy(os.path.join(root, "sets.json"), os.path.join(work, "data", "sets.json"))
+    from utils import parseIAM
+    idx = {"sets": sets, "pages": {}, "index": {}}
+    for name in pages:
+        lines, writer = parseIAM.getLineBoundaries(os.path.join(root, "xmls", name + ".xml"))
+        idx["pages"][name] = {"writer": writer, "lines": [[list(b), t] for b, t in lines]}
+    char_file = os.path.join(ROOT, "handwriting_line_generation_amd", "data", "IAM_char_set.json")
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        for split in ("train", "valid", "test"):
+            for A, extra in ((2, {}), (3, {}), (2, {"short": 1})):
+                cfg = dict({"img_height": 64, "a_batch_size": A, "char_file": char_file, "max_width": 1400}, **extra)
+                ds = ref_iam.AuthorHWDataset(root, split, cfg)
+                key = "%s_a%d%s" % (split, A, "_short" if extra else "")
+                idx["index"][key] = {"lineIndex": [[a, list(l)] for a, l in ds.lineIndex], "max_char_len": ds.max_char_len, "author_list": ds.author_list,
+                                     "len": len(ds), "authors": {a: [[os.path.relpath(pth, root), list(b), t] for pth, b, t in v] for a, v in ds.authors.items()}}
+    finally:
+        os.chdir(cwd)
+    with open(os.path.join(GOLD, "iam_index.json"), "w") as f:
+        json.dump(idx, f, separators=(",", ":"))
+    print("iam_index.json", {k: v["len"] for k, v in idx["index"].items()})
 
 
 if __name__ == "__main__":
