@@ -59,6 +59,7 @@ class AuthorRIMESLinesDataset(AuthorHWDataset):
         short = config.get("short", False)
         self.lineIndex = []
         self.max_char_len = 0
+        i = None
         for author, lines in self.authors.items():
             self.max_char_len = max(self.max_char_len, max(len(l[2]) for l in lines))
             if split == "train" and self.batch_size == 2:
@@ -67,17 +68,24 @@ class AuthorRIMESLinesDataset(AuthorHWDataset):
                     combs = combs[:short]
                 self.lineIndex += [(author, list(c)) for c in combs]
                 continue
-            stop = False
+            # `short`: the reference tests its loop variable after the loop, where it may be stale (see AuthorHWDataset)
             for i in range(len(lines) // self.batch_size):
                 self.lineIndex.append((author, [self.batch_size * i + n for n in range(self.batch_size)]))
                 if short and i >= short:
-                    stop = True
                     break
-            if stop:
-                continue
+            if short:
+                if i is None:
+                    raise NameError("name 'i' is not defined (the reference fails the same way)")
+                if i >= short:
+                    continue
             leftover = len(lines) % self.batch_size
             fill = self.batch_size - leftover
-            self.lineIndex.append((author, list(range(fill)) + [len(lines) - (1 + i) for i in range(leftover)]))
+            last = []
+            for i in range(fill):
+                last.append(i)
+            for i in range(leftover):
+                last.append(len(lines) - (1 + i))
+            self.lineIndex.append((author, last))
         if config.get("overfit"):
             self.lineIndex = self.lineIndex[:10]
         with open(config["char_file"]) as f:

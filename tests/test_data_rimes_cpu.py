@@ -51,8 +51,12 @@ def test_rimes_parser_and_item_index_equal_the_references(rimes_dir):
     pages = parse_rimes_xml(os.path.join(rimes_dir, "lines_training_2011.xml"))
     assert {k: [[i, list(b), t] for i, b, t in v] for k, v in pages.items()} == gold["pages"]
     for key, ref in gold["index"].items():
-        split, A = key.split("_a")
-        ds = AuthorRIMESLinesDataset(rimes_dir, split, {"img_height": 64, "a_batch_size": int(A), "char_file": CHAR_FILE, "max_width": 1300})
+        parts = key.split("_")
+        split, A = parts[0], parts[1][1:]
+        cfg = {"img_height": 64, "a_batch_size": int(A), "char_file": CHAR_FILE, "max_width": 1300}
+        if len(parts) > 2:
+            cfg["short"] = 1
+        ds = AuthorRIMESLinesDataset(rimes_dir, split, cfg)
         assert [[a, list(l)] for a, l in ds.lineIndex] == ref["lineIndex"], key
         assert ds.max_char_len == ref["max_char_len"] and ds.author_list == ref["author_list"] and len(ds) == ref["len"]
 

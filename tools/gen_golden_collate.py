@@ -60,9 +60,9 @@ def main():
     idx = {"pages": {k: [[img, list(b), t] for img, b, t in v] for k, v in pages.items()}, "index": {}}
     char_file = os.path.join(ROOT, "handwriting_line_generation_amd", "data", "RIMES_characterset_lines.json")
     for split in ("train", "valid"):
-        for A in (2, 3):
-            ds = ref_rimes.AuthorRIMESLinesDataset(work, split, {"img_height": 64, "a_batch_size": A, "char_file": char_file, "max_width": 1300})
-            idx["index"]["%s_a%d" % (split, A)] = {"lineIndex": [[a, list(l)] for a, l in ds.lineIndex], "max_char_len": ds.max_char_len,
+        for A, extra in ((2, {}), (3, {}), (2, {"short": 1}), (3, {"short": 1})):
+            ds = ref_rimes.AuthorRIMESLinesDataset(work, split, dict({"img_height": 64, "a_batch_size": A, "char_file": char_file, "max_width": 1300}, **extra))
+            idx["index"]["%s_a%d%s" % (split, A, "_short" if extra else "")] = {"lineIndex": [[a, list(l)] for a, l in ds.lineIndex], "max_char_len": ds.max_char_len,
                                                     "author_list": ds.author_list, "len": len(ds)}
     with open(os.path.join(GOLD, "rimes_index.json"), "w") as f:
         json.dump(idx, f, separators=(",", ":"))
