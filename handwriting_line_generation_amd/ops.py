@@ -662,6 +662,12 @@ def colsum(x2d, out=None, accumulate=False):
 # ----------------------------------------------------------------------------------------------
 # normalisation + activation
 # ----------------------------------------------------------------------------------------------
+def _affine_stamp(gamma, beta):
+    """(version counters, optimizer epoch) of a norm's affine parameters: HipAdam writes through raw pointers behind torch's version
+    counters and bumps WEIGHT_EPOCH of the parameter's group instead"""
+    return tuple((p._version, WEIGHT_EPOCH.get(getattr(p, "_hwg_group", None), 0)) for p in (gamma, beta) if p is not None)
+
+
 class _Norm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, mode, groups, eps, mask, act, slope, running_mean, running_var, momentum):
@@ -677,6 +683,8 @@ class _Norm(Function):
         ctx.save_for_backward(x, y, gamma, mask, mean, rstd)
         ctx.cfg = (mode, groups, act, slope, N, HW, C, beta is not None)
         ctx.param_refs = (gamma, beta)
+        # the backward pass recomputes relu / leaky-relu gates from x and the affine it reads THEN: remember which weights the forward saw
+        ctx.wstamp = _affine_stamp(gamma, beta) if act in (ACT_RELU, ACT_LRELU) else None
         return y
 
     @staticmethod
@@ -686,6 +694,9 @@ class _Norm(Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         gref, bref = ctx.param_refs
+        if ctx.wstamp is not None and ctx.wstamp != _affine_stamp(gref, bref):
+            raise L.HwgError("norm backward after its affine parameters changed (optimizer step / in-place write between forward and backward): the "
+                             "activation gates are recomputed from x and the current affine and would be wrong; run backward before stepping")
         direct = (gamma is None or _direct(gref)) and (not has_beta or _direct(bref))
         if direct:
             dgamma = _grad_buffer(gref) if gamma is not None else None

@@ -250,7 +250,14 @@ def control_group():
     return _CTL[0]
 
 
-_SPAN_CACHE = {}     # (id(flat), key) -> sorted list of segment indices every rank reduces for that (lesson, stash position)
+def _span_cache(flat):
+    """per FlatParams instance: key (lesson, stash position) -> sorted list of segment indices every rank reduces for that key. (It lived in a
+    module-level dict keyed by id(flat) once: a FlatParams built later in the same process could inherit the id - and the segment indices -
+    of a freed one.)"""
+    c = getattr(flat, "_span_cache", None)
+    if c is None:
+        c = flat._span_cache = {}
+    return c
 
 
 def segment_spans(flat, segs):
@@ -274,16 +281,16 @@ def start_stash_allreduce(stash, world, flat=None, key=None):
     segments the OR-ed mask touches are remembered; every later occurrence starts its reductions at once from the remembered segments, and
     the masks travel with the ONE exchange `allreduce_gradient_sets` makes per lesson anyway (which also verifies the remembered
     segments still cover the set, and widens them - on every rank alike - if they do not). Without `flat` the whole buffer travels.
-    Returns the stash as a list [buffer, mask, pending work(s), mask already exchanged, segments reduced]."""
+    Returns the stash as a list [buffer, mask, pending work(s), mask already exchanged, segments reduced, key]."""
     import torch.distributed as dist
-    st = [stash[0], stash[1], None, False, None]
+    st = [stash[0], stash[1], None, False, None, key]
     if world > 1 or FORCE_DP:
         _require_group()
         if flat is None:
             _count(st[0])
             st[2] = [(dist.all_reduce(st[0], op=dist.ReduceOp.SUM, async_op=True), st[0])]
         else:
-            segs = _SPAN_CACHE.get((id(flat), key)) if key is not None else None
+            segs = _span_cache(flat).get(key) if key is not None else None
             if segs is None:
                 m = torch.from_numpy(np.asarray(st[1]).astype(np.int32))
                 _count(m)
@@ -292,7 +299,7 @@ def start_stash_allreduce(stash, world, flat=None, key=None):
                 st[3] = True
                 segs = sorted(set(flat.segment_of[np.nonzero(st[1])[0]].tolist()))
                 if key is not None:
-                    _SPAN_CACHE[(id(flat), key)] = segs
+                    _span_cache(flat)[key] = segs
             st[4] = list(segs)
             st[2] = []
             for a, b in segment_spans(flat, segs):
@@ -363,10 +370,9 @@ def allreduce_gradient_sets(flat, stashes, world, device):
                         view = s[0][a:b]
                         _count(view)
                         pending.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True), view))
-                    for ck, segs in _SPAN_CACHE.items():
-                        if segs is not None and ck[0] == id(flat) and sorted(segs) == sorted(s[4]):
-                            _SPAN_CACHE[ck] = sorted(set(segs) | need)
                     s[4] = sorted(set(s[4]) | need)
+                    if len(s) > 5 and s[5] is not None:          # only the entry of this stash's own key is widened
+                        _span_cache(flat)[s[5]] = list(s[4])
         else:
             for a, b in touched_spans(flat, s[1]):
                 view = s[0][a:b]

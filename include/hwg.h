@@ -162,6 +162,8 @@ int hwg_colsum(const float* x, long long rows, int C, float* out, int accumulate
  * mean/rstd are [N][C] outputs kept for the backward pass.
  * hwg_norm_bwd takes the forward call's gamma / beta: with relu / leaky relu fused it recomputes the activation gate (the sign of the
  * pre-activation, bit-identical to the forward pass) from x instead of reading y - `y` may be NULL then; tanh needs y.
+ * CONSTRAINT: gamma / beta must still hold the forward call's values (no optimizer step or in-place write between forward and backward);
+ * ops._Norm stamps the parameters' version / optimizer epoch at forward time and refuses a backward pass after a change.
  * ------------------------------------------------------------------------------------------ */
 size_t hwg_norm_workspace(int N, int HW, int C);
 int hwg_norm_fwd(const float* x, float* y, int N, int HW, int C, int mode, int groups, float eps,

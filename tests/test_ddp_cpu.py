@@ -60,7 +60,7 @@ def _worker(rank, world, port, out):
     mine = flat.flat_grad.clone()
     allreduce_gradient_sets(flat, stashes, world, torch.device("cpu"))
     al = [torch.zeros_like(again_buf) for _ in range(world)]; dist.all_gather(al, again_buf)
-    ok_again = torch.allclose(again[0], sum(al) / world) and again[1][0] and 0 in fp._SPAN_CACHE[(id(flat), ("auto", 0))]
+    ok_again = torch.allclose(again[0], sum(al) / world) and again[1][0] and 0 in fp._span_cache(flat)[("auto", 0)]
     stashes = stashes[:3]
     # gather every rank's original sets to rank-independent expectation
     gl = [torch.zeros_like(mine) for _ in range(world)]; dist.all_gather(gl, mine)

@@ -82,3 +82,61 @@ def test_skip_unused_grads_changes_no_weight_and_no_loss(cuda, tmp_path):
     for k, v in sa.items():
         assert torch.equal(v, sb[k]), "%s differs with skip_unused_grads" % k
     assert any(ta[k] for k in ta if k.startswith("hwr.")) and not any(tb[k] for k in tb if k.startswith("hwr."))
+
+
+def test_masked_stash_holds_zeros_outside_its_mask(cuda):
+    """FlatParams.stash() copies only the tensors that have a gradient; a pooled buffer must nevertheless hold ZEROS everywhere else,
+    because data-parallel segment all-reduces sum whole sub-network ranges of it (trainer/flat_params.py: stale / dirty clearing).
+    Stash with mask A, release, stash with a different mask B: the reused buffer is exactly zero outside B and equals the gradient inside B;
+    same when the first stash's mask was widened in place (what the OR over the ranks does) before its release."""
+    import numpy as np
+    from handwriting_line_generation_amd.trainer.flat_params import FlatParams
+    g = torch.Generator().manual_seed(3)
+    shapes = [(7,), (33, 5), (130,), (4, 4, 3, 3), (70001,), (9,), (256, 17)]
+    params = [torch.nn.Parameter(torch.randn(*s, generator=g).to(cuda)) for s in shapes]
+    flat = FlatParams(params, {"main": params[:5], "disc": params[5:]}, names=["a.w%d" % i if i < 3 else "b.w%d" % i for i in range(len(params))])
+    pos_of = {id(flat.params[pi]): k for k, pi in enumerate(flat.order)}
+
+    def fill(which, seed):
+        gg = torch.Generator().manual_seed(seed)
+        want = {}
+        for i in which:
+            v = torch.randn(*shapes[i], generator=gg).to(cuda)
+            params[i].grad.copy_(v)
+            flat.touched[pos_of[id(params[i])]] = True
+            want[i] = v
+        return want
+
+    def check(stash, want):
+        buf, mask = stash[0], stash[1]
+        expect = torch.zeros_like(buf)
+        for i, v in want.items():
+            k = pos_of[id(params[i])]
+            assert mask[k]
+            expect[int(flat.offsets[k]): int(flat.offsets[k]) + v.numel()] = v.flatten()
+        assert int(mask.sum()) == len(want)
+        assert torch.equal(buf, expect), "stash differs from (gradient inside the mask, zero outside): %d elements" % int((buf != expect).sum())
+        assert float(flat.flat_grad.abs().max()) == 0.0, "the gradient buffer must be zero after a stash"
+
+    A, B, C = [0, 2, 4, 6], [1, 2, 5], [3]
+    want = fill(A, 1)
+    s1 = flat.stash(); flat.touched[:] = False
+    check(s1, want)
+    flat.release(s1)
+    want = fill(B, 2)
+    s2 = flat.stash(); flat.touched[:] = False
+    assert s2[0].data_ptr() == s1[0].data_ptr(), "the pooled buffer should have been reused"
+    check(s2, want)
+    # widen the mask in place before the release (a data-parallel OR marks tensors another rank touched; their slots may then be non-zero)
+    k3 = pos_of[id(params[3])]
+    s2[1][k3] = True
+    s2[0][int(flat.offsets[k3]): int(flat.offsets[k3]) + 5] = 7.0          # what an all-reduce could have summed in
+    flat.release(s2)
+    want = fill(C + [0], 3)
+    s3 = flat.stash(); flat.touched[:] = False
+    check(s3, want)
+    flat.release(s3)
+    want = fill([5], 4)                                                     # a set that overlaps nothing of the previous one
+    s4 = flat.stash(); flat.touched[:] = False
+    check(s4, want)
+    torch.cuda.synchronize()
