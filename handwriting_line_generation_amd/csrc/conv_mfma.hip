@@ -624,14 +624,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
 }
 
 // dw = (accumulate ? dw : 0) + sum over the partial images; entries past R*S*K*C of a partial image are the K bias partials.
+// The four reduce schedules below are __device__ bodies parameterised by (block id, block count) so that the same code runs as a launch of
+// its own (one weight gradient) and as one entry of the table-driven launch that sums the partial images of a whole backward pass
+// (wgrad_reduce_multi_kernel). Every output element is summed over the partial images in a fixed order that does not depend on the grid.
 // Four consecutive elements per thread (16-byte loads from every partial image); requires C % 4 == 0 (the kernel's own requirement).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int RS, int S, int K, int C,
-                                                           long long sa, long long sb, long long sr, long long ss, int accumulate,
-                                                           long long pstride, float* dbias, int bias_accumulate) {
+__device__ __forceinline__ void wgrad_reduce_vec4_body(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int RS, int S, int K, int C,
+                                                       long long sa, long long sb, long long sr, long long ss, int accumulate,
+                                                       long long pstride, float* dbias, int bias_accumulate, int bid, int nb) {
   const long long total = (long long)RS * K * C;
   const long long all = total + (dbias ? K : 0);
   const long long n4 = all >> 2;     // total, K and pstride are multiples of 4
-  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < n4; j += (long long)gridDim.x * blockDim.x) {
+  for (long long j = bid * (long long)blockDim.x + threadIdx.x; j < n4; j += (long long)nb * blockDim.x) {
     const long long i = j << 2;
     float4 sum = *reinterpret_cast<const float4*>(part + i);
     int sp = 1;
@@ -662,13 +665,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (int u = 0; u < 4; ++u) dw[o + u * sb] = accumulate ? dw[o + u * sb] + e[u] : e[u];
   }
 }
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int RS, int S, int K, int C,
+                                                           long long sa, long long sb, long long sr, long long ss, int accumulate,
+                                                           long long pstride, float* dbias, int bias_accumulate) {
+  wgrad_reduce_vec4_body(part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss, accumulate, pstride, dbias, bias_accumulate, blockIdx.x, gridDim.x);
+}
 // scalar variant for the taps-as-N kernel (C == 1)
-__global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int RS, int S, int K,
-                                                                  int C, long long sa, long long sb, long long sr, long long ss, int accumulate,
-                                                                  long long pstride, float* dbias, int bias_accumulate) {
+__device__ __forceinline__ void wgrad_reduce_scalar_body(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int RS, int S, int K,
+                                                         int C, long long sa, long long sb, long long sr, long long ss, int accumulate,
+                                                         long long pstride, float* dbias, int bias_accumulate, int bid, int nb) {
   const long long total = (long long)RS * K * C;
   const long long all = total + (dbias ? K : 0);
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < all; i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = bid * (long long)blockDim.x + threadIdx.x; i < all; i += (long long)nb * blockDim.x) {
     float sum = 0.f;
     for (int sp = 0; sp < nsplit; ++sp) sum += part[(long long)sp * pstride + i];
     if (i >= total) {
@@ -684,19 +692,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* _
     dw[o] = accumulate ? dw[o] + sum : sum;
   }
 }
+__global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int RS, int S, int K,
+                                                                  int C, long long sa, long long sb, long long sr, long long ss, int accumulate,
+                                                                  long long pstride, float* dbias, int bias_accumulate) {
+  wgrad_reduce_scalar_body(part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss, accumulate, pstride, dbias, bias_accumulate, blockIdx.x, gridDim.x);
+}
 
 // same sum with SL "split lanes" per output: used when there are few outputs and many partial images (thread t of a workgroup owns
 // output t % OUT and partials t / OUT, t / OUT + SL, ...; the lanes are combined through LDS in lane order, so still deterministic)
 template <int SL>
-__global__ __launch_bounds__(256) void wgrad_reduce_lanes_kernel(const float* part, float* dw, int nsplit, int RS, int S, int K, int C,
-                                                                 long long sa, long long sb, long long sr, long long ss, int accumulate,
-                                                                 long long pstride, float* dbias, int bias_accumulate) {
-  constexpr int OUT = 256 / SL;
-  __shared__ float red[SL][OUT];
+__device__ __forceinline__ void wgrad_reduce_lanes_body(const float* part, float* dw, int nsplit, int RS, int S, int K, int C,
+                                                        long long sa, long long sb, long long sr, long long ss, int accumulate,
+                                                        long long pstride, float* dbias, int bias_accumulate, int bid, float* red) {
+  constexpr int OUT = 256 / SL;           // red: [SL][OUT] floats of LDS
   const long long total = (long long)RS * K * C;
   const long long all = total + (dbias ? K : 0);
   const int ol = threadIdx.x % OUT, lane = threadIdx.x / OUT;
-  const long long i = (long long)blockIdx.x * OUT + ol;
+  const long long i = (long long)bid * OUT + ol;
   float sum = 0.f;
   if (i < all) {
     int sp = lane;
@@ -707,12 +719,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_lanes_kernel(const float* pa
     }
     for (; sp < nsplit; sp += SL) sum += part[(long long)sp * pstride + i];
   }
-  red[lane][ol] = sum;
+  red[lane * OUT + ol] = sum;
   __syncthreads();
   if (lane == 0 && i < all) {
     float t = 0.f;
 #pragma unroll
-    for (int l = 0; l < SL; ++l) t += red[l][ol];
+    for (int l = 0; l < SL; ++l) t += red[l * OUT + ol];
     if (i >= total) {
       const int kb = (int)(i - total);
       dbias[kb] = bias_accumulate ? dbias[kb] + t : t;
@@ -726,22 +738,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_lanes_kernel(const float* pa
     dw[o] = accumulate ? dw[o] + t : t;
   }
 }
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_lanes_kernel(const float* part, float* dw, int nsplit, int RS, int S, int K, int C,
+                                                                 long long sa, long long sb, long long sr, long long ss, int accumulate,
+                                                                 long long pstride, float* dbias, int bias_accumulate) {
+  __shared__ float red[256];
+  wgrad_reduce_lanes_body<SL>(part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss, accumulate, pstride, dbias, bias_accumulate, blockIdx.x, red);
+}
 
 // Tap-contiguous weights (ss == 1, sr == S, sb == R*S - every weight this package owns): the sums of 256 / SL neighbouring (k, c) pairs go
 // through LDS and leave as whole runs of R*S*(256/SL) consecutive floats. The plain kernel above writes a tap at a time, 4 bytes every
 // R*S*4, and was bound by those scattered stores (27 us for 512x512x3x3 with 4 partial images, 38 MB read + 9 MB written).
 // Thread t: pair t % KC, partial images t / KC, t / KC + SL, ... (combined through LDS in lane order: a fixed order, deterministic).
 template <int SL, int RSC>
-__global__ __launch_bounds__(256) void wgrad_reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int RS_rt, int K, int C,
-                                                                long long sa, int accumulate, long long pstride, float* dbias, int bias_accumulate,
-                                                                int main_blocks) {
+__device__ __forceinline__ void wgrad_reduce_rows_body(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int RS_rt, int K, int C,
+                                                       long long sa, int accumulate, long long pstride, float* dbias, int bias_accumulate,
+                                                       int main_blocks, int bid, float* red) {
   constexpr int KC = 256 / SL;
-  const int RS = RSC ? RSC : RS_rt;
-  extern __shared__ float red[];          // [SL][KC][RS] (+1 float of padding per pair)
+  const int RS = RSC ? RSC : RS_rt;        // red: [SL][KC][RS] (+1 float of padding per pair) of LDS
   const int ldp = RS | 1;
   const long long KCtot = (long long)K * C;
-  if ((int)blockIdx.x >= main_blocks) {    // the K bias sums behind every partial image
-    const int k = ((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
+  if (bid >= main_blocks) {    // the K bias sums behind every partial image
+    const int k = (bid - main_blocks) * 256 + threadIdx.x;
     if (k >= K) return;
     float s = 0.f;
     for (int sp = 0; sp < nsplit; ++sp) s += part[(long long)sp * pstride + RS * KCtot + k];
@@ -749,7 +767,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_rows_kernel(const float* __r
     return;
   }
   const int pl = threadIdx.x % KC, sl = threadIdx.x / KC;
-  const long long base = (long long)blockIdx.x * KC;
+  const long long base = (long long)bid * KC;
   const long long kc = base + pl;
   if (kc < KCtot) {
     if (RSC) {
@@ -783,6 +801,52 @@ __global__ __launch_bounds__(256) void wgrad_reduce_rows_kernel(const float* __r
     const long long k = q / C;
     const long long o = k * sa + (q - k * C) * RS + t;
     dw[o] = accumulate ? dw[o] + s : s;
+  }
+}
+template <int SL, int RSC>
+__global__ __launch_bounds__(256) void wgrad_reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int RS_rt, int K, int C,
+                                                                long long sa, int accumulate, long long pstride, float* dbias, int bias_accumulate,
+                                                                int main_blocks) {
+  extern __shared__ float red_rows[];
+  wgrad_reduce_rows_body<SL, RSC>(part, dw, nsplit, RS_rt, K, C, sa, accumulate, pstride, dbias, bias_accumulate, main_blocks, blockIdx.x, red_rows);
+}
+
+// ---- one launch for the partial images of a whole backward pass ----------------------------------------------------------------
+// A backward pass leaves one set of partial images per weight gradient (65 per training step); summed layer by layer that was 65 launches
+// of 5..25 us, most of them too small to stream at memory rate. With deferral on (hwg_wgrad_defer_next before the weight-gradient call, the
+// caller keeps the partial images alive in its own arena) the reduce of a weight gradient is only queued; hwg_wgrad_defer_flush sums
+// everything queued so far with one launch per 32 entries: block -> (entry, block of that entry's own schedule), entries by value in the
+// kernel arguments (no table upload). Each entry runs exactly the schedule it would have run alone, so results are bit-identical.
+// Two queued gradients of the SAME tensor (a network applied twice in one pass) go to consecutive launches, in queue order.
+enum { RED_VEC4 = 0, RED_SCALAR = 1, RED_LANES32 = 2, RED_LANES4 = 3, RED_ROWS = 4 /* + 2 * rsc_index + (SL == 4) */ };
+struct RedEntry {
+  const float* part; float* dw; float* dbias;
+  long long pstride, sa, sb, sr, ss;
+  int nsplit, RS, S, K, C, accumulate, bias_accumulate, variant, first_block, nblocks, main_blocks, tag;
+};
+constexpr int RED_MAX = 32;
+struct RedTable { int n, pad; RedEntry e[RED_MAX]; };
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedTable t) {
+  extern __shared__ float red_multi[];
+  int lo = 0, hi = t.n - 1;
+  while (lo < hi) {   // last entry whose first_block <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.e[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const RedEntry& e = t.e[lo];
+  const int bid = (int)blockIdx.x - e.first_block;
+  switch (e.variant) {
+    case RED_VEC4: wgrad_reduce_vec4_body(e.part, e.dw, e.nsplit, e.RS, e.S, e.K, e.C, e.sa, e.sb, e.sr, e.ss, e.accumulate, e.pstride, e.dbias, e.bias_accumulate, bid, e.nblocks); break;
+    case RED_SCALAR: wgrad_reduce_scalar_body(e.part, e.dw, e.nsplit, e.RS, e.S, e.K, e.C, e.sa, e.sb, e.sr, e.ss, e.accumulate, e.pstride, e.dbias, e.bias_accumulate, bid, e.nblocks); break;
+    case RED_LANES32: wgrad_reduce_lanes_body<32>(e.part, e.dw, e.nsplit, e.RS, e.S, e.K, e.C, e.sa, e.sb, e.sr, e.ss, e.accumulate, e.pstride, e.dbias, e.bias_accumulate, bid, red_multi); break;
+    case RED_LANES4: wgrad_reduce_lanes_body<4>(e.part, e.dw, e.nsplit, e.RS, e.S, e.K, e.C, e.sa, e.sb, e.sr, e.ss, e.accumulate, e.pstride, e.dbias, e.bias_accumulate, bid, red_multi); break;
+#define HWG_ROWS_CASE(ID, SL, RSC) \
+    case RED_ROWS + ID: wgrad_reduce_rows_body<SL, RSC>(e.part, e.dw, e.nsplit, e.RS, e.K, e.C, e.sa, e.accumulate, e.pstride, e.dbias, e.bias_accumulate, e.main_blocks, bid, red_multi); break;
+    HWG_ROWS_CASE(0, 1, 9) HWG_ROWS_CASE(1, 4, 9) HWG_ROWS_CASE(2, 1, 16) HWG_ROWS_CASE(3, 4, 16) HWG_ROWS_CASE(4, 1, 3) HWG_ROWS_CASE(5, 4, 3)
+    HWG_ROWS_CASE(6, 1, 0) HWG_ROWS_CASE(7, 4, 0)
+#undef HWG_ROWS_CASE
+    default: break;
   }
 }
 
@@ -1386,10 +1450,10 @@ static WgPlan plan_wgrad_tapn(const hwg_conv_desc* d) {
 
 // sums the partial images part[split][tap][K][C] (+ K bias sums at the end of every image, pstride floats apart) in a fixed order and writes
 // dw through the weight's strides (shared by the direct and the Winograd weight-gradient kernels)
-int hwg_wgrad_reduce_launch(const float* part, float* dw, int nsplit, int RS, int S, int K, int C, long long sa, long long sb, long long sr,
-                            long long ss, int accumulate, long long pstride, float* dbias, int bias_accumulate, hipStream_t st) {
-  const long long total = (long long)RS * K * C + (dbias ? K : 0);
-  if (total >= (1ll << 31)) { hwg_set_error("wgrad_reduce: weight image too large for 32-bit element indices"); return HWG_ERR_ARG; }
+struct RedSchedule { int variant, nblocks, main_blocks; size_t lds; };
+static RedSchedule reduce_schedule(int nsplit, int RS, int S, int K, int C, long long sb, long long sr, long long ss, bool has_bias) {
+  RedSchedule r; r.main_blocks = 0; r.lds = 0;
+  const long long total = (long long)RS * K * C + (has_bias ? K : 0);
   // large filters cut into few ranges (the 256..512-channel layers): row-contiguous stores. Measured (tools/probes/probe_r3_reduce.txt, whole weight
   // gradient): 512x512x3x3 / 4 images 144 -> 138 us, 256x256x3x3 / 16 images 48.7 -> 45.0 us, 512x512x1x3 / 4 images 32.6 -> 31.0 us; with many
   // images of a small filter the lane-split kernels below stay ahead (128x128x3x3 / 62 images 38 vs 44 us).
@@ -1397,33 +1461,117 @@ int hwg_wgrad_reduce_launch(const float* part, float* dw, int nsplit, int RS, in
   if (ss == 1 && sr == S && sb == RS && hwg_tune().wgrad_reduce_rows && RS <= 49 && pairs >= 65536 && nsplit <= 16) {
     const int sl = nsplit >= 8 && pairs <= 65536 ? 4 : 1;
     const int kc = 256 / sl;
-    const int main_blocks = (int)hwg_cdiv(pairs, kc);
-    const int blocks = main_blocks + (dbias ? hwg_cdiv(K, 256) : 0);
-    const size_t lds = (size_t)256 * (RS | 1) * sizeof(float);
-#define HWG_ROWS(SL, RSC)                                                                                                                       \
-  hipLaunchKernelGGL((wgrad_reduce_rows_kernel<SL, RSC>), dim3(blocks), dim3(256), lds, st, part, dw, nsplit, RS, K, C, sa, accumulate, pstride, \
-                     dbias, bias_accumulate, main_blocks)
-    if (RS == 9) { if (sl == 4) HWG_ROWS(4, 9); else HWG_ROWS(1, 9); }
-    else if (RS == 16) { if (sl == 4) HWG_ROWS(4, 16); else HWG_ROWS(1, 16); }
-    else if (RS == 3) { if (sl == 4) HWG_ROWS(4, 3); else HWG_ROWS(1, 3); }
-    else { if (sl == 4) HWG_ROWS(4, 0); else HWG_ROWS(1, 0); }
-#undef HWG_ROWS
-    HWG_LAUNCH_CHECK("conv_wgrad_reduce");
+    r.main_blocks = (int)hwg_cdiv(pairs, kc);
+    r.nblocks = r.main_blocks + (has_bias ? hwg_cdiv(K, 256) : 0);
+    r.lds = (size_t)256 * (RS | 1) * sizeof(float);
+    const int rsc = RS == 9 ? 0 : RS == 16 ? 1 : RS == 3 ? 2 : 3;
+    r.variant = RED_ROWS + 2 * rsc + (sl == 4 ? 1 : 0);
+    return r;
+  }
+  if (nsplit >= 64 && total <= 65536) { r.variant = RED_LANES32; r.nblocks = hwg_cdiv(total, 8); r.lds = 1024; }
+  else if (nsplit >= 8 && total <= 262144) { r.variant = RED_LANES4; r.nblocks = hwg_cdiv(total, 64); r.lds = 1024; }
+  else if (C % 4 == 0) { r.variant = RED_VEC4; r.nblocks = hwg_stream_grid(total / 4, 256); }
+  else { r.variant = RED_SCALAR; r.nblocks = hwg_stream_grid(total, 256); }
+  return r;
+}
+
+#include <mutex>
+#include <vector>
+namespace {
+thread_local int g_defer_next = 0;          // set by hwg_wgrad_defer_next, consumed (and cleared) by the next weight-gradient entry point
+std::mutex g_defer_mu;                       // queued from the autograd engine's thread, flushed from the caller's
+std::vector<RedEntry> g_defer_queue;
+}  // namespace
+int hwg_prof_current_tag();
+void hwg_prof_add_child(int parent, int kind, int tag, double work);
+bool hwg_wgrad_defer_take() { const bool d = g_defer_next != 0; g_defer_next = 0; return d; }
+extern "C" int hwg_wgrad_defer_next(void) { g_defer_next = 1; return HWG_OK; }
+extern "C" long long hwg_wgrad_defer_pending(void) { std::lock_guard<std::mutex> lock(g_defer_mu); return (long long)g_defer_queue.size(); }
+
+int hwg_wgrad_reduce_launch(const float* part, float* dw, int nsplit, int RS, int S, int K, int C, long long sa, long long sb, long long sr,
+                            long long ss, int accumulate, long long pstride, float* dbias, int bias_accumulate, hipStream_t st, bool defer) {
+  const long long total = (long long)RS * K * C + (dbias ? K : 0);
+  if (total >= (1ll << 31)) { hwg_set_error("wgrad_reduce: weight image too large for 32-bit element indices"); return HWG_ERR_ARG; }
+  const RedSchedule r = reduce_schedule(nsplit, RS, S, K, C, sb, sr, ss, dbias != nullptr);
+  if (defer) {
+    RedEntry e;
+    e.part = part; e.dw = dw; e.dbias = dbias; e.pstride = pstride; e.sa = sa; e.sb = sb; e.sr = sr; e.ss = ss;
+    e.nsplit = nsplit; e.RS = RS; e.S = S; e.K = K; e.C = C; e.accumulate = accumulate; e.bias_accumulate = bias_accumulate;
+    e.variant = r.variant; e.first_block = 0; e.nblocks = r.nblocks; e.main_blocks = r.main_blocks; e.tag = hwg_prof_current_tag();
+    std::lock_guard<std::mutex> lock(g_defer_mu);
+    g_defer_queue.push_back(e);
     return HWG_OK;
   }
-  if (nsplit >= 64 && total <= 65536)
-    hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<32>, dim3(hwg_cdiv(total, 8)), dim3(256), 0, st, part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss,
+  const int v = r.variant;
+  if (v >= RED_ROWS) {
+#define HWG_ROWS(SL, RSC)                                                                                                                          \
+  hipLaunchKernelGGL((wgrad_reduce_rows_kernel<SL, RSC>), dim3(r.nblocks), dim3(256), r.lds, st, part, dw, nsplit, RS, K, C, sa, accumulate, pstride, \
+                     dbias, bias_accumulate, r.main_blocks)
+    switch (v - RED_ROWS) {
+      case 0: HWG_ROWS(1, 9); break;  case 1: HWG_ROWS(4, 9); break;  case 2: HWG_ROWS(1, 16); break;  case 3: HWG_ROWS(4, 16); break;
+      case 4: HWG_ROWS(1, 3); break;  case 5: HWG_ROWS(4, 3); break;  case 6: HWG_ROWS(1, 0); break;   default: HWG_ROWS(4, 0); break;
+    }
+#undef HWG_ROWS
+  } else if (v == RED_LANES32)
+    hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<32>, dim3(r.nblocks), dim3(256), 0, st, part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss,
                        accumulate, pstride, dbias, bias_accumulate);
-  else if (nsplit >= 8 && total <= 262144)
-    hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<4>, dim3(hwg_cdiv(total, 64)), dim3(256), 0, st, part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss,
+  else if (v == RED_LANES4)
+    hipLaunchKernelGGL(wgrad_reduce_lanes_kernel<4>, dim3(r.nblocks), dim3(256), 0, st, part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss,
                        accumulate, pstride, dbias, bias_accumulate);
-  else if (C % 4 == 0)
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(hwg_stream_grid(total / 4, 256)), dim3(256), 0, st, part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss,
+  else if (v == RED_VEC4)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(r.nblocks), dim3(256), 0, st, part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss,
                        accumulate, pstride, dbias, bias_accumulate);
   else
-    hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, st, part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss,
+    hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3(r.nblocks), dim3(256), 0, st, part, dw, nsplit, RS, S, K, C, sa, sb, sr, ss,
                        accumulate, pstride, dbias, bias_accumulate);
   HWG_LAUNCH_CHECK("conv_wgrad_reduce");
+  return HWG_OK;
+}
+
+// sums every queued set of partial images (see wgrad_reduce_multi_kernel); returns the number of launches made through *launches
+extern "C" int hwg_wgrad_defer_flush(void* stream, int* launches) {
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<RedEntry> q;
+  {
+    std::lock_guard<std::mutex> lock(g_defer_mu);
+    q.swap(g_defer_queue);
+  }
+  int made = 0;
+  std::vector<int> pass(q.size(), 0);
+  int npass = 0;
+  for (size_t i = 0; i < q.size(); ++i) {          // the k-th queued gradient of a tensor goes to pass k (same accumulation order as undeferred)
+    for (size_t j = 0; j < i; ++j)
+      if (q[j].dw == q[i].dw || (q[i].dbias && q[j].dbias == q[i].dbias)) pass[i] = pass[j] + 1 > pass[i] ? pass[j] + 1 : pass[i];
+    if (pass[i] + 1 > npass) npass = pass[i] + 1;
+  }
+  for (int ps = 0; ps < npass; ++ps) {
+    size_t i = 0;
+    while (i < q.size()) {
+      RedTable t; t.n = 0; t.pad = 0;
+      int blocks = 0; size_t lds = 1024; double bytes = 0.0;
+      int member[RED_MAX]; double mbytes[RED_MAX];
+      for (; i < q.size() && t.n < RED_MAX; ++i) {
+        if (pass[i] != ps) continue;
+        RedEntry e = q[i];
+        e.first_block = blocks;
+        blocks += e.nblocks;
+        const RedSchedule r = reduce_schedule(e.nsplit, e.RS, e.S, e.K, e.C, e.sb, e.sr, e.ss, e.dbias != nullptr);
+        if (r.lds > lds) lds = r.lds;
+        const double b = 4.0 * ((double)e.RS * e.K * e.C + (e.dbias ? e.K : 0)) * (e.nsplit + 1 + (e.accumulate ? 1 : 0));
+        member[t.n] = e.tag; mbytes[t.n] = b; bytes += b;
+        t.e[t.n++] = e;
+      }
+      if (t.n == 0) break;
+      const int prof = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, bytes, st);
+      hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), lds, st, t);
+      hwg_prof_close(prof, st);
+      if (prof >= 0)                               // the launch's time is shared out over its entries' layers in proportion to their bytes
+        for (int m = 0; m < t.n; ++m) hwg_prof_add_child(prof, HWG_PROF_WGRAD_REDUCE, member[m], mbytes[m]);
+      HWG_LAUNCH_CHECK("wgrad_reduce_multi");
+      ++made;
+    }
+  }
+  if (launches) *launches = made;
   return HWG_OK;
 }
 
@@ -1442,6 +1590,7 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
   if (rc) return rc;
   HWG_REQUIRE(u && v && dw, "conv_wgrad: null pointer");
   hipStream_t st = (hipStream_t)stream;
+  const bool defer = hwg_wgrad_defer_take();      // consumed here whatever path runs: a stale flag must never reach a later call
   if (wgrad_is_direct(d)) {
     HWG_REQUIRE(!dbias, "conv_wgrad: the fused bias gradient is not available on the direct (K<=2 / C<=2) path, use hwg_colsum");
     return hwg_conv_wgrad_direct_impl(d, u, v, dw, sa, sb, sr, ss, accumulate, workspace, workspace_bytes, st);
@@ -1481,7 +1630,7 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
   HWG_LAUNCH_CHECK("conv_wgrad");
   const int prof2 = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, 4.0 * ((double)d->R * d->S * d->K * d->C + (dbias ? d->K : 0)) * (p.nsplit + 1), st);
   rc = hwg_wgrad_reduce_launch((const float*)workspace, dw, p.nsplit, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias,
-                               bias_accumulate, st);
+                               bias_accumulate, st, defer);
   hwg_prof_close(prof2, st);
   if (rc) return rc;
   return HWG_OK;

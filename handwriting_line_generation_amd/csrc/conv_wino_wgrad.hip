@@ -270,7 +270,8 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgK a) {
 }  // namespace
 
 int hwg_wgrad_reduce_launch(const float* part, float* dw, int nsplit, int RS, int S, int K, int C, long long sa, long long sb, long long sr,
-                            long long ss, int accumulate, long long pstride, float* dbias, int bias_accumulate, hipStream_t st);
+                            long long ss, int accumulate, long long pstride, float* dbias, int bias_accumulate, hipStream_t st, bool defer);
+bool hwg_wgrad_defer_take();
 
 namespace {
 struct WgPlan { int kt, ct, nsplit, MP; };
@@ -323,6 +324,7 @@ extern "C" size_t hwg_wino_wgrad_workspace(const hwg_conv_desc* d) {
 
 extern "C" int hwg_wino_wgrad(const hwg_conv_desc* d, const float* dy, const float* x, float* dw, long long sa, long long sb, long long sr,
                               long long ss, int accumulate, float* dbias, int bias_accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  const bool defer = hwg_wgrad_defer_take();
   HWG_REQUIRE(d && dy && x && dw, "wino_wgrad: null pointer");
   HWG_REQUIRE(hwg_wino_wgrad_supported(d), "wino_wgrad: needs a 3x3 stride-1 dilation-1 convolution with K, C >= 16");
   const size_t need = hwg_wino_wgrad_workspace(d);
@@ -351,7 +353,7 @@ extern "C" int hwg_wino_wgrad(const hwg_conv_desc* d, const float* dy, const flo
   // the partial images have the direct kernel's layout ([split][tap][K][C] + K bias sums): same fixed-order reduce into the weight's layout
   prof = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, (double)need, st);
   const int rc = hwg_wgrad_reduce_launch((const float*)workspace, dw, p.nsplit, 9, 3, d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias,
-                                         bias_accumulate, st);
+                                         bias_accumulate, st, defer);
   hwg_prof_close(prof, st);
   if (rc) return rc;
   return HWG_OK;

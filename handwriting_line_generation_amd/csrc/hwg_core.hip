@@ -12,7 +12,7 @@ void hwg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* hwg_last_error(void) { return g_err; }
-extern "C" int hwg_abi_version(void) { return 5; }
+extern "C" int hwg_abi_version(void) { return 6; }
 
 #include <atomic>
 static std::atomic<unsigned> g_tuning_epoch{1};
@@ -98,7 +98,7 @@ extern "C" int hwg_device_ok(void) {
 // out of the measured duration. Off by default; never synchronises except in hwg_prof_stop().
 #include <atomic>
 namespace {
-struct ProfRec { hipEvent_t e0, e1; int kind, tag, launched; double work; };
+struct ProfRec { hipEvent_t e0, e1; int kind, tag, launched; double work; int parent; };   // parent >= 0: a share of that record's time
 ProfRec* g_prof = nullptr;
 int g_prof_cap = 0;
 std::atomic<int> g_prof_n{0};
@@ -115,13 +115,22 @@ int hwg_prof_open(int kind, double work, hipStream_t st) {
   if (!g_prof_on.load(std::memory_order_relaxed)) return -1;
   const int i = g_prof_n.fetch_add(1);
   if (i >= g_prof_cap) return -1;
-  g_prof[i].kind = kind; g_prof[i].tag = g_prof_tag; g_prof[i].work = work; g_prof[i].launched = 0;
+  g_prof[i].kind = kind; g_prof[i].tag = g_prof_tag; g_prof[i].work = work; g_prof[i].launched = 0; g_prof[i].parent = -1;
   g_prof_cur = i; g_prof_cur_launches = 0;
   return i;
 }
 void hwg_prof_close(int i, hipStream_t st) {
   (void)st;
   if (i >= 0 && g_prof_cur == i) { g_prof[i].launched = g_prof_cur_launches; g_prof_cur = -1; }
+}
+int hwg_prof_current_tag() { return g_prof_tag; }
+// a launch that serves several layers (the table-driven weight-gradient reduce): its time is reported as one record per layer, the
+// parent's duration shared out in proportion to `work` (the parent itself is not reported)
+void hwg_prof_add_child(int parent, int kind, int tag, double work) {
+  if (parent < 0 || !g_prof_on.load(std::memory_order_relaxed)) return;
+  const int i = g_prof_n.fetch_add(1);
+  if (i >= g_prof_cap) return;
+  g_prof[i].kind = kind; g_prof[i].tag = tag; g_prof[i].work = work; g_prof[i].launched = 0; g_prof[i].parent = parent;
 }
 HwgProfEv hwg_prof_launch_events() {
   HwgProfEv ev = {nullptr, nullptr};
@@ -157,16 +166,23 @@ extern "C" int hwg_prof_stop(int* kinds, int* tags, double* work, float* ms, int
   int n = g_prof_n.load();
   if (n > g_prof_cap) n = g_prof_cap;
   int out = 0;
+  double* child_work = new double[n > 0 ? n : 1]();     // per parent: total work of its children
+  for (int i = 0; i < n; ++i)
+    if (g_prof[i].parent >= 0 && g_prof[i].parent < n) child_work[g_prof[i].parent] += g_prof[i].work;
   for (int i = 0; i < n; ++i) {
     float t = 0.f;
-    if (g_prof[i].launched <= 0) continue;      // bracket opened, nothing launched (an error path)
-    (void)hipEventSynchronize(g_prof[i].e1);
-    if (hipEventElapsedTime(&t, g_prof[i].e0, g_prof[i].e1) != hipSuccess) continue;
+    const int src = g_prof[i].parent >= 0 ? g_prof[i].parent : i;
+    if (src >= n || g_prof[src].launched <= 0) continue;      // bracket opened, nothing launched (an error path)
+    if (g_prof[i].parent < 0 && child_work[i] > 0.0) continue; // reported through its children
+    (void)hipEventSynchronize(g_prof[src].e1);
+    if (hipEventElapsedTime(&t, g_prof[src].e0, g_prof[src].e1) != hipSuccess) continue;
+    if (g_prof[i].parent >= 0) t = (float)(t * g_prof[i].work / child_work[src]);
     if (out < capacity && kinds && tags && work && ms) {
       kinds[out] = g_prof[i].kind; tags[out] = g_prof[i].tag; work[out] = g_prof[i].work; ms[out] = t;
     }
     ++out;
   }
+  delete[] child_work;
   for (int i = 0; i < g_prof_cap; ++i) { (void)hipEventDestroy(g_prof[i].e0); (void)hipEventDestroy(g_prof[i].e1); }
   delete[] g_prof;
   g_prof = nullptr; g_prof_cap = 0; g_prof_n.store(0);

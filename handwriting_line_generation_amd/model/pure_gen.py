@@ -108,6 +108,20 @@ class _EqualConv1x1(nn.Module):
         return ops.conv2d(x, ops.scale(self.conv.weight_orig, self.scale), self.conv.bias)
 
 
+class GenTape:
+    """one taped generator forward: `image` is the leaf the losses see, `style_src` the (autograd) style tensor the generator was fed"""
+
+    def __init__(self, tape, image, style_in, style_src):
+        self.tape, self.image, self.style_in, self.style_src = tape, image, style_in, style_src
+
+    def backward_sets(self, grads, targets):
+        """grads: S gradients of the image; targets[s]: None or (buffer, mask) = where set s's parameter gradients go (ops.grad_set).
+        One pass through the generator for all sets -> the S gradients of the style input"""
+        with ops.scope("G"):
+            res = self.tape.backward_sets(self.image, grads, targets)
+        return res.get(id(self.style_in))
+
+
 class SpacedGenerator(nn.Module):
     def __init__(self, n_class, style_size, dim=256, output_dim=1, n_style_trans=6, emb_dropout=False, append_style=False, small=False):
         super().__init__()
@@ -130,6 +144,11 @@ class SpacedGenerator(nn.Module):
         self.gen = self.conv  # alias present in the reference's state-dict
         self._affine_bank = None
         self._style_chain = None
+        # tape mode (set by the GAN trainer around its balanced lessons): the forward is recorded on an ops.Tape instead of autograd's graph
+        # and the result is a leaf; the trainer collects the two or three gradients the lesson's loss groups leave on that leaf and sends
+        # them through the generator in ONE backward pass (GenTape.backward_sets)
+        self.tape_mode = False
+        self.open_tapes = []
 
     def embed_style(self, style):
         h = ops.pixel_norm(style.contiguous())
@@ -145,7 +164,28 @@ class SpacedGenerator(nn.Module):
 
     def forward(self, content, style, return_intermediate=False):
         with ops.scope("G"):
+            if self.tape_mode and torch.is_grad_enabled() and not return_intermediate:
+                return self._forward_taped(content, style)
             return self._forward(content, style, return_intermediate)
+
+    def _forward_taped(self, content, style):
+        if content.requires_grad:
+            raise ops.L.HwgError("taped generator forward: the content rows carry no gradient in any lesson")
+        tape = ops.Tape()
+        s_in = tape.watch(style.detach())
+        ops.TAPE = tape
+        try:
+            with torch.no_grad():
+                y = self._forward(content, s_in)
+        finally:
+            ops.TAPE = None
+        y.requires_grad_(True)          # a leaf: the losses' backward passes stop here and leave their gradient in y.grad
+        self.open_tapes.append(GenTape(tape, y, s_in, style if style.requires_grad else None))
+        return y
+
+    def take_tapes(self):
+        tapes, self.open_tapes = self.open_tapes, []
+        return tapes
 
     def _forward(self, content, style, return_intermediate=False):
         """content [T,B,n_class] (time major, as in the reference) or NHWC [B,1,T,n_class]; style [B,style]; -> NCHW [B,1,64,4T]"""

@@ -21,9 +21,165 @@ class Function(torch.autograd.Function):
     arguments for functorch wrappers and checks for a setup_context override - 10-25 us per call on the host, several times what the
     forward of a small op costs here, for ~140 ops per training step. None of these ops is used under functorch transforms."""
 
+    # how `backward` treats S gradient sets stacked along the batch axis (Tape.backward_sets): "loop" = called once per set on that set's
+    # slice (ops whose backward reads saved per-sample state), "stacked" = called once on the stacked gradient (stateless in the batch),
+    # "native" = the class implements backward_sets(ctx, S, targets, *stacked_grads) itself
+    sets = "loop"
+
     @classmethod
     def apply(cls, *args):
+        if TAPE is not None:
+            return TAPE.record(cls, args)
         return super(torch.autograd.Function, cls).apply(*args)
+
+
+# ---- explicit tape (a sub-network run outside autograd so that SEVERAL upstream gradients can go through it in one pass) ----------------
+# The balanced GAN lessons send two or three different gradients through the generator, one backward pass each, on layers that fill a
+# quarter of the chip at 8 lines. With the generator's forward recorded on a Tape its backward can take the S gradients stacked along the
+# batch axis: data-gradient convolutions, blurs and resamplings run ONCE on S x N samples; ops that read saved per-sample state (AdaIN,
+# weight gradients, the style MLP) run per set on slices, each set accumulating its parameter gradients into its own buffer (grad_set).
+TAPE = None
+
+
+class _TapeCtx:
+    """the part of torch.autograd's ctx the Functions of this module use"""
+
+    def __init__(self, needs):
+        self.needs_input_grad = needs
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *a):
+        pass
+
+    def set_materialize_grads(self, v):
+        pass
+
+
+class SetGrad:
+    """gradient of one taped tensor for S sets: `stacked` [S*N, ...] (sets along the batch axis) and / or `parts` (one tensor per set)"""
+
+    __slots__ = ("stacked", "parts", "S")
+
+    def __init__(self, S, stacked=None, parts=None):
+        self.S, self.stacked, self.parts = S, stacked, parts
+
+    def get_parts(self):
+        if self.parts is None:
+            n = self.stacked.shape[0] // self.S
+            self.parts = [self.stacked[i * n:(i + 1) * n] for i in range(self.S)]
+        return self.parts
+
+    def get_stacked(self):
+        if self.stacked is None:
+            self.stacked = self.parts[0] if self.S == 1 else torch.cat([p.contiguous() for p in self.parts], dim=0)
+        return self.stacked
+
+    def add(self, other):
+        a, b = self.get_parts(), other.get_parts()
+        out = []
+        for x, y in zip(a, b):
+            z = torch.empty_like(x)
+            L.call("hwg_axpby", x.contiguous(), 1.0, y.contiguous(), 1.0, z, x.numel(), _stream())
+            out.append(z)
+        return SetGrad(self.S, parts=out)
+
+
+class Tape:
+    def __init__(self):
+        self.nodes = []          # (Function class | "alias", ctx, inputs (the original argument tuple), outputs tuple)
+        self.live = {}           # id(tensor) -> tensor, for every tensor a gradient can arrive at (keeps the ids valid)
+
+    def watch(self, t):
+        self.live[id(t)] = t
+        return t
+
+    def record(self, cls, args):
+        global TAPE
+        needs = tuple(isinstance(a, torch.Tensor) and (id(a) in self.live or (a.requires_grad and a.is_leaf)) for a in args)
+        ctx = _TapeCtx(needs)
+        TAPE = None             # ops called from inside a forward are part of it, not nodes of their own
+        try:
+            out = cls.forward(ctx, *args)
+        finally:
+            TAPE = self
+        if any(needs):
+            outs = out if isinstance(out, tuple) else (out,)
+            for o in outs:
+                if isinstance(o, torch.Tensor):
+                    self.live[id(o)] = o
+            self.nodes.append((cls, ctx, args, outs))
+        return out
+
+    def alias(self, new, old):
+        """`new` is a reshape of the taped tensor `old` (same elements, same order)"""
+        if id(old) in self.live:
+            self.live[id(new)] = new
+            self.nodes.append(("alias", tuple(old.shape[1:]), (old,), (new,)))
+        return new
+
+    def backward_sets(self, out, grads, targets):
+        """send S gradients of `out` (list of [N, ...] tensors) through the recorded ops in one pass. targets[s]: where set s accumulates its
+        parameter gradients - None = the parameters' own .grad, else (flat buffer, touched mask) as produced by FlatParams.stash().
+        -> {id(watched input): list of S gradient tensors}"""
+        global GRAD_SET
+        S = len(grads)
+        g = {id(out): SetGrad(S, parts=[x.contiguous() for x in grads])}
+        prev = GRAD_SET
+        try:
+            for cls, ctx, args, outs in reversed(self.nodes):
+                gouts = [g.pop(id(o), None) if isinstance(o, torch.Tensor) else None for o in outs]
+                if all(x is None for x in gouts):
+                    continue
+                if cls == "alias":
+                    st = gouts[0].get_stacked()
+                    gin = [SetGrad(S, stacked=st.reshape((st.shape[0],) + ctx))]
+                else:
+                    for i, x in enumerate(gouts):      # a multi-output op with a missing output gradient: zeros, as autograd materialises them
+                        if x is None and isinstance(outs[i], torch.Tensor):
+                            z = torch.zeros((S * outs[i].shape[0],) + tuple(outs[i].shape[1:]), dtype=outs[i].dtype, device=outs[i].device)
+                            gouts[i] = SetGrad(S, stacked=z)
+                    gin = self._node_backward(cls, ctx, gouts, S, targets)
+                for a, need, gi in zip(args, ctx.needs_input_grad if cls != "alias" else (True,), gin):
+                    if gi is None or not need:
+                        continue
+                    if a.requires_grad and a.is_leaf and id(a) not in self.live:
+                        # a parameter whose gradient came back as a tensor (not accumulated in place by the kernel): add it to its set's buffer
+                        for s_, part in enumerate(gi.get_parts()):
+                            GRAD_SET = targets[s_]
+                            buf = _grad_buffer(a)
+                            L.call("hwg_axpby", part.contiguous(), 1.0, buf, 1.0, buf, buf.numel(), _stream())
+                        continue
+                    k = id(a)
+                    g[k] = gi if k not in g else g[k].add(gi)
+        finally:
+            GRAD_SET = prev
+        return {k: v.get_parts() for k, v in g.items()}
+
+    @staticmethod
+    def _node_backward(cls, ctx, gouts, S, targets):
+        global GRAD_SET
+        mode = cls.sets if S > 1 else "loop"
+        if mode == "native":
+            res = cls.backward_sets(ctx, S, targets, *[x.get_stacked() for x in gouts])
+            return [None if r is None else (r if isinstance(r, SetGrad) else SetGrad(S, stacked=r)) for r in res]
+        if mode == "stacked":
+            GRAD_SET = targets[0]
+            res = cls.backward(ctx, *[x.get_stacked() for x in gouts])
+            res = res if isinstance(res, tuple) else (res,)
+            return [None if r is None else SetGrad(S, stacked=r) for r in res]
+        per_set = []
+        for s_ in range(S):
+            GRAD_SET = targets[s_]
+            res = cls.backward(ctx, *[x.get_parts()[s_] for x in gouts])
+            per_set.append(res if isinstance(res, tuple) else (res,))
+        out = []
+        for i in range(len(per_set[0])):
+            col = [r[i] for r in per_set]
+            out.append(None if col[0] is None else SetGrad(S, parts=col))
+        return out
 
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
@@ -123,11 +279,54 @@ _side_hold = []      # operands of side-stream launches: kept alive until the jo
 
 
 def join_side_stream():
-    """make torch's current stream wait for every weight gradient enqueued on the side stream so far"""
+    """make torch's current stream wait for every weight gradient enqueued on the side stream so far, then sum the weight-gradient partial
+    images whose reduction was deferred (flush_deferred_reduce): after this call every parameter gradient is complete on the current stream"""
     for key in list(_side_dirty):
         L.call("hwg_stream_join", _side_streams[key][1], _stream())
     _side_dirty.clear()
     del _side_hold[:]
+    if _defer["count"]:
+        flush_deferred_reduce()
+
+
+# ---- deferred sum of the weight-gradient partial images -------------------------------------------------------------------
+# A weight gradient leaves one partial image per pixel range in its workspace and sums them with a launch of its own: 65 launches of
+# 5..25 us per training step, too small to stream at memory rate. With DEFER_REDUCE on (the trainers switch it on around their backward
+# passes and call join_side_stream() after every backward()), a weight gradient's workspace comes out of a private arena instead of the
+# shared scratch buffer, its sum is only queued (hwg_wgrad_defer_next), and flush_deferred_reduce() sums everything queued with one
+# table-driven launch per 32 gradients. Bit-identical to the undeferred order (same schedule per gradient, several gradients of one tensor in
+# queue order). Gradients are undefined between the backward call and the flush.
+DEFER_REDUCE = False
+_defer = {"count": 0, "offset": 0, "arena": {}, "launches": 0, "flushes": 0, "fallbacks": 0}
+DEFER_ARENA_BYTES = int(os.environ.get("HWG_DEFER_ARENA_MB", "1536")) << 20
+
+
+def _defer_workspace(nbytes, device):
+    """`nbytes` of the arena that stays untouched until the next flush, or None when the arena is full (the caller then sums at once)"""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    arena = _defer["arena"].get(key)
+    if arena is None:
+        arena = _defer["arena"][key] = torch.empty(DEFER_ARENA_BYTES, dtype=torch.uint8, device=device)
+        for st in _side_streams.values():
+            arena.record_stream(st[0])
+    off = _defer["offset"]
+    need = (int(nbytes) + 255) & ~255
+    if off + need > arena.numel():
+        _defer["fallbacks"] += 1
+        return None
+    _defer["offset"] = off + need
+    _defer["count"] += 1
+    return arena[off: off + need]
+
+
+def flush_deferred_reduce():
+    """sum every queued set of partial images on the current stream (call after the side stream has been joined)"""
+    import numpy as np
+    n = np.zeros(1, dtype=np.int32)
+    L.call("hwg_wgrad_defer_flush", _stream(), n.ctypes.data)
+    _defer["launches"] += int(n[0]); _defer["flushes"] += 1
+    _defer["count"] = 0
+    _defer["offset"] = 0
 
 
 def _chk(t, name, dtype=torch.float32):
@@ -154,8 +353,44 @@ def _direct(p):
     return DIRECT_PARAM_GRADS and p is not None and p.is_leaf and p.requires_grad
 
 
+# Gradient-set redirect: None = parameter gradients accumulate into param.grad (views of the trainer's flat buffer). Otherwise
+# (buffer, touched mask) of a stashed gradient set (FlatParams.stash()): kernels accumulate into the SAME offsets of that buffer and the
+# set's mask is marked - how the batched generator backward (Tape.backward_sets) and the per-set style-extractor passes put every set's
+# gradients where the reference's sequential backward + clone-and-zero would have put them.
+GRAD_SET = None
+_set_views = {}
+
+
+class grad_set:
+    def __init__(self, target):
+        self.target = target
+
+    def __enter__(self):
+        global GRAD_SET
+        self.prev = GRAD_SET
+        GRAD_SET = self.target
+
+    def __exit__(self, *exc):
+        global GRAD_SET
+        GRAD_SET = self.prev
+
+
 def _grad_buffer(p):
     """the buffer parameter gradients accumulate into (zero-initialised on first use)"""
+    gs = GRAD_SET
+    if gs is not None:
+        info = getattr(p, "_hwg_flat", None)
+        if info is None:
+            raise L.HwgError("gradient-set redirect needs parameters that live in a FlatParams buffer")
+        flat, k = info
+        buf, mask = gs
+        mask[k] = True
+        key = (buf.data_ptr(), id(flat), k)
+        v = _set_views.get(key)
+        if v is None:
+            off = int(flat.offsets[k])
+            v = _set_views[key] = buf[off: off + int(flat.numel[k])].view_as(p)
+        return v
     if p.grad is None:
         p.grad = torch.zeros_like(p)
     touch = getattr(p, "_hwg_touch", None)
@@ -509,20 +744,43 @@ class _Conv2d(Function):
         ctx.geom = (stride, padding, dilation, transposed, P, Q)
         return y
 
+    sets = "native"
+
     @staticmethod
     def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = _Conv2d._dgrad(ctx, dy) if ctx.needs_input_grad[0] else None
+        dw_, db = _Conv2d._wgrad(ctx, dy)
+        return dx, dw_, db, None, None, None, None, None
+
+    @staticmethod
+    def backward_sets(ctx, S, targets, dy):
+        """S gradient sets stacked along the batch axis (Tape.backward_sets): ONE data-gradient launch over S x N samples (the generator's
+        layers fill a quarter of the chip at 8 lines), one weight gradient per set (x is shared, every set accumulates into its own buffer)"""
+        global GRAD_SET
+        dy = dy.contiguous()
+        dx = _Conv2d._dgrad(ctx, dy) if ctx.needs_input_grad[0] else None
+        n = dy.shape[0] // S
+        dws, dbs = [], []
+        for s_ in range(S):
+            GRAD_SET = targets[s_]
+            dw_, db = _Conv2d._wgrad(ctx, dy[s_ * n:(s_ + 1) * n])
+            dws.append(dw_); dbs.append(db)
+        return (dx, None if dws[0] is None else SetGrad(S, parts=dws), None if dbs[0] is None else SetGrad(S, parts=dbs), None, None, None, None, None)
+
+    @staticmethod
+    def _dgrad(ctx, dy):
         x, weight = ctx.saved_tensors
         _RUN_SCOPE[0] = ctx.scope
         stride, padding, dilation, transposed, P, Q = ctx.geom
-        dy = dy.contiguous()
         N, H, W, C = x.shape
+        N = dy.shape[0]              # (may be a multiple of x's batch: several gradient sets through the same layer)
         R, S = _taps(weight)
         sh, sw = stride; ph, pw = padding; dh, dw = dilation
         K = dy.shape[3]
-        dx = dw_ = db = None
-        bias_done = False
+        dx = None
         st = _stream()
-        if ctx.needs_input_grad[0]:
+        if True:
             # data gradient: contraction over K (dy's channels) producing C channels
             Kp = _cpad(K, C, fractional=(not transposed and (sh != 1 or sw != 1)))
             dyin = _pad_channels(dy, Kp) if Kp != K else dy
@@ -548,6 +806,21 @@ class _Conv2d(Function):
                 wino = _wino_ok(N, P, Q, Kp, C, R, S, (sh, sw), (ph, pw), (dh, dw), H, W)
                 wp = _pack(weight, C, K, R, S, K * R * S, R * S, flip=0, Bpad=Kp, wino=wino)
                 dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (sh, sw), (ph, pw), (dh, dw), H, W, 0, wino)
+        return dx
+
+    @staticmethod
+    def _wgrad(ctx, dy):
+        """-> (dw, db) as tensors, or None where the kernel accumulated straight into the parameter's gradient buffer"""
+        x, weight = ctx.saved_tensors
+        _RUN_SCOPE[0] = ctx.scope
+        stride, padding, dilation, transposed, P, Q = ctx.geom
+        N, H, W, C = x.shape
+        R, S = _taps(weight)
+        sh, sw = stride; ph, pw = padding; dh, dw = dilation
+        K = dy.shape[3]
+        dw_ = db = None
+        bias_done = False
+        st = _stream()
         wref, bref = ctx.param_refs
         if ctx.needs_input_grad[1]:
             direct = _direct(wref)
@@ -564,8 +837,9 @@ class _Conv2d(Function):
             else:
                 u, v = x, dy
                 sa, sb = K * R * S, R * S
+            dws = _defer_workspace(need, x.device) if (DEFER_REDUCE and direct and engine != 1 and need) else None
             if engine == 0:
-                ws = workspace(need, x.device)
+                ws = dws if dws is not None else workspace(need, x.device)
                 if PROF_SHAPES is not None:
                     _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad", ctx.scope))
                 dbias = bacc = None
@@ -576,6 +850,8 @@ class _Conv2d(Function):
                     bias_done = True
                     if not bdirect:
                         db = dbias
+                if dws is not None and (dbias is None or bacc):
+                    L.call("hwg_wgrad_defer_next")
                 L.call("hwg_wino_wgrad", d.ptr, u, v, dw_, sa, sb, S, 1, 1 if direct else 0, dbias, bacc or 0, ws, ws.numel(), st)
                 if direct:
                     dw_ = None
@@ -597,7 +873,7 @@ class _Conv2d(Function):
                 else:
                     dw_ = valid.reshape(weight.shape).contiguous()
             else:
-                ws = workspace(need, x.device)
+                ws = dws if dws is not None else workspace(need, x.device)
                 if PROF_SHAPES is not None:
                     _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad", ctx.scope))
                 # the bias gradient (column sums of dy) rides along when dy is the kernel's anchor operand and the MFMA path runs
@@ -610,14 +886,19 @@ class _Conv2d(Function):
                     bias_done = True
                     if not bdirect:
                         db = dbias
+                defer = dws is not None and (dbias is None or bacc)
                 if SIDE_WGRAD and direct and (dbias is None or bacc):
                     s2, raw2, skey = _side_stream(x.device)
                     L.call("hwg_stream_fork", st, raw2)      # dy (and x) are complete on the main stream at this point
-                    ws2 = _side_workspace(need, x.device, s2)
+                    ws2 = dws if defer else _side_workspace(need, x.device, s2)
+                    if defer:
+                        L.call("hwg_wgrad_defer_next")
                     L.call("hwg_conv_wgrad", d.ptr, u, v, dw_, sa, sb, S, 1, 1, dbias, bacc or 0, ws2, ws2.numel(), raw2)
                     _side_hold.append((u, v))
                     _side_dirty.add(skey)
                 else:
+                    if defer:
+                        L.call("hwg_wgrad_defer_next")
                     L.call("hwg_conv_wgrad", d.ptr, u, v, dw_, sa, sb, S, 1, 1 if direct else 0, dbias, bacc or 0, ws, ws.numel(), st)
                 if direct:
                     dw_ = None
@@ -626,7 +907,7 @@ class _Conv2d(Function):
                 colsum(dy.view(-1, K), out=_grad_buffer(bref), accumulate=True)
             else:
                 db = colsum(dy.view(-1, K))
-        return dx, dw_, db, None, None, None, None, None
+        return dw_, db
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
@@ -761,6 +1042,32 @@ class _AdaIN(Function):
                ws, ws.numel(), _stream())
         return dx, None, (None if direct else dnw.view(wshape)), dgamma, dbeta, None, None, None
 
+    sets = "native"
+
+    @staticmethod
+    def backward_sets(ctx, S, targets, dy):
+        """S gradient sets stacked along the batch axis: the saved activations are shared, so the kernel runs once per set on that set's slice
+        and writes its slice of the stacked results (no concatenation pass); the noise-weight gradient of set s goes to set s's buffer"""
+        global GRAD_SET
+        u, noise, gamma, mean, rstd = ctx.saved_tensors
+        noise_scale, slope, N, HW, C, wshape = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty((S * N,) + tuple(u.shape[1:]), dtype=torch.float32, device=u.device)
+        dgamma = torch.empty((S * N, C), dtype=torch.float32, device=u.device)
+        dbeta = torch.empty_like(dgamma)
+        (nwref,) = ctx.param_refs
+        if not _direct(nwref):
+            raise L.HwgError("batched AdaIN backward needs the noise weight's gradient buffer (a leaf parameter)")
+        ws = workspace(L.query("hwg_norm_workspace", N, HW, C), u.device)
+        st = _stream()
+        for s_ in range(S):
+            GRAD_SET = targets[s_]
+            dnw = _grad_buffer(nwref)
+            sl = slice(s_ * N, (s_ + 1) * N)
+            L.call("hwg_adain_bwd", dy[sl], u, noise, noise_scale, slope, gamma, mean, rstd, dx[sl], dgamma[sl], dbeta[sl], dnw, None, 1, N, HW, C,
+                   ws, ws.numel(), st)
+        return dx, None, None, dgamma, dbeta, None, None, None
+
 
 def adain_epilogue(x, noise, noise_w, gamma, beta, noise_scale, slope=0.2, eps=1e-5):
     return _AdaIN.apply(x, noise, noise_w, gamma, beta, noise_scale, slope, eps)
@@ -858,6 +1165,8 @@ def pixel_norm(x, eps=1e-8):
 # pooling / resampling / padding / concat
 # ----------------------------------------------------------------------------------------------
 class _AvgPool(Function):
+    sets = "stacked"
+
     @staticmethod
     def forward(ctx, x, kh, kw):
         _chk(x, "avgpool input")
@@ -870,6 +1179,7 @@ class _AvgPool(Function):
     @staticmethod
     def backward(ctx, dy):
         N, H, W, C, kh, kw = ctx.cfg
+        N = dy.shape[0]           # (several gradient sets stacked along the batch axis: Tape.backward_sets)
         dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
         L.call("hwg_avgpool_bwd", dy.contiguous(), dx, N, H, W, C, kh, kw, _stream())
         return dx, None, None
@@ -911,6 +1221,8 @@ def max_pool2d(x, kernel, stride=None, padding=0):
 
 
 class _Upsample(Function):
+    sets = "stacked"
+
     @staticmethod
     def forward(ctx, x, fh, fw):
         _chk(x, "upsample input")
@@ -923,6 +1235,7 @@ class _Upsample(Function):
     @staticmethod
     def backward(ctx, dy):
         N, H, W, C, fh, fw = ctx.cfg
+        N = dy.shape[0]
         dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
         L.call("hwg_upsample_nearest_bwd", dy.contiguous(), dx, N, H, W, C, fh, fw, _stream())
         return dx, None, None
@@ -934,6 +1247,8 @@ def upsample_nearest(x, scale):
 
 
 class _Blur(Function):
+    sets = "stacked"
+
     @staticmethod
     def forward(ctx, x):
         _chk(x, "blur input")
@@ -952,6 +1267,8 @@ def blur3(x):
 
 
 class _Pad2d(Function):
+    sets = "stacked"
+
     @staticmethod
     def forward(ctx, x, pt, pb, pl, pr, mode, value):
         _chk(x, "pad input")
@@ -964,6 +1281,7 @@ class _Pad2d(Function):
     @staticmethod
     def backward(ctx, dy):
         N, H, W, C, pt, pb, pl, pr, mode = ctx.cfg
+        N = dy.shape[0]
         dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
         L.call("hwg_pad2d_bwd", dy.contiguous(), dx, N, H, W, C, pt, pb, pl, pr, mode, _stream())
         return dx, None, None, None, None, None, None
@@ -977,6 +1295,7 @@ def pad2d(x, left, right, top=0, bottom=0, mode="constant", value=0.0):
 
 class _CatChannels(Function):
     """concatenate along C; parts that are 2-D [N, c] are broadcast over the pixels of sample n"""
+    sets = "stacked"
 
     @staticmethod
     def forward(ctx, ref_shape, *parts):
@@ -999,6 +1318,7 @@ class _CatChannels(Function):
     def backward(ctx, dy):
         N, H, W, widths, bc = ctx.cfg
         dy = dy.contiguous()
+        N = dy.shape[0]
         Ct = sum(widths)
         rows = N * H * W
         grads = []
@@ -1041,6 +1361,7 @@ def permute4(x, dims, strides):
 
 class _ToNCHW(Function):
     """layout change at the module boundary (NHWC -> NCHW copy); only used for multi-channel boundary tensors"""
+    sets = "stacked"
 
     @staticmethod
     def forward(ctx, x):
@@ -1054,6 +1375,8 @@ class _ToNCHW(Function):
 
 
 class _ToNHWC(Function):
+    sets = "stacked"
+
     @staticmethod
     def forward(ctx, x):
         N, C, H, W = x.shape
@@ -1066,11 +1389,17 @@ class _ToNHWC(Function):
 
 
 def to_nchw(x):
-    return x.reshape(x.shape[0], 1, x.shape[1], x.shape[2]) if x.shape[3] == 1 else _ToNCHW.apply(x)
+    if x.shape[3] == 1:
+        y = x.reshape(x.shape[0], 1, x.shape[1], x.shape[2])
+        return TAPE.alias(y, x) if TAPE is not None else y
+    return _ToNCHW.apply(x)
 
 
 def to_nhwc(x):
-    return x.reshape(x.shape[0], x.shape[2], x.shape[3], 1) if x.shape[1] == 1 else _ToNHWC.apply(x.contiguous())
+    if x.shape[1] == 1:
+        y = x.reshape(x.shape[0], x.shape[2], x.shape[3], 1)
+        return TAPE.alias(y, x) if TAPE is not None else y
+    return _ToNHWC.apply(x.contiguous())
 
 
 # ----------------------------------------------------------------------------------------------
@@ -1727,11 +2056,13 @@ class LinearBank:
         gb = [_grad_buffer(m.bias) if m.bias.requires_grad else None for m in self.linears]
         addr = [g.data_ptr() if g is not None else 0 for g in gw + gb]
         key = tuple(addr)
-        if self._gkey != key:
+        if self._gkey is None:
+            self._gkey = {}
+        tab = self._gkey.get(key)           # (one table per destination: the parameters' own gradients, or a stashed set's buffer)
+        if tab is None:
             ptrs = h2d(np.array(addr, dtype=np.int64), device)
-            self._gtab = (ptrs[:self.L], ptrs[self.L:])
-            self._gkey = key
-        return self._gtab
+            tab = self._gkey[key] = (ptrs[:self.L], ptrs[self.L:])
+        return tab
 
     def params(self):
         return [m.weight for m in self.linears] + [m.bias for m in self.linears]
@@ -1807,11 +2138,13 @@ class MLPChain:
         gb = [_grad_buffer(m.bias) if m.bias.requires_grad else None for m in self.linears]
         addr = [g.data_ptr() if g is not None else 0 for g in gw + gb]
         key = tuple(addr)
-        if self._gkey != key:
+        if self._gkey is None:
+            self._gkey = {}
+        tab = self._gkey.get(key)
+        if tab is None:
             p = h2d(np.array(addr, dtype=np.int64), device)
-            self._gtab = (p[:self.L], p[self.L:])
-            self._gkey = key
-        return self._gtab
+            tab = self._gkey[key] = (p[:self.L], p[self.L:])
+        return tab
 
     def params(self):
         return [m.weight for m in self.linears] + [m.bias for m in self.linears]

@@ -36,6 +36,8 @@ class AutoTrainer(BaseTrainer):
         import torch.distributed as dist
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         ops.SIDE_WGRAD = bool(tr.get("side_stream_wgrad", False))   # process-global switch: every trainer states its own choice
+        import os
+        self._defer_reduce = bool(int(tr.get("defer_wgrad_reduce", os.environ.get("HWG_DEFER_REDUCE", "1")) or 0))
 
     def _next_instance(self):
         try:
@@ -56,8 +58,12 @@ class AutoTrainer(BaseTrainer):
             v = ops.scale(v, self.lossWeights[name[:-4]])
             scaled[name] = v
             loss = v if isinstance(loss, int) else ops.add(loss, v)
-        loss.backward()
-        ops.join_side_stream()
+        ops.DEFER_REDUCE = self._defer_reduce     # partial-image sums of the pass in one table-driven launch (ops.flush_deferred_reduce)
+        try:
+            loss.backward()
+        finally:
+            ops.DEFER_REDUCE = False
+            ops.join_side_stream()
         allreduce_gradient_sets(self.flat, (), self.world, self.gpu)
         if getattr(self, "pre_clip_hook", None) is not None:     # parity tests read the gradients where the reference clips them
             self.pre_clip_hook(iteration)

@@ -100,6 +100,10 @@ class FlatParams:
 
     def _make_hook(self, k):
         def hook(p):
+            if ops.GRAD_SET is not None:
+                # autograd added a returned gradient to param.grad while a gradient-set redirect was active: that gradient belongs to the
+                # redirected set's buffer, not to the current one (every op on a redirected pass must accumulate through ops._grad_buffer)
+                raise RuntimeError("parameter gradient accumulated by autograd under ops.grad_set (tensor %d)" % k)
             self.touched[k] = True
         return hook
 

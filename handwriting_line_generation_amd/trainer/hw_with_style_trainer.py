@@ -121,6 +121,9 @@ class HWWithStyleTrainer(BaseTrainer):
         ops.SIDE_WGRAD = self._side_wgrad is True
         self._pending_log = None
         self.pre_clip_hook = None
+        self._defer_reduce = bool(int(tr.get("defer_wgrad_reduce", os.environ.get("HWG_DEFER_REDUCE", "1")) or 0))
+        # the two or three gradients a balanced lesson sends through the generator go through it in one pass (see _generator_backward)
+        self._batch_gen_backward = bool(int(tr.get("batch_gen_backward", os.environ.get("HWG_BATCH_GEN_BWD", "1")) or 0))
         # Dead-gradient elimination (off by default = the reference's launches). The reference computes two families of parameter gradients
         # that nothing ever reads: the frozen recogniser's (it is in no optimizer; 11 backward traversals per cycle) and the
         # discriminator's in gen / auto lessons (optimizer_discriminator.zero_grad() drops them before the next disc lesson reads any).
@@ -205,7 +208,15 @@ class HWWithStyleTrainer(BaseTrainer):
             # alone would leave its peers waiting in the gradient all-reduce)
             if self._skip_together(all(l == 0 for l in instance["label_lengths"])):
                 return None
-            losses = self.run_gen(instance, lesson)
+            gen = getattr(self.model, "generator", None)
+            taped = self._batch_gen_backward and self.balance_loss and gen is not None and hasattr(gen, "tape_mode")
+            if taped:
+                gen.tape_mode = True
+            try:
+                losses = self.run_gen(instance, lesson)
+            finally:
+                if taped:
+                    gen.tape_mode = False
             pred = None
         else:
             pred, losses = self.run_hwr(instance)
@@ -225,22 +236,74 @@ class HWWithStyleTrainer(BaseTrainer):
                 loss = v if isinstance(loss, int) else ops.add(loss, v)
 
         lkey = tuple(lesson) if lesson else ()
-        if self.balance_loss:
-            for pos, part in enumerate((autoGenLoss, recogLoss)):
-                if not isinstance(part, int):
-                    part.backward(retain_graph=True)
-                    ops.join_side_stream()
-                    self.saved_grads.append(self._stash((lkey, pos)))
-        else:
-            for part in (recogLoss, autoGenLoss):
-                if not isinstance(part, int):
-                    loss = part if isinstance(loss, int) else ops.add(loss, part)
-        if not isinstance(loss, int):
-            loss.backward()
-            ops.join_side_stream()
+        # the sums of the weight-gradient partial images of a backward pass are queued and made by one table-driven launch at the
+        # join_side_stream() behind it (ops.DEFER_REDUCE; bit-identical, ~65 small launches per step less)
+        ops.DEFER_REDUCE = self._defer_reduce
+        tapes = self._gen_tapes()
+        try:
+            if self.balance_loss:
+                sets = []           # per separately balanced loss group: (stash or None = the current set, [gradient left on each tape's image])
+                for pos, part in enumerate((autoGenLoss, recogLoss)):
+                    if not isinstance(part, int):
+                        part.backward(retain_graph=True)
+                        ops.join_side_stream()
+                        if tapes:
+                            st = self.flat.stash()                        # its all-reduce starts once the generator's share has been added
+                            sets.append((st, (lkey, pos), self._take_image_grads(tapes)))
+                        else:
+                            self.saved_grads.append(self._stash((lkey, pos)))
+            else:
+                for part in (recogLoss, autoGenLoss):
+                    if not isinstance(part, int):
+                        loss = part if isinstance(loss, int) else ops.add(loss, part)
+            if not isinstance(loss, int):
+                loss.backward()
+                ops.join_side_stream()
+            if tapes:
+                sets.append((None, None, self._take_image_grads(tapes)))
+                self._generator_backward(tapes, sets)
+        finally:
+            ops.DEFER_REDUCE = False
+            ops.join_side_stream()      # (an exception inside backward must not leave queued sums behind)
         if self.balance_loss and "no-step" in lesson:
             self.saved_grads.append(self._stash((lkey, 2)))
         return scaled, pred
+
+    # -- batched generator backward ----------------------------------------------------------------------------------------------
+    def _gen_tapes(self):
+        """the taped generator forwards of this iteration (model.generator.tape_mode, switched on in run_gen for balanced training lessons)"""
+        gen = getattr(self.model, "generator", None)
+        return gen.take_tapes() if gen is not None and hasattr(gen, "take_tapes") else []
+
+    @staticmethod
+    def _take_image_grads(tapes):
+        out = []
+        for t in tapes:
+            out.append(t.image.grad)
+            t.image.grad = None
+        return out
+
+    def _generator_backward(self, tapes, sets):
+        """The reference walks the generator (and, behind it, the style extractor) once per balanced loss group (trainer :300-338: up to three
+        backward() calls on the same graph). Here every group's backward pass stopped at the generated image (a leaf, pure_gen.GenTape); now
+        the gradients the groups left there go through the generator TOGETHER, stacked along the batch axis - its layers fill a quarter of
+        the chip at 8 lines - each group's parameter gradients accumulating into that group's own buffer (ops.grad_set: the stash of the
+        group, or the current gradient set for the last one), then each group's style gradient through the style extractor's graph."""
+        for ti, tape in enumerate(tapes):
+            members = [(st, g[ti]) for st, _, g in sets if g[ti] is not None]
+            if not members:
+                continue
+            targets = [None if st is None else (st[0], st[1]) for st, _ in members]
+            dstyles = tape.backward_sets([g for _, g in members], targets)
+            if tape.style_src is not None and dstyles is not None:
+                for k, ((st, _), ds) in enumerate(zip(members, dstyles)):
+                    with ops.grad_set(targets[k]):
+                        tape.style_src.backward(ds, retain_graph=k + 1 < len(members))
+                        ops.join_side_stream()
+        ops.join_side_stream()
+        for st, key, _ in sets:
+            if st is not None:
+                self.saved_grads.append(start_stash_allreduce(st, self.world, self.flat, key=key))
 
     def _apply_step(self, lesson, iteration, instance, scaled, pred):
         """Gradient consumption (trainer :340-391): data-parallel averaging of every gradient set, balancing of the stashed sets into the

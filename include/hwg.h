@@ -119,6 +119,19 @@ int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const float* v, float
                    long long sa, long long sb, long long sr, long long ss, int accumulate,
                    float* dbias, int bias_accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Deferred sum of the weight-gradient partial images (reference: the per-parameter gradient accumulation autograd does after every backward
+ * node, trainer/hw_with_style_trainer.py:300-338 reads the results only after the pass). hwg_conv_wgrad / hwg_wino_wgrad write one partial
+ * image per pixel range into the workspace and sum them into dw (+dbias) with a launch of their own - 65 such launches per training step, most
+ * too small to stream at memory rate. hwg_wgrad_defer_next() marks the calling thread's NEXT weight-gradient call: its sum is queued instead of
+ * launched, and the caller must keep that call's workspace alive and untouched (its own arena, not a shared scratch buffer) until
+ * hwg_wgrad_defer_flush(stream, &launches) has been enqueued, which sums everything queued so far (any thread) with one table-driven launch
+ * per 32 gradients: every gradient runs the schedule it would have run alone (bit-identical results), several gradients of the same tensor
+ * are summed in queue order by consecutive launches. dw / dbias are undefined between the call and the flush. The mark is consumed by the next
+ * hwg_conv_wgrad / hwg_wino_wgrad call whatever path it takes (paths without partial images simply ignore it). */
+int hwg_wgrad_defer_next(void);
+long long hwg_wgrad_defer_pending(void);
+int hwg_wgrad_defer_flush(void* stream, int* launches);
+
 /* Winograd F(2x2,3x3) path for 3x3 / stride 1 / dilation 1 convolutions with C % 16 == 0 and K >= 16 (same call sites as
  * hwg_conv_fwd: the 3x3 layers of model/discriminator_ap.py:84-131, model/cnn_only_hwr.py:31-32, model/pure_gen.py:161-197,
  * model/char_style.py:65-71, model/autoencoder.py:346-395 and their data gradients). Input, filter and output transforms are

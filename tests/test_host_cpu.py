@@ -17,7 +17,7 @@ def test_cabi_exports_every_declared_symbol():
     exported = {l.split()[-1] for l in out.splitlines() if " T hwg_" in l}
     assert set(_lib.DECLS) <= exported, sorted(set(_lib.DECLS) - exported)
     assert exported <= set(_lib.DECLS), "exported but undeclared: %s" % sorted(exported - set(_lib.DECLS))
-    assert _lib.abi_version() == 5 and len(_lib.DECLS) >= 90
+    assert _lib.abi_version() == 6 and len(_lib.DECLS) >= 100
 
 
 def test_kernels_refuse_cpu_tensors():

@@ -892,3 +892,58 @@ RANDOM_CONV_CASES = _random_conv_cases(int(_os.environ.get("HWG_TEST_RANDOM_CONV
 def test_conv_random_geometry(cuda, case):
     """seeded random conv / conv-transpose geometries (odd sizes, 1-pixel maps, RIMES channel counts, dilation, every schedule branch)"""
     test_conv_fwd_bwd(cuda, case)
+
+
+def test_deferred_wgrad_reduce_is_bit_identical(cuda):
+    """ops.DEFER_REDUCE: the sums of the weight-gradient partial images of a whole backward pass are queued and made by ONE table-driven
+    launch per 32 gradients (hwg_wgrad_defer_flush). Every reduce schedule of the library (vec4, scalar / taps-as-N, 4- and 32-lane, row-contiguous
+    with and without lanes, Winograd weight gradient) and a tensor that receives TWO gradients in one pass (a layer applied twice: summed in
+    queue order by consecutive launches) must come out bit-identical to the launch-per-gradient path, bias gradients included."""
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(21)
+    layers = [  # N, H, W, C, K, R, S, pad
+        (2, 6, 70, 512, 512, 3, 3, (1, 1)),      # row-contiguous reduce (>= 65536 pairs)
+        (2, 8, 40, 256, 256, 3, 3, (1, 1)),      # row-contiguous, lanes
+        (4, 20, 64, 64, 64, 3, 3, (0, 1)),       # Winograd weight gradient, many ranges
+        (4, 16, 48, 128, 128, 3, 3, (1, 1)),
+        (2, 30, 100, 1, 64, 7, 7, (0, 3)),       # taps-as-N (scalar reduce)
+        (2, 1, 60, 256, 256, 1, 3, (0, 1)),      # 1-D layer
+        (2, 24, 80, 16, 16, 3, 3, (1, 1)),       # narrow all-taps kernel
+        (2, 12, 40, 32, 64, 4, 4, (1, 1)),
+    ]
+    ws = []
+    for (N, H, W, C, K, R, S, pad) in layers:
+        w = torch.nn.Parameter((torch.randn(K, C, R, S, generator=g) * 0.05).to(cuda))
+        b = torch.nn.Parameter((torch.randn(K, generator=g) * 0.05).to(cuda))
+        ws.append((w, b))
+    xs = [torch.randn(N, H, W, C, generator=g).to(cuda) for (N, H, W, C, K, R, S, pad) in layers]
+    x_twice = torch.randn(3, 10, 33, 128, generator=g).to(cuda)        # layer 3 applied a second time, on another geometry
+
+    def run(defer):
+        for w, b in ws:
+            w.grad = None; b.grad = None
+        loss = 0
+        for (w, b), x, (N, H, W, C, K, R, S, pad) in zip(ws, xs, layers):
+            xx = x.clone().requires_grad_(True)
+            stride = (2, 2) if R == 4 else (1, 1)
+            y = ops.conv2d(xx, w, b, stride, pad)
+            loss = loss + (y * y).sum() * 1e-3
+        y2 = ops.conv2d(x_twice.clone().requires_grad_(True), ws[3][0], ws[3][1], (1, 1), (1, 1))
+        loss = loss + (y2 * y2).sum() * 1e-3
+        ops.DEFER_REDUCE = defer
+        try:
+            loss.backward()
+        finally:
+            ops.DEFER_REDUCE = False
+            before = ops._defer["launches"]
+            ops.join_side_stream()
+        torch.cuda.synchronize()
+        return [(w.grad.clone(), b.grad.clone()) for w, b in ws], ops._defer["launches"] - before
+
+    ref, n0 = run(False)
+    got, n1 = run(True)
+    assert n0 == 0 and 2 <= n1 <= 3, (n0, n1)          # one launch + one more for the second gradient of the shared layer
+    for i, ((rw, rb), (gw, gb)) in enumerate(zip(ref, got)):
+        assert torch.equal(rw, gw), "layer %d weight gradient differs: max %.3e" % (i, float((rw - gw).abs().max()))
+        assert torch.equal(rb, gb), "layer %d bias gradient differs" % i
+        assert float(rw.abs().max()) > 0

@@ -84,6 +84,79 @@ def test_skip_unused_grads_changes_no_weight_and_no_loss(cuda, tmp_path):
     assert any(ta[k] for k in ta if k.startswith("hwr.")) and not any(tb[k] for k in tb if k.startswith("hwr."))
 
 
+def test_deferred_reduce_and_eager_reduce_train_to_the_same_bits(cuda, tmp_path):
+    """trainer.defer_wgrad_reduce (default on): the partial-image sums of every backward pass in one table-driven launch. Two curriculum
+    cycles with it on and off from the same seeds: every logged loss and every parameter / buffer must be BIT-identical, and the deferred
+    run must really have gone through the multi-reduce launches."""
+    from handwriting_line_generation_amd import ops, rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    outs = []
+    for defer in (False, True):
+        rng.set_mode("device", seed=11)
+        torch.manual_seed(3); np.random.seed(3); random.seed(3)
+        trainer, _ = build_gan_trainer("iam_gan", 2, 2, width=256, label_len=12, workdir=str(tmp_path / ("d%d" % defer)))
+        trainer._defer_reduce = defer
+        torch.manual_seed(5); np.random.seed(5); random.seed(5)
+        before = ops._defer["launches"]
+        logs = [trainer._train_iteration(it) for it in range(14)]
+        torch.cuda.synchronize()
+        outs.append((logs, {k: v.detach().clone() for k, v in trainer.model.state_dict().items()}, ops._defer["launches"] - before))
+    (la, sa, na), (lb, sb, nb) = outs
+    assert na == 0 and nb >= 14, (na, nb)
+    for it, (a, b) in enumerate(zip(la, lb)):
+        assert a == b, "iteration %d: %s vs %s" % (it, a, b)
+    for k, v in sa.items():
+        assert torch.equal(v, sb[k]), "%s differs with the deferred reduce" % k
+
+
+def test_batched_generator_backward_equals_one_pass_per_loss_group(cuda, tmp_path):
+    """trainer.batch_gen_backward (default on): the two / three gradients a balanced lesson sends through the generator (reference trainer
+    :300-338, one backward() per loss group) go through it in ONE pass, stacked along the batch axis, every group accumulating into its
+    own buffer. Against the sequential passes from the same seeds: identical None-patterns, every balanced gradient (read where the
+    reference clips) equal to fp32 reordering noise, identical losses in the first cycle."""
+    from handwriting_line_generation_amd import rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    runs = []
+    for batched in (False, True):
+        rng.set_mode("device", seed=11)
+        torch.manual_seed(3); np.random.seed(3); random.seed(3)
+        trainer, _ = build_gan_trainer("iam_gan", 2, 2, width=256, label_len=12, workdir=str(tmp_path / ("b%d" % batched)))
+        trainer._batch_gen_backward = batched
+        torch.manual_seed(5); np.random.seed(5); random.seed(5)
+        grads = {}
+
+        def hook(it, trainer=trainer, grads=grads):
+            f = trainer.flat
+            pos_of = {id(f.params[pi]): k for k, pi in enumerate(f.order)}
+            grads[it] = {n: (p.grad.detach().clone() if f.touched[pos_of[id(p)]] else None) for n, p in trainer.model.named_parameters()}
+        trainer.pre_clip_hook = hook
+        logs = [trainer._train_iteration(it) for it in range(7)]
+        torch.cuda.synchronize()
+        runs.append((logs, grads))
+    (la, ga), (lb, gb) = runs
+    assert set(ga) == set(gb) and len(ga) >= 3
+    worst = 0.0
+    for it in sorted(ga):
+        for n, a in ga[it].items():
+            b = gb[it][n]
+            assert (a is None) == (b is None), "iteration %d %s: gradient present in one run only" % (it, n)
+            if a is None:
+                continue
+            na = float(a.double().norm())
+            if na < 1e-12:
+                assert float(b.abs().max()) < 1e-10, (it, n)
+                continue
+            e = float((a.double() - b.double()).norm()) / na
+            worst = max(worst, e)
+            # the first step's gradients are identical up to the schedule the planner picks for 2 / 3 x the batch (fp32 summation order);
+            # later iterations start from weights that differ by those roundings through Adam's sign-like first steps
+            assert e < (2e-4 if it <= 2 else 5e-2), "iteration %d %s: relative difference %.2e" % (it, n, e)
+    assert any(n.startswith("generator.") and v is not None for n, v in ga[max(ga)].items())
+    for k in la[1]:
+        assert abs(la[1][k] - lb[1][k]) <= 1e-5 * max(1.0, abs(la[1][k])), (k, la[1][k], lb[1][k])
+    print("batched vs sequential generator backward: worst relative gradient difference %.2e" % worst)
+
+
 def test_masked_stash_holds_zeros_outside_its_mask(cuda):
     """FlatParams.stash() copies only the tensors that have a gradient; a pooled buffer must nevertheless hold ZEROS everywhere else,
     because data-parallel segment all-reduces sum whole sub-network ranges of it (trainer/flat_params.py: stale / dirty clearing).
