@@ -54,6 +54,8 @@ class ExpertBank:
                     break
             if ok:
                 host = np.array([[p.grad.data_ptr() for p in self.params[k]] for k in KINDS], dtype=np.int64)
+                self._gptr_static_host = host
+                self._set_tabs = {}
                 dev = ops.h2d(host, device)
                 self._gptr_dev = {k: dev[i] for i, k in enumerate(KINDS)}
                 self._flat_idx = (owner, [np.array(v, dtype=np.int64) for v in idx])
@@ -77,9 +79,22 @@ class ExpertBank:
         """gradient-buffer tables; allocates / marks-as-touched the buffers of the experts present in this batch.
         The walk over (kinds x present experts) runs once per plan (= once per forward): the touched flags it sets live until the
         trainer's next zero_grad, which is always followed by a new forward and hence a new plan."""
-        if plan.get("grads_ready") and self._gptr_dev:
+        gs = ops.GRAD_SET
+        if gs is None and plan.get("grads_ready") and self._gptr_dev:
             return self._gptr_dev
         present = plan["present"]
+        if gs is not None:
+            # gradient-set redirect (ops.grad_set): the same offsets of the set's buffer, the set's mask (one table per buffer, built once)
+            if not self._static_grads(device):
+                raise L.HwgError("expert bank under a gradient-set redirect needs parameters that live in a FlatParams buffer")
+            flat, idx = self._flat_idx
+            buf, mask = gs
+            mask[np.concatenate([idx[e] for e in present])] = True
+            tab = self._set_tabs.get(buf.data_ptr())
+            if tab is None:
+                dev = ops.h2d(self._gptr_static_host + (buf.data_ptr() - flat.flat_grad.data_ptr()), device)
+                tab = self._set_tabs[buf.data_ptr()] = {k: dev[i] for i, k in enumerate(KINDS)}
+            return tab
         if self._static_grads(device):
             # trainer case: every expert gradient is a persistent view of the flat buffer -> one static pointer table for all experts,
             # and "touched" is one vectorised assignment over the flat indices of the present experts' tensors

@@ -32,6 +32,7 @@ class FlatParams:
         Parameters in no group form the group 'rest'. names (optional, parallel to params): dotted parameter names; their first component
         (the sub-network) defines the `segments` that data-parallel stash reductions travel in."""
         self.params = list(params)
+        self.names = list(names) if names is not None else None
         self.device = self.params[0].device
         ids = {id(p): i for i, p in enumerate(self.params)}
         order, self.group_range = [], {}
@@ -100,11 +101,13 @@ class FlatParams:
 
     def _make_hook(self, k):
         def hook(p):
-            if ops.GRAD_SET is not None:
-                # autograd added a returned gradient to param.grad while a gradient-set redirect was active: that gradient belongs to the
-                # redirected set's buffer, not to the current one (every op on a redirected pass must accumulate through ops._grad_buffer)
-                raise RuntimeError("parameter gradient accumulated by autograd under ops.grad_set (tensor %d)" % k)
-            self.touched[k] = True
+            # (fires for every parameter whose AccumulateGrad node a backward pass reaches, also when the op accumulated in place through
+            # ops._grad_buffer and returned None.) Under a gradient-set redirect the pass belongs to that set: mark its mask, not the current one
+            gs = ops.GRAD_SET
+            if gs is not None:
+                gs[1][k] = True
+            else:
+                self.touched[k] = True
         return hook
 
     # -- pointer tables -----------------------------------------------------------------------------

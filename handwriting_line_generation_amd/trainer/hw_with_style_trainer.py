@@ -297,9 +297,14 @@ class HWWithStyleTrainer(BaseTrainer):
             dstyles = tape.backward_sets([g for _, g in members], targets)
             if tape.style_src is not None and dstyles is not None:
                 for k, ((st, _), ds) in enumerate(zip(members, dstyles)):
+                    v0 = self.flat.flat_grad._version
                     with ops.grad_set(targets[k]):
                         tape.style_src.backward(ds, retain_graph=k + 1 < len(members))
                         ops.join_side_stream()
+                    if targets[k] is not None and self.flat.flat_grad._version != v0:
+                        # every op behind the style accumulates its parameter gradients through ops._grad_buffer (which follows the redirect);
+                        # a gradient RETURNED to autograd would have been added to param.grad, i.e. to the wrong set
+                        raise RuntimeError("autograd accumulated a parameter gradient into the current set during a redirected backward pass")
         ops.join_side_stream()
         for st, key, _ in sets:
             if st is not None:
