@@ -392,6 +392,10 @@ struct WgK {
   int Mtot, chunk, tiles_v;
   int bias_on;          // also produce the column sums of u (the layer's bias gradient) from the tiles that pass through LDS anyway
   long long pstride;    // floats per partial image: R*S*K*C (+K bias partials)
+  // gradient sets (hwg_conv_wgrad_sets): u holds `sets` anchors of Mtot rows each, back to back, v is shared. Workgroup blockIdx.x works on set
+  // blockIdx.x / gx as workgroup blockIdx.x % gx of a gx-wide launch and writes partial image blockIdx.x. sets == 1: gx == gridDim.x.
+  int sets, gx;
+  int set_on_v;         // 0: the sets differ in u (v shared); 1: the sets differ in v ([N,H,W,C] each, back to back) and share u (transposed layers)
 };
 
 // TAPN: single-channel gathered tensor (C == 1, first layers): the GEMM's N dimension is the taps (<= BNV) instead of C, so one
@@ -417,7 +421,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
   const int RS = a.R * a.S;
   const int tu = blockIdx.y / a.tiles_v, tv = blockIdx.y % a.tiles_v;
   const int k0 = tu * BMU, c0 = tv * BNV;
-  const int pb = blockIdx.x * a.chunk;
+  const int set = a.sets > 1 ? (int)blockIdx.x / a.gx : 0;
+  const int bx = (int)blockIdx.x - set * a.gx;
+  const float* __restrict__ au = a.u + (a.set_on_v ? 0ll : (long long)set * a.Mtot * a.K);
+  const float* __restrict__ av = a.v + (a.set_on_v ? (long long)set * a.N * a.H * a.W * a.C : 0ll);
+  const int pb = bx * a.chunk;
   const int pe = min(pb + a.chunk, a.Mtot);
 
   int u_kp[U_IT], u_c4[U_IT];
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
     for (int it = 0; it < U_IT; ++it) {
       const int m = pbase + u_kp[it];
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (u_ok[it] && m < pe) val = *reinterpret_cast<const float4*>(a.u + (long long)m * a.K + k0 + u_c4[it] * 4);
+      if (u_ok[it] && m < pe) val = *reinterpret_cast<const float4*>(au + (long long)m * a.K + k0 + u_c4[it] * 4);
       ru[it] = val;
     }
 #pragma unroll
@@ -482,14 +490,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
             const int ih = v_p[it] * a.sh - a.ph + rr * a.dh;
             const int iw = v_q[it] * a.sw - a.pw + ss * a.dw;
             const bool ok = tp < RS && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-            e[j] = ok ? a.v[((long long)v_n[it] * a.H + ih) * a.W + iw] : 0.f;
+            e[j] = ok ? av[((long long)v_n[it] * a.H + ih) * a.W + iw] : 0.f;
           }
           val = make_float4(e[0], e[1], e[2], e[3]);
         } else {
           const int ih = v_p[it] * a.sh - a.ph + r * a.dh;
           const int iw = v_q[it] * a.sw - a.pw + s * a.dw;
           if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
-            val = *reinterpret_cast<const float4*>(a.v + (((long long)v_n[it] * a.H + ih) * a.W + iw) * a.C + c0 + v_c4[it] * 4);
+            val = *reinterpret_cast<const float4*>(av + (((long long)v_n[it] * a.H + ih) * a.W + iw) * a.C + c0 + v_c4[it] * 4);
         }
       }
       rv[it] = val;
@@ -1301,7 +1309,10 @@ __global__ __launch_bounds__(512) void wgrad_narrow_kernel(WgK a, int kbn, int c
   const int ch = lane & 15, j = lane >> 4;
   const int kch = min(kb * 16 + ch, a.K - 1), cch = min(cb * 16 + ch, a.C - 1);      // clamped: ragged blocks are masked at the store
   const long long G4 = ((long long)a.Mtot + 3) >> 2;
-  const long long gs = (long long)blockIdx.x * streams + stream, GS = (long long)gridDim.x * streams;
+  const int set = a.sets > 1 ? (int)blockIdx.x / a.gx : 0;
+  const float* __restrict__ au = a.u + (a.set_on_v ? 0ll : (long long)set * a.Mtot * a.K);
+  const float* __restrict__ avv = a.v + (a.set_on_v ? (long long)set * a.N * a.H * a.W * a.C : 0ll);
+  const long long gs = (long long)((int)blockIdx.x - set * a.gx) * streams + stream, GS = (long long)a.gx * streams;
   const long long g0 = G4 * gs / GS, g1 = G4 * (gs + 1) / GS;
   f32x4 acc[NT];
 #pragma unroll
@@ -1336,7 +1347,7 @@ __global__ __launch_bounds__(512) void wgrad_narrow_kernel(WgK a, int kbn, int c
       cq -= a.Q;
       if (++cp == a.P) { cp = 0; ++cn; }
     }
-    av = a.u[(long long)mm * a.K + kch];
+    av = au[(long long)mm * a.K + kch];
     const int ih0 = p * a.sh - a.ph, iw0 = q * a.sw - a.pw;
     int roff[R], coff[S], rokm = 0, cokm = 0;
 #pragma unroll
@@ -1355,7 +1366,7 @@ __global__ __launch_bounds__(512) void wgrad_narrow_kernel(WgK a, int kbn, int c
 #pragma unroll
     for (int r = 0; r < R; ++r) {
 #pragma unroll
-      for (int s2 = 0; s2 < S; ++s2) bv[r * S + s2] = a.v[roff[r] + coff[s2]];
+      for (int s2 = 0; s2 < S; ++s2) bv[r * S + s2] = avv[roff[r] + coff[s2]];
       m2 |= ((rokm >> r) & 1 ? cokm : 0) << (r * S);
     }
     okm = mv ? (m2 | (1 << NT)) : 0;
@@ -1583,21 +1594,23 @@ extern "C" size_t hwg_conv_wgrad_workspace(const hwg_conv_desc* d) {
   return (size_t)p.nsplit * ((size_t)d->R * d->S * d->K * d->C + d->K) * sizeof(float);
 }
 
-extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const float* v, float* dw,
-                              long long sa, long long sb, long long sr, long long ss, int accumulate,
-                              float* dbias, int bias_accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+// one weight gradient, or `sets` of them that share the gathered tensor v (u = the sets' anchors back to back): one launch, one partial-image
+// range and one (possibly deferred) sum per set
+static int conv_wgrad_run(const hwg_conv_desc* d, const float* u, const float* v, int sets, int set_on_v, float* const* dws,
+                          long long sa, long long sb, long long sr, long long ss, int accumulate,
+                          float* const* dbiases, int bias_accumulate, void* workspace, size_t workspace_bytes, hipStream_t st, bool defer) {
   int rc = check_desc(d, "conv_wgrad");
   if (rc) return rc;
-  HWG_REQUIRE(u && v && dw, "conv_wgrad: null pointer");
-  hipStream_t st = (hipStream_t)stream;
-  const bool defer = hwg_wgrad_defer_take();      // consumed here whatever path runs: a stale flag must never reach a later call
+  HWG_REQUIRE(u && v && dws && dws[0] && sets >= 1, "conv_wgrad: null pointer");
+  float* const dbias = dbiases ? dbiases[0] : nullptr;
   if (wgrad_is_direct(d)) {
+    HWG_REQUIRE(sets == 1, "conv_wgrad_sets: not available on the direct (K<=2 / C<=2) path (hwg_conv_wgrad_sets_supported)");
     HWG_REQUIRE(!dbias, "conv_wgrad: the fused bias gradient is not available on the direct (K<=2 / C<=2) path, use hwg_colsum");
-    return hwg_conv_wgrad_direct_impl(d, u, v, dw, sa, sb, sr, ss, accumulate, workspace, workspace_bytes, st);
+    return hwg_conv_wgrad_direct_impl(d, u, v, dws[0], sa, sb, sr, ss, accumulate, workspace, workspace_bytes, st);
   }
   const bool tapn = wgrad_is_tapn(d);
   HWG_REQUIRE(d->K % 4 == 0 && (tapn || d->C % 4 == 0), "conv_wgrad: channels must be multiples of 4 (K=%d C=%d)", d->K, d->C);
-  const size_t need = hwg_conv_wgrad_workspace(d);
+  const size_t need = hwg_conv_wgrad_workspace(d) * (size_t)sets;
   if (!workspace || workspace_bytes < need) {
     hwg_set_error("conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     return HWG_ERR_WORKSPACE;
@@ -1615,10 +1628,12 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
   k.tiles_v = p.tiles_v;
   k.bias_on = dbias ? 1 : 0;
   k.pstride = (long long)d->R * d->S * d->K * d->C + d->K;
-  dim3 grid(p.nsplit, p.tiles_u * p.tiles_v, tapn ? 1 : d->R * d->S);
-  const int prof = hwg_prof_open(HWG_PROF_WGRAD, 2.0 * k.Mtot * d->K * d->C * d->R * d->S, st);
-  if (narrow && d->R == 3) hipLaunchKernelGGL((wgrad_narrow_kernel<3, 3>), dim3(p.nsplit), dim3(512), 0, st, k, hwg_cdiv(d->K, 16), hwg_cdiv(d->C, 16));
-  else if (narrow) hipLaunchKernelGGL((wgrad_narrow_kernel<4, 4>), dim3(p.nsplit), dim3(512), 0, st, k, hwg_cdiv(d->K, 16), hwg_cdiv(d->C, 16));
+  k.sets = sets; k.gx = p.nsplit; k.set_on_v = set_on_v;
+  const int gx = p.nsplit * sets;
+  dim3 grid(gx, p.tiles_u * p.tiles_v, tapn ? 1 : d->R * d->S);
+  const int prof = hwg_prof_open(HWG_PROF_WGRAD, 2.0 * sets * k.Mtot * d->K * d->C * d->R * d->S, st);
+  if (narrow && d->R == 3) hipLaunchKernelGGL((wgrad_narrow_kernel<3, 3>), dim3(gx), dim3(512), 0, st, k, hwg_cdiv(d->K, 16), hwg_cdiv(d->C, 16));
+  else if (narrow) hipLaunchKernelGGL((wgrad_narrow_kernel<4, 4>), dim3(gx), dim3(512), 0, st, k, hwg_cdiv(d->K, 16), hwg_cdiv(d->C, 16));
   // 16 waves and 32-pixel K steps on the big tile: +10 % over 8 waves x 16 pixels (331 -> 299 us on 512x512x3x3 at 6096 pixels)
   else if (p.cfg == 0) hipLaunchKernelGGL((wgrad_mfma_kernel<128, 128, 32, 4, 4, 1>), grid, dim3(1024), 0, st, k);
   // 64x64: two wave groups split every 32-pixel K step between them (8 waves; 5..10 % over 4 waves on every measured shape)
@@ -1628,12 +1643,41 @@ extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const floa
   hwg_prof_close(prof, st);
   hwg_note_plan(HWG_PROF_WGRAD, narrow ? 100 + d->R : (tapn ? 10 + p.cfg : p.cfg), p.nsplit);   // 103 / 104: all-taps narrow kernel, 1x: taps-as-N
   HWG_LAUNCH_CHECK("conv_wgrad");
-  const int prof2 = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, 4.0 * ((double)d->R * d->S * d->K * d->C + (dbias ? d->K : 0)) * (p.nsplit + 1), st);
-  rc = hwg_wgrad_reduce_launch((const float*)workspace, dw, p.nsplit, d->R * d->S, d->S, d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias,
-                               bias_accumulate, st, defer);
-  hwg_prof_close(prof2, st);
-  if (rc) return rc;
+  for (int s_ = 0; s_ < sets; ++s_) {
+    const int prof2 = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, 4.0 * ((double)d->R * d->S * d->K * d->C + (dbias ? d->K : 0)) * (p.nsplit + 1), st);
+    rc = hwg_wgrad_reduce_launch((const float*)workspace + (long long)s_ * p.nsplit * k.pstride, dws[s_], p.nsplit, d->R * d->S, d->S, d->K, d->C, sa, sb,
+                                 sr, ss, accumulate, k.pstride, dbiases ? dbiases[s_] : nullptr, bias_accumulate, st, defer);
+    hwg_prof_close(prof2, st);
+    if (rc) return rc;
+  }
   return HWG_OK;
+}
+
+extern "C" int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const float* v, float* dw,
+                              long long sa, long long sb, long long sr, long long ss, int accumulate,
+                              float* dbias, int bias_accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  const bool defer = hwg_wgrad_defer_take();      // consumed here whatever path runs: a stale flag must never reach a later call
+  float* dws[1] = {dw};
+  float* dbs[1] = {dbias};
+  return conv_wgrad_run(d, u, v, 1, 0, dws, sa, sb, sr, ss, accumulate, dbias ? dbs : nullptr, bias_accumulate, workspace, workspace_bytes,
+                        (hipStream_t)stream, defer);
+}
+
+extern "C" int hwg_conv_wgrad_sets_supported(const hwg_conv_desc* d) {
+  if (!d || wgrad_is_direct(d)) return 0;
+  return d->K % 4 == 0 && (wgrad_is_tapn(d) || d->C % 4 == 0);
+}
+
+extern "C" int hwg_conv_wgrad_sets(const hwg_conv_desc* d, const float* u, const float* v, int sets, int set_on_v, const long long* dw_ptrs,
+                                   long long sa, long long sb, long long sr, long long ss, int accumulate,
+                                   const long long* dbias_ptrs, int bias_accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  const bool defer = hwg_wgrad_defer_take();
+  HWG_REQUIRE(sets >= 1 && sets <= 8 && dw_ptrs, "conv_wgrad_sets: 1..8 sets");
+  float* dws[8]; float* dbs[8];
+  for (int i = 0; i < sets; ++i) { dws[i] = (float*)(uintptr_t)dw_ptrs[i]; dbs[i] = dbias_ptrs ? (float*)(uintptr_t)dbias_ptrs[i] : nullptr; }
+  HWG_REQUIRE(!(set_on_v && dbias_ptrs), "conv_wgrad_sets: the fused bias gradient sums the anchor u, which the sets share here");
+  return conv_wgrad_run(d, u, v, sets, set_on_v, dws, sa, sb, sr, ss, accumulate, dbias_ptrs ? dbs : nullptr, bias_accumulate, workspace, workspace_bytes,
+                        (hipStream_t)stream, defer);
 }
 
 static long long colsum_chunks(long long rows) {

@@ -30,6 +30,7 @@ struct WinoWgK {
   int N, H, W, C, K, P, Q, ph, pw, TP, TQ2;
   int MP;            // tile pairs: N * TP * TQ2
   int kt, ct, nsplit;
+  int sets;          // gradient sets: dy holds `sets` tensors [N,P,Q,K] back to back, x is shared; nsplit pixel ranges (and partial images) per set
   int bias_on;       // also emit the column sums of dy (the bias gradient) from the dy tiles that pass through anyway
   long long pstride; // 9*K*C + K
 };
@@ -179,7 +180,8 @@ __device__ __forceinline__ void wg_rounds(const WinoWgK& a, float* smem, f32x4 (
 }
 
 template <int DBG>
-__global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgK a) {
+__global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgK a_in) {
+  WinoWgK a = a_in;
   constexpr int LDC = 68;                 // exchange row stride: the four row groups of a C/D block land 16 banks apart
   constexpr int XCH = 16 * 32 * LDC;      // epilogue exchange image [16 positions][32 k][64 c], aliases the operand buffers
   __shared__ __attribute__((aligned(16))) float smem[(2 * WG_BUF > XCH + 256) ? 2 * WG_BUF : XCH + 256];
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgK a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // work item: every XCD takes a contiguous run of the (split, k-tile, c-tile) sequence - the workgroups of one pixel range share
   // their x / dy reads through that XCD's L2
-  const int total = a.kt * a.ct * a.nsplit;
+  const int total = a.kt * a.ct * a.nsplit * a.sets;
   int w = blockIdx.x;
   {
     const int xcd = w & 7, slot = w >> 3;
@@ -197,7 +199,10 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgK a) {
   }
   const int c0 = (w % a.ct) * 64;
   const int k0 = ((w / a.ct) % a.kt) * 64;
-  const int split = w / (a.ct * a.kt);
+  const int split_all = w / (a.ct * a.kt);        // (set, pixel range of that set)
+  const int set = split_all / a.nsplit;
+  const int split = split_all - set * a.nsplit;
+  a.dy += (long long)set * a.N * a.P * a.Q * a.K;
   const int p_lo = (int)((long long)a.MP * split / a.nsplit);
   const int p_hi = (int)((long long)a.MP * (split + 1) / a.nsplit);
   const int rounds = (p_hi - p_lo + 3) >> 2;
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgK a) {
   // wavefronts, so the blocks cross through LDS (two halves of 32 k rows); partial image [split][tap][K][C] like the direct kernel's.
   // C/D layout of a 16x16 block: column (c) = lane & 15, row (k) = (lane >> 4) * 4 + e
   float* X = smem;
-  float* out = a.part + (long long)split * a.pstride;
+  float* out = a.part + (long long)split_all * a.pstride;
   if (a.bias_on && c0 == 0) {              // the four dy wavefronts saw every dy element of this k-tile and pixel range exactly once
     float* bs = smem + XCH;
     __syncthreads();
@@ -322,27 +327,27 @@ extern "C" size_t hwg_wino_wgrad_workspace(const hwg_conv_desc* d) {
   return (size_t)p.nsplit * (9 * (size_t)d->K * d->C + d->K) * sizeof(float);
 }
 
-extern "C" int hwg_wino_wgrad(const hwg_conv_desc* d, const float* dy, const float* x, float* dw, long long sa, long long sb, long long sr,
-                              long long ss, int accumulate, float* dbias, int bias_accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-  const bool defer = hwg_wgrad_defer_take();
-  HWG_REQUIRE(d && dy && x && dw, "wino_wgrad: null pointer");
+static int wino_wgrad_run(const hwg_conv_desc* d, const float* dy, const float* x, int sets, float* const* dws, long long sa, long long sb,
+                          long long sr, long long ss, int accumulate, float* const* dbiases, int bias_accumulate, void* workspace,
+                          size_t workspace_bytes, hipStream_t st, bool defer) {
+  HWG_REQUIRE(d && dy && x && dws && dws[0] && sets >= 1, "wino_wgrad: null pointer");
   HWG_REQUIRE(hwg_wino_wgrad_supported(d), "wino_wgrad: needs a 3x3 stride-1 dilation-1 convolution with K, C >= 16");
-  const size_t need = hwg_wino_wgrad_workspace(d);
+  const size_t need = hwg_wino_wgrad_workspace(d) * (size_t)sets;
   if (!workspace || workspace_bytes < need) {
     hwg_set_error("wino_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     return HWG_ERR_WORKSPACE;
   }
-  hipStream_t st = (hipStream_t)stream;
+  float* const dbias = dbiases ? dbiases[0] : nullptr;
   const WgPlan p = plan_wino_wgrad(d);
   WinoWgK k;
   k.x = x; k.dy = dy; k.part = (float*)workspace;
   k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.P = d->P; k.Q = d->Q; k.ph = d->pad_h; k.pw = d->pad_w;
   k.TP = hwg_cdiv(d->P, 2); k.TQ2 = hwg_cdiv(hwg_cdiv(d->Q, 2), 2);
-  k.MP = p.MP; k.kt = p.kt; k.ct = p.ct; k.nsplit = p.nsplit;
+  k.MP = p.MP; k.kt = p.kt; k.ct = p.ct; k.nsplit = p.nsplit; k.sets = sets;
   k.bias_on = dbias ? 1 : 0;
   k.pstride = 9ll * d->K * d->C + d->K;
-  const int total = p.kt * p.ct * p.nsplit;
-  int prof = hwg_prof_open(HWG_PROF_WGRAD_WINO, 2.0 * d->N * d->P * d->Q * (double)d->K * d->C * 9.0, st);
+  const int total = p.kt * p.ct * p.nsplit * sets;
+  int prof = hwg_prof_open(HWG_PROF_WGRAD_WINO, 2.0 * sets * d->N * d->P * d->Q * (double)d->K * d->C * 9.0, st);
   const int dbg = hwg_tune().wwg_debug;
   if (dbg == 1) hipLaunchKernelGGL(wino_wgrad_kernel<1>, dim3((total + 7) / 8 * 8), dim3(512), 0, st, k);
   else if (dbg == 2) hipLaunchKernelGGL(wino_wgrad_kernel<2>, dim3((total + 7) / 8 * 8), dim3(512), 0, st, k);
@@ -351,10 +356,32 @@ extern "C" int hwg_wino_wgrad(const hwg_conv_desc* d, const float* dy, const flo
   hwg_note_plan(HWG_PROF_WGRAD_WINO, 0, p.nsplit);
   HWG_LAUNCH_CHECK("wino_wgrad");
   // the partial images have the direct kernel's layout ([split][tap][K][C] + K bias sums): same fixed-order reduce into the weight's layout
-  prof = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, (double)need, st);
-  const int rc = hwg_wgrad_reduce_launch((const float*)workspace, dw, p.nsplit, 9, 3, d->K, d->C, sa, sb, sr, ss, accumulate, k.pstride, dbias,
-                                         bias_accumulate, st, defer);
-  hwg_prof_close(prof, st);
-  if (rc) return rc;
+  for (int s_ = 0; s_ < sets; ++s_) {
+    prof = hwg_prof_open(HWG_PROF_WGRAD_REDUCE, (double)need / sets, st);
+    const int rc = hwg_wgrad_reduce_launch((const float*)workspace + (long long)s_ * p.nsplit * k.pstride, dws[s_], p.nsplit, 9, 3, d->K, d->C, sa, sb, sr,
+                                           ss, accumulate, k.pstride, dbiases ? dbiases[s_] : nullptr, bias_accumulate, st, defer);
+    hwg_prof_close(prof, st);
+    if (rc) return rc;
+  }
   return HWG_OK;
+}
+
+extern "C" int hwg_wino_wgrad(const hwg_conv_desc* d, const float* dy, const float* x, float* dw, long long sa, long long sb, long long sr,
+                              long long ss, int accumulate, float* dbias, int bias_accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  const bool defer = hwg_wgrad_defer_take();
+  float* dws[1] = {dw};
+  float* dbs[1] = {dbias};
+  return wino_wgrad_run(d, dy, x, 1, dws, sa, sb, sr, ss, accumulate, dbias ? dbs : nullptr, bias_accumulate, workspace, workspace_bytes,
+                        (hipStream_t)stream, defer);
+}
+
+extern "C" int hwg_wino_wgrad_sets(const hwg_conv_desc* d, const float* dy, const float* x, int sets, const long long* dw_ptrs, long long sa,
+                                   long long sb, long long sr, long long ss, int accumulate, const long long* dbias_ptrs, int bias_accumulate,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  const bool defer = hwg_wgrad_defer_take();
+  HWG_REQUIRE(sets >= 1 && sets <= 8 && dw_ptrs, "wino_wgrad_sets: 1..8 sets");
+  float* dws[8]; float* dbs[8];
+  for (int i = 0; i < sets; ++i) { dws[i] = (float*)(uintptr_t)dw_ptrs[i]; dbs[i] = dbias_ptrs ? (float*)(uintptr_t)dbias_ptrs[i] : nullptr; }
+  return wino_wgrad_run(d, dy, x, sets, dws, sa, sb, sr, ss, accumulate, dbias_ptrs ? dbs : nullptr, bias_accumulate, workspace, workspace_bytes,
+                        (hipStream_t)stream, defer);
 }

@@ -584,7 +584,7 @@ def tuning_reload():
     per-geometry choices are cached here as well. Call this after changing such a variable in a running process."""
     global WINOGRAD
     WINOGRAD = bool(int(os.environ.get("HWG_WINO", "1") or 1))
-    _wino_choice.clear(); _wino_wgrad_choice.clear(); _conv_plans.clear(); _wgrad_plans.clear()
+    _wino_choice.clear(); _wino_wgrad_choice.clear(); _conv_plans.clear(); _wgrad_plans.clear(); _wgrad_sets_ok.clear()
     L.call("hwg_tuning_reload")
 
 
@@ -674,6 +674,7 @@ def _taps(weight):
 
 
 _wgrad_plans = {}
+_wgrad_sets_ok = {}
 
 
 def _make_wgrad_plan(N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, P, Q, transposed):
@@ -760,13 +761,107 @@ class _Conv2d(Function):
         global GRAD_SET
         dy = dy.contiguous()
         dx = _Conv2d._dgrad(ctx, dy) if ctx.needs_input_grad[0] else None
-        n = dy.shape[0] // S
-        dws, dbs = [], []
+        grouped = _Conv2d._wgrad_sets(ctx, dy, S, targets) if S > 1 else None
+        if grouped is not None:
+            dws, dbs = grouped
+        else:
+            n = dy.shape[0] // S
+            dws, dbs = [], []
+            for s_ in range(S):
+                GRAD_SET = targets[s_]
+                dw_, db = _Conv2d._wgrad(ctx, dy[s_ * n:(s_ + 1) * n])
+                dws.append(dw_); dbs.append(db)
+        return (dx, None if dws[0] is None else SetGrad(S, parts=dws), None if dbs[0] is None else SetGrad(S, parts=dbs), None, None, None, None, None)
+
+    @staticmethod
+    def _wgrad_sets(ctx, dy, S, targets):
+        """the S weight gradients of this layer as ONE launch (hwg_conv_wgrad_sets / hwg_wino_wgrad_sets: the layer input is shared, every set
+        has its own pixel ranges, partial images and destination buffer). -> (per-set dw list, per-set db list) with None where the kernels
+        accumulated in place, or None when this layer has no grouped path (channel-padded copies, K <= 2 / C <= 2 direct kernels)"""
+        global GRAD_SET
+        import numpy as np
+        if not ctx.needs_input_grad[1]:
+            return None
+        x, weight = ctx.saved_tensors
+        _RUN_SCOPE[0] = ctx.scope
+        stride, padding, dilation, transposed, P, Q = ctx.geom
+        N, H, W, C = x.shape
+        R, S_ = _taps(weight)
+        sh, sw = stride; ph, pw = padding; dh, dw = dilation
+        K = dy.shape[3]
+        pkey = (N, H, W, C, K, R, S_, sh, sw, ph, pw, dh, dw, P, Q, transposed)
+        plan = _wgrad_plans.get(pkey)
+        if plan is None:
+            plan = _wgrad_plans[pkey] = _make_wgrad_plan(*pkey)
+        d, engine, need, Kq, Cq, tiny_end, tap_gemm = plan
+        ok = _wgrad_sets_ok.get(pkey)
+        if ok is None:
+            ok = _wgrad_sets_ok[pkey] = engine != 1 and not (engine == 0 and transposed) and not tiny_end and (
+                engine == 0 or bool(L.query("hwg_conv_wgrad_sets_supported", d.ptr)))
+        if not ok:
+            return None
+        wref, bref = ctx.param_refs
+        direct = _direct(wref)
+        want_bias = ctx.has_bias and ctx.needs_input_grad[2]
+        fuse_bias = want_bias and not transposed and (engine == 0 or (d.K > 2 and (d.C > 2 or tap_gemm)))
+        bdirect = _direct(bref) if want_bias else False
+        dws, dbs, dws_out, dbs_out = [], [], [], []
         for s_ in range(S):
             GRAD_SET = targets[s_]
-            dw_, db = _Conv2d._wgrad(ctx, dy[s_ * n:(s_ + 1) * n])
-            dws.append(dw_); dbs.append(db)
-        return (dx, None if dws[0] is None else SetGrad(S, parts=dws), None if dbs[0] is None else SetGrad(S, parts=dbs), None, None, None, None, None)
+            dws.append(_grad_buffer(wref) if direct else torch.empty_like(weight))
+            dws_out.append(None if direct else dws[-1])
+            if fuse_bias:
+                dbs.append(_grad_buffer(bref) if bdirect else torch.empty((K,), dtype=torch.float32, device=x.device))
+                dbs_out.append(None if bdirect else dbs[-1])
+        wptr = np.array([t.data_ptr() for t in dws], dtype=np.int64)
+        bptr = np.array([t.data_ptr() for t in dbs], dtype=np.int64) if fuse_bias else None
+        if not transposed:
+            u, v, set_on_v = dy, x, 0
+            sa, sb = C * R * S_, R * S_
+        else:
+            u, v, set_on_v = x, dy, 1
+            sa, sb = K * R * S_, R * S_
+        acc = 1 if direct else 0
+        bacc = 1 if (fuse_bias and bdirect) else 0
+        total = need * S
+        can_defer = DEFER_REDUCE and direct and (not fuse_bias or bdirect) and total
+        ws = _defer_workspace(total, x.device) if can_defer else None
+        defer = ws is not None
+        st = _stream()
+        if PROF_SHAPES is not None:
+            _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S_, (sh, sw), (ph, pw), (dh, dw), "wgrad", ctx.scope))
+        side = SIDE_WGRAD and direct and engine == 2 and (not fuse_bias or bdirect)
+        if side:
+            s2, raw2, skey = _side_stream(x.device)
+            L.call("hwg_stream_fork", st, raw2)
+            if ws is None:
+                ws = _side_workspace(total, x.device, s2)
+            st = raw2
+            _side_hold.append((u, v))
+            _side_dirty.add(skey)
+        elif ws is None:
+            ws = workspace(total, x.device)
+        if defer:
+            L.call("hwg_wgrad_defer_next")
+        if engine == 0:
+            L.call("hwg_wino_wgrad_sets", d.ptr, u, v, S, wptr.ctypes.data, sa, sb, S_, 1, acc, bptr.ctypes.data if fuse_bias else None, bacc,
+                   ws, ws.numel(), st)
+        else:
+            L.call("hwg_conv_wgrad_sets", d.ptr, u, v, S, set_on_v, wptr.ctypes.data, sa, sb, S_, 1, acc, bptr.ctypes.data if fuse_bias else None, bacc,
+                   ws, ws.numel(), st)
+        if want_bias and not fuse_bias:
+            n = dy.shape[0] // S
+            for s_ in range(S):
+                GRAD_SET = targets[s_]
+                part = dy[s_ * n:(s_ + 1) * n]
+                if bdirect:
+                    colsum(part.view(-1, K), out=_grad_buffer(bref), accumulate=True)
+                    dbs_out.append(None)
+                else:
+                    dbs_out.append(colsum(part.view(-1, K)))
+        if not dbs_out:
+            dbs_out = [None] * S
+        return dws_out, dbs_out
 
     @staticmethod
     def _dgrad(ctx, dy):

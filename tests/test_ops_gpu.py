@@ -947,3 +947,78 @@ def test_deferred_wgrad_reduce_is_bit_identical(cuda):
         assert torch.equal(rw, gw), "layer %d weight gradient differs: max %.3e" % (i, float((rw - gw).abs().max()))
         assert torch.equal(rb, gb), "layer %d bias gradient differs" % i
         assert float(rw.abs().max()) > 0
+
+
+def test_tape_backward_sets_equal_separate_backward_passes(cuda):
+    """ops.Tape.backward_sets: S upstream gradients through a recorded sub-network in ONE pass (data-gradient convolutions, blur and
+    resampling on S x N samples; AdaIN per set on slices of a preallocated result; the S weight gradients of a layer as one grouped launch,
+    hwg_conv_wgrad_sets / hwg_wino_wgrad_sets, incl. a transposed layer whose sets differ in the gathered tensor) with every set's parameter
+    gradients redirected into its own flat buffer (ops.grad_set) - against S separate autograd backward passes of the same ops."""
+    import numpy as np
+    from handwriting_line_generation_amd import ops
+    from handwriting_line_generation_amd.trainer.flat_params import FlatParams
+    g = torch.Generator().manual_seed(5)
+    N, H, W, C0, C1, C2 = 2, 8, 36, 64, 64, 32
+
+    def P(*shape, s=0.05):
+        return torch.nn.Parameter((torch.randn(*shape, generator=g) * s).to(cuda))
+    w1, b1 = P(C1, C0, 3, 3), P(C1)                   # 3x3 (Winograd weight gradient at these sizes or the direct one: the planner's choice)
+    nw = P(1, C1, 1, 1, s=0.3)
+    wt, bt = P(C1, C2, 4, 4), P(C2)                   # transposed, stride 2
+    w3, b3 = P(16, C2, 3, 3), P(16)                   # narrow output
+    w4 = P(1, 16, 1, 1, s=0.5)                        # K = 1 head (direct kernels: no grouped path)
+    params = [w1, b1, nw, wt, bt, w3, b3, w4]
+    flat = FlatParams(params, {"main": params})
+    x = torch.randn(N, H, W, C0, generator=g).to(cuda)
+    gam, bet = (torch.randn(N, C1, generator=g) * 0.5 + 1).to(cuda), (torch.randn(N, C1, generator=g) * 0.1).to(cuda)
+    noise = torch.randn(N, H, W, C1, generator=g).to(cuda)
+
+    def net(xin, gm, bt_):
+        h = ops.conv2d(xin, w1, b1, 1, 1)
+        h = ops.adain_epilogue(h, noise, nw, gm, bt_, 0.7, 0.2)
+        h = ops.conv_transpose2d(h, wt, bt, stride=2, padding=1)
+        h = ops.blur3(h)
+        h = ops.conv2d(h, w3, b3, 1, 1)
+        h = ops.upsample_nearest(h, (2, 1))
+        return ops.tanh(ops.conv2d(h, w4, None))
+    S = 3
+    # reference: one autograd backward pass per set
+    xa = x.clone().requires_grad_(True); ga = gam.clone().requires_grad_(True); ba = bet.clone().requires_grad_(True)
+    ya = net(xa, ga, ba)
+    ups = [torch.randn(ya.shape, generator=g).to(cuda) for _ in range(S)]
+    want = []
+    for s_ in range(S):
+        flat.zero_grad("main")
+        xa.grad = ga.grad = ba.grad = None
+        ya.backward(ups[s_], retain_graph=True)
+        ops.join_side_stream()
+        want.append((flat.flat_grad.clone(), flat.touched.copy(), xa.grad.clone(), ga.grad.clone(), ba.grad.clone()))
+    # tape: forward recorded once, the three gradients through it together; sets 0 and 1 into stash buffers, set 2 into the parameters' own gradients
+    flat.zero_grad("main")
+    tape = ops.Tape()
+    xt, gt, bt2 = tape.watch(x.clone()), tape.watch(gam.clone()), tape.watch(bet.clone())
+    ops.TAPE = tape
+    try:
+        with torch.no_grad():
+            yt = net(xt, gt, bt2)
+    finally:
+        ops.TAPE = None
+    assert torch.equal(yt, ya.detach())
+    bufs = [(torch.zeros_like(flat.flat_grad), np.zeros(flat.nt, dtype=bool)) for _ in range(S - 1)]
+    targets = [bufs[0], bufs[1], None]
+    res = tape.backward_sets(yt, ups, targets)
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    for s_ in range(S):
+        fg, touched, dx, dg, db = want[s_]
+        got_flat = bufs[s_][0] if s_ < S - 1 else flat.flat_grad
+        got_mask = bufs[s_][1] if s_ < S - 1 else flat.touched
+        assert np.array_equal(got_mask, touched), "set %d: touched pattern" % s_
+        for k, pi in enumerate(flat.order):
+            a = fg[int(flat.offsets[k]): int(flat.offsets[k]) + int(flat.numel[k])]
+            b = got_flat[int(flat.offsets[k]): int(flat.offsets[k]) + int(flat.numel[k])]
+            _close(b, a, "set %d parameter %d gradient" % (s_, pi), tol=2e-5)
+        _close(res[id(xt)][s_], dx, "set %d dx" % s_, tol=2e-5)
+        _close(res[id(gt)][s_], dg, "set %d dgamma" % s_, tol=2e-5)
+        _close(res[id(bt2)][s_], db, "set %d dbeta" % s_, tol=2e-5)
+    assert float(bufs[0][0].abs().max()) > 0 and not torch.equal(bufs[0][0], bufs[1][0])
