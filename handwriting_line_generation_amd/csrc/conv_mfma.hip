@@ -1594,6 +1594,32 @@ extern "C" size_t hwg_conv_wgrad_workspace(const hwg_conv_desc* d) {
   return (size_t)p.nsplit * ((size_t)d->R * d->S * d->K * d->C + d->K) * sizeof(float);
 }
 
+// Pixel ranges per set when `sets` gradients run as one launch: the schedule is planned for the whole launch (sets x the pixels) and its ranges
+// are shared out over the sets - the per-set plan would fill the chip once per set, i.e. `sets` times as many partial images to write and sum.
+static WgPlan plan_wgrad_sets(const hwg_conv_desc* d, int sets, bool tapn, bool narrow) {
+  if (sets <= 1) {
+    WgPlan p = tapn ? plan_wgrad_tapn(d) : plan_wgrad(d);
+    if (narrow) p.nsplit = narrow_blocks(d);
+    return p;
+  }
+  hwg_conv_desc all = *d;
+  all.N *= sets;
+  WgPlan p = tapn ? plan_wgrad_tapn(&all) : plan_wgrad(&all);
+  const long long Mset = (long long)d->N * d->P * d->Q;
+  if (narrow) {
+    int nb = narrow_blocks(&all) / sets;
+    p.nsplit = nb < 1 ? 1 : nb;
+    return p;
+  }
+  wg_split(p, Mset, hwg_cdiv(p.nsplit, sets));
+  return p;
+}
+extern "C" size_t hwg_conv_wgrad_sets_workspace(const hwg_conv_desc* d, int sets) {
+  if (!d || sets < 1 || wgrad_is_direct(d)) return 0;
+  const WgPlan p = plan_wgrad_sets(d, sets, wgrad_is_tapn(d), wgrad_is_narrow(d));
+  return (size_t)sets * p.nsplit * ((size_t)d->R * d->S * d->K * d->C + d->K) * sizeof(float);
+}
+
 // one weight gradient, or `sets` of them that share the gathered tensor v (u = the sets' anchors back to back): one launch, one partial-image
 // range and one (possibly deferred) sum per set
 static int conv_wgrad_run(const hwg_conv_desc* d, const float* u, const float* v, int sets, int set_on_v, float* const* dws,
@@ -1610,14 +1636,13 @@ static int conv_wgrad_run(const hwg_conv_desc* d, const float* u, const float* v
   }
   const bool tapn = wgrad_is_tapn(d);
   HWG_REQUIRE(d->K % 4 == 0 && (tapn || d->C % 4 == 0), "conv_wgrad: channels must be multiples of 4 (K=%d C=%d)", d->K, d->C);
-  const size_t need = hwg_conv_wgrad_workspace(d) * (size_t)sets;
+  const size_t need = sets == 1 ? hwg_conv_wgrad_workspace(d) : hwg_conv_wgrad_sets_workspace(d, sets);
   if (!workspace || workspace_bytes < need) {
     hwg_set_error("conv_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     return HWG_ERR_WORKSPACE;
   }
   const bool narrow = wgrad_is_narrow(d);
-  WgPlan p = tapn ? plan_wgrad_tapn(d) : plan_wgrad(d);
-  if (narrow) p.nsplit = narrow_blocks(d);
+  const WgPlan p = plan_wgrad_sets(d, sets, tapn, narrow);
   WgK k;
   k.u = u; k.v = v; k.part = (float*)workspace;
   k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.R = d->R; k.S = d->S;

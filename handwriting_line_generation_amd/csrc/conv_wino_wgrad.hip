@@ -281,7 +281,7 @@ bool hwg_wgrad_defer_take();
 namespace {
 struct WgPlan { int kt, ct, nsplit, MP; };
 
-WgPlan plan_wino_wgrad(const hwg_conv_desc* d) {
+WgPlan plan_wino_wgrad(const hwg_conv_desc* d, int sets = 1) {
   WgPlan p;
   p.kt = hwg_cdiv(d->K, 64);
   p.ct = hwg_cdiv(d->C, 64);
@@ -289,7 +289,7 @@ WgPlan plan_wino_wgrad(const hwg_conv_desc* d) {
   p.MP = d->N * TP * TQ2;
   const int rounds_all = hwg_cdiv(p.MP, 4);
   // one workgroup per CU (128 KB of LDS): as many pixel ranges as fill the 256 CUs once, at least 4 rounds each
-  int ns = 256 / (p.kt * p.ct);
+  int ns = 256 / (p.kt * p.ct * sets);     // (several gradient sets in one launch share the chip: fewer, longer pixel ranges per set)
   if (ns < 1) ns = 1;
   const int cap = rounds_all / 4 > 1 ? rounds_all / 4 : 1;
   if (ns > cap) ns = cap;
@@ -327,18 +327,24 @@ extern "C" size_t hwg_wino_wgrad_workspace(const hwg_conv_desc* d) {
   return (size_t)p.nsplit * (9 * (size_t)d->K * d->C + d->K) * sizeof(float);
 }
 
+extern "C" size_t hwg_wino_wgrad_sets_workspace(const hwg_conv_desc* d, int sets) {
+  if (!hwg_wino_wgrad_supported(d) || sets < 1) return 0;
+  const WgPlan p = plan_wino_wgrad(d, sets);
+  return (size_t)sets * p.nsplit * (9 * (size_t)d->K * d->C + d->K) * sizeof(float);
+}
+
 static int wino_wgrad_run(const hwg_conv_desc* d, const float* dy, const float* x, int sets, float* const* dws, long long sa, long long sb,
                           long long sr, long long ss, int accumulate, float* const* dbiases, int bias_accumulate, void* workspace,
                           size_t workspace_bytes, hipStream_t st, bool defer) {
   HWG_REQUIRE(d && dy && x && dws && dws[0] && sets >= 1, "wino_wgrad: null pointer");
   HWG_REQUIRE(hwg_wino_wgrad_supported(d), "wino_wgrad: needs a 3x3 stride-1 dilation-1 convolution with K, C >= 16");
-  const size_t need = hwg_wino_wgrad_workspace(d) * (size_t)sets;
+  const size_t need = hwg_wino_wgrad_sets_workspace(d, sets);
   if (!workspace || workspace_bytes < need) {
     hwg_set_error("wino_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     return HWG_ERR_WORKSPACE;
   }
   float* const dbias = dbiases ? dbiases[0] : nullptr;
-  const WgPlan p = plan_wino_wgrad(d);
+  const WgPlan p = plan_wino_wgrad(d, sets);
   WinoWgK k;
   k.x = x; k.dy = dy; k.part = (float*)workspace;
   k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.P = d->P; k.Q = d->Q; k.ph = d->pad_h; k.pw = d->pad_w;

@@ -584,7 +584,7 @@ def tuning_reload():
     per-geometry choices are cached here as well. Call this after changing such a variable in a running process."""
     global WINOGRAD
     WINOGRAD = bool(int(os.environ.get("HWG_WINO", "1") or 1))
-    _wino_choice.clear(); _wino_wgrad_choice.clear(); _conv_plans.clear(); _wgrad_plans.clear(); _wgrad_sets_ok.clear()
+    _wino_choice.clear(); _wino_wgrad_choice.clear(); _conv_plans.clear(); _wgrad_plans.clear(); _wgrad_sets_ok.clear(); _wgrad_sets_ws.clear()
     L.call("hwg_tuning_reload")
 
 
@@ -675,6 +675,7 @@ def _taps(weight):
 
 _wgrad_plans = {}
 _wgrad_sets_ok = {}
+_wgrad_sets_ws = {}
 
 
 def _make_wgrad_plan(N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, P, Q, transposed):
@@ -823,7 +824,10 @@ class _Conv2d(Function):
             sa, sb = K * R * S_, R * S_
         acc = 1 if direct else 0
         bacc = 1 if (fuse_bias and bdirect) else 0
-        total = need * S
+        tkey = (pkey, S)
+        total = _wgrad_sets_ws.get(tkey)
+        if total is None:
+            total = _wgrad_sets_ws[tkey] = L.query("hwg_wino_wgrad_sets_workspace" if engine == 0 else "hwg_conv_wgrad_sets_workspace", d.ptr, S)
         can_defer = DEFER_REDUCE and direct and (not fuse_bias or bdirect) and total
         ws = _defer_workspace(total, x.device) if can_defer else None
         defer = ws is not None

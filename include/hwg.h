@@ -122,10 +122,12 @@ int hwg_conv_wgrad(const hwg_conv_desc* d, const float* u, const float* v, float
 /* Gradient sets: `sets` weight gradients of one layer whose anchors differ (u / dy = the sets' [N,P,Q,K] tensors back to back) and whose
  * gathered tensor (v / x, [N,H,W,C]) is shared - the two or three upstream gradients a balanced lesson sends through the generator
  * (reference trainer/hw_with_style_trainer.py:300-338 runs one backward() per loss group on the same activations). One launch; set s is
- * summed into the buffers dw_ptrs[s] / dbias_ptrs[s] (host arrays of device addresses). d describes ONE set; workspace = sets x the
- * single-gradient workspace. set_on_v != 0 (hwg_conv_wgrad_sets only): the sets differ in the GATHERED tensor v instead and share the anchor u
+ * summed into the buffers dw_ptrs[s] / dbias_ptrs[s] (host arrays of device addresses). d describes ONE set; workspace =
+ * hwg_*_wgrad_sets_workspace(d, sets) bytes (the pixel ranges are planned for the whole launch and shared out over the sets). set_on_v != 0 (hwg_conv_wgrad_sets only): the sets differ in the GATHERED tensor v instead and share the anchor u
  * (transposed layers, whose anchor is the layer input); no fused bias gradient then. hwg_conv_wgrad_sets_supported: the layer runs on the MFMA path (not the K <= 2 / C <= 2 direct kernels). */
 int hwg_conv_wgrad_sets_supported(const hwg_conv_desc* d);
+size_t hwg_conv_wgrad_sets_workspace(const hwg_conv_desc* d, int sets);
+size_t hwg_wino_wgrad_sets_workspace(const hwg_conv_desc* d, int sets);
 int hwg_conv_wgrad_sets(const hwg_conv_desc* d, const float* u, const float* v, int sets, int set_on_v, const long long* dw_ptrs,
                         long long sa, long long sb, long long sr, long long ss, int accumulate,
                         const long long* dbias_ptrs, int bias_accumulate, void* workspace, size_t workspace_bytes, void* stream);

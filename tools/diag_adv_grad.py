@@ -48,8 +48,8 @@ def main():
     hip = {k: p.grad.detach().double().cpu() for k, p in g.named_parameters() if p.grad is not None}
 
     def oracle(dtype):
-        gs = {k: (v.detach().to(dtype) if v.dtype.is_floating_point else v.clone()) for k, v in gsd.items()}
-        ds = {k: (v.detach().to(dtype) if v.dtype.is_floating_point else v.clone()) for k, v in dsd.items()}
+        gs = {k: (v.detach().to(dtype).clone() if v.dtype.is_floating_point else v.clone()) for k, v in gsd.items()}
+        ds = {k: (v.detach().to(dtype).clone() if v.dtype.is_floating_point else v.clone()) for k, v in dsd.items()}
         for k in gnames:
             gs[k].requires_grad_(True)
         rl = torch.randn_like
