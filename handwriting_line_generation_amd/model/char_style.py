@@ -116,6 +116,11 @@ class CharStyleEncoder(nn.Module):
 
     # workload counters (bench.py reports them: how many character windows / distinct experts a style extraction ran)
     stats = {"calls": 0, "windows": 0, "experts": 0}
+    # Parity instrumentation (tests/test_pipeline_gpu.py): which character sits in which column is a DISCRETE decision - the arg-max of the
+    # recogniser's log-probs - and a near-tie resolves differently under another fp32 summation order, which changes the loss graph itself
+    # (another expert, another window). `last_argmax` keeps the map of the last call [B', T]; `forced_argmax` (same shape) overrides it.
+    last_argmax = None
+    forced_argmax = None
 
     def forward(self, x, recog):
         with ops.scope("StyleEx"):
@@ -152,6 +157,10 @@ class CharStyleEncoder(nn.Module):
 
         # which classes were recognised where (one small D2H copy)
         pred = pred_fetch.get().numpy().reshape(B, T0)
+        if self.forced_argmax is not None:
+            assert tuple(self.forced_argmax.shape) == (B, T0), "forced arg-max map has shape %s, expected %s" % (self.forced_argmax.shape, (B, T0))
+            pred = np.asarray(self.forced_argmax).astype(pred.dtype)
+        self.last_argmax = pred.copy()
         if Wf > T0:   # the log-probs were replicate-padded to the feature length: the arg-max map pads the same way
             d = Wf - T0
             pred = np.pad(pred, ((0, 0), (d // 2, d // 2 + d % 2)), mode="edge")
