@@ -332,14 +332,21 @@ def test_full_size_layers_vs_fp64(cuda, layer, engine):
     elif engine == "direct":
         assert fwd_plan[0] == 0 and wgrad_plan[0] == 1, (fwd_plan, wgrad_plan)
     worst = 0.0
+    rels = {}
     for got, key in ((nchw(y), "y"), (nchw(xg.grad), "dx"), (wg.grad, "dw"), (bg.grad, "db")):
         want = ref[key]
         rel = float((got.detach().cpu().double() - want).norm() / want.norm())
         mx = float((got.detach().cpu().double() - want).abs().max() / want.abs().max())
         worst = max(worst, mx)
+        rels[key] = rel
         assert rel < 3e-6 and mx < 1e-4, "%s [%s, forward %s, weight gradient %s] %s: rel L2 %.2e, max/max %.2e vs fp64" % (
             layer[0], engine, fwd_plan, wgrad_plan, key, rel, mx)
-    print("\n%s [%s]: forward plan %s, weight-gradient plan %s, worst max-norm error vs fp64 %.2e" % (layer[0], engine, fwd_plan, wgrad_plan, worst))
+    line = "%-13s [%-6s] forward plan %s, weight-gradient plan %s: rel L2 vs fp64  y %.2e  dx %.2e  dw %.2e  db %.2e; worst max-norm %.2e" % (
+        layer[0], engine, fwd_plan, wgrad_plan, rels["y"], rels["dx"], rels["dw"], rels["db"], worst)
+    print("\n" + line)
+    if os.environ.get("HWG_PARITY_SUMMARY"):     # per-engine forward / gradient error of the full-size layers (Winograd F(2x2,3x3) vs direct vs fp64)
+        with open(os.environ["HWG_PARITY_SUMMARY"], "a") as fh:
+            fh.write("full-size layer " + line + "\n")
 
 
 _FULL_REF = {}

@@ -229,6 +229,14 @@ def test_count_lesson_recogniser_gradients_and_gate_flips(cuda):
             assert aflips + act_flips + pool_flips > 0, "%s: %.2e from fp64 with every recorded decision equal to the clean schedule's" % (tag, err)
             assert err <= 1e-2, "%s: %.2e" % (tag, err)
     print("\n".join(lines))
+    _summary(lines)
+
+
+def _summary(lines):
+    import os
+    if os.environ.get("HWG_PARITY_SUMMARY"):
+        with open(os.environ["HWG_PARITY_SUMMARY"], "a") as fh:
+            fh.write("\n".join(lines) + "\n\n")
 
 
 def test_adversarial_generator_gradients_are_as_far_from_fp64_as_the_references(cuda):
@@ -291,8 +299,10 @@ def test_adversarial_generator_gradients_are_as_far_from_fp64_as_the_references(
             rows.append((seed, eh, eo))
     finally:
         rng.set_mode("device")
-    print("adversarial generator gradients, pooled relative error vs fp64 per seed (HIP / fp32 oracle): " +
-          ", ".join("%d: %.2e / %.2e" % r for r in rows))
+    line = ("adversarial generator gradients -mean(D(G(.))), full width, pooled relative error vs fp64 per seed (HIP / fp32 oracle): " +
+            ", ".join("%d: %.2e / %.2e" % r for r in rows))
+    print(line)
+    _summary([line])
     worst_oracle = max(r[2] for r in rows)
     for seed, eh, eo in rows:
         assert eh <= max(1e-4, 3 * worst_oracle), "seed %d: HIP %.2e, the oracle's worst draw %.2e" % (seed, eh, worst_oracle)
