@@ -488,7 +488,7 @@ def main():
         if roofline:
             # HBM bytes per launch of the dominant kernel: PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately with rocprofv3 on this
             # same command and corrected per MI355X_MICROARCH.md) are committed under profiles/; they cannot be collected from inside bench.py
-            for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", name)))
                     if pm.get("workload") == args.workload and dom in pm["kernels"]:
@@ -501,7 +501,7 @@ def main():
             # ... and per layer shape (tools/pmc_shapes.py replays the step's top conv shapes under the same counters): measured HBM bytes against
             # the one-pass operand bytes 4*(input + weights + output), weighted by this run's launch counts
             try:
-                shapes_file = "r03_pmc_shapes.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_shapes.json")) else "r02_pmc_shapes.json"
+                shapes_file = next((f for f in ("r04_pmc_shapes.json", "r03_pmc_shapes.json", "r02_pmc_shapes.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r02_pmc_shapes.json")
                 ps = json.load(open(os.path.join(ROOT, "profiles", shapes_file)))
                 launches = {(k, repr(sh)): v[2] for (k, sh), v in by_shape.items()}
                 tot = {}

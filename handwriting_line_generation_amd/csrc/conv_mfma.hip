@@ -1495,6 +1495,7 @@ std::vector<RedEntry> g_defer_queue;
 }  // namespace
 int hwg_prof_current_tag();
 void hwg_prof_add_child(int parent, int kind, int tag, double work);
+int hwg_pg_defer_flush(hipStream_t st, int* launches);
 bool hwg_wgrad_defer_take() { const bool d = g_defer_next != 0; g_defer_next = 0; return d; }
 extern "C" int hwg_wgrad_defer_next(void) { g_defer_next = 1; return HWG_OK; }
 extern "C" long long hwg_wgrad_defer_pending(void) { std::lock_guard<std::mutex> lock(g_defer_mu); return (long long)g_defer_queue.size(); }
@@ -1583,7 +1584,7 @@ extern "C" int hwg_wgrad_defer_flush(void* stream, int* launches) {
     }
   }
   if (launches) *launches = made;
-  return HWG_OK;
+  return hwg_pg_defer_flush(st, launches);      // the generator epilogues' queued parameter-gradient sums (norm_act.hip)
 }
 
 extern "C" size_t hwg_conv_wgrad_workspace(const hwg_conv_desc* d) {

@@ -366,7 +366,8 @@ template <bool PRE>
 __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* dy, const float* x, const float* y, float* dx, Geo g,
                                                         const float* mean, const float* rstd, const float* gamma, int per_sample,
                                                         const float* c1, const float* c2, const float* mask, int act, float slope,
-                                                        const float* noise, float pre_slope, double* part2, InlineStats is, const float* beta) {
+                                                        const float* noise, float pre_slope, double* part2, InlineStats is, const float* beta,
+                                                        float* pg_gamma, float* pg_beta, int pg_accumulate) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ __attribute__((aligned(16))) float s_a[NS_MAXC];
   __shared__ __attribute__((aligned(16))) float s_b[NS_MAXC];
@@ -438,6 +439,25 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* dy, const f
     }
   }
   if (PRE) block_reduce_store<2>(acc, g, part2, sm);
+  // parameter gradients of a shared (per-channel) affine, IN / GN: sum of the moment partials over samples and chunks. It was a launch of its
+  // own between the two passes (param_grad_kernel, 11 launches per training step); now the first sample's workgroups do it behind their
+  // streaming work, one wavefront per channel, in the same order (lane-strided items, butterfly) - bit-identical.
+  if (!PRE && (pg_gamma || pg_beta) && blockIdx.y == 0 && is.part) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const int items = g.N * g.chunks;
+    for (int c = blockIdx.x * 4 + wv; c < g.C; c += gridDim.x * 4) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int it = lane; it < items; it += 64) {
+        const double* p = is.part + ((size_t)it * g.C + c) * 2;
+        s1 += p[0]; s2 += p[1];
+      }
+      s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+      if (lane == 0) {
+        if (pg_gamma) pg_gamma[c] = (pg_accumulate ? pg_gamma[c] : 0.f) + (float)s2;
+        if (pg_beta) pg_beta[c] = (pg_accumulate ? pg_beta[c] : 0.f) + (float)s1;
+      }
+    }
+  }
 }
 
 // dbias[c] = sum part2[...][c][0];  dnoise_w[c] = nscale * sum part2[...][c][1]; one wavefront per channel
@@ -626,12 +646,10 @@ extern "C" int hwg_norm_bwd(const float* dy, const float* x, const float* y, flo
     is.part = part; is.cpg = (mode == MODE_GN) ? C / groups : 1; is.gamma = gamma; is.per_sample = affine_per_sample;
     is.out_a = affine_per_sample ? dgamma : nullptr; is.out_b = affine_per_sample ? dbeta : nullptr; is.accumulate = accumulate;
   }
-  if (mode != MODE_BN && !affine_per_sample && (dgamma || dbeta)) {
-    hipLaunchKernelGGL(param_grad_kernel, dim3(hwg_cdiv(C, 4)), dim3(256), 0, st, (const double*)part, g, dgamma, dbeta, accumulate);
-    HWG_LAUNCH_CHECK("norm_bwd.param_grad");
-  }
+  const bool fold_pg = mode != MODE_BN && !affine_per_sample && (dgamma || dbeta);    // summed by the apply pass's first-sample workgroups
   hipLaunchKernelGGL(apply_bwd_kernel<false>, grid, dim3(256), 0, st, dy, x, y, dx, g, mean, rstd, gamma, affine_per_sample,
-                     (const float*)c1, (const float*)c2, chan_mask, act, slope, nullptr, 0.f, nullptr, is, beta);
+                     (const float*)c1, (const float*)c2, chan_mask, act, slope, nullptr, 0.f, nullptr, is, beta,
+                     fold_pg ? dgamma : (float*)nullptr, fold_pg ? dbeta : (float*)nullptr, accumulate);
   HWG_LAUNCH_CHECK("norm_bwd.apply");
   return HWG_OK;
 }
@@ -657,10 +675,83 @@ extern "C" int hwg_adain_fwd(const float* x, const float* noise, const float* no
   return HWG_OK;
 }
 
+// ---- deferred parameter-gradient sums of the generator epilogue -------------------------------------------------------------------
+// adain_param_grad_kernel sums the [n][chunk][c][2] partials the apply pass just wrote: a 5 us launch behind each of the generator's ten
+// epilogues, per backward pass. With the caller's deferral mark set (hwg_wgrad_defer_next: the workspace then lives in the caller's arena
+// until the flush) the sum is queued and hwg_wgrad_defer_flush makes all of them with one table-driven launch - same arithmetic per channel.
+#include <mutex>
+#include <vector>
+bool hwg_wgrad_defer_take();
+namespace {
+struct PgEntry { const double* part2; float* dbias; float* dnw; float nscale; int items, C, accumulate, first_block; };
+constexpr int PG_MAX = 64;
+struct PgTable { int n, pad; PgEntry e[PG_MAX]; };
+std::mutex g_pg_mu;
+std::vector<PgEntry> g_pg_queue;
+
+__global__ __launch_bounds__(256) void adain_param_grad_multi_kernel(const PgTable t) {
+  int lo = 0, hi = t.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.e[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PgEntry& e = t.e[lo];
+  const int lane = threadIdx.x & 63;
+  const int c = (((int)blockIdx.x - e.first_block) * 256 + threadIdx.x) >> 6;
+  if (c >= e.C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int it = lane; it < e.items; it += 64) {
+    const double* p = e.part2 + ((size_t)it * e.C + c) * 2;
+    s1 += p[0]; s2 += p[1];
+  }
+  s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+  if (lane == 0) {
+    if (e.dbias) e.dbias[c] = (e.accumulate ? e.dbias[c] : 0.f) + (float)s1;
+    if (e.dnw) e.dnw[c] = (e.accumulate ? e.dnw[c] : 0.f) + (float)(s2 * (double)e.nscale);
+  }
+}
+}  // namespace
+
+// called by hwg_wgrad_defer_flush (conv_mfma.hip): the queued epilogue parameter-gradient sums, several sums into one buffer in queue order
+int hwg_pg_defer_flush(hipStream_t st, int* launches) {
+  std::vector<PgEntry> q;
+  {
+    std::lock_guard<std::mutex> lock(g_pg_mu);
+    q.swap(g_pg_queue);
+  }
+  std::vector<int> pass(q.size(), 0);
+  int npass = 0;
+  for (size_t i = 0; i < q.size(); ++i) {
+    for (size_t j = 0; j < i; ++j)
+      if ((q[i].dnw && q[j].dnw == q[i].dnw) || (q[i].dbias && q[j].dbias == q[i].dbias)) pass[i] = pass[j] + 1 > pass[i] ? pass[j] + 1 : pass[i];
+    if (pass[i] + 1 > npass) npass = pass[i] + 1;
+  }
+  for (int ps = 0; ps < npass; ++ps) {
+    size_t i = 0;
+    while (i < q.size()) {
+      PgTable t; t.n = 0; t.pad = 0;
+      int blocks = 0;
+      for (; i < q.size() && t.n < PG_MAX; ++i) {
+        if (pass[i] != ps) continue;
+        PgEntry e = q[i];
+        e.first_block = blocks;
+        blocks += hwg_cdiv(e.C, 4);
+        t.e[t.n++] = e;
+      }
+      if (t.n == 0) break;
+      hipLaunchKernelGGL(adain_param_grad_multi_kernel, dim3(blocks), dim3(256), 0, st, t);
+      HWG_LAUNCH_CHECK("adain_param_grad_multi");
+      if (launches) ++*launches;
+    }
+  }
+  return HWG_OK;
+}
+
 extern "C" int hwg_adain_bwd(const float* dy, const float* u, const float* noise, float noise_scale, float slope,
                              const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
                              float* dnoise_w, float* dbias, int accumulate_params, int N, int HW, int C,
                              void* ws, size_t ws_bytes, void* stream) {
+  const bool defer = hwg_wgrad_defer_take();
   int rc = check_geo(N, HW, C, "adain_bwd");
   if (rc) return rc;
   HWG_REQUIRE(dy && u && noise && gamma && mean && rstd && dx && dgamma && dbeta, "adain_bwd: null pointer");
@@ -679,9 +770,16 @@ extern "C" int hwg_adain_bwd(const float* dy, const float* u, const float* noise
   InlineStats is = {};
   is.part = part; is.cpg = 1; is.gamma = gamma; is.per_sample = 1; is.out_a = dgamma; is.out_b = dbeta; is.accumulate = 0;
   hipLaunchKernelGGL(apply_bwd_kernel<true>, grid, dim3(256), red_smem(g), st, dy, u, (const float*)nullptr, dx, g, mean, rstd, gamma, 1,
-                     (const float*)c1, (const float*)c2, (const float*)nullptr, 0, 0.f, noise, slope, part2, is, (const float*)nullptr);
+                     (const float*)c1, (const float*)c2, (const float*)nullptr, 0, 0.f, noise, slope, part2, is, (const float*)nullptr,
+                     (float*)nullptr, (float*)nullptr, 0);
   HWG_LAUNCH_CHECK("adain_bwd.apply");
-  if (dnoise_w || dbias) {
+  if ((dnoise_w || dbias) && defer) {
+    PgEntry e;
+    e.part2 = part2; e.dbias = dbias; e.dnw = dnoise_w; e.nscale = noise_scale; e.items = g.N * g.chunks; e.C = g.C; e.accumulate = accumulate_params;
+    e.first_block = 0;
+    std::lock_guard<std::mutex> lock(g_pg_mu);
+    g_pg_queue.push_back(e);
+  } else if (dnoise_w || dbias) {
     hipLaunchKernelGGL(adain_param_grad_kernel, dim3(hwg_cdiv(C, 4)), dim3(256), 0, st, (const double*)part2, g, noise_scale, dbias, dnoise_w,
                        accumulate_params);
     HWG_LAUNCH_CHECK("adain_bwd.param_grad");

@@ -1136,7 +1136,12 @@ class _AdaIN(Function):
         (nwref,) = ctx.param_refs
         direct = _direct(nwref)
         dnw = _grad_buffer(nwref) if direct else torch.empty((C,), dtype=torch.float32, device=u.device)
-        ws = workspace(L.query("hwg_norm_workspace", N, HW, C), u.device)
+        need = L.query("hwg_norm_workspace", N, HW, C)
+        ws = _defer_workspace(need, u.device) if (DEFER_REDUCE and direct) else None      # the noise-weight sum joins the pass's one deferred launch
+        if ws is not None:
+            L.call("hwg_wgrad_defer_next")
+        else:
+            ws = workspace(need, u.device)
         L.call("hwg_adain_bwd", dy, u, noise, noise_scale, slope, gamma, mean, rstd, dx, dgamma, dbeta, dnw, None, 1 if direct else 0, N, HW, C,
                ws, ws.numel(), _stream())
         return dx, None, (None if direct else dnw.view(wshape)), dgamma, dbeta, None, None, None
@@ -1157,12 +1162,17 @@ class _AdaIN(Function):
         (nwref,) = ctx.param_refs
         if not _direct(nwref):
             raise L.HwgError("batched AdaIN backward needs the noise weight's gradient buffer (a leaf parameter)")
-        ws = workspace(L.query("hwg_norm_workspace", N, HW, C), u.device)
+        need = L.query("hwg_norm_workspace", N, HW, C)
         st = _stream()
         for s_ in range(S):
             GRAD_SET = targets[s_]
             dnw = _grad_buffer(nwref)
             sl = slice(s_ * N, (s_ + 1) * N)
+            ws = _defer_workspace(need, u.device) if DEFER_REDUCE else None
+            if ws is not None:
+                L.call("hwg_wgrad_defer_next")
+            else:
+                ws = workspace(need, u.device)
             L.call("hwg_adain_bwd", dy[sl], u, noise, noise_scale, slope, gamma, mean, rstd, dx[sl], dgamma[sl], dbeta[sl], dnw, None, 1, N, HW, C,
                    ws, ws.numel(), st)
         return dx, None, None, dgamma, dbeta, None, None, None
