@@ -2,7 +2,7 @@
  (A) recogniser parameter gradients when the loss reaches the recogniser only through the style extractor's `recog` input (count lesson)
  (B) the discriminator's gradient with respect to its input image (adversarial gradient that the generator receives)"""
 import sys, torch, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import torch_ref
 from handwriting_line_generation_amd import rng, ops
 from handwriting_line_generation_amd.harness import load_config
