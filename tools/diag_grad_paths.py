@@ -1,7 +1,7 @@
 """Diagnostic (GPU box): two gradient paths the teacher-forced trainer parity flagged, each isolated against the oracle in fp32 and fp64.
  (A) recogniser parameter gradients when the loss reaches the recogniser only through the style extractor's `recog` input (count lesson)
  (B) the discriminator's gradient with respect to its input image (adversarial gradient that the generator receives)"""
-import sys, torch, numpy as np
+import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import torch_ref
 from handwriting_line_generation_amd import rng, ops
