@@ -5,6 +5,7 @@ from the declared ABI. There is no CPU fallback: if the shared library is missin
 this module fails, and calling any kernel without a HIP device raises.
 """
 import ctypes
+import sys
 import os
 import re
 
@@ -95,26 +96,43 @@ for _name, (_res, _args) in DECLS.items():
 # against hwg.h at compile time) instead of ctypes' per-argument conversion: ~1 us instead of 5-9 us per call, ~450 calls per training
 # step. The thunks are handed the addresses of the symbols of the library loaded above.
 _PYCALL_PATH = os.path.join(_PKG_DIR, "_hwgcall.so")
-if not os.path.exists(_PYCALL_PATH):
-    raise ImportError("_hwgcall.so not found at %s - build it with `make -C handwriting_line_generation_amd/csrc`" % _PYCALL_PATH)
 import importlib.util as _ilu  # noqa: E402
 
-_spec = _ilu.spec_from_file_location("handwriting_line_generation_amd._hwgcall", _PYCALL_PATH)
-_hwgcall = _ilu.module_from_spec(_spec)
-_spec.loader.exec_module(_hwgcall)
-for _name in DECLS:
-    _hwgcall.bind(_name, ctypes.cast(getattr(_dll, _name), ctypes.c_void_p).value)
+_hwgcall = None
+try:
+    if os.environ.get("HWG_NO_THUNKS"):
+        raise ImportError("disabled by HWG_NO_THUNKS")
+    if not os.path.exists(_PYCALL_PATH):
+        raise ImportError("not built")
+    _spec = _ilu.spec_from_file_location("handwriting_line_generation_amd._hwgcall", _PYCALL_PATH)
+    _hwgcall = _ilu.module_from_spec(_spec)
+    _spec.loader.exec_module(_hwgcall)
+    for _name in DECLS:
+        _hwgcall.bind(_name, ctypes.cast(getattr(_dll, _name), ctypes.c_void_p).value)
+except Exception as _e:  # noqa: BLE001 - e.g. thunks built for another interpreter (Python.h of a different version), or not built at all
+    import warnings
+    warnings.warn("handwriting_line_generation_amd: the call thunks (_hwgcall.so) are unusable (%r); falling back to ctypes calls, ~5 us slower "
+                  "per kernel launch - rebuild with `make -C handwriting_line_generation_amd/csrc PYTHON=%s`" % (_e, sys.executable))
+    _hwgcall = None
+
+
+def _ctypes_entry(fn):
+    """ctypes fallback for one entry point: tensors -> their device address, everything else as it is (argtypes do the rest)"""
+    def call(*args):
+        return fn(*[a.data_ptr() if hasattr(a, "data_ptr") else a for a in args])
+    return call
 
 
 class HwgError(RuntimeError):
     pass
 
 
+_FN = {name: (getattr(_hwgcall, name) if _hwgcall is not None else _ctypes_entry(getattr(_dll, name))) for name in DECLS}
+
+
 def last_error():
-    return _hwgcall.hwg_last_error()
-
-
-_FN = {name: getattr(_hwgcall, name) for name in DECLS}
+    e = _FN["hwg_last_error"]()
+    return e.decode() if isinstance(e, bytes) else e
 
 
 def call(name, *args):
@@ -131,8 +149,8 @@ def query(name, *args):
 
 
 def device_ok():
-    return bool(_hwgcall.hwg_device_ok())
+    return bool(_FN["hwg_device_ok"]())
 
 
 def abi_version():
-    return int(_hwgcall.hwg_abi_version())
+    return int(_FN["hwg_abi_version"]())

@@ -1029,3 +1029,31 @@ def test_tape_backward_sets_equal_separate_backward_passes(cuda):
         _close(res[id(gt)][s_], dg, "set %d dgamma" % s_, tol=2e-5)
         _close(res[id(bt2)][s_], db, "set %d dbeta" % s_, tol=2e-5)
     assert float(bufs[0][0].abs().max()) > 0 and not torch.equal(bufs[0][0], bufs[1][0])
+
+
+def test_ctypes_fallback_without_the_call_thunks(cuda):
+    """_lib falls back to plain ctypes calls (with a warning) when _hwgcall.so cannot be used - thunks built for another interpreter, or not
+    built; HWG_NO_THUNKS=1 forces that path: a convolution forward / backward through it must equal the thunk path's bits."""
+    import subprocess
+    import sys
+    code = (
+        "import torch, warnings\n"
+        "warnings.simplefilter('ignore')\n"
+        "from handwriting_line_generation_amd import _lib, ops\n"
+        "g = torch.Generator().manual_seed(1)\n"
+        "x = torch.randn(2, 9, 20, 32, generator=g).cuda().requires_grad_(True)\n"
+        "w = (torch.randn(48, 32, 3, 3, generator=g) * 0.1).cuda().requires_grad_(True)\n"
+        "b = torch.randn(48, generator=g).cuda().requires_grad_(True)\n"
+        "y = ops.conv2d(x, w, b, 1, 1)\n"
+        "(y * y).sum().backward()\n"
+        "torch.cuda.synchronize()\n"
+        "print(_lib._hwgcall is None, float(y.double().sum()), float(w.grad.double().abs().sum()), float(x.grad.double().abs().sum()), float(b.grad.double().sum()))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for no_thunks in ("", "1"):
+        env = dict(os.environ, PYTHONPATH=root, HWG_NO_THUNKS=no_thunks)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1].split())
+    assert outs[0][0] == "False" and outs[1][0] == "True", outs
+    assert outs[0][1:] == outs[1][1:], outs
