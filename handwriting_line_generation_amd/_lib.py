@@ -118,6 +118,9 @@ except Exception as _e:  # noqa: BLE001 - e.g. thunks built for another interpre
 
 def _ctypes_entry(fn):
     """ctypes fallback for one entry point: tensors -> their device address, everything else as it is (argtypes do the rest)"""
+    # (descriptors travel as addresses - ConvDesc.ptr - like every other pointer: typed struct pointers become void*)
+    fn.argtypes = [ctypes.c_void_p if (isinstance(t, type) and issubclass(t, ctypes._Pointer)) else t for t in (fn.argtypes or [])]
+
     def call(*args):
         return fn(*[a.data_ptr() if hasattr(a, "data_ptr") else a for a in args])
     return call

@@ -40,20 +40,42 @@ class GroupNorm(nn.GroupNorm):
 
 
 class _BatchNormBase:
+    """`num_batches_tracked` (an int64 buffer nothing on the training path reads: momentum is fixed) is counted on the host and folded into the
+    buffer when the state dict is taken or loaded - the reference's `+= 1` on the device was one launch per BatchNorm layer and forward pass
+    (seven per recogniser forward)."""
+
     def _fwd(self, x, act, slope):
         if self.training:
             y = ops.batch_norm_train(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps, ACT[act], slope)
-            self.num_batches_tracked += 1
+            self._tracked_pending = getattr(self, "_tracked_pending", 0) + 1
             return y
         return ops.norm_apply_frozen(x, self.running_mean, self.running_var, self.eps, self.weight, self.bias, ACT[act], slope)
 
+    def flush_tracked(self):
+        n = getattr(self, "_tracked_pending", 0)
+        if n and self.num_batches_tracked is not None:
+            self.num_batches_tracked += n
+        self._tracked_pending = 0
 
-class BatchNorm2d(nn.BatchNorm2d, _BatchNormBase):
+    def state_dict(self, *args, **kwargs):
+        self.flush_tracked()
+        return super().state_dict(*args, **kwargs)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):      # (a parent's state_dict() reaches the layer here)
+        self.flush_tracked()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._tracked_pending = 0
+        super()._load_from_state_dict(*args, **kwargs)
+
+
+class BatchNorm2d(_BatchNormBase, nn.BatchNorm2d):
     def forward(self, x, act="none", slope=0.0):
         return self._fwd(x, act, slope)
 
 
-class BatchNorm1d(nn.BatchNorm1d, _BatchNormBase):
+class BatchNorm1d(_BatchNormBase, nn.BatchNorm1d):
     def forward(self, x, act="none", slope=0.0):
         return self._fwd(x, act, slope)
 
