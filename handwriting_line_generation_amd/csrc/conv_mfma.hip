@@ -908,6 +908,44 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry*
   }
 }
 
+// The same for weights that are a device-side scalar multiple of a stored tensor - the spectral-norm layers' W_bar / sigma (reference:
+// model/discriminator_ap.py:31-32, recomputed on every forward): every image a forward / backward pass of the network will ask for (direct and
+// mirrored tap order, Winograd domain) is written straight from W_bar with the factor applied on the way, in ONE launch per forward pass,
+// instead of one scale launch plus two or three pack launches per layer. dst = dst_base + dst_off floats, factor = scale_base[scale_idx]: the
+// table is static, the image buffer and the sigma vector are fresh per forward pass.
+struct PackEntryS {
+  PackEntry e;
+  long long dst_off;
+  int scale_idx, pad;
+};
+__global__ __launch_bounds__(256) void pack_weight_multi_scaled_kernel(const PackEntryS* table, int n, float* dst_base, const float* scale_base) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].e.first_block <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackEntry e = table[lo].e;
+  float* dst = dst_base + table[lo].dst_off;
+  const float sc = scale_base[table[lo].scale_idx];
+  const long long base = ((long long)blockIdx.x - e.first_block) * PACK_PER_BLOCK;
+#pragma unroll
+  for (int j = 0; j < PACK_PER_BLOCK / 256; ++j) {
+    const long long i = base + j * 256 + threadIdx.x;
+    if (i >= e.total) break;
+    if (e.mode == 1) {
+      wino_pack_one(e.src, dst, i, e.A, e.Apad, e.B, e.Bpad, e.sa, e.sb, e.sr, e.ss, e.flip, sc);
+      continue;
+    }
+    const int b = (int)(i % e.Bpad);
+    const long long t = i / e.Bpad;
+    const int aa = (int)(t % e.A);
+    const int tap = (int)(t / e.A);
+    int r = tap / e.S, s2 = tap % e.S;
+    if (e.flip) { r = e.R - 1 - r; s2 = e.S - 1 - s2; }
+    dst[i] = (b < e.B) ? __fmul_rn(e.src[aa * e.sa + b * e.sb + r * e.sr + s2 * e.ss], sc) : 0.f;
+  }
+}
+
 // column sums: x[rows][C] -> part[chunks][C]  (single chunk: straight into out)
 // V = 4: block = 16 float4 column groups (64 columns) x 16 row lanes, 256-byte coalesced row segments; V = 1: 64 columns x 4 row lanes
 template <int V>
@@ -1111,6 +1149,15 @@ extern "C" int hwg_conv_pack_weight_multi(const void* table, int n_entries, long
   HWG_REQUIRE(table && n_entries > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "conv_pack_weight_multi: bad arguments");
   hipLaunchKernelGGL(pack_weight_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table, n_entries);
   HWG_LAUNCH_CHECK("conv_pack_weight_multi");
+  return HWG_OK;
+}
+
+extern "C" int hwg_conv_pack_weight_multi_scaled(const void* table, int n_entries, long long total_blocks, float* dst_base, const float* scale_base,
+                                                 void* stream) {
+  HWG_REQUIRE(table && dst_base && scale_base && n_entries > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "conv_pack_weight_multi_scaled: bad arguments");
+  hipLaunchKernelGGL(pack_weight_multi_scaled_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackEntryS*)table, n_entries,
+                     dst_base, scale_base);
+  HWG_LAUNCH_CHECK("conv_pack_weight_multi_scaled");
   return HWG_OK;
 }
 

@@ -23,7 +23,7 @@ static __device__ __forceinline__ void wino_filter_transform(const float g[3][3]
 }
 
 static __device__ __forceinline__ void wino_pack_one(const float* src, float* dst, long long i, int A, int Apad, int B, int Bpad, long long sa,
-                                              long long sb, long long sr, long long ss, int flip) {
+                                              long long sb, long long sr, long long ss, int flip, float scale = 1.f) {
   const int b = (int)(i % Bpad);
   const int aa = (int)(i / Bpad);
   float g[3][3];
@@ -33,7 +33,7 @@ static __device__ __forceinline__ void wino_pack_one(const float* src, float* ds
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       const int rr = flip ? 2 - r : r, s2 = flip ? 2 - s : s;
-      g[r][s] = ok ? src[aa * sa + b * sb + rr * sr + s2 * ss] : 0.f;
+      g[r][s] = ok ? __fmul_rn(src[aa * sa + b * sb + rr * sr + s2 * ss], scale) : 0.f;   // (rounded product: the transform must see w * scale, not an fma)
     }
   float U[4][4];
   wino_filter_transform(g, U);

@@ -434,6 +434,15 @@ def _pack(weight, A, B, R, S, sa, sb, flip, Bpad=None, wino=False):
     Apad = (A + 15) // 16 * 16 if wino else A
     if wino:
         Bpad = (B + 15) // 16 * 16
+    pre = getattr(weight, "_hwg_prepack", None)
+    if pre is not None:
+        # a spectral-norm layer's W_bar / sigma: its images were written by the network's one scaled multi-pack launch (SpectralBank.update);
+        # an image nobody asked for before is packed here, from the tensor itself, and joins the launch from the next forward pass on
+        variant = (A, B, Bpad, R, S, sa, sb, int(flip), int(bool(wino)), Apad)
+        img = pre.images.get(variant)
+        if img is not None:
+            return img
+        pre.miss(variant, weight)
     key = hit = group = None
     if weight.is_leaf:
         group = getattr(weight, "_hwg_group", None)
@@ -1668,9 +1677,10 @@ class _SpectralScale(Function):
     """W_sn = W_bar / sigma with sigma = u^T W v treated as a function of W_bar (u, v constants) - discriminator_ap.py:31-32"""
 
     @staticmethod
-    def forward(ctx, w_bar, u, v, sigma, inv_sigma):
+    def forward(ctx, w_bar, u, v, sigma, inv_sigma, lazy):
         out = torch.empty_like(w_bar)
-        L.call("hwg_scale_by_ptr", w_bar, inv_sigma, out, w_bar.numel(), _stream())
+        if not lazy:          # lazy: every image the convolutions need comes from the bank's scaled multi-pack; the tensor itself is only a handle
+            L.call("hwg_scale_by_ptr", w_bar, inv_sigma, out, w_bar.numel(), _stream())
         ctx.save_for_backward(w_bar, u, v, sigma)
         return out
 
@@ -1682,7 +1692,7 @@ class _SpectralScale(Function):
         dwbar = torch.empty_like(w_bar)
         ws = workspace(L.query("hwg_spectral_workspace", R, K), w_bar.device)
         L.call("hwg_spectral_bwd", dwsn.contiguous(), w_bar, u, v, sigma, dwbar, R, K, 0, ws, ws.numel(), _stream())
-        return dwbar, None, None, None, None
+        return dwbar, None, None, None, None, None
 
 
 def spectral_normalize(w_bar, u, v, eps=1e-12):
@@ -1695,7 +1705,23 @@ def spectral_normalize(w_bar, u, v, eps=1e-12):
     un, vn = torch.empty_like(u), torch.empty_like(v)
     with torch.no_grad():
         L.call("hwg_spectral_update_to", w_bar.detach(), u, v, un, vn, R, K, eps, sig[0:1], sig[1:2], ws, ws.numel(), _stream())
-    return _SpectralScale.apply(w_bar, un, vn, sig[0:1], sig[1:2])
+    return _SpectralScale.apply(w_bar, un, vn, sig[0:1], sig[1:2], False)
+
+
+class _Prepack:
+    """images of one spectral-norm layer's normalised weight for one forward pass (`images`: variant -> tensor), and what to do on a miss"""
+
+    __slots__ = ("images", "bank", "layer", "w_bar", "inv_sigma", "materialised")
+
+    def __init__(self, images, bank, layer, w_bar, inv_sigma, materialised):
+        self.images, self.bank, self.layer, self.w_bar, self.inv_sigma, self.materialised = images, bank, layer, w_bar, inv_sigma, materialised
+
+    def miss(self, variant, weight):
+        self.bank.request(self.layer, variant)
+        if not self.materialised:      # the handle has no values yet: W_bar / sigma into it now, the ordinary pack follows
+            with torch.no_grad():
+                L.call("hwg_scale_by_ptr", self.w_bar, self.inv_sigma, weight, weight.numel(), _stream())
+            self.materialised = True
 
 
 class SpectralBank:
@@ -1722,6 +1748,36 @@ class SpectralBank:
         dev = self.layers[0][0].device
         self.table = h2d(torch.from_numpy(rec.view(np.uint8)), dev)
         self.ws = torch.empty(self.total, dtype=torch.float32, device=dev)
+        # scaled multi-pack: the weight images the layers' convolutions asked for so far, (layer, variant) in request order
+        self.requests = []
+        self._ptab = None
+        self.prepack = bool(int(os.environ.get("HWG_SN_PREPACK", "1") or 0))
+
+    def request(self, layer, variant):
+        if (layer, variant) not in self.requests:
+            self.requests.append((layer, variant))
+            self._ptab = None
+
+    def _pack_table(self):
+        import numpy as np
+        if self._ptab is None:
+            dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("A", "<i4"), ("B", "<i4"), ("Bpad", "<i4"), ("R", "<i4"), ("S", "<i4"), ("flip", "<i4"),
+                           ("sa", "<i8"), ("sb", "<i8"), ("sr", "<i8"), ("ss", "<i8"), ("total", "<i8"), ("first_block", "<i8"),
+                           ("mode", "<i4"), ("Apad", "<i4"), ("dst_off", "<i8"), ("scale_idx", "<i4"), ("pad", "<i4")])
+            assert dt.itemsize == 112
+            host = np.zeros(len(self.requests), dtype=dt)
+            blocks = off = 0
+            spans = []
+            for i, (layer, (A, B, Bpad, R, S, sa, sb, flip, wino, Apad)) in enumerate(self.requests):
+                total = Apad * Bpad if wino else R * S * A * Bpad
+                host[i] = (self.layers[layer][0].data_ptr(), 0, A, B, Bpad, R, S, flip, sa, sb, S, 1, total, blocks, wino, Apad, off, 2 * layer + 1, 0)
+                shape = (Bpad // 16, 16, Apad, 16) if wino else (R * S, A, Bpad)
+                floats = 16 * Apad * Bpad if wino else total        # (Winograd: one thread per (a, b) pair writes its 16 positions)
+                spans.append((off, floats, shape))
+                blocks += (total + PACK_PER_BLOCK - 1) // PACK_PER_BLOCK
+                off += (floats + 3) // 4 * 4
+            self._ptab = (h2d(torch.from_numpy(host.view(np.uint8)), self.ws.device), blocks, off, spans)
+        return self._ptab
 
     def valid(self):
         return all((w.data_ptr(), u.data_ptr(), v.data_ptr()) == p for (w, u, v), p in zip(self.layers, self.ptrs))
@@ -1733,14 +1789,33 @@ class SpectralBank:
         sig = torch.empty(2 * len(self.layers), dtype=torch.float32, device=dev)
         with torch.no_grad():
             L.call("hwg_spectral_update_multi", self.table, len(self.layers), self.max_R, self.max_K, eps, self.ws, copies, sig, _stream())
-        return [(copies[off: off + R], copies[off + R: off + R + K], sig[2 * i: 2 * i + 1], sig[2 * i + 1: 2 * i + 2])
-                for i, (off, R, K) in enumerate(self.spans)]
+        images = [{} for _ in self.layers]
+        if self.prepack and self.requests:
+            tab, blocks, total, spans = self._pack_table()
+            buf = torch.empty(total, dtype=torch.float32, device=dev)
+            with torch.no_grad():
+                L.call("hwg_conv_pack_weight_multi_scaled", tab, len(self.requests), blocks, buf, sig, _stream())
+            for (layer, variant), (off, n, shape) in zip(self.requests, spans):
+                images[layer][variant] = buf[off: off + n].view(shape)
+        out = []
+        for i, (off, R, K) in enumerate(self.spans):
+            inv = sig[2 * i + 1: 2 * i + 2]
+            pre = _Prepack(images[i], self, i, self.layers[i][0], inv, False) if self.prepack else None
+            out.append((copies[off: off + R], copies[off + R: off + R + K], sig[2 * i: 2 * i + 1], inv, pre))
+        return out
 
 
 def spectral_scale(w_bar, fresh):
-    """W / sigma from a SpectralBank.update() record (the power iteration already ran)"""
-    un, vn, sigma, inv_sigma = fresh
-    return _SpectralScale.apply(w_bar, un, vn, sigma, inv_sigma)
+    """W / sigma from a SpectralBank.update() record (the power iteration already ran). With the bank's scaled multi-pack on, the returned
+    tensor is a handle: the images the convolutions need were written by that launch and hang on the handle (`_hwg_prepack`); its own
+    values are only computed if a convolution asks for an image the bank has not seen yet."""
+    un, vn, sigma, inv_sigma, pre = fresh
+    lazy = pre is not None and len(pre.images) > 0
+    w = _SpectralScale.apply(w_bar, un, vn, sigma, inv_sigma, lazy)
+    if pre is not None:
+        pre.materialised = not lazy
+        w._hwg_prepack = pre
+    return w
 
 
 # ----------------------------------------------------------------------------------------------

@@ -92,6 +92,11 @@ int hwg_conv_pack_weight(const float* src, float* dst, int A, int B, int Bpad, i
  * (96 bytes) where total = R*S*A*Bpad and first_block = running sum of ceil(total/1024); total_blocks = that sum over all entries.
  * mode 1 = the Winograd filter transform of hwg_wino_pack_weight (then Apad = ceil16(A), Bpad = ceil16(B), total = Apad*Bpad). */
 int hwg_conv_pack_weight_multi(const void* table, int n_entries, long long total_blocks, void* stream);
+/* ... and for weights that are a device-side scalar multiple of a stored tensor: the spectral-norm layers' W_bar / sigma
+ * (model/discriminator_ap.py:31-32, recomputed on every forward pass). Records of 112 bytes: the 96-byte record above followed by
+ * { long long dst_off; int scale_idx; int pad; }: the image goes to dst_base + dst_off floats (the record's own dst is ignored), every source
+ * element is multiplied (rounded product) by scale_base[scale_idx] - all images a pass through the network needs, one launch per forward. */
+int hwg_conv_pack_weight_multi_scaled(const void* table, int n_entries, long long total_blocks, float* dst_base, const float* scale_base, void* stream);
 
 /* y[N,P,Q,K] = gather-conv(x[N,H,W,C], w[R*S][K][C]) (+ bias[K] if bias != NULL).
  * transposed==0: standard convolution. transposed==1: conv-transpose with stride>1.

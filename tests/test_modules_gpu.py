@@ -179,3 +179,50 @@ def test_discriminator_hinge_step_gradients_vs_fp64(cuda):
         assert not bad, "; ".join(bad)
     finally:
         rng.set_mode("device")
+
+
+def test_spectral_weight_images_from_the_scaled_multi_pack_are_bit_identical(cuda):
+    """ops.SpectralBank writes every image (direct / mirrored tap order, Winograd domain) of every spectral-norm layer's W_bar / sigma with ONE
+    launch per forward pass (hwg_conv_pack_weight_multi_scaled), from the second pass on (the first pass records what the convolutions ask
+    for). Against the per-layer scale + pack launches: outputs, input gradient and every parameter gradient of three consecutive
+    forward / backward passes bit-identical, u / v updated alike, and the multi-pack really in use."""
+    from handwriting_line_generation_amd import model as M, ops, rng
+    rng.set_mode("host")
+    try:
+        runs = []
+        for prepack in (False, True):
+            m = M.DiscriminatorAP(64, use_low=True)
+            m.load_state_dict(torch_ref.seeded_state_dict(m, 33))
+            m.train().to(cuda)
+            g = torch.Generator().manual_seed(8)
+            rec = []
+            for it in range(3):
+                x = (torch.rand(4, 1, 64, 256 if it < 2 else 192, generator=g) * 2 - 1).to(cuda).requires_grad_(True)
+                torch.manual_seed(cases.FWD_SEED + it)
+                for p in m.parameters():
+                    p.grad = None
+                if it == 0:
+                    m(x.detach())                              # builds the bank
+                    for b in m._sn_banks.values():
+                        b.prepack = prepack
+                        b.requests.clear(); b._ptab = None
+                preds = m(x)
+                sum((p * p).sum() for p in preds).backward()
+                torch.cuda.synchronize()
+                rec.append(([p.detach().clone() for p in preds], x.grad.clone(),
+                            {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None},
+                            {k: v.detach().clone() for k, v in m.state_dict().items() if k.endswith(("weight_u", "weight_v"))}))
+            used = sum(len(b.requests) for b in m._sn_banks.values())
+            runs.append((rec, used))
+        (ra, ua), (rb, ub) = runs
+        assert ub >= 20, ub                                        # ten layers x (forward + mirrored [+ Winograd]) images
+        for it in range(3):
+            for a, b in zip(ra[it][0], rb[it][0]):
+                assert torch.equal(a, b), "pass %d: outputs differ" % it
+            assert torch.equal(ra[it][1], rb[it][1]), "pass %d: input gradient differs" % it
+            for k in ra[it][2]:
+                assert torch.equal(ra[it][2][k], rb[it][2][k]), "pass %d: gradient of %s differs" % (it, k)
+            for k in ra[it][3]:
+                assert torch.equal(ra[it][3][k], rb[it][3][k]), "pass %d: %s differs" % (it, k)
+    finally:
+        rng.set_mode("device")
