@@ -82,14 +82,27 @@ class StyledConvBlock(nn.Module):
             return self.conv1[1](self.conv1[0](x))
         return self.conv1[2](self.conv1[1](ops.upsample_nearest(x, self.up_scale)))
 
-    def forward(self, x, style, affine=None):
-        """affine: ((gamma1, beta1), (gamma2, beta2)) when the generator evaluated all style affines in one launch"""
+    def out_shape(self, N, H, W):
+        """(H, W, C) of this block's activations for an input of H x W pixels"""
+        C = self.noise1.weight_orig.shape[1]
+        if self.kind == "initial":
+            return 4 * H, W, C                      # ConvTranspose (4,3), pad (0,1): one row -> four
+        if self.kind == "fused":
+            return 2 * H, 2 * W, C
+        if self.kind == "up":
+            return H * self.up_scale[0], W * self.up_scale[1], C
+        return H, W, C
+
+    def forward(self, x, style, affine=None, noise=None):
+        """affine: ((gamma1, beta1), (gamma2, beta2)) when the generator evaluated all style affines in one launch; noise: the forward
+        pass's rng.NoiseBlock (all noise tensors of the pass from one launch)"""
+        draw = noise.next if noise is not None else rng.noise_like_nhwc
         h = self._first(x)
         g, b = affine[0] if affine is not None else self.adain1(style)
-        h = ops.adain_epilogue(h, rng.noise_like_nhwc(h), self.noise1.weight_orig, g, b, self.noise1.scale, 0.2)
+        h = ops.adain_epilogue(h, draw(h), self.noise1.weight_orig, g, b, self.noise1.scale, 0.2)
         h = self.conv2(h)
         g, b = affine[1] if affine is not None else self.adain2(style)
-        return ops.adain_epilogue(h, rng.noise_like_nhwc(h), self.noise2.weight_orig, g, b, self.noise2.scale, 0.2)
+        return ops.adain_epilogue(h, draw(h), self.noise2.weight_orig, g, b, self.noise2.scale, 0.2)
 
 
 class _EqualConv1x1(nn.Module):
@@ -203,7 +216,13 @@ class SpacedGenerator(nn.Module):
             if self._affine_bank is None:
                 self._affine_bank = ops.LinearBank([m for blk in self.conv for m in (blk.adain1.style, blk.adain2.style)], halves=2)
             pairs = self._affine_bank(emb)
+        shapes, hw = [], (1, T)
+        for blk in self.conv:
+            h_, w_, c_ = blk.out_shape(B, *hw)
+            shapes += [(B, h_, w_, c_)] * 2
+            hw = (h_, w_)
+        noise = rng.NoiseBlock(shapes, x.device)
         for i, blk in enumerate(self.conv):
-            x = blk(x, emb, None if pairs is None else (pairs[2 * i], pairs[2 * i + 1]))
+            x = blk(x, emb, None if pairs is None else (pairs[2 * i], pairs[2 * i + 1]), noise)
         y = ops.tanh(self.out[0](x))
         return ops.to_nchw(y)

@@ -77,6 +77,29 @@ def noise_like_nhwc(x):
     return _dev_rng().randn((N, H, W, C), x.device)
 
 
+class NoiseBlock:
+    """the noise tensors of one generator forward pass. Device mode: ONE Philox launch over the total element count when the first tensor is
+    asked for, later requests are views of that buffer (ten launches per forward pass were ten launches of 4-6 us). Host mode (parity
+    tests): every request is its own draw from torch's CPU generator, in the reference's order and shapes."""
+
+    def __init__(self, shapes, device):
+        self.shapes, self.device, self.buf, self.k, self.off = list(shapes), device, None, 0, 0
+
+    def next(self, x):
+        shape = tuple(x.shape)
+        if _state["mode"] == "host" or self.k >= len(self.shapes) or tuple(self.shapes[self.k]) != shape:
+            self.k = len(self.shapes)           # (a shape off the plan: fall back to single draws for the rest of the pass)
+            return noise_like_nhwc(x)
+        if self.buf is None:
+            total = sum(((a * b * c * d) + 3) // 4 * 4 for a, b, c, d in self.shapes)
+            self.buf = _dev_rng().randn((total,), self.device)
+        n = shape[0] * shape[1] * shape[2] * shape[3]
+        out = self.buf[self.off: self.off + n].view(shape)
+        self.off += (n + 3) // 4 * 4
+        self.k += 1
+        return out
+
+
 def channel_mask(N, C, p, device):
     """feature-dropout mask [N,C] holding 0 or 1/(1-p) (what F.dropout2d multiplies by)"""
     if _state["mode"] == "host":
