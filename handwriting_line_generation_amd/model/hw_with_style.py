@@ -32,6 +32,18 @@ def correct_pred_async(pred, label):
     return ops.dtw_align_async(pred.detach().contiguous(), label)
 
 
+class StyleTape:
+    """one taped (recogniser -> style extractor) forward: `style` is the leaf the rest of the lesson sees"""
+
+    def __init__(self, tape, style):
+        self.tape, self.style = tape, style
+
+    def backward(self, grad, target):
+        """one loss group's style gradient through the style extractor and the recogniser behind it; its parameter gradients accumulate
+        into `target` (ops.grad_set: None = the parameters' own gradients, or a stashed set's (buffer, mask))"""
+        self.tape.backward_sets(self.style, [grad], [target])
+
+
 class HWWithStyle(BaseModel):
     def __init__(self, config):
         super().__init__(config)
@@ -172,7 +184,34 @@ class HWWithStyle(BaseModel):
             return pend.result()[0]
         return correct_pred(self.pred, label)
 
+    # tape mode (set by the GAN trainer around its training lessons): recogniser-on-real-lines + style extractor are recorded on an
+    # ops.Tape instead of autograd's graph and the style comes back as a leaf; the trainer sends each loss group's style gradient through
+    # the tape itself (one pass per group, the passes on streams of their own - see HWWithStyleTrainer._style_backward)
+    style_tape_mode = False
+
+    def take_style_tapes(self):
+        tapes, self.open_style_tapes = getattr(self, "open_style_tapes", []), []
+        return tapes
+
     def extract_style(self, image, label, a_batch_size=None):
+        if self.style_tape_mode and torch.is_grad_enabled() and self.pred is None and not image.requires_grad:
+            tape = ops.Tape()
+            ops.TAPE = tape
+            try:
+                with torch.no_grad():
+                    style = self._extract_style(image, label, a_batch_size)
+            finally:
+                ops.TAPE = None
+            tape._adopt_views([style])          # (the last op's result may come back as a reshape of the taped tensor)
+            if id(style) in tape.live:          # (nothing on the path requires a gradient otherwise: frozen everything)
+                style.requires_grad_(True)
+                if not hasattr(self, "open_style_tapes"):
+                    self.open_style_tapes = []
+                self.open_style_tapes.append(StyleTape(tape, style))
+            return style
+        return self._extract_style(image, label, a_batch_size)
+
+    def _extract_style(self, image, label, a_batch_size=None):
         if self.pred is None:
             self.pred = self.hwr(image, None)
             if label is not None and self.spaced_label is None and self.use_hwr_pred_for_style:

@@ -96,8 +96,20 @@ class Tape:
         self.live[id(t)] = t
         return t
 
+    def _adopt_views(self, args):
+        """torch-level reshapes of taped tensors (`y.view(rows, O)`, `.reshape(B, -1)`): autograd would track them; here a contiguous view of
+        a contiguous live tensor with the same element count becomes an alias node. Any other view of a live tensor is an error."""
+        for a in args:
+            if isinstance(a, torch.Tensor) and id(a) not in self.live and a._base is not None and id(a._base) in self.live:
+                base = a._base
+                if not (a.is_contiguous() and base.is_contiguous() and a.numel() == base.numel() and a.data_ptr() == base.data_ptr()):
+                    raise L.HwgError("taped forward: unsupported view of a taped tensor (shape %s of base %s)" % (tuple(a.shape), tuple(base.shape)))
+                self.live[id(a)] = a
+                self.nodes.append(("alias", tuple(base.shape), (base,), (a,)))
+
     def record(self, cls, args):
         global TAPE
+        self._adopt_views(args)
         needs = tuple(isinstance(a, torch.Tensor) and (id(a) in self.live or (a.requires_grad and a.is_leaf)) for a in args)
         ctx = _TapeCtx(needs)
         TAPE = None             # ops called from inside a forward are part of it, not nodes of their own
@@ -117,7 +129,7 @@ class Tape:
         """`new` is a reshape of the taped tensor `old` (same elements, same order)"""
         if id(old) in self.live:
             self.live[id(new)] = new
-            self.nodes.append(("alias", tuple(old.shape[1:]), (old,), (new,)))
+            self.nodes.append(("alias", tuple(old.shape), (old,), (new,)))
         return new
 
     def backward_sets(self, out, grads, targets):
@@ -133,9 +145,8 @@ class Tape:
                 gouts = [g.pop(id(o), None) if isinstance(o, torch.Tensor) else None for o in outs]
                 if all(x is None for x in gouts):
                     continue
-                if cls == "alias":
-                    st = gouts[0].get_stacked()
-                    gin = [SetGrad(S, stacked=st.reshape((st.shape[0],) + ctx))]
+                if cls == "alias":      # ctx = the base tensor's shape; per set: the same elements in the base's shape
+                    gin = [SetGrad(S, parts=[p_.contiguous().reshape(ctx) for p_ in gouts[0].get_parts()])]
                 else:
                     for i, x in enumerate(gouts):      # a multi-output op with a missing output gradient: zeros, as autograd materialises them
                         if x is None and isinstance(outs[i], torch.Tensor):
@@ -238,7 +249,9 @@ _ws_cache = {}
 def workspace(nbytes, device):
     """Shared scratch buffer (stream ordered, contents are dead once the call that used it returns)."""
     nbytes = int(nbytes)
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    # one buffer per (device, stream): passes that run concurrently on different streams (the per-set style passes of the GAN trainer) must
+    # not share scratch memory; torch's allocator ties the buffer to the stream that is current when it is created
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -319,6 +332,9 @@ def _defer_workspace(nbytes, device):
     return arena[off: off + need]
 
 
+DEFER_KEEP_ARENA = False     # passes on several streams in flight: a flush must not hand the arena's start to the next pass (reset after the join)
+
+
 def flush_deferred_reduce():
     """sum every queued set of partial images on the current stream (call after the side stream has been joined)"""
     import numpy as np
@@ -326,6 +342,11 @@ def flush_deferred_reduce():
     L.call("hwg_wgrad_defer_flush", _stream(), n.ctypes.data)
     _defer["launches"] += int(n[0]); _defer["flushes"] += 1
     _defer["count"] = 0
+    if not DEFER_KEEP_ARENA:
+        _defer["offset"] = 0
+
+
+def reset_defer_arena():
     _defer["offset"] = 0
 
 

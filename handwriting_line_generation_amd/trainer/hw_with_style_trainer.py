@@ -124,6 +124,10 @@ class HWWithStyleTrainer(BaseTrainer):
         self._defer_reduce = bool(int(tr.get("defer_wgrad_reduce", os.environ.get("HWG_DEFER_REDUCE", "1")) or 0))
         # the two or three gradients a balanced lesson sends through the generator go through it in one pass (see _generator_backward)
         self._batch_gen_backward = bool(int(tr.get("batch_gen_backward", os.environ.get("HWG_BATCH_GEN_BWD", "1")) or 0))
+        # recogniser-on-real-lines + style extractor on a tape as well: each loss group's pass through them runs on a stream of its own
+        self._tape_style = bool(int(tr.get("tape_style", os.environ.get("HWG_TAPE_STYLE", "1")) or 0))
+        self._concurrent_style_passes = bool(int(tr.get("concurrent_style_passes", os.environ.get("HWG_CONCURRENT_STYLE", "1")) or 0))
+        self._style_streams = None
         # Dead-gradient elimination (off by default = the reference's launches). The reference computes two families of parameter gradients
         # that nothing ever reads: the frozen recogniser's (it is in no optimizer; 11 backward traversals per cycle) and the
         # discriminator's in gen / auto lessons (optimizer_discriminator.zero_grad() drops them before the next disc lesson reads any).
@@ -212,11 +216,13 @@ class HWWithStyleTrainer(BaseTrainer):
             taped = self._batch_gen_backward and self.balance_loss and gen is not None and hasattr(gen, "tape_mode")
             if taped:
                 gen.tape_mode = True
+                self.model.style_tape_mode = self._tape_style
             try:
                 losses = self.run_gen(instance, lesson)
             finally:
                 if taped:
                     gen.tape_mode = False
+                    self.model.style_tape_mode = False
             pred = None
         else:
             pred, losses = self.run_hwr(instance)
@@ -239,17 +245,19 @@ class HWWithStyleTrainer(BaseTrainer):
         # the sums of the weight-gradient partial images of a backward pass are queued and made by one table-driven launch at the
         # join_side_stream() behind it (ops.DEFER_REDUCE; bit-identical, ~65 small launches per step less)
         ops.DEFER_REDUCE = self._defer_reduce
-        tapes = self._gen_tapes()
+        gtapes = self._gen_tapes()
+        stapes = self.model.take_style_tapes() if hasattr(self.model, "take_style_tapes") else []
+        taped = bool(gtapes or stapes)
+        sets = []           # per separately balanced loss group: (stash or None = the current set, key, gradients left on the taped leaves)
         try:
             if self.balance_loss:
-                sets = []           # per separately balanced loss group: (stash or None = the current set, [gradient left on each tape's image])
                 for pos, part in enumerate((autoGenLoss, recogLoss)):
                     if not isinstance(part, int):
                         part.backward(retain_graph=True)
                         ops.join_side_stream()
-                        if tapes:
-                            st = self.flat.stash()                        # its all-reduce starts once the generator's share has been added
-                            sets.append((st, (lkey, pos), self._take_image_grads(tapes)))
+                        if taped:
+                            st = self.flat.stash()                        # its all-reduce starts once the taped networks' share has been added
+                            sets.append((st, (lkey, pos), self._take_leaf_grads(gtapes, stapes)))
                         else:
                             self.saved_grads.append(self._stash((lkey, pos)))
             else:
@@ -259,9 +267,9 @@ class HWWithStyleTrainer(BaseTrainer):
             if not isinstance(loss, int):
                 loss.backward()
                 ops.join_side_stream()
-            if tapes:
-                sets.append((None, None, self._take_image_grads(tapes)))
-                self._generator_backward(tapes, sets)
+            if taped:
+                sets.append((None, None, self._take_leaf_grads(gtapes, stapes)))
+                self._taped_backward(gtapes, stapes, sets)
         finally:
             ops.DEFER_REDUCE = False
             ops.join_side_stream()      # (an exception inside backward must not leave queued sums behind)
@@ -269,46 +277,88 @@ class HWWithStyleTrainer(BaseTrainer):
             self.saved_grads.append(self._stash((lkey, 2)))
         return scaled, pred
 
-    # -- batched generator backward ----------------------------------------------------------------------------------------------
+    # -- taped networks: generator (all loss groups in one pass) and recogniser + style extractor (one pass per group, concurrently) ------
     def _gen_tapes(self):
         """the taped generator forwards of this iteration (model.generator.tape_mode, switched on in run_gen for balanced training lessons)"""
         gen = getattr(self.model, "generator", None)
         return gen.take_tapes() if gen is not None and hasattr(gen, "take_tapes") else []
 
     @staticmethod
-    def _take_image_grads(tapes):
-        out = []
-        for t in tapes:
-            out.append(t.image.grad)
+    def _take_leaf_grads(gtapes, stapes):
+        out = ([], [])
+        for t in gtapes:
+            out[0].append(t.image.grad)
             t.image.grad = None
+        for t in stapes:
+            out[1].append(t.style.grad)
+            t.style.grad = None
         return out
 
-    def _generator_backward(self, tapes, sets):
-        """The reference walks the generator (and, behind it, the style extractor) once per balanced loss group (trainer :300-338: up to three
-        backward() calls on the same graph). Here every group's backward pass stopped at the generated image (a leaf, pure_gen.GenTape); now
-        the gradients the groups left there go through the generator TOGETHER, stacked along the batch axis - its layers fill a quarter of
-        the chip at 8 lines - each group's parameter gradients accumulating into that group's own buffer (ops.grad_set: the stash of the
-        group, or the current gradient set for the last one), then each group's style gradient through the style extractor's graph."""
-        for ti, tape in enumerate(tapes):
-            members = [(st, g[ti]) for st, _, g in sets if g[ti] is not None]
+    def _taped_backward(self, gtapes, stapes, sets):
+        """The reference walks the generator - and, behind it, the style extractor and the recogniser that fed it - once per balanced loss group
+        (trainer :300-338: up to three backward() calls on the same graph). Here every group's backward pass stopped at the taped leaves (the
+        generated image, pure_gen.GenTape; the extracted style, hw_with_style.StyleTape). Now (1) the gradients the groups left on an image
+        go through the generator TOGETHER, stacked along the batch axis - its layers fill a quarter of the chip at 8 lines - each group's
+        parameter gradients accumulating into that group's own buffer (ops.grad_set: the stash of the group, or the current gradient set for
+        the last one); (2) each group's style gradient goes through the style extractor and the recogniser, one pass per group, the passes
+        on streams of their own: they read the same activations, write different buffers, and a single pass leaves much of the chip idle
+        (130-workgroup convolutions, latency-bound normalisation passes)."""
+        targets = [None if st is None else (st[0], st[1]) for st, _, _ in sets]
+        style_g = {id(t.style): [g[1][j] for _, _, g in sets] for j, t in enumerate(stapes)}
+        for ti, tape in enumerate(gtapes):
+            members = [si for si, (_, _, g) in enumerate(sets) if g[0][ti] is not None]
             if not members:
                 continue
-            targets = [None if st is None else (st[0], st[1]) for st, _ in members]
-            dstyles = tape.backward_sets([g for _, g in members], targets)
-            if tape.style_src is not None and dstyles is not None:
-                for k, ((st, _), ds) in enumerate(zip(members, dstyles)):
+            dstyles = tape.backward_sets([sets[si][2][0][ti] for si in members], [targets[si] for si in members])
+            if tape.style_src is None or dstyles is None:
+                continue
+            mine = style_g.get(id(tape.style_src))
+            for k, si in enumerate(members):
+                if mine is not None:            # the style came from a taped extraction: collected per group, walked below
+                    mine[si] = dstyles[k] if mine[si] is None else ops.add(mine[si], dstyles[k])
+                else:                           # an autograd style (tape mode off for the extractor): its graph, under the group's redirect
                     v0 = self.flat.flat_grad._version
-                    with ops.grad_set(targets[k]):
-                        tape.style_src.backward(ds, retain_graph=k + 1 < len(members))
+                    with ops.grad_set(targets[si]):
+                        tape.style_src.backward(dstyles[k], retain_graph=k + 1 < len(members))
                         ops.join_side_stream()
-                    if targets[k] is not None and self.flat.flat_grad._version != v0:
+                    if targets[si] is not None and self.flat.flat_grad._version != v0:
                         # every op behind the style accumulates its parameter gradients through ops._grad_buffer (which follows the redirect);
                         # a gradient RETURNED to autograd would have been added to param.grad, i.e. to the wrong set
                         raise RuntimeError("autograd accumulated a parameter gradient into the current set during a redirected backward pass")
         ops.join_side_stream()
+        for tape in stapes:
+            members = [(si, g) for si, g in enumerate(style_g[id(tape.style)]) if g is not None]
+            if len(members) > 1 and self._concurrent_style_passes:
+                self._style_passes_on_streams(tape, members, targets)
+            else:
+                for si, g in members:
+                    tape.backward(g, targets[si])
+                    ops.join_side_stream()
         for st, key, _ in sets:
             if st is not None:
                 self.saved_grads.append(start_stash_allreduce(st, self.world, self.flat, key=key))
+
+    def _style_passes_on_streams(self, tape, members, targets):
+        main = torch.cuda.current_stream()
+        if self._style_streams is None:
+            self._style_streams = [torch.cuda.Stream(device=self.gpu) for _ in range(4)]
+        side_wgrad, ops.SIDE_WGRAD = ops.SIDE_WGRAD, False      # the passes are each other's filler; one shared side stream would chain them
+        ops.DEFER_KEEP_ARENA = True                              # a pass's flush must not hand the arena's start to the next pass
+        used = []
+        try:
+            for k, (si, g) in enumerate(members):
+                s = self._style_streams[k % len(self._style_streams)]
+                s.wait_stream(main)                              # the style gradients (and every activation) are complete on the main stream
+                with torch.cuda.stream(s):
+                    tape.backward(g, targets[si])
+                    ops.join_side_stream()                       # this pass's deferred sums, on its own stream
+                used.append(s)
+        finally:
+            for s in used:
+                main.wait_stream(s)
+            ops.DEFER_KEEP_ARENA = False
+            ops.reset_defer_arena()
+            ops.SIDE_WGRAD = side_wgrad
 
     def _apply_step(self, lesson, iteration, instance, scaled, pred):
         """Gradient consumption (trainer :340-391): data-parallel averaging of every gradient set, balancing of the stashed sets into the

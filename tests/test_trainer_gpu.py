@@ -163,6 +163,40 @@ def test_batched_generator_backward_equals_one_pass_per_loss_group(cuda, tmp_pat
     print("batched vs sequential generator backward: worst relative gradient difference %.2e" % worst)
 
 
+def test_style_passes_on_streams_are_bit_identical_to_one_stream(cuda, tmp_path):
+    """trainer.concurrent_style_passes (default on): the per-loss-group backward passes through the taped style extractor + recogniser run
+    on streams of their own (same kernels, same per-set order, different buffers). Against the same passes one after the other on the main
+    stream: every balanced gradient (read where the reference clips), every logged loss and every parameter after two curriculum cycles
+    must be BIT-identical - a cross-stream race (scratch memory, allocator reuse, deferred sums) would show up here."""
+    from handwriting_line_generation_amd import rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    runs = []
+    for conc in (False, True):
+        rng.set_mode("device", seed=11)
+        torch.manual_seed(3); np.random.seed(3); random.seed(3)
+        trainer, _ = build_gan_trainer("iam_gan", 2, 2, width=256, label_len=12, workdir=str(tmp_path / ("c%d" % conc)))
+        trainer._concurrent_style_passes = conc
+        torch.manual_seed(5); np.random.seed(5); random.seed(5)
+        grads = {}
+
+        def hook(it, trainer=trainer, grads=grads):
+            f = trainer.flat
+            grads[it] = (f.flat_grad.clone(), f.touched.copy())
+        trainer.pre_clip_hook = hook
+        logs = [trainer._train_iteration(it) for it in range(14)]
+        torch.cuda.synchronize()
+        runs.append((logs, grads, {k: v.detach().clone() for k, v in trainer.model.state_dict().items()}, trainer._style_streams is not None))
+    (la, ga, sa, ua), (lb, gb, sb, ub) = runs
+    assert not ua and ub, "the concurrent run must really have used its streams"
+    for it in sorted(ga):
+        assert np.array_equal(ga[it][1], gb[it][1]), "iteration %d: None-pattern differs" % it
+        assert torch.equal(ga[it][0], gb[it][0]), "iteration %d: balanced gradients differ (%d elements)" % (it, int((ga[it][0] != gb[it][0]).sum()))
+    for it, (a, b) in enumerate(zip(la, lb)):
+        assert a == b, "iteration %d: %s vs %s" % (it, a, b)
+    for k, v in sa.items():
+        assert torch.equal(v, sb[k]), "%s differs" % k
+
+
 def test_masked_stash_holds_zeros_outside_its_mask(cuda):
     """FlatParams.stash() copies only the tensors that have a gradient; a pooled buffer must nevertheless hold ZEROS everywhere else,
     because data-parallel segment all-reduces sum whole sub-network ranges of it (trainer/flat_params.py: stale / dirty clearing).
