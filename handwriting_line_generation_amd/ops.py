@@ -91,21 +91,30 @@ class Tape:
     def __init__(self):
         self.nodes = []          # (Function class | "alias", ctx, inputs (the original argument tuple), outputs tuple)
         self.live = {}           # id(tensor) -> tensor, for every tensor a gradient can arrive at (keeps the ids valid)
+        self.by_mem = {}         # (address, elements) of the contiguous live tensors -> tensor (how reshapes of them are recognised)
 
     def watch(self, t):
-        self.live[id(t)] = t
+        self._live(t)
         return t
 
     def _adopt_views(self, args):
-        """torch-level reshapes of taped tensors (`y.view(rows, O)`, `.reshape(B, -1)`): autograd would track them; here a contiguous view of
-        a contiguous live tensor with the same element count becomes an alias node. Any other view of a live tensor is an error."""
+        """torch-level reshapes of taped tensors (`y.view(rows, O)`, `.reshape(B, -1)`, also of results that are themselves views): autograd
+        would track them; here a contiguous tensor that covers exactly the memory of a contiguous live tensor becomes an alias node. Any
+        other view of a live tensor is an error."""
         for a in args:
-            if isinstance(a, torch.Tensor) and id(a) not in self.live and a._base is not None and id(a._base) in self.live:
-                base = a._base
-                if not (a.is_contiguous() and base.is_contiguous() and a.numel() == base.numel() and a.data_ptr() == base.data_ptr()):
-                    raise L.HwgError("taped forward: unsupported view of a taped tensor (shape %s of base %s)" % (tuple(a.shape), tuple(base.shape)))
+            if not isinstance(a, torch.Tensor) or id(a) in self.live or a._base is None:
+                continue
+            base = self.by_mem.get((a.data_ptr(), a.numel())) if a.is_contiguous() else None
+            if base is not None:
                 self.live[id(a)] = a
                 self.nodes.append(("alias", tuple(base.shape), (base,), (a,)))
+            elif (a._base.data_ptr(), a._base.numel()) in self.by_mem:
+                raise L.HwgError("taped forward: unsupported view of a taped tensor (shape %s of base %s)" % (tuple(a.shape), tuple(a._base.shape)))
+
+    def _live(self, t):
+        self.live[id(t)] = t
+        if t.is_contiguous():
+            self.by_mem.setdefault((t.data_ptr(), t.numel()), t)
 
     def record(self, cls, args):
         global TAPE
@@ -121,14 +130,14 @@ class Tape:
             outs = out if isinstance(out, tuple) else (out,)
             for o in outs:
                 if isinstance(o, torch.Tensor):
-                    self.live[id(o)] = o
+                    self._live(o)
             self.nodes.append((cls, ctx, args, outs))
         return out
 
     def alias(self, new, old):
         """`new` is a reshape of the taped tensor `old` (same elements, same order)"""
         if id(old) in self.live:
-            self.live[id(new)] = new
+            self._live(new)
             self.nodes.append(("alias", tuple(old.shape), (old,), (new,)))
         return new
 
