@@ -352,6 +352,9 @@ def main():
             ops.prof_enable(True)
         trainer._side_wgrad = False
         ops.SIDE_WGRAD = False
+        conc = getattr(trainer, "_concurrent_style_passes", None)
+        if conc is not None:
+            trainer._concurrent_style_passes = False     # (same reason: the per-group style passes share the chip when they run on their own streams)
         barrier()
         tp = time.perf_counter()
         for _ in range(PROF_CYCLES * cycle):
@@ -365,6 +368,8 @@ def main():
             prof = ops.prof_stop()
         trainer._side_wgrad = side_wgrad
         ops.SIDE_WGRAD = side_wgrad is True
+        if conc is not None:
+            trainer._concurrent_style_passes = conc
 
     # Secondary figure, AFTER the timed region that `value` reports: the same loop with dead-gradient elimination on (trainer.skip_unused_grads:
     # no weight-gradient kernels for the frozen recogniser and for the discriminator outside disc lessons - SURVEY 8d's "minimum necessary"
@@ -545,6 +550,7 @@ def main():
                               "collectives_per_step": round(comm["collectives"] / args.steps, 2),
                               "allreduce_mbytes_per_step": round(comm["bytes"] / args.steps / 1e6, 2)},
             "side_stream_wgrad": side_wgrad,   # off in the roofline-profiled cycles, which run after the timed region
+            "concurrent_style_passes": getattr(trainer, "_concurrent_style_passes", None),   # likewise off in the profiled cycles
             # sclk / mclk / socket power sampled from sysfs every 100 ms during the timed region (min / mean / max), and rocm-smi's view
             "clocks": clock_report,
             "hbm_peak_mb": round(torch.cuda.max_memory_allocated() / 1e6, 1),   # peak of torch's allocator on rank 0 (weights, optimizer state, flat gradient sets, activations, arenas)
