@@ -1379,7 +1379,10 @@ static WinoPlan plan_wino_model(const hwg_conv_desc* d) {
     const long long blocks = (long long)hwg_cdiv(M, p.tm) * hwg_cdiv(d->K, p.tn);
     for (int ns = 1; ns <= 8 && ns * 2 <= (chunks > 1 ? chunks : 2); ns *= 2) {
       if (ns > 1 && (chunks / ns < 2 || out_bytes * ns > 1.5e9)) break;
-      const double rounds = (double)hwg_cdiv(blocks * ns, 256);
+      // workgroups are handed out dynamically: beyond three full rounds the last, partly filled one costs about half a round, not a whole
+      // one (round 4, tools/plan_sweep.py: 8x6x127x512->512 at split 4 = 4.1 rounds measured 258 us, modelled 272 with ceil -> 253)
+      const double q = (double)(blocks * ns) / 256.0;
+      const double rounds = q <= 3.0 ? (double)hwg_cdiv(blocks * ns, 256) : q + 0.5;
       double t = rounds * (wc.fixed_us + 4.0 * hwg_cdiv(chunks, ns) * wc.step_us) * 1e-6;
       if (ns > 1) t += (ns + 1) * out_bytes / 3.0e12 + 6e-6;
       if (t < best_t) { best_t = t; best = p; best.nsplit = ns; }
