@@ -260,7 +260,10 @@ def main():
     # front (the loader wraps around; the text lessons draw from the corpus on the host as the reference does)
     trainer.data_loader.make_resident(min(args.warmup + args.steps + 21, 192), trainer.gpu)
     trainer.data_loader_iter = iter(trainer.data_loader)
-    trainer.async_log = True   # losses of step i are read back while step i+1 runs (flushed inside the timed region)
+    # losses of step i are read back while steps i+1 .. i+lag run (every read-back still happens inside the timed region: flush_log() before
+    # the closing barrier). lag 1 pins the host to the GPU once per lesson, which starves the short gen / disc lessons (host enqueue time
+    # ~ GPU time there, tools/host_time.py) of the lead the host gains during the long auto lessons; lag 2 lets that lead carry over.
+    trainer.async_log = int(os.environ.get("HWG_LOG_LAG", "2"))
     cycle = 7 if gan else 1   # lessons of the shipped GAN curriculum: count, gen, auto, disc, gen, auto, disc
 
     def barrier():
@@ -550,6 +553,7 @@ def main():
                               "collectives_per_step": round(comm["collectives"] / args.steps, 2),
                               "allreduce_mbytes_per_step": round(comm["bytes"] / args.steps / 1e6, 2)},
             "side_stream_wgrad": side_wgrad,   # off in the roofline-profiled cycles, which run after the timed region
+            "log_lag": int(trainer.async_log),
             "concurrent_style_passes": getattr(trainer, "_concurrent_style_passes", None),   # likewise off in the profiled cycles
             # sclk / mclk / socket power sampled from sysfs every 100 ms during the timed region (min / mean / max), and rocm-smi's view
             "clocks": clock_report,

@@ -1,3 +1,4 @@
+import collections
 """GAN / recogniser training step on HIP kernels (reference: trainer/hw_with_style_trainer.py:21-1023).
 
 `_train_iteration` keeps the reference's control flow - curriculum lesson, loss weighting, the up-to-three backward
@@ -111,6 +112,8 @@ class HWWithStyleTrainer(BaseTrainer):
         # the exchange never waits for the GPU stream the way a device collective + .item() would
         self._dp = self.world > 1 or (flat_params_mod.FORCE_DP and dist.is_available() and dist.is_initialized())
         self._ctl_group = flat_params_mod.control_group() if self._dp else None
+        # pipelined logging: 0 / False = the reference's behaviour (each iteration returns its own losses: the host drains the GPU every
+        # iteration), n >= 1 = iteration i returns the losses of iteration i - n, so the host may run up to n iterations ahead of the GPU
         self.async_log = tr.get("async_log", False)
         # optional: weight-gradient kernels on a second HIP stream (fills the CUs the data-gradient chain leaves idle: +2.7 % steps/s);
         # off by default because co-running kernels inflate the per-kernel durations the roofline measurement relies on
@@ -119,7 +122,7 @@ class HWWithStyleTrainer(BaseTrainer):
         side = tr.get("side_stream_wgrad", os.environ.get("HWG_SIDE_WGRAD", "0"))
         self._side_wgrad = "auto" if side == "auto" else bool(int(side or 0)) if isinstance(side, str) else bool(side)
         ops.SIDE_WGRAD = self._side_wgrad is True
-        self._pending_log = None
+        self._pending_log = collections.deque()
         self.pre_clip_hook = None
         self._defer_reduce = bool(int(tr.get("defer_wgrad_reduce", os.environ.get("HWG_DEFER_REDUCE", "1")) or 0))
         # the two or three gradients a balanced lesson sends through the generator go through it in one pass (see _generator_backward)
@@ -406,8 +409,8 @@ class HWWithStyleTrainer(BaseTrainer):
         if self.async_log:
             # pipelined logging: return the PREVIOUS iteration's values so that this iteration's kernels need not be drained
             # before the next iteration is enqueued (the reference's `.item()` per loss does exactly that drain)
-            prev, self._pending_log = self._pending_log, pending
-            return self._resolve_log(prev) if prev is not None else {}
+            self._pending_log.append(pending)
+            return self._resolve_log(self._pending_log.popleft()) if len(self._pending_log) > int(self.async_log) else {}
         return self._resolve_log(pending)
 
     def _resolve_log(self, pending):
@@ -421,8 +424,10 @@ class HWWithStyleTrainer(BaseTrainer):
         return {"loss": total, **log_losses, "CER": cer, "WER": wer}
 
     def flush_log(self):
-        prev, self._pending_log = self._pending_log, None
-        return self._resolve_log(prev) if prev is not None else {}
+        log = {}
+        while self._pending_log:          # every outstanding iteration is checked (NaN / inf assertions); the newest one's losses are returned
+            log = self._resolve_log(self._pending_log.popleft())
+        return log
 
     # ------------------------------------------------------------------------------------------
     def run_hwr(self, instance):

@@ -112,3 +112,12 @@ def test_getcer_known_answers_from_the_reference():
             cer2, wer2, strs2 = AutoTrainer.getCER(stub, texts, pred)
             assert strs2 == strs and abs(cer2 - ref["cer"]) < 1e-12 and abs(wer2 - ref["wer"]) < 1e-12
     assert any(r["cer"] > 0 for r in gold["cer_kats"])       # the corrupted trials really have errors
+
+
+def test_call_thunks_refuse_values_that_do_not_fit_the_c_types():
+    """the generated fast-call thunks narrow Python ints to the `int` / `size_t` the C-ABI declares: out-of-range values raise instead of wrapping"""
+    from handwriting_line_generation_amd import _lib as L
+    with pytest.raises(OverflowError):
+        L.call("hwg_prof_start", 1 << 40)                       # int capacity
+    with pytest.raises(OverflowError):
+        L.call("hwg_conv_pack_weight", None, None, 1 << 33, *([1] * 9), None)   # int A (13 arguments: checked before the call is made)
