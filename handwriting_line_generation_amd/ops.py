@@ -1712,6 +1712,7 @@ class _SpectralScale(Function):
         if not lazy:          # lazy: every image the convolutions need comes from the bank's scaled multi-pack; the tensor itself is only a handle
             L.call("hwg_scale_by_ptr", w_bar, inv_sigma, out, w_bar.numel(), _stream())
         ctx.save_for_backward(w_bar, u, v, sigma)
+        ctx.leaf = w_bar if isinstance(w_bar, torch.nn.Parameter) and w_bar.requires_grad else None
         return out
 
     @staticmethod
@@ -1719,8 +1720,13 @@ class _SpectralScale(Function):
         w_bar, u, v, sigma = ctx.saved_tensors
         R = w_bar.shape[0]
         K = w_bar.numel() // R
-        dwbar = torch.empty_like(w_bar)
         ws = workspace(L.query("hwg_spectral_workspace", R, K), w_bar.device)
+        if ctx.leaf is not None:
+            # W_bar is a parameter: its gradient is added where parameter gradients live (the current set or the redirected one), like the
+            # convolutions' - returning it would cost the autograd engine an add_ launch per layer and would not follow ops.grad_set
+            L.call("hwg_spectral_bwd", dwsn.contiguous(), w_bar, u, v, sigma, _grad_buffer(ctx.leaf), R, K, 1, ws, ws.numel(), _stream())
+            return None, None, None, None, None, None
+        dwbar = torch.empty_like(w_bar)
         L.call("hwg_spectral_bwd", dwsn.contiguous(), w_bar, u, v, sigma, dwbar, R, K, 0, ws, ws.numel(), _stream())
         return dwbar, None, None, None, None, None
 
