@@ -124,6 +124,50 @@ __global__ void sn_bwd_kernel(const float* dWsn, const float* u, const float* v,
   }
 }
 
+// ---- the backward passes of all spectral-norm layers of a network in two launches (hwg_spectral_bwd_multi) ----------------------------------
+// entries by value in the kernel arguments; block -> (entry, block of that entry's own launch): every entry runs exactly the partial
+// schedule and the element arithmetic hwg_spectral_bwd would have run for it alone, so the results are bit-identical.
+struct SnBwdEntry {
+  const float* dWsn; const float* Wbar; const float* u; const float* v; const float* sigma; float* dst;
+  int R, K, np, part_off, dot_first, bwd_first, bwd_blocks, accumulate;
+};
+constexpr int SNB_MAX = 16;
+struct SnBwdTable { int n, pad; SnBwdEntry e[SNB_MAX]; };
+__global__ __launch_bounds__(256) void sn_dot_multi_kernel(const SnBwdTable t, double* part) {
+  __shared__ double sm[16];
+  int k = t.n - 1;
+  while (k > 0 && t.e[k].dot_first > (int)blockIdx.x) --k;
+  const SnBwdEntry e = t.e[k];
+  const int b = blockIdx.x - e.dot_first;
+  const long long n = (long long)e.R * e.K;
+  double s = 0.0;
+  for (long long i = b * 256LL + threadIdx.x; i < n; i += (long long)e.np * 256) s += (double)e.dWsn[i] * (double)e.Wbar[i];
+  s = block_sum_d(s, sm);
+  if (threadIdx.x == 0) part[e.part_off + b] = s;
+}
+__global__ __launch_bounds__(256) void sn_bwd_multi_kernel(const SnBwdTable t, const double* part) {
+  __shared__ float s_coef;
+  int k = t.n - 1;
+  while (k > 0 && t.e[k].bwd_first > (int)blockIdx.x) --k;
+  const SnBwdEntry e = t.e[k];
+  const int b = blockIdx.x - e.bwd_first;
+  if (threadIdx.x == 0) {
+    double dot = 0.0;
+    for (int i = 0; i < e.np; ++i) dot += part[e.part_off + i];
+    const double sg = (double)*e.sigma;
+    s_coef = (float)(dot / (sg * sg));
+  }
+  __syncthreads();
+  const float coef = s_coef;
+  const float inv = 1.f / *e.sigma;
+  const long long n = (long long)e.R * e.K;
+  for (long long i = b * 256LL + threadIdx.x; i < n; i += (long long)e.bwd_blocks * 256) {
+    const int r = (int)(i / e.K), c = (int)(i % e.K);
+    const float g = e.dWsn[i] * inv - coef * e.u[r] * e.v[c];
+    e.dst[i] = e.accumulate ? e.dst[i] + g : g;
+  }
+}
+
 // ---------------- reductions for losses ----------------
 // mode 0: sum |a-b|   1: sum (a-b)^2   2: sum a   3: sum relu(1-a)   4: sum relu(1+a)
 __device__ __forceinline__ float loss_term(float a, float b, int mode) {
@@ -299,6 +343,40 @@ extern "C" int hwg_spectral_bwd(const float* dWsn, const float* Wbar, const floa
   HWG_LAUNCH_CHECK("sn_dot");
   hipLaunchKernelGGL(sn_bwd_kernel, dim3(hwg_stream_grid(n, 256)), dim3(256), 0, st, dWsn, u, v, sigma, (const double*)part, np, dWbar, R, K, accumulate);
   HWG_LAUNCH_CHECK("sn_bwd");
+  return HWG_OK;
+}
+
+// hwg_spectral_bwd for up to 16 layers at once. `table`: n host records {dWsn, Wbar, u, v, sigma, dst (8-byte addresses), R, K, accumulate,
+// pad (4-byte ints)} = 64 bytes each; workspace: hwg_spectral_bwd_multi_workspace(n) bytes.
+extern "C" size_t hwg_spectral_bwd_multi_workspace(int n) { return (size_t)(n > 0 ? n : 1) * 512 * sizeof(double); }
+extern "C" int hwg_spectral_bwd_multi(const void* table, int n, void* ws, size_t ws_bytes, void* stream) {
+  HWG_REQUIRE(table && n > 0 && n <= SNB_MAX, "spectral_bwd_multi: 1..16 layers per call");
+  if (!ws || ws_bytes < hwg_spectral_bwd_multi_workspace(n)) { hwg_set_error("spectral_bwd_multi: workspace too small"); return HWG_ERR_WORKSPACE; }
+  struct Rec { unsigned long long dWsn, Wbar, u, v, sigma, dst; int R, K, accumulate, pad; };
+  static_assert(sizeof(Rec) == 64, "record layout");
+  const Rec* rec = (const Rec*)table;
+  SnBwdTable t;
+  t.n = n; t.pad = 0;
+  int dot_blocks = 0, bwd_blocks = 0, part_off = 0;
+  for (int i = 0; i < n; ++i) {
+    const Rec& r = rec[i];
+    HWG_REQUIRE(r.dWsn && r.Wbar && r.u && r.v && r.sigma && r.dst && r.R > 0 && r.K > 0, "spectral_bwd_multi: bad record");
+    SnBwdEntry& e = t.e[i];
+    e.dWsn = (const float*)r.dWsn; e.Wbar = (const float*)r.Wbar; e.u = (const float*)r.u; e.v = (const float*)r.v;
+    e.sigma = (const float*)r.sigma; e.dst = (float*)r.dst;
+    e.R = r.R; e.K = r.K; e.accumulate = r.accumulate;
+    const long long nn = (long long)r.R * r.K;
+    e.np = dot_parts(nn);
+    e.part_off = part_off; part_off += e.np;
+    e.dot_first = dot_blocks; dot_blocks += e.np;
+    e.bwd_blocks = hwg_stream_grid(nn, 256);
+    e.bwd_first = bwd_blocks; bwd_blocks += e.bwd_blocks;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sn_dot_multi_kernel, dim3(dot_blocks), dim3(256), 0, st, t, (double*)ws);
+  HWG_LAUNCH_CHECK("sn_dot_multi");
+  hipLaunchKernelGGL(sn_bwd_multi_kernel, dim3(bwd_blocks), dim3(256), 0, st, t, (const double*)ws);
+  HWG_LAUNCH_CHECK("sn_bwd_multi");
   return HWG_OK;
 }
 

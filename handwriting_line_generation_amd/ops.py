@@ -206,9 +206,14 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 NORM_IN, NORM_GN, NORM_BN = 0, 1, 2
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream if hasattr(torch._C, "_cuda_getCurrentRawStream") else None
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
-    # raw hipStream_t of torch's current stream (the Python Stream object is ~20 us to build, this is ~1 us)
-    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+    # raw hipStream_t of torch's current stream (the Python Stream object is ~20 us to build, torch.cuda.current_device() re-checks the lazy
+    # initialisation on every call: ~1 us; the two C entry points together ~0.3 us - this runs ~430 times per training step)
+    return _raw_stream(_get_device())
 
 
 _copy_streams = {}
@@ -307,7 +312,7 @@ def join_side_stream():
         L.call("hwg_stream_join", _side_streams[key][1], _stream())
     _side_dirty.clear()
     del _side_hold[:]
-    if _defer["count"]:
+    if _defer["count"] or _sn_defer:
         flush_deferred_reduce()
 
 
@@ -319,7 +324,9 @@ def join_side_stream():
 # table-driven launch per 32 gradients. Bit-identical to the undeferred order (same schedule per gradient, several gradients of one tensor in
 # queue order). Gradients are undefined between the backward call and the flush.
 DEFER_REDUCE = False
-_defer = {"count": 0, "offset": 0, "arena": {}, "launches": 0, "flushes": 0, "fallbacks": 0}
+_defer = {"count": 0, "offset": 0, "arena": {}, "launches": 0, "flushes": 0, "fallbacks": 0, "sn_launches": 0}
+_sn_defer = []       # queued spectral-norm backward passes: (dW_sn, W_bar, u, v, sigma, destination, R, K), tensors held until the flush
+_SN_BWD_REC = [("dWsn", "<u8"), ("Wbar", "<u8"), ("u", "<u8"), ("v", "<u8"), ("sigma", "<u8"), ("dst", "<u8"), ("R", "<i4"), ("K", "<i4"), ("acc", "<i4"), ("pad", "<i4")]
 DEFER_ARENA_BYTES = int(os.environ.get("HWG_DEFER_ARENA_MB", "1536")) << 20
 
 
@@ -353,6 +360,16 @@ def flush_deferred_reduce():
     _defer["count"] = 0
     if not DEFER_KEEP_ARENA:
         _defer["offset"] = 0
+    if _sn_defer:          # queued spectral-norm backward passes (their dW_sn inputs are complete: summed eagerly, or by the launch above)
+        for i in range(0, len(_sn_defer), 16):
+            chunk = _sn_defer[i: i + 16]
+            rec = np.zeros(len(chunk), dtype=_SN_BWD_REC)
+            for k, (dwsn, w_bar, u, v, sigma, dst, R, K) in enumerate(chunk):
+                rec[k] = (dwsn.data_ptr(), w_bar.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr(), dst.data_ptr(), R, K, 1, 0)
+            ws = workspace(L.query("hwg_spectral_bwd_multi_workspace", len(chunk)), chunk[0][0].device)
+            L.call("hwg_spectral_bwd_multi", rec.ctypes.data, len(chunk), ws, ws.numel(), _stream())
+            _defer["sn_launches"] += 1
+        del _sn_defer[:]
 
 
 def reset_defer_arena():
@@ -1724,7 +1741,13 @@ class _SpectralScale(Function):
         if ctx.leaf is not None:
             # W_bar is a parameter: its gradient is added where parameter gradients live (the current set or the redirected one), like the
             # convolutions' - returning it would cost the autograd engine an add_ launch per layer and would not follow ops.grad_set
-            L.call("hwg_spectral_bwd", dwsn.contiguous(), w_bar, u, v, sigma, _grad_buffer(ctx.leaf), R, K, 1, ws, ws.numel(), _stream())
+            dst = _grad_buffer(ctx.leaf)
+            if DEFER_REDUCE:
+                # nothing reads a parameter gradient before the join behind the backward pass: the layers of a network are queued and walk
+                # backward together there, two launches instead of two per layer (flush_deferred_reduce -> hwg_spectral_bwd_multi)
+                _sn_defer.append((dwsn.contiguous(), w_bar, u, v, sigma, dst, R, K))
+                return None, None, None, None, None, None
+            L.call("hwg_spectral_bwd", dwsn.contiguous(), w_bar, u, v, sigma, dst, R, K, 1, ws, ws.numel(), _stream())
             return None, None, None, None, None, None
         dwbar = torch.empty_like(w_bar)
         L.call("hwg_spectral_bwd", dwsn.contiguous(), w_bar, u, v, sigma, dwbar, R, K, 0, ws, ws.numel(), _stream())

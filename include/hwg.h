@@ -299,6 +299,11 @@ int hwg_spectral_update_multi(const void* table, int n, int max_R, int max_K, fl
 int hwg_scale_by_ptr(const float* x, const float* scale, float* out, long long n, void* stream);
 int hwg_spectral_bwd(const float* dWsn, const float* Wbar, const float* u, const float* v, const float* sigma, float* dWbar, int R, int K,
                      int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* the same for up to 16 layers in two launches (block -> layer, each layer on its own partial schedule: bit-identical to n single calls).
+ * table: n host records of 64 bytes {dWsn, Wbar, u, v, sigma, dWbar: 8-byte addresses; R, K, accumulate, pad: 4-byte ints}
+ * (reference: the ten SpectralNorm layers of DiscriminatorAP walk backward one by one, model/discriminator_ap.py:11-65) */
+size_t hwg_spectral_bwd_multi_workspace(int n);
+int hwg_spectral_bwd_multi(const void* table, int n, void* ws, size_t ws_bytes, void* stream);
 size_t hwg_loss_workspace(void);
 /* out (+)= scale * mean(term); mode 0 |a-b|, 1 (a-b)^2, 2 a, 3 relu(1-a), 4 relu(1+a) */
 int hwg_loss_fwd(const float* a, const float* b, long long n, int mode, float scale, float* out, int accumulate, void* ws, size_t ws_bytes,

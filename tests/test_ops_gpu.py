@@ -3,6 +3,8 @@ Tolerance: 1e-4 of the reference's max magnitude (BASELINE.json north_star: fp32
 import os
 import zlib
 
+import numpy as np
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -1057,3 +1059,36 @@ def test_ctypes_fallback_without_the_call_thunks(cuda):
         outs.append(r.stdout.strip().splitlines()[-1].split())
     assert outs[0][0] == "False" and outs[1][0] == "True", outs
     assert outs[0][1:] == outs[1][1:], outs
+
+
+def test_spectral_backward_of_several_layers_in_two_launches_is_bit_identical(cuda):
+    """hwg_spectral_bwd_multi (the discriminator's spectral-norm layers walking backward together) against one hwg_spectral_bwd per layer:
+    the same bits in every destination, accumulating into non-zero gradients, for layer sizes on both sides of the partial-count steps"""
+    from handwriting_line_generation_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(9)
+    shapes = [(64, 1 * 9), (128, 64 * 9), (256, 128 * 9), (128, 256 * 3), (1, 256 * 9), (16, 7)]
+    layers = []
+    for R, K in shapes:
+        t = lambda *s: torch.randn(*s, generator=g).to(cuda)     # noqa: E731
+        layers.append(dict(dwsn=t(R, K), wbar=t(R, K), u=t(R), v=t(K), sigma=(torch.rand(1, generator=g) + 0.5).to(cuda), dst0=t(R, K), R=R, K=K))
+    st = torch.cuda.current_stream().cuda_stream
+    single = []
+    for l in layers:
+        dst = l["dst0"].clone()
+        ws = ops.workspace(L.query("hwg_spectral_workspace", l["R"], l["K"]), cuda)
+        L.call("hwg_spectral_bwd", l["dwsn"], l["wbar"], l["u"], l["v"], l["sigma"], dst, l["R"], l["K"], 1, ws, ws.numel(), st)
+        single.append(dst)
+    rec = np.zeros(len(layers), dtype=ops._SN_BWD_REC)
+    multi = [l["dst0"].clone() for l in layers]
+    for k, l in enumerate(layers):
+        rec[k] = (l["dwsn"].data_ptr(), l["wbar"].data_ptr(), l["u"].data_ptr(), l["v"].data_ptr(), l["sigma"].data_ptr(), multi[k].data_ptr(), l["R"], l["K"], 1, 0)
+    ws = ops.workspace(L.query("hwg_spectral_bwd_multi_workspace", len(layers)), cuda)
+    L.call("hwg_spectral_bwd_multi", rec.ctypes.data, len(layers), ws, ws.numel(), st)
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(zip(single, multi)):
+        assert torch.equal(a, b), "layer %d %s" % (k, shapes[k])
+        # and the arithmetic itself against the closed form in fp64
+        l = layers[k]
+        sg = l["sigma"].double()
+        want = l["dst0"].double() + l["dwsn"].double() / sg - (l["dwsn"].double() * l["wbar"].double()).sum() / sg ** 2 * torch.outer(l["u"].double(), l["v"].double())
+        assert float((b.double() - want).abs().max()) < 2e-5 * float(want.abs().max())

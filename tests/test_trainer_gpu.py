@@ -97,16 +97,47 @@ def test_deferred_reduce_and_eager_reduce_train_to_the_same_bits(cuda, tmp_path)
         trainer, _ = build_gan_trainer("iam_gan", 2, 2, width=256, label_len=12, workdir=str(tmp_path / ("d%d" % defer)))
         trainer._defer_reduce = defer
         torch.manual_seed(5); np.random.seed(5); random.seed(5)
-        before = ops._defer["launches"]
+        before, sn_before = ops._defer["launches"], ops._defer["sn_launches"]
         logs = [trainer._train_iteration(it) for it in range(14)]
         torch.cuda.synchronize()
-        outs.append((logs, {k: v.detach().clone() for k, v in trainer.model.state_dict().items()}, ops._defer["launches"] - before))
-    (la, sa, na), (lb, sb, nb) = outs
+        outs.append((logs, {k: v.detach().clone() for k, v in trainer.model.state_dict().items()}, ops._defer["launches"] - before,
+                     ops._defer["sn_launches"] - sn_before))
+    (la, sa, na, sna), (lb, sb, nb, snb) = outs
     assert na == 0 and nb >= 14, (na, nb)
+    # the discriminator's spectral-norm layers walked backward together (hwg_spectral_bwd_multi) in every backward pass that reached it
+    assert sna == 0 and snb >= 10, (sna, snb)
     for it, (a, b) in enumerate(zip(la, lb)):
         assert a == b, "iteration %d: %s vs %s" % (it, a, b)
     for k, v in sa.items():
         assert torch.equal(v, sb[k]), "%s differs with the deferred reduce" % k
+
+
+def test_pipelined_logging_returns_the_same_losses_n_iterations_later(cuda, tmp_path):
+    """trainer.async_log = n: iteration i returns the losses of iteration i - n (the host may run n iterations ahead of the GPU), flush_log()
+    resolves what is outstanding. Against synchronous logging from the same seeds: the same log dictionaries, shifted by n; the same weights."""
+    from handwriting_line_generation_amd import rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    runs = {}
+    for lag in (0, 1, 3):
+        rng.set_mode("device", seed=11)
+        torch.manual_seed(3); np.random.seed(3); random.seed(3)
+        trainer, _ = build_gan_trainer("iam_gan", 2, 2, width=256, label_len=12, workdir=str(tmp_path / ("l%d" % lag)))
+        trainer.async_log = lag
+        torch.manual_seed(5); np.random.seed(5); random.seed(5)
+        logs = [trainer._train_iteration(it) for it in range(9)]
+        last = trainer.flush_log()
+        assert trainer.flush_log() == {}                      # nothing outstanding after a flush
+        torch.cuda.synchronize()
+        runs[lag] = (logs, last, {k: v.detach().clone() for k, v in trainer.model.state_dict().items()})
+    sync_logs = runs[0][0]
+    assert all(l and "loss" in l for l in sync_logs) and runs[0][1] == {}
+    for lag in (1, 3):
+        logs, last, state = runs[lag]
+        assert logs[:lag] == [{}] * lag
+        assert logs[lag:] == sync_logs[:9 - lag], "lag %d: the pipelined logs are not the synchronous ones shifted" % lag
+        assert last == sync_logs[-1]
+        for k, v in runs[0][2].items():
+            assert torch.equal(v, state[k]), "%s differs with async_log=%d" % (k, lag)
 
 
 def test_batched_generator_backward_equals_one_pass_per_loss_group(cuda, tmp_path):

@@ -18,5 +18,5 @@ for it in range(14, 56): tr._train_iteration(it)
 pr.disable()
 tr.flush_log(); torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(45)
+st.sort_stats("tottime").print_stats(140)
 st.sort_stats("cumulative").print_stats(60)
