@@ -992,7 +992,10 @@ class _Conv2d(Function):
             else:
                 u, v = x, dy
                 sa, sb = K * R * S, R * S
-            dws = _defer_workspace(need, x.device) if (DEFER_REDUCE and direct and engine != 1 and need) else None
+            # the sum of the partial images may wait for the flush behind the backward pass where nothing reads the gradient earlier: a
+            # parameter's buffer, or the dW_sn of a spectral-norm layer whose own backward is queued for the same flush (_SpectralScale)
+            late = direct or getattr(wref, "_hwg_sn_defer", False)
+            dws = _defer_workspace(need, x.device) if (DEFER_REDUCE and late and engine != 1 and need) else None
             if engine == 0:
                 ws = dws if dws is not None else workspace(need, x.device)
                 if PROF_SHAPES is not None:
@@ -1764,7 +1767,9 @@ def spectral_normalize(w_bar, u, v, eps=1e-12):
     un, vn = torch.empty_like(u), torch.empty_like(v)
     with torch.no_grad():
         L.call("hwg_spectral_update_to", w_bar.detach(), u, v, un, vn, R, K, eps, sig[0:1], sig[1:2], ws, ws.numel(), _stream())
-    return _SpectralScale.apply(w_bar, un, vn, sig[0:1], sig[1:2], False)
+    w = _SpectralScale.apply(w_bar, un, vn, sig[0:1], sig[1:2], False)
+    w._hwg_sn_defer = isinstance(w_bar, torch.nn.Parameter) and w_bar.requires_grad
+    return w
 
 
 class _Prepack:
@@ -1871,6 +1876,8 @@ def spectral_scale(w_bar, fresh):
     un, vn, sigma, inv_sigma, pre = fresh
     lazy = pre is not None and len(pre.images) > 0
     w = _SpectralScale.apply(w_bar, un, vn, sigma, inv_sigma, lazy)
+    # read by _Conv2d._wgrad: with deferral on, this weight's gradient is consumed at the flush behind the backward pass (_SpectralScale.backward)
+    w._hwg_sn_defer = isinstance(w_bar, torch.nn.Parameter) and w_bar.requires_grad
     if pre is not None:
         pre.materialised = not lazy
         w._hwg_prepack = pre
@@ -2051,6 +2058,8 @@ class _Scale(Function):
 
 
 def scale(x, c):
+    if float(c) == 1.0:       # (the adversarial losses carry weight 1 in every shipped config: no launch, forward or backward)
+        return x
     return _Scale.apply(x.contiguous(), c)
 
 

@@ -11,6 +11,7 @@ timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT
 timeout 600 python bench.py --steps 140 --warmup 14 --no-cpu-baseline > $OUT/bench_line_long.json 2>> $OUT/bench_err.log
 HWG_BENCH_NO_MINNEC=1 HWG_CONV_DUMP=$OUT/conv_shapes.txt timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -f csv -- python3 bench.py $STEPS --no-cpu-baseline --no-gen > $OUT/kt.log 2>&1
 cp $OUT/kt/*kernel_stats.csv $OUT/kernel_stats_b4a2_w512.csv 2>/dev/null || find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_b4a2_w512.csv \;
+python tools/launch_census.py $OUT/kernel_stats_b4a2_w512.csv $OUT/kt.log > $OUT/launch_census.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $c | cut -d' ' -f1)
   HWG_BENCH_NO_MINNEC=1 timeout 400 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$tag -o p -- python3 bench.py --steps 7 --warmup 7 --no-cpu-baseline --no-gen > $OUT/pmc_$tag.log 2>&1
