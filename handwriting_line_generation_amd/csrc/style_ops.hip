@@ -147,6 +147,10 @@ __global__ __launch_bounds__(256) void linear_bank_fwd_kernel(const float* __res
   while (l + 1 < L && first_wave[l + 1] <= w) ++l;
   const int o = w - first_wave[l];
   const float* W = reinterpret_cast<const float*>(wptr[l]) + (long long)o * I;
+  // rows b0 .. b0 + nb of the batch (blockIdx.y: 16 rows each; training batches are one chunk, a generation service's 64-256 lines several)
+  const int b0 = blockIdx.y * LB_MAXB;
+  const int nb = min(B - b0, LB_MAXB);
+  const float* __restrict__ xb = x + (long long)b0 * I;
   float acc[LB_MAXB];
 #pragma unroll
   for (int b = 0; b < LB_MAXB; ++b) acc[b] = 0.f;
@@ -154,15 +158,15 @@ __global__ __launch_bounds__(256) void linear_bank_fwd_kernel(const float* __res
     const float wv = W[i];
 #pragma unroll
     for (int b = 0; b < LB_MAXB; ++b)
-      if (b < B) acc[b] += wv * x[(long long)b * I + i];
+      if (b < nb) acc[b] += wv * xb[(long long)b * I + i];
   }
   const int C = O[l] / halves, h = o / C, c = o - h * C;
   const float bias = bptr ? reinterpret_cast<const float*>(bptr[l])[o] : 0.f;
 #pragma unroll
   for (int b = 0; b < LB_MAXB; ++b) {
-    if (b < B) {
+    if (b < nb) {
       const float v = wave_sum(acc[b]);
-      if (lane == 0) y[off[l] + ((long long)h * B + b) * C + c] = v + bias;
+      if (lane == 0) y[off[l] + ((long long)h * B + b0 + b) * C + c] = v + bias;
     }
   }
 }
@@ -252,10 +256,15 @@ __global__ __launch_bounds__(1024) void mlp_chain_fwd_kernel(const float* __rest
 #pragma unroll
     for (int u = 0; u < PER; ++u) nxt[u] = W0[tid + u * 1024];
   }
+  // rows b0 .. b0 + nb of the batch (one workgroup per BM rows: the rows of an MLP are independent)
+  const int b0 = blockIdx.x * BM;
+  const int nb = min(B - b0, BM);
+  x += (long long)b0 * DD;
+  acts += (long long)b0 * DD;
   for (int t = tid; t < BM * DD; t += 1024) {
-    const float v = t < B * DD ? x[t] : 0.f;
+    const float v = t < nb * DD ? x[t] : 0.f;
     h[t] = v;
-    if (t < B * DD) acts[t] = v;
+    if (t < nb * DD) acts[t] = v;
   }
   for (int l = 0; l < L; ++l) {
     const float* __restrict__ bias = reinterpret_cast<const float*>(bptr[l]);
@@ -282,9 +291,9 @@ __global__ __launch_bounds__(1024) void mlp_chain_fwd_kernel(const float* __rest
     }
     __syncthreads();
     for (int t = tid; t < BM * DD; t += 1024) {
-      const float v = t < B * DD ? hn[t] : 0.f;
+      const float v = t < nb * DD ? hn[t] : 0.f;
       h[t] = v;
-      if (t < B * DD) acts[(long long)(l + 1) * B * DD + t] = v;
+      if (t < nb * DD) acts[(long long)(l + 1) * B * DD + t] = v;
     }
   }
 }
@@ -414,9 +423,9 @@ extern "C" int hwg_gather_scores(const float* x, int B, int Wx, int C, const int
 
 extern "C" int hwg_linear_bank_fwd(const float* x, const void* wptr, const void* bptr, const int* O, const int* first_wave, const void* off, int L, int B,
                                    int I, int halves, int total_outputs, float* y, void* stream) {
-  HWG_REQUIRE(x && wptr && O && first_wave && off && y && L > 0 && B > 0 && B <= LB_MAXB && I > 0 && halves > 0 && total_outputs > 0,
-              "linear_bank_fwd: bad arguments (B <= %d)", LB_MAXB);
-  hipLaunchKernelGGL(linear_bank_fwd_kernel, dim3(hwg_cdiv(total_outputs, 4)), dim3(256), 0, (hipStream_t)stream, x, (const long long*)wptr,
+  HWG_REQUIRE(x && wptr && O && first_wave && off && y && L > 0 && B > 0 && B <= 65535 * LB_MAXB && I > 0 && halves > 0 && total_outputs > 0,
+              "linear_bank_fwd: bad arguments");
+  hipLaunchKernelGGL(linear_bank_fwd_kernel, dim3(hwg_cdiv(total_outputs, 4), hwg_cdiv(B, LB_MAXB)), dim3(256), 0, (hipStream_t)stream, x, (const long long*)wptr,
                      (const long long*)bptr, O, first_wave, (const long long*)off, L, B, I, halves, y);
   HWG_LAUNCH_CHECK("linear_bank_fwd");
   return HWG_OK;
@@ -450,11 +459,11 @@ extern "C" int hwg_linear_bank_bwd(const float* x, const void* dyptr, const void
 }
 
 extern "C" int hwg_mlp_chain_fwd(const float* x, const void* wptr, const void* bptr, int L, int B, int D, float slope, float* acts, void* stream) {
-  HWG_REQUIRE(x && wptr && bptr && acts && L > 0 && B > 0 && B <= MC_MAXB && D > 0 && D <= MC_MAXD, "mlp_chain_fwd: bad arguments (B <= %d, D <= %d)",
-              MC_MAXB, MC_MAXD);
+  HWG_REQUIRE(x && wptr && bptr && acts && L > 0 && B > 0 && D > 0 && D <= MC_MAXD, "mlp_chain_fwd: bad arguments (D <= %d)", MC_MAXD);
   hipStream_t st = (hipStream_t)stream;
   HWG_REQUIRE(D == 64 || D == 128, "mlp_chain_fwd: D must be 64 or 128 (got %d)", D);
-#define HWG_MC_FWD(DD_, BM_) hipLaunchKernelGGL((mlp_chain_fwd_kernel<DD_, BM_>), dim3(1), dim3(1024), 0, st, x, (const long long*)wptr, (const long long*)bptr, L, B, slope, acts)
+  // forward: any number of rows, one workgroup per 8 / 16 of them (the backward kernel keeps the whole batch in one workgroup: B <= 16)
+#define HWG_MC_FWD(DD_, BM_) hipLaunchKernelGGL((mlp_chain_fwd_kernel<DD_, BM_>), dim3(hwg_cdiv(B, BM_)), dim3(1024), 0, st, x, (const long long*)wptr, (const long long*)bptr, L, B, slope, acts)
   if (D == 128 && B <= 8) HWG_MC_FWD(128, 8);
   else if (D == 128) HWG_MC_FWD(128, 16);
   else HWG_MC_FWD(64, 16);

@@ -333,7 +333,7 @@ int hwg_segment_weighted_mean_bwd(const float* dout, const float* wgt, const int
 int hwg_gather_scores(const float* x, int B, int Wx, int C, const int* idx_b, const int* idx_pos, const int* idx_cls, int n, float* out, void* stream);
 
 /* Bank of L linear layers that share one input (the generator's ten AdaIN style -> (gamma, beta) affines, pure_gen.py:52-69, in one
- * launch instead of ten): y_l = x W_l^T + b_l, x [B][I] (B <= 16), W_l [O_l][I] and b_l [O_l] through device pointer tables.
+ * launch instead of ten): y_l = x W_l^T + b_l, x [B][I] (forward: any B, 16 rows per block; backward: B <= 16), W_l [O_l][I] and b_l [O_l] through device pointer tables.
  * Layer l's outputs are written as `halves` contiguous [B][O_l/halves] blocks starting at y + off[l]; first_wave[L+1] is the
  * running sum of O_l (neuron -> layer map), total_outputs = first_wave[L]. The backward ADDS dW_l / db_l into the tables'
  * buffers and writes dx [B][I] (optional); dyptr[l*halves + h] is the gradient of block h of layer l (0 = unused output). */
@@ -347,7 +347,7 @@ int hwg_linear_bank_bwd(const float* x, const void* dyptr, const void* wptr, con
 /* Chain of L square Linear(D,D)+LeakyReLU layers (the generator's style-embedding MLP, pure_gen.py:29-38) in one single-workgroup
  * launch per direction: h_{l+1} = lrelu(W_l h_l + b_l, slope). acts [L+1][B][D] receives every h_l (acts[0] = x, acts[L] = output) and is
  * what the backward consumes; the backward ADDS dW_l / db_l into the tables' buffers (null entry = frozen) and writes dx (optional).
- * B <= 16, D = 64 or 128, L <= 8. */
+ * D = 64 or 128, L <= 8; forward: any B (one workgroup per 8 / 16 rows), backward: B <= 16. */
 int hwg_mlp_chain_fwd(const float* x, const void* wptr, const void* bptr, int L, int B, int D, float slope, float* acts, void* stream);
 int hwg_mlp_chain_bwd(const float* dout, const float* acts, const void* wptr, const void* gwptr, const void* gbptr, int L, int B, int D,
                       float slope, float* dx, void* stream);

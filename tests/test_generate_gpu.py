@@ -184,3 +184,45 @@ def test_forward_generate_interpolate_match_oracle(cuda, tmp_path):
     finally:
         rng.set_mode("device")
         model.train()
+
+
+def test_large_generation_batches_take_the_banked_style_path(cuda, tmp_path):
+    """forward-only calls run the style MLP (hwg_mlp_chain_fwd) and the ten AdaIN affines (hwg_linear_bank_fwd) as one launch each for ANY
+    batch (row chunks of 16 per block); with gradients enabled batches above 16 lines take the per-layer path. Same generator output either
+    way (different summation order in the style path: within the 1e-4 of BASELINE's north star on the tanh image, and no worse in the later
+    row chunks than in the first), for a batch that is not a multiple of the chunk."""
+    from handwriting_line_generation_amd import ops, rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    torch.manual_seed(0)
+    trainer, cfg = build_gan_trainer("iam_gan", 1, 2, width=256, label_len=12, workdir=str(tmp_path))
+    gen = trainer.model.generator
+    gen.eval()
+    g = torch.Generator().manual_seed(4)
+    B, T = 40, 23
+    idx = torch.randint(0, cfg["model"]["num_class"], (T, B), generator=g)
+    content = torch.nn.functional.one_hot(idx, cfg["model"]["num_class"]).float().to(trainer.gpu)
+    style = torch.randn(B, cfg["model"]["style_dim"], generator=g).to(trainer.gpu)
+    calls = []
+    orig = ops.L.call
+
+    def call(fn, *a):
+        calls.append(fn)
+        return orig(fn, *a)
+    ops.L.call = call
+    try:
+        rng.set_mode("device", seed=21)
+        with torch.no_grad():
+            banked = gen(content, style)
+        n_banked = (calls.count("hwg_linear_bank_fwd"), calls.count("hwg_mlp_chain_fwd"))
+        del calls[:]
+        rng.set_mode("device", seed=21)
+        layered = gen(content, style).detach()
+        n_layered = (calls.count("hwg_linear_bank_fwd"), calls.count("hwg_mlp_chain_fwd"))
+    finally:
+        ops.L.call = orig
+        rng.set_mode("device")
+    assert n_banked == (1, 1) and n_layered == (0, 0), (n_banked, n_layered)
+    assert banked.shape == layered.shape == (B, 1, 64, 4 * T)
+    err = (banked - layered).abs().amax(dim=(1, 2, 3))
+    assert float(err.max()) < 1e-4, err
+    assert float(err[16:].max()) < 4 * float(err[:16].max()) + 1e-6, err
