@@ -783,6 +783,13 @@ class _Conv2d(Function):
             K = weight.shape[1]
             assert weight.shape[0] == C, "conv_transpose: weight expects %d input channels, got %d" % (weight.shape[0], C)
             oph, opw = output_padding
+            if H == 1 and sh == 1 and ph == 0 and dh == 1 and dw == 1 and R > 1 and oph == 0:
+                # ONE input row (the generator's 1-D -> 2-D lift, ConvTranspose (4,3)): output row p takes tap row r = p and nothing else, so
+                # the layer is its own stride-(R, sw) twin. Run as that fractionally strided layer every output row is a parity class with
+                # its 1 x S taps; as a stride-1 layer it is a correlation over R x S taps of which R - 1 rows only ever meet padding
+                # (4 x the multiplies: 62 -> 25 us at 8 lines, 325 -> 100 us at a generation batch of 64). Backward follows ctx.geom.
+                sh = R
+                stride = (R, sw)
             P = (H - 1) * sh - 2 * ph + dh * (R - 1) + 1 + oph
             Q = (W - 1) * sw - 2 * pw + dw * (S - 1) + 1 + opw
             Cp = _cpad(C, K, fractional=(sh != 1 or sw != 1))
