@@ -5,6 +5,7 @@
 //   (model/pure_gen.py:205-214) is fused into the first/last stage of the InstanceNorm pipeline.
 // Moments are accumulated in fp64 across threads so var = E[x^2]-E[x]^2 is safe.
 #include "hwg_common.h"
+#include "philox.h"
 
 namespace {
 
@@ -57,9 +58,13 @@ __device__ __forceinline__ void block_reduce_store(const float4 (&acc)[NV], cons
 }
 
 // ---------------- forward stage 1: moments of x (optionally of u = lrelu(x + nw*noise), which is also written) -------------
-template <bool NOISE>
+// NOISE: 0 = moments of x, 1 = of u = lrelu(x + nw*noise) with the noise read from a tensor, 2 = the same with the noise DRAWN here: element
+// i of the tensor takes normal i % 4 of Philox counter ctr0 + i / 4 (philox.h) - exactly the value hwg_randn(seed, offset = ctr0) would have
+// written to a noise tensor, without the tensor (forward-only calls: nothing reads the noise again)
+template <int NOISE>
 __global__ __launch_bounds__(256) void moments_fwd_kernel(const float* x, Geo g, double* part,
-                                                          const float* noise, const float* nw, float nscale, float slope, float* u) {
+                                                          const float* noise, const float* nw, float nscale, float slope, float* u,
+                                                          unsigned long long seed, unsigned long long ctr0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x;
   const int cl = tid % g.L, pl = tid / g.L;
@@ -85,7 +90,8 @@ __global__ __launch_bounds__(256) void moments_fwd_kernel(const float* x, Geo g,
         const int pp = p + q * g.PP;
         offs[q] = ((size_t)n * g.HW + (pp < p1 ? pp : p)) * g.C + cl * 4;
         vv[q] = *reinterpret_cast<const float4*>(x + offs[q]);
-        if (NOISE) nn[q] = *reinterpret_cast<const float4*>(noise + offs[q]);
+        if (NOISE == 1) nn[q] = *reinterpret_cast<const float4*>(noise + offs[q]);
+        if (NOISE == 2) nn[q] = hwg_randn4(seed, ctr0 + (offs[q] >> 2));
       }
 #pragma unroll
       for (int q = 0; q < NU; ++q) {
@@ -600,7 +606,8 @@ extern "C" int hwg_norm_fwd(const float* x, float* y, int N, int HW, int C, int 
   hipStream_t st = (hipStream_t)stream;
   double* part = (double*)ws;
   dim3 grid(g.chunks, N);
-  hipLaunchKernelGGL(moments_fwd_kernel<false>, grid, dim3(256), red_smem(g), st, x, g, part, nullptr, nullptr, 0.f, 0.f, nullptr);
+  hipLaunchKernelGGL(moments_fwd_kernel<0>, grid, dim3(256), red_smem(g), st, x, g, part, (const float*)nullptr, (const float*)nullptr, 0.f, 0.f,
+                     (float*)nullptr, 0ull, 0ull);
   HWG_LAUNCH_CHECK("norm_fwd.moments");
   InlineStats is = {};
   if (mode == MODE_BN) {   // batch statistics span the samples: separate finalize pass (also updates the running statistics)
@@ -665,13 +672,38 @@ extern "C" int hwg_adain_fwd(const float* x, const float* noise, const float* no
   hipStream_t st = (hipStream_t)stream;
   double* part = (double*)ws;
   dim3 grid(g.chunks, N);
-  hipLaunchKernelGGL(moments_fwd_kernel<true>, grid, dim3(256), red_smem(g), st, x, g, part, noise, noise_w, noise_scale, slope, u);
+  hipLaunchKernelGGL(moments_fwd_kernel<1>, grid, dim3(256), red_smem(g), st, x, g, part, noise, noise_w, noise_scale, slope, u, 0ull, 0ull);
   HWG_LAUNCH_CHECK("adain_fwd.moments");
   InlineStats is = {};
   is.part = part; is.cpg = 1; is.eps = eps; is.out_a = mean; is.out_b = rstd;
   hipLaunchKernelGGL(apply_fwd_kernel, grid, dim3(256), 0, st, (const float*)u, y, g, (const float*)mean, (const float*)rstd, gamma, beta, 1,
                      (const float*)nullptr, 0, 0.f, is);
   HWG_LAUNCH_CHECK("adain_fwd.apply");
+  return HWG_OK;
+}
+
+// hwg_adain_fwd with the noise drawn inside the kernel (forward-only calls): the values are those hwg_randn(seed, offset) writes for a
+// tensor of N*HW*C elements, which is never materialised - one write and one read pass of the largest tensors of a generation call less.
+// `u` may alias `x` (every element is read once, by the thread that overwrites it).
+extern "C" int hwg_adain_fwd_rng(const float* x, unsigned long long seed, unsigned long long offset, const float* noise_w, float noise_scale,
+                                 float slope, const float* gamma, const float* beta, float eps, float* u, float* y, float* mean, float* rstd,
+                                 int N, int HW, int C, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_geo(N, HW, C, "adain_fwd_rng");
+  if (rc) return rc;
+  HWG_REQUIRE(x && noise_w && gamma && beta && u && y && mean && rstd, "adain_fwd_rng: null pointer");
+  Geo g = make_geo(N, HW, C);
+  if (!ws || ws_bytes < hwg_norm_workspace(N, HW, C)) { hwg_set_error("adain_fwd_rng: workspace too small"); return HWG_ERR_WORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)ws;
+  dim3 grid(g.chunks, N);
+  hipLaunchKernelGGL(moments_fwd_kernel<2>, grid, dim3(256), red_smem(g), st, x, g, part, (const float*)nullptr, noise_w, noise_scale, slope, u,
+                     (unsigned long long)seed, (unsigned long long)offset);
+  HWG_LAUNCH_CHECK("adain_fwd_rng.moments");
+  InlineStats is = {};
+  is.part = part; is.cpg = 1; is.eps = eps; is.out_a = mean; is.out_b = rstd;
+  hipLaunchKernelGGL(apply_fwd_kernel, grid, dim3(256), 0, st, (const float*)u, y, g, (const float*)mean, (const float*)rstd, gamma, beta, 1,
+                     (const float*)nullptr, 0, 0.f, is);
+  HWG_LAUNCH_CHECK("adain_fwd_rng.apply");
   return HWG_OK;
 }
 

@@ -6,6 +6,7 @@
 //   ptrs*      : int64 array of device addresses, one per tensor (0 = tensor absent -> chunk skipped)
 //   chunk_tensor / chunk_off : one entry per fixed-size chunk of a tensor, so one launch covers all tensors.
 #include "hwg_common.h"
+#include "philox.h"
 
 namespace {
 
@@ -227,35 +228,15 @@ __global__ __launch_bounds__(256) void mt_adam_kernel(MtArgs a, const float* ste
   }
 }
 
-// ---------------- Philox4x32-10 ----------------
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
-  const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-  c[0] = hi1 ^ c[1] ^ k[0]; c[1] = lo1; c[2] = hi0 ^ c[3] ^ k[1]; c[3] = lo0;
-  k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
-}
-__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t (&out)[4]) {
-  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
-  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-#pragma unroll
-  for (int r = 0; r < 10; ++r) philox_round(c, k);
-  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
-}
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.f / 16777216.f); }  // (0,1)
+// ---------------- Philox4x32-10 (philox.h) ----------------
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t (&out)[4]) { hwg_philox4(seed, ctr, out); }
+__device__ __forceinline__ float u01(uint32_t x) { return hwg_u01(x); }
 
 __global__ void randn_kernel(float* out, long long n, uint64_t seed, uint64_t offset) {
   const long long n4 = (n + 3) / 4;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    uint32_t r[4];
-    philox4(seed, offset + (uint64_t)i, r);
-    const float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]), u3 = u01(r[3]);
-    const float ra = sqrtf(-2.f * logf(u0)), rb = sqrtf(-2.f * logf(u2));
-    float s0, c0, s1, c1;
-    sincosf(6.2831853071795864f * u1, &s0, &c0);
-    sincosf(6.2831853071795864f * u3, &s1, &c1);
-    const float v[4] = {ra * c0, ra * s0, rb * c1, rb * s1};
+    const float4 z = hwg_randn4(seed, offset + (uint64_t)i);
+    const float v[4] = {z.x, z.y, z.z, z.w};
     for (int e = 0; e < 4; ++e)
       if (i * 4 + e < n) out[i * 4 + e] = v[e];
   }

@@ -1244,7 +1244,39 @@ class _AdaIN(Function):
         return dx, None, None, dgamma, dbeta, None, None, None
 
 
+class VirtualNoise:
+    """a noise tensor that is never written: `shape` standard normals = what hwg_randn(seed, offset) would put into a tensor of that shape
+    (rng.NoiseBlock hands these out in forward-only passes; adain_epilogue draws the values inside its kernel)"""
+
+    __slots__ = ("seed", "offset", "shape")
+
+    def __init__(self, seed, offset, shape):
+        self.seed, self.offset, self.shape = int(seed), int(offset), tuple(shape)
+
+    def materialise(self, device):
+        out = torch.empty(self.shape, dtype=torch.float32, device=device)
+        L.call("hwg_randn", out, out.numel(), self.seed, self.offset, _stream())
+        return out
+
+
 def adain_epilogue(x, noise, noise_w, gamma, beta, noise_scale, slope=0.2, eps=1e-5):
+    if isinstance(noise, VirtualNoise):
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (x, noise_w, gamma, beta)):
+            noise = noise.materialise(x.device)          # (a backward pass will read the noise)
+        else:
+            for t, n in ((x, "x"), (noise_w, "noise weight"), (gamma, "gamma"), (beta, "beta")):
+                _chk(t, "adain " + n)
+            assert tuple(x.shape) == noise.shape
+            N, C = x.shape[0], x.shape[-1]
+            HW = x.numel() // (N * C)
+            u = torch.empty_like(x)
+            y = torch.empty_like(x)
+            mean = torch.empty((N, C), dtype=torch.float32, device=x.device)
+            rstd = torch.empty_like(mean)
+            ws = workspace(L.query("hwg_norm_workspace", N, HW, C), x.device)
+            L.call("hwg_adain_fwd_rng", x, noise.seed, noise.offset, noise_w, noise_scale, slope, gamma, beta, eps, u, y, mean, rstd, N, HW, C,
+                   ws, ws.numel(), _stream())
+            return y
     return _AdaIN.apply(x, noise, noise_w, gamma, beta, noise_scale, slope, eps)
 
 

@@ -84,16 +84,30 @@ class NoiseBlock:
 
     def __init__(self, shapes, device):
         self.shapes, self.device, self.buf, self.k, self.off = list(shapes), device, None, 0, 0
+        # forward-only pass with the device generator: the stream positions are reserved as for the one launch, but nothing is written -
+        # requests return ops.VirtualNoise records and the consumer (ops.adain_epilogue) draws the same values inside its kernel
+        self.virtual = _state["mode"] != "host" and not torch.is_grad_enabled()
+        self.base = None
 
     def next(self, x):
         shape = tuple(x.shape)
         if _state["mode"] == "host" or self.k >= len(self.shapes) or tuple(self.shapes[self.k]) != shape:
             self.k = len(self.shapes)           # (a shape off the plan: fall back to single draws for the rest of the pass)
             return noise_like_nhwc(x)
+        n = shape[0] * shape[1] * shape[2] * shape[3]
+        if self.virtual:
+            if self.base is None:
+                total = sum(((a * b * c * d) + 3) // 4 * 4 for a, b, c, d in self.shapes)
+                g = _dev_rng()
+                self.base = (g.seed, g.offset)
+                g.offset += total // 4
+            out = ops.VirtualNoise(self.base[0], self.base[1] + self.off // 4, shape)
+            self.off += (n + 3) // 4 * 4
+            self.k += 1
+            return out
         if self.buf is None:
             total = sum(((a * b * c * d) + 3) // 4 * 4 for a, b, c, d in self.shapes)
             self.buf = _dev_rng().randn((total,), self.device)
-        n = shape[0] * shape[1] * shape[2] * shape[3]
         out = self.buf[self.off: self.off + n].view(shape)
         self.off += (n + 3) // 4 * 4
         self.k += 1

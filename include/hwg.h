@@ -219,6 +219,11 @@ int hwg_norm_frozen_fwd(const float* x, float* y, int N, int HW, int C, const fl
 int hwg_adain_fwd(const float* x, const float* noise, const float* noise_w, float noise_scale, float slope,
                   const float* gamma, const float* beta, float eps, float* u, float* y, float* mean, float* rstd,
                   int N, int HW, int C, void* ws, size_t ws_bytes, void* stream);
+/* the same with the noise drawn in the kernel (forward-only calls): element i of the [N][HW][C] tensor takes the value hwg_randn(seed, offset)
+ * writes to element i of a tensor of that size; no noise tensor exists. u may alias x. */
+int hwg_adain_fwd_rng(const float* x, unsigned long long seed, unsigned long long offset, const float* noise_w, float noise_scale, float slope,
+                      const float* gamma, const float* beta, float eps, float* u, float* y, float* mean, float* rstd, int N, int HW, int C,
+                      void* ws, size_t ws_bytes, void* stream);
 int hwg_adain_bwd(const float* dy, const float* u, const float* noise, float noise_scale, float slope,
                   const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
                   float* dnoise_w, float* dbias, int accumulate_params, int N, int HW, int C,

@@ -226,3 +226,50 @@ def test_large_generation_batches_take_the_banked_style_path(cuda, tmp_path):
     err = (banked - layered).abs().amax(dim=(1, 2, 3))
     assert float(err.max()) < 1e-4, err
     assert float(err[16:].max()) < 4 * float(err[:16].max()) + 1e-6, err
+
+
+def test_forward_only_generator_draws_its_noise_in_the_kernel_bit_identically(cuda, tmp_path):
+    """device generator, no gradients: rng.NoiseBlock hands out VirtualNoise records and ops.adain_epilogue draws the normals inside its kernel
+    (hwg_adain_fwd_rng) - the same Philox counters, the same Box-Muller arithmetic (csrc/philox.h) as the one hwg_randn launch of a training
+    pass. The image must be BIT-identical to the pass that materialises the noise, the stream must advance by the same amount, and no
+    hwg_randn may run."""
+    from handwriting_line_generation_amd import ops, rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    torch.manual_seed(0)
+    trainer, cfg = build_gan_trainer("iam_gan", 1, 2, width=256, label_len=12, workdir=str(tmp_path))
+    gen = trainer.model.generator
+    gen.eval()
+    g = torch.Generator().manual_seed(6)
+    B, T = 5, 19
+    idx = torch.randint(0, cfg["model"]["num_class"], (T, B), generator=g)
+    content = torch.nn.functional.one_hot(idx, cfg["model"]["num_class"]).float().to(trainer.gpu)
+    style = torch.randn(B, cfg["model"]["style_dim"], generator=g).to(trainer.gpu)
+    calls = []
+    orig = ops.L.call
+
+    def call(fn, *a):
+        calls.append(fn)
+        return orig(fn, *a)
+    ops.L.call = call
+    try:
+        rng.set_mode("device", seed=33)
+        with torch.no_grad():
+            virt = gen(content, style)
+        off_virtual = rng.device_rng().offset
+        n_virtual = (calls.count("hwg_randn"), calls.count("hwg_adain_fwd_rng"), calls.count("hwg_adain_fwd"))
+        del calls[:]
+        rng.set_mode("device", seed=33)
+        real = gen(content, style).detach()            # gradients enabled: the noise tensors exist (one hwg_randn), hwg_adain_fwd reads them
+        off_real = rng.device_rng().offset
+        n_real = (calls.count("hwg_randn"), calls.count("hwg_adain_fwd_rng"), calls.count("hwg_adain_fwd"))
+    finally:
+        ops.L.call = orig
+        rng.set_mode("device")
+    assert n_virtual == (0, 10, 0) and n_real == (1, 0, 10), (n_virtual, n_real)
+    assert off_virtual == off_real > 0
+    assert torch.equal(virt, real)
+    # a VirtualNoise record materialises to the very tensor the training pass would have read
+    v = ops.VirtualNoise(33, 7, (2, 3, 5, 4))
+    want = torch.empty(2, 3, 5, 4, device=trainer.gpu)
+    ops.L.call("hwg_randn", want, want.numel(), 33, 7, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(v.materialise(trainer.gpu), want)
