@@ -393,7 +393,11 @@ int hwg_conv_to1_fwd_impl(const hwg_conv_desc* d, const float* x, const float* w
   k.P = d->P; k.Q = d->Q; k.accumulate = accumulate;
   const long long M = (long long)d->N * d->P * d->Q;
   const int E = d->R * d->S * (d->C / 4);
-  const int lpp = E <= 4 ? 4 : E <= 16 ? 16 : 64;
+  // lanes per pixel: enough to cover the taps x channel groups of a small pixel, otherwise the channel groups of ONE tap (the lanes then walk
+  // the taps: 4 or 16 pixels per wave instead of one - the autoencoder decoder's 3x3 64 -> 1 head ran one wave per pixel, 321 us at 28 lines)
+  const int C4 = d->C / 4;
+  int lpp = E <= 4 ? 4 : E <= 16 ? 16 : 64;
+  if (hwg_tune().to1_lanes && E > 16 && C4 <= 16) lpp = C4 <= 4 ? 4 : 16;
   long long blocks = (M * lpp / 64 + 3) / 4;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;

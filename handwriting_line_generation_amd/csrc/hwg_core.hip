@@ -47,6 +47,7 @@ const HwgTune& hwg_tune() {
     t->wwg_debug = tune_int("HWG_WWG_DEBUG", 0);
     t->conv_pf = tune_int("HWG_CONV_PF", 3);
     t->conv_lds = tune_int("HWG_CONV_LDS", 1);
+    t->to1_lanes = tune_int("HWG_TO1_LANES", 1);
     t->wgrad_reduce_rows = tune_int("HWG_WGRAD_REDUCE_ROWS", 1);
     t->conv_wk = tune_int("HWG_CONV_WK", 2);
     t->c1_mfma = tune_int("HWG_C1_MFMA", 1);
