@@ -86,7 +86,8 @@ class NoiseBlock:
         self.shapes, self.device, self.buf, self.k, self.off = list(shapes), device, None, 0, 0
         # forward-only pass with the device generator: the stream positions are reserved as for the one launch, but nothing is written -
         # requests return ops.VirtualNoise records and the consumer (ops.adain_epilogue) draws the same values inside its kernel
-        self.virtual = _state["mode"] != "host" and not torch.is_grad_enabled()
+        # (a taped forward - ops.TAPE set - runs under no_grad too, but its backward pass reads the noise: not forward-only)
+        self.virtual = _state["mode"] != "host" and not torch.is_grad_enabled() and ops.TAPE is None
         self.base = None
 
     def next(self, x):

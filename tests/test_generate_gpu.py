@@ -262,10 +262,23 @@ def test_forward_only_generator_draws_its_noise_in_the_kernel_bit_identically(cu
         real = gen(content, style).detach()            # gradients enabled: the noise tensors exist (one hwg_randn), hwg_adain_fwd reads them
         off_real = rng.device_rng().offset
         n_real = (calls.count("hwg_randn"), calls.count("hwg_adain_fwd_rng"), calls.count("hwg_adain_fwd"))
+        # a TAPED forward (the GAN trainer's balanced lessons) runs under no_grad as well, but its backward pass reads the noise and every
+        # epilogue must be on the tape: not a forward-only pass
+        del calls[:]
+        rng.set_mode("device", seed=33)
+        gen.tape_mode = True
+        try:
+            taped = gen(content, style.clone().requires_grad_(True))
+            tapes = gen.take_tapes()
+        finally:
+            gen.tape_mode = False
+        n_taped = (calls.count("hwg_randn"), calls.count("hwg_adain_fwd_rng"), calls.count("hwg_adain_fwd"))
     finally:
         ops.L.call = orig
         rng.set_mode("device")
     assert n_virtual == (0, 10, 0) and n_real == (1, 0, 10), (n_virtual, n_real)
+    assert n_taped == (1, 0, 10) and len(tapes) == 1 and torch.equal(taped.detach(), real), n_taped
+    assert sum(1 for nd in tapes[0].tape.nodes if getattr(nd[0], "__name__", "") == "_AdaIN") == 10
     assert off_virtual == off_real > 0
     assert torch.equal(virt, real)
     # a VirtualNoise record materialises to the very tensor the training pass would have read

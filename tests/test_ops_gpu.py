@@ -57,6 +57,11 @@ CONV_CASES = [
     ("convT_s1_3x3", 2, 6, 20, 32, 32, 3, 3, (1, 1), (1, 1), (1, 1), True),
     ("convT_6x3", 2, 1, 12, 32, 64, 6, 3, (1, 1), (0, 0), (1, 1), True),
     ("convT_to1", 2, 8, 20, 32, 1, 3, 3, (1, 1), (1, 1), (1, 1), True),
+    # one row on the narrow side: the data gradient of a pad-0 layer whose output has ONE row, and the forward of a transposed layer with
+    # one input row, both run as their stride-(R, 1) twins (row classes with 1 x S taps each)
+    ("onerow_out_3x3_c64", 2, 3, 40, 64, 48, 3, 3, (1, 1), (0, 1), (1, 1), False),
+    ("onerow_out_6x3_c32", 3, 6, 25, 32, 64, 6, 3, (1, 1), (0, 0), (1, 1), False),
+    ("onerow_out_3x3_c512", 2, 3, 30, 512, 512, 3, 3, (1, 1), (0, 0), (1, 1), False),
     # Winograd F(2x2,3x3) path (3x3 / stride 1 / dilation 1, >= 16 output channels): odd sizes, every padding the networks use
     # (0/1 forward, 2 = data gradient of pad 0), channel counts off the tile sizes, the split-channel schedule, 16-wide layers
     ("wino_odd_pad1", 3, 9, 13, 16, 16, 3, 3, (1, 1), (1, 1), (1, 1), False),
