@@ -968,7 +968,11 @@ class _Conv2d(Function):
                 else:
                     assert dh == 1 and dw == 1, "strided conv backward needs dilation 1"
                     wp = _pack(weight, C, K, R, S, R * S, C * R * S, flip=0, Bpad=Kp)
-                    dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (sh, sw), (ph, pw), (1, 1), H, W, 1)
+                    # (one output row, H == R: the vertical stride never moves - stride R gives every input row its own class of 1 x S taps
+                    # where stride sh pairs each class with R / sh tap rows of which all but one meet nothing; the style extractor's last
+                    # 4x4 stride-(2,1) layer)
+                    she = R if (P == 1 and ph == 0 and H == R and R > sh) else sh
+                    dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (she, sw), (ph, pw), (1, 1), H, W, 1)
             else:
                 # gradient of a transposed conv is an ordinary (strided) correlation of dy
                 wino = _wino_ok(N, P, Q, Kp, C, R, S, (sh, sw), (ph, pw), (dh, dw), H, W)

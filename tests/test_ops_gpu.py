@@ -62,6 +62,8 @@ CONV_CASES = [
     ("onerow_out_3x3_c64", 2, 3, 40, 64, 48, 3, 3, (1, 1), (0, 1), (1, 1), False),
     ("onerow_out_6x3_c32", 3, 6, 25, 32, 64, 6, 3, (1, 1), (0, 0), (1, 1), False),
     ("onerow_out_3x3_c512", 2, 3, 30, 512, 512, 3, 3, (1, 1), (0, 0), (1, 1), False),
+    ("onerow_out_4x4_s21", 2, 4, 41, 64, 64, 4, 4, (2, 1), (0, 0), (1, 1), False),
+    ("onerow_out_4x4_s22", 2, 4, 40, 32, 48, 4, 4, (2, 2), (0, 1), (1, 1), False),
     # Winograd F(2x2,3x3) path (3x3 / stride 1 / dilation 1, >= 16 output channels): odd sizes, every padding the networks use
     # (0/1 forward, 2 = data gradient of pad 0), channel counts off the tile sizes, the split-channel schedule, 16-wide layers
     ("wino_odd_pad1", 3, 9, 13, 16, 16, 3, 3, (1, 1), (1, 1), (1, 1), False),
