@@ -200,6 +200,52 @@ __global__ __launch_bounds__(256) void conv_to1_kernel(DirK a) {
   }
 }
 
+// 3x3 / stride 1 / one output channel on <= 64 input channels (the autoencoder decoder's image head): LPP lanes hold one tap's channel groups,
+// the nine filter taps of a lane stay in registers and the nine input loads of a pixel are in flight together (the generic loop above
+// issues them one by one behind a bounds test: 266 us at 28 x 64 x 512 x 64, latency bound at 0.9 TB/s).
+template <int LPP>
+__global__ __launch_bounds__(256) void conv_to1_3x3_kernel(DirK a) {
+  constexpr int PPW = 64 / LPP;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / LPP, li = lane % LPP;
+  const long long wave = (blockIdx.x * 256LL + threadIdx.x) >> 6;
+  const long long nwaves = (gridDim.x * 256LL) >> 6;
+  const bool active = li < (a.C >> 2);
+  float4 w[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+    w[t] = active ? *reinterpret_cast<const float4*>(a.w + (long long)t * a.C + li * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float bias = a.bias ? a.bias[0] : 0.f;
+  const long long M = (long long)a.N * a.P * a.Q;
+  for (long long m0 = wave * PPW; m0 < M; m0 += nwaves * PPW) {
+    const long long m = m0 + sub;
+    const bool mv = m < M;
+    const long long mm = mv ? m : 0;
+    const int q = (int)(mm % a.Q);
+    const long long t2 = mm / a.Q;
+    const int p = (int)(t2 % a.P);
+    const int n = (int)(t2 / a.P);
+    float4 xv[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int ih = p - a.ph + r, iw = q - a.pw + s;
+        const bool ok = mv && active && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        xv[r * 3 + s] = ok ? *reinterpret_cast<const float4*>(a.x + (((long long)n * a.H + ih) * a.W + iw) * a.C + li * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc += xv[t].x * w[t].x + xv[t].y * w[t].y + xv[t].z * w[t].z + xv[t].w * w[t].w;
+#pragma unroll
+    for (int o = LPP / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (li == 0 && mv) {
+      const float v = acc + bias;
+      a.y[m] = a.accumulate ? a.y[m] + v : v;
+    }
+  }
+}
+
 // ---- direct weight gradient: one side of the contraction has <= 2 channels ----
 // big_on_anchor != 0 : u is [M][K] with K large, v is single channel (C == 1):   part[blk][tap][k]      = sum_m u[m][k] * v[g(m,tap)]
 // big_on_anchor == 0 : u is [M][K<=2],          v is [.., C] with C large:        part[blk][tap][ko][c]  = sum_m u[m][ko] * v[g(m,tap)][c]
@@ -402,7 +448,10 @@ int hwg_conv_to1_fwd_impl(const hwg_conv_desc* d, const float* x, const float* w
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   const int prof = hwg_prof_open(HWG_PROF_CONV_DIRECT, 2.0 * d->N * d->P * d->Q * d->K * d->C * d->R * d->S, st);
-  if (lpp == 4) hipLaunchKernelGGL(conv_to1_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, k);
+  const bool r3 = hwg_tune().to1_lanes && d->K == 1 && d->R == 3 && d->S == 3 && d->stride_h == 1 && d->stride_w == 1 && d->dil_h == 1 && d->dil_w == 1 &&
+                  C4 > 4 && C4 <= 16;
+  if (r3) hipLaunchKernelGGL(conv_to1_3x3_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, k);
+  else if (lpp == 4) hipLaunchKernelGGL(conv_to1_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, k);
   else if (lpp == 16) hipLaunchKernelGGL(conv_to1_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, k);
   else hipLaunchKernelGGL(conv_to1_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, st, k);
   hwg_prof_close(prof, st);

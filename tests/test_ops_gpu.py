@@ -52,6 +52,9 @@ CONV_CASES = [
     ("to1_1x1", 3, 1, 20, 256, 1, 1, 1, (1, 1), (0, 0), (1, 1), False),
     ("to2_1x1", 3, 1, 20, 32, 2, 1, 1, (1, 1), (0, 0), (1, 1), False),
     ("to1_16", 2, 16, 40, 16, 1, 1, 1, (1, 1), (0, 0), (1, 1), False),
+    ("to1_3x3_c64", 2, 20, 50, 64, 1, 3, 3, (1, 1), (1, 1), (1, 1), False),          # the nine-loads-in-flight 3x3 head kernel (decoder image head)
+    ("to1_3x3_c32_pad01", 3, 9, 31, 32, 1, 3, 3, (1, 1), (0, 1), (1, 1), False),
+    ("to1_3x3_c48", 2, 7, 23, 48, 1, 3, 3, (1, 1), (1, 1), (1, 1), False),           # (12 of the 16 lanes of a pixel hold channels)
     ("convT_lift_4x3", 2, 1, 30, 208, 256, 4, 3, (1, 1), (0, 1), (1, 1), True),
     ("convT_s2_4x4", 2, 8, 20, 64, 32, 4, 4, (2, 2), (1, 1), (1, 1), True),
     ("convT_s1_3x3", 2, 6, 20, 32, 32, 3, 3, (1, 1), (1, 1), (1, 1), True),
