@@ -205,6 +205,11 @@ class BaseTrainer:
                 self._save_checkpoint(self.iteration, {})
             elif self.save_step_minor and self.iteration % self.save_step_minor == 0:
                 self._save_checkpoint(self.iteration, {}, minor=True)
+        # pipelined logging (trainer.async_log = n): the losses of the last n iterations are still outstanding - resolve them (their
+        # non-finite checks run there) before train() returns
+        flush = getattr(self, "flush_log", None)
+        if flush is not None:
+            flush()
 
     def _minor_log(self, log):
         self.logger.info("Train " + ",\t".join("%s: %s" % kv for kv in log.items()))
