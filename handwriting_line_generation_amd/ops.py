@@ -491,7 +491,10 @@ def _pack(weight, A, B, R, S, sa, sb, flip, Bpad=None, wino=False):
             return img
         pre.miss(variant, weight)
     key = hit = group = None
-    if weight.is_leaf:
+    # cached per PARAMETER only: under no_grad (taped forwards, the discriminator lessons' detached generator pass) every derived weight - the
+    # fused-upsample 4x4 image, an equal-lr scaled copy - is a "leaf" too, and caching those kept one entry (the temporary and its packed image)
+    # alive per forward pass for the rest of the run
+    if isinstance(weight, torch.nn.Parameter):
         group = getattr(weight, "_hwg_group", None)
         epoch = WEIGHT_EPOCH.get(group, 0)
         key = (id(weight), weight.data_ptr(), A, B, Bpad, sa, sb, int(flip), bool(wino))

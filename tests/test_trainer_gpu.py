@@ -140,6 +140,33 @@ def test_pipelined_logging_returns_the_same_losses_n_iterations_later(cuda, tmp_
             assert torch.equal(v, state[k]), "%s differs with async_log=%d" % (k, lag)
 
 
+def test_nothing_accumulates_from_cycle_to_cycle(cuda, tmp_path):
+    """long runs: the packed-weight cache must hold parameters only (under no_grad - taped forwards, the disc lessons' detached generator pass -
+    every derived weight is a "leaf" too: caching those kept one temporary + its packed image alive per generator pass, 0.4 MB per step at
+    the bench batch), and torch's allocated bytes at the same point of the curriculum cycle must not creep."""
+    import gc
+    from handwriting_line_generation_amd import ops, rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    rng.set_mode("device", seed=11)
+    torch.manual_seed(3); np.random.seed(3); random.seed(3)
+    trainer, _ = build_gan_trainer("iam_gan", 2, 2, width=256, label_len=12, workdir=str(tmp_path))
+    trainer.data_loader.make_resident(8, trainer.gpu)            # a ring of batches: the same shapes come round again
+    trainer.data_loader_iter = iter(trainer.data_loader)
+
+    def mark():
+        trainer.flush_log(); torch.cuda.synchronize(); gc.collect()
+        return len(ops._pack_cache), torch.cuda.memory_allocated()
+    for it in range(28):
+        trainer._train_iteration(it)
+    n0, a0 = mark()
+    for it in range(28, 84):
+        trainer._train_iteration(it)
+    n1, a1 = mark()
+    assert all(isinstance(e[3], torch.nn.Parameter) for e in ops._pack_cache.values())
+    assert n1 == n0, "packed-weight cache grew from %d to %d entries over 8 cycles" % (n0, n1)
+    assert a1 - a0 < 16e6, "allocated bytes grew by %.1f MB over 8 cycles" % ((a1 - a0) / 1e6)
+
+
 def test_batched_generator_backward_equals_one_pass_per_loss_group(cuda, tmp_path):
     """trainer.batch_gen_backward (default on): the two / three gradients a balanced lesson sends through the generator (reference trainer
     :300-338, one backward() per loss group) go through it in ONE pass, stacked along the batch axis, every group accumulating into its
