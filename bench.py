@@ -557,7 +557,7 @@ def main():
             "concurrent_style_passes": getattr(trainer, "_concurrent_style_passes", None),   # likewise off in the profiled cycles
             # sclk / mclk / socket power sampled from sysfs every 100 ms during the timed region (min / mean / max), and rocm-smi's view
             "clocks": clock_report,
-            "hbm_peak_mb": round(torch.cuda.max_memory_allocated() / 1e6, 1),   # peak of torch's allocator on rank 0 (weights, optimizer state, flat gradient sets, activations, arenas)
+            "hbm_peak_mb": round(max(torch.cuda.max_memory_allocated(), getattr(trainer, "hbm_peak_bytes", 0)) / 1e6, 1),   # peak of torch's allocator on rank 0 (weights, optimizer state, flat gradient sets, activations, arenas)
             "inputs_resident": True,     # one synthetic batch per step built and uploaded before the timed region (SyntheticLoader.make_resident)
             # load of the per-character expert bank (K18): style extractions in the timed region, character windows and distinct experts per call
             "style_extractor_load": {"recogniser": "peaked (70% blanks, +10 logit on one class per column)" if wl.get("peaked") else "random-init on uniform-noise lines",

@@ -130,6 +130,9 @@ class HWWithStyleTrainer(BaseTrainer):
         # recogniser-on-real-lines + style extractor on a tape as well: each loss group's pass through them runs on a stream of its own
         self._tape_style = bool(int(tr.get("tape_style", os.environ.get("HWG_TAPE_STYLE", "1")) or 0))
         self._concurrent_style_passes = bool(int(tr.get("concurrent_style_passes", os.environ.get("HWG_CONCURRENT_STYLE", "1")) or 0))
+        self._trim_every = int(tr.get("alloc_trim_every", os.environ.get("HWG_ALLOC_TRIM_EVERY", "1000")) or 0)
+        self.allocator_trims = 0
+        self.hbm_peak_bytes = 0
         self._style_streams = None
         # Dead-gradient elimination (off by default = the reference's launches). The reference computes two families of parameter gradients
         # that nothing ever reads: the frozen recogniser's (it is in no optimizer; 11 backward traversals per cycle) and the
@@ -172,7 +175,23 @@ class HWWithStyleTrainer(BaseTrainer):
         position of the set in the lesson): the ranges to reduce are agreed between the ranks once per key, see start_stash_allreduce)"""
         return start_stash_allreduce(self.flat.stash(), self.world, self.flat, key=key)
 
+    def _trim_allocator(self):
+        """Generated lines have a width drawn per batch (4 T', T' from `insert_spaces`), so the activations of every step ask torch's caching
+        allocator for block sizes it has not seen: over thousands of steps the cache splinters (15.8 GB reserved for 4.1 GB allocated after
+        5600 steps at the bench batch) and the same logical buffers land on ever different addresses - `tools/mem_watch.py`: 69 steps/s at
+        step 5600 against 75-76 with the cache released every 700 steps (the rest of the decline from 80 is the workload itself: the spacer
+        learns longer lines, T' 110 -> 150). Every `trainer.alloc_trim_every` iterations (default 1000, 0 = never): if the cache holds more
+        than twice the peak in use since the last trim, give it back (a device synchronisation and a few re-allocations, once per trim)."""
+        self.hbm_peak_bytes = max(self.hbm_peak_bytes, torch.cuda.max_memory_allocated(self.gpu))     # (the allocator's own peak restarts below)
+        if torch.cuda.memory_reserved(self.gpu) > 2 * torch.cuda.max_memory_allocated(self.gpu):
+            torch.cuda.synchronize(self.gpu)
+            torch.cuda.empty_cache()
+            self.allocator_trims += 1
+        torch.cuda.reset_peak_memory_stats(self.gpu)
+
     def _train_iteration(self, iteration):
+        if self._trim_every and iteration and iteration % self._trim_every == 0 and self.gpu is not None:
+            self._trim_allocator()
         if not self.model.training:   # nn.Module.train() walks all ~3000 sub-modules; only do it when the mode actually changes
             self.model.train()
         lesson = self.curriculum.getLesson(iteration) if self.curriculum else None

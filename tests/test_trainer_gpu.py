@@ -167,6 +167,31 @@ def test_nothing_accumulates_from_cycle_to_cycle(cuda, tmp_path):
     assert a1 - a0 < 16e6, "allocated bytes grew by %.1f MB over 8 cycles" % ((a1 - a0) / 1e6)
 
 
+def test_allocator_trim_changes_nothing_but_the_cache(cuda, tmp_path):
+    """trainer.alloc_trim_every: the periodic release of torch's cached blocks (long runs with per-batch line widths splinter the cache) fires
+    when the cache holds more than twice the peak in use, and leaves losses and weights bit-identical"""
+    from handwriting_line_generation_amd import rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    outs = []
+    for every in (0, 7):
+        rng.set_mode("device", seed=11)
+        torch.manual_seed(3); np.random.seed(3); random.seed(3)
+        trainer, _ = build_gan_trainer("iam_gan", 2, 2, width=256, label_len=12, workdir=str(tmp_path / ("t%d" % every)))
+        trainer._trim_every = every
+        torch.manual_seed(5); np.random.seed(5); random.seed(5)
+        hog = torch.empty(16 << 30, dtype=torch.uint8, device=trainer.gpu)      # a block that is free (cached) by the time of the first trim
+        del hog
+        torch.cuda.reset_peak_memory_stats()
+        logs = [trainer._train_iteration(it) for it in range(15)]
+        torch.cuda.synchronize()
+        outs.append((logs, {k: v.detach().clone() for k, v in trainer.model.state_dict().items()}, trainer.allocator_trims))
+    (la, sa, ta), (lb, sb, tb) = outs
+    assert ta == 0 and tb >= 1, (ta, tb)
+    assert la == lb
+    for k, v in sa.items():
+        assert torch.equal(v, sb[k]), k
+
+
 def test_batched_generator_backward_equals_one_pass_per_loss_group(cuda, tmp_path):
     """trainer.batch_gen_backward (default on): the two / three gradients a balanced lesson sends through the generator (reference trainer
     :300-338, one backward() per loss group) go through it in ONE pass, stacked along the batch axis, every group accumulating into its
