@@ -167,7 +167,7 @@ class SpacedGenerator(nn.Module):
         h = ops.pixel_norm(style.contiguous())
         lin = [m for m in self.style_emb if isinstance(m, Linear)]
         # (the chain's backward kernel holds the whole batch in one workgroup: 16 rows; forward-only calls - generation - take any batch)
-        if (h.shape[0] <= 16 or not torch.is_grad_enabled()) and h.shape[1] in (64, 128) and len(lin) <= 8:
+        if (h.shape[0] <= 16 or (not torch.is_grad_enabled() and ops.TAPE is None)) and h.shape[1] in (64, 128) and len(lin) <= 8:
             # the six Linear(128,128)+LeakyReLU layers run as one single-workgroup launch per direction (36 launches -> 2 per pass)
             if self._style_chain is None:
                 self._style_chain = ops.MLPChain(lin, 0.2)
@@ -213,7 +213,7 @@ class SpacedGenerator(nn.Module):
         # the ten style -> (gamma, beta) affines of the five blocks share their input: one bank launch instead of ten tiny GEMMs
         # (and one gradient kernel instead of ten data-gradient GEMMs + nine accumulations of d(emb))
         pairs = None
-        if B <= 16 or not torch.is_grad_enabled():       # (backward: 16 rows at most; forward-only calls take any batch, 16 rows per block)
+        if B <= 16 or (not torch.is_grad_enabled() and ops.TAPE is None):       # (backward: 16 rows at most - a taped forward runs under no_grad and IS followed by one; forward-only calls take any batch, 16 rows per block)
             if self._affine_bank is None:
                 self._affine_bank = ops.LinearBank([m for blk in self.conv for m in (blk.adain1.style, blk.adain2.style)], halves=2)
             pairs = self._affine_bank(emb)

@@ -361,8 +361,18 @@ def flush_deferred_reduce():
     if not DEFER_KEEP_ARENA:
         _defer["offset"] = 0
     if _sn_defer:          # queued spectral-norm backward passes (their dW_sn inputs are complete: summed eagerly, or by the launch above)
-        for i in range(0, len(_sn_defer), 16):
-            chunk = _sn_defer[i: i + 16]
+        # a launch adds every entry's result to its destination with a plain read-modify-write: two entries with the SAME destination (the
+        # discriminator applied twice in one backward pass - a lesson with both 'disc' and 'gen') must not share a launch. The k-th
+        # occurrence of a destination goes to pass k, passes run one after the other in queue order (as hwg_wgrad_defer_flush does for convs).
+        passes, seen = [], {}
+        for e in _sn_defer:
+            k = seen.get(e[5].data_ptr(), 0)
+            seen[e[5].data_ptr()] = k + 1
+            if k == len(passes):
+                passes.append([])
+            passes[k].append(e)
+        chunks = [pas[i: i + 16] for pas in passes for i in range(0, len(pas), 16)]
+        for chunk in chunks:
             rec = np.zeros(len(chunk), dtype=_SN_BWD_REC)
             for k, (dwsn, w_bar, u, v, sigma, dst, R, K) in enumerate(chunk):
                 rec[k] = (dwsn.data_ptr(), w_bar.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr(), dst.data_ptr(), R, K, 1, 0)

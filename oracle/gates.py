@@ -1,0 +1,319 @@
+"""Test infrastructure (never imported by the product): compact records of the DISCRETE decisions a training iteration takes - the sign
+behind every ReLU / LeakyReLU and the winner of every max-pool window - so that a gradient comparison can say whether an fp32 implementation
+took the same branch as the reference's fp64 run at every gate, instead of allowing for gate flips blindly.
+
+The gates of the reference (all through torch.nn.functional, patched by `RefRecorder`):
+  model/cnn_only_hwr.py:38-41,64-90 (ReLU after every conv / BatchNorm), :45-55 (MaxPool2d)
+  model/pure_gen.py:37 (style MLP LeakyReLU), :195-213 (LeakyReLU behind conv + noise in every StyledConvBlock)
+  model/discriminator_ap.py:79-130 (LeakyReLU behind conv / GroupNorm / Dropout2d)
+  model/char_style.py:46-49 (Conv2dBlock activation), :89-109 (experts), :163-188 (prep, MaxPool1d), :288 (F.relu)
+  model/count_cnn.py:15-22, model/autoencoder.py:349-390 (Encoder2)
+
+A record = one gated tensor of one call, in the reference's element order (sample, channel, spatial...):
+  name      module path of the gate in the reference ("hwr.cnn.relu2", "generator.conv.0.lrelu1", "encoder.conv1.3", ...)
+  kind      "act" (decision = pre-activation > 0) | "pool" (decision = 1 + winner position inside the window, 0 for a window whose maximum is <= 0)
+  N, M      samples, decisions per sample
+  hashes    uint64 [N][ceil(M / bs)]: one hash per block of `bs` consecutive decisions of a sample (bs = block_size(M))
+  nz        the NZ smallest |pre-activation| of the record: flat index into [N][M] and the value ("act" only)
+Blocks are per SAMPLE so that a record can be matched sample by sample, whatever batch composition or call order the other side uses.
+"""
+import json
+
+import numpy as np
+
+NZ = 32
+_MULT = None
+
+
+def block_size(M):
+    """4096 decisions per hash for large tensors; small tensors get at least ~8 blocks per sample (a flip then still leaves most blocks equal,
+    which is what the content matching needs)"""
+    bs = 4096
+    while bs > 16 and bs * 8 > M:
+        bs //= 2
+    return bs
+
+
+def _multipliers():
+    global _MULT
+    if _MULT is None:
+        x = np.uint64(0x9E3779B97F4A7C15)
+        out = np.empty(4096 // 8, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            for i in range(out.size):          # splitmix64 stream, forced odd
+                x = x + np.uint64(0x9E3779B97F4A7C15)
+                z = x
+                z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+                z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+                out[i] = (z ^ (z >> np.uint64(31))) | np.uint64(1)
+        _MULT = out
+    return _MULT
+
+
+def block_hashes(dec):
+    """dec: uint8 [N][M] -> uint64 [N][nblk]; a multiply-add hash over the block's bytes taken as little-endian 64-bit words (zero padded)"""
+    dec = np.ascontiguousarray(dec, dtype=np.uint8)
+    N, M = dec.shape
+    bs = block_size(M)
+    nblk = (M + bs - 1) // bs
+    if nblk * bs != M:
+        pad = np.zeros((N, nblk * bs), dtype=np.uint8)
+        pad[:, :M] = dec
+        dec = pad
+    words = dec.reshape(N, nblk, bs // 8, 8).view(np.uint64).reshape(N, nblk, bs // 8)
+    with np.errstate(over="ignore"):
+        h = (words * _multipliers()[: bs // 8]).sum(axis=2, dtype=np.uint64)
+        h ^= h >> np.uint64(29)
+    return h
+
+
+def pool_codes(winner, live):
+    """winner: position of the maximum inside its window (0 .. kh*kw-1), live: maximum > 0  ->  uint8 decisions"""
+    return np.where(live, winner.astype(np.int64) + 1, 0).astype(np.uint8)
+
+
+class GateFile:
+    """reader / writer of tests/golden/<case>_gates.npz: records grouped by iteration key "unit:position" """
+
+    def __init__(self):
+        self.meta = {}        # key -> list of [name, kind, N, M, offset into hashes, ref32_flips]
+        self.hashes = []
+        self.nz_idx = []
+        self.nz_val = []
+        self._off = 0
+
+    def add(self, key, name, kind, M, hashes, nz_idx, nz_val, ref32_flips):
+        N, nblk = hashes.shape
+        assert nblk == (M + block_size(M) - 1) // block_size(M)
+        self.meta.setdefault(key, []).append([name, kind, int(N), int(M), self._off, ref32_flips, len(self.nz_idx)])
+        self.hashes.append(hashes.reshape(-1))
+        self._off += hashes.size
+        self.nz_idx.append(nz_idx)
+        self.nz_val.append(nz_val)
+
+    def save(self, path):
+        np.savez_compressed(path, meta=np.frombuffer(json.dumps(self.meta, separators=(",", ":")).encode(), dtype=np.uint8),
+                            hashes=np.concatenate(self.hashes) if self.hashes else np.zeros(0, np.uint64),
+                            nz_idx=np.stack(self.nz_idx) if self.nz_idx else np.zeros((0, NZ), np.int64),
+                            nz_val=np.stack(self.nz_val).astype(np.float32) if self.nz_val else np.zeros((0, NZ), np.float32))
+
+
+def load(path):
+    """-> {key: [record dict]} with keys name, kind, N, M, hashes [N][nblk], nz_idx [NZ] (-1 = unused), nz_val [NZ], ref32_flips"""
+    z = np.load(path)
+    meta = json.loads(bytes(z["meta"]).decode())
+    hashes, nz_idx, nz_val = z["hashes"], z["nz_idx"], z["nz_val"]
+    out = {}
+    for key, recs in meta.items():
+        lst = []
+        for name, kind, N, M, off, flips, row in recs:
+            bs = block_size(M)
+            nblk = (M + bs - 1) // bs
+            lst.append({"name": name, "kind": kind, "N": N, "M": M, "hashes": hashes[off:off + N * nblk].reshape(N, nblk),
+                        "nz_idx": nz_idx[row], "nz_val": nz_val[row], "ref32_flips": flips})
+        out[key] = lst
+    return out
+
+
+def near_zero(pre_flat):
+    """the NZ elements of smallest magnitude: (flat indices int64 [NZ], values float64 [NZ]); unused slots are -1 / 0"""
+    idx = np.full(NZ, -1, dtype=np.int64)
+    val = np.zeros(NZ, dtype=np.float64)
+    n = pre_flat.size
+    if n:
+        k = min(NZ, n)
+        a = np.abs(pre_flat)
+        sel = np.argpartition(a, k - 1)[:k] if k < n else np.arange(n)
+        sel = sel[np.argsort(a[sel], kind="stable")]
+        idx[:k] = sel
+        val[:k] = pre_flat[sel]
+    return idx, val
+
+
+class Matcher:
+    """Matches the gated tensors of another implementation's iteration, sample by sample, with the reference records of that iteration and
+    counts the decisions that differ. The other side may run its networks in another order, on other batch compositions, or gate a tensor
+    the reference has no record for (those stay unmatched): a sample is matched by CONTENT - the untaken reference sample of the same kind
+    and size that agrees in the most blocks, accepted when at least half of the blocks agree."""
+
+    def __init__(self, records):
+        self.records = records
+        self.by_size = {}
+        for ri, r in enumerate(records):
+            self.by_size.setdefault((r["kind"], r["M"]), []).append(ri)
+        self.taken = [np.zeros(r["N"], dtype=bool) for r in records]
+        self.flips = {}            # record name -> decisions that differ (lower bound: >= 1 per differing block, exact where the near-zero list covers them)
+        self.blocks = {}           # record name -> (differing blocks, compared blocks)
+        self.unmatched_other = 0
+
+    def feed(self, kind, dec, optional=False):
+        """dec: uint8 [N][M] decisions of one gated tensor of the other implementation"""
+        N, M = dec.shape
+        cands = self.by_size.get((kind, M), [])
+        if not cands:
+            self.unmatched_other += 0 if optional else N
+            return
+        h = block_hashes(dec)
+        nblk = h.shape[1]
+        for n in range(N):
+            best, best_score = None, -1
+            for ri in cands:
+                r = self.records[ri]
+                score = (r["hashes"] == h[n][None, :]).sum(axis=1)
+                score = np.where(self.taken[ri], -1, score)
+                j = int(score.argmax())
+                if score[j] > best_score:
+                    best, best_score = (ri, j), int(score[j])
+                    if best_score == nblk:
+                        break
+            if best is None or best_score * 2 < nblk:
+                self.unmatched_other += 0 if optional else 1
+                continue
+            ri, j = best
+            self.taken[ri][j] = True
+            r = self.records[ri]
+            differ = nblk - best_score
+            exact = 0
+            if kind == "act" and differ:
+                lo, hi = j * M, (j + 1) * M
+                for i, v in zip(r["nz_idx"], r["nz_val"]):
+                    if lo <= i < hi and bool(dec[n, i - lo]) != bool(v > 0):
+                        exact += 1
+            name = r["name"]
+            self.flips[name] = self.flips.get(name, 0) + max(differ, exact)
+            b = self.blocks.get(name, (0, 0))
+            self.blocks[name] = (b[0] + differ, b[1] + nblk)
+
+    def unmatched_reference(self):
+        """[(record name, samples never matched)]"""
+        return [(r["name"], int((~t).sum())) for r, t in zip(self.records, self.taken) if not t.all()]
+
+    def flips_by_network(self):
+        out = {}
+        for name, c in self.flips.items():
+            net = name.split(".")[0]
+            out[net] = out.get(net, 0) + c
+        return out
+
+
+# the gates a gradient passes on its way from a sub-network's parameters to the losses = the gates whose flips move that gradient (a flipped gate
+# UPSTREAM of a parameter moves its gradient by the rounding-size change of the forward value only): per sub-network of the parameter, the
+# sub-networks whose gates lie downstream of it in some lesson (trainer/hw_with_style_trainer.py:514-892)
+DOWNSTREAM = {
+    "discriminator": {"discriminator"},
+    "spacer": {"spacer"},
+    "generator": {"generator", "discriminator", "hwr", "encoder"},
+    "style_extractor": {"style_extractor", "spacer", "generator", "discriminator", "hwr", "encoder"},
+    "hwr": {"hwr", "style_extractor", "spacer", "generator", "discriminator", "encoder"},
+}
+
+
+class RefRecorder:
+    """Build-container side: patches torch.nn.functional's relu / leaky_relu / max_pool1d / max_pool2d (every gate of the reference goes through
+    them) and names each call by the innermost module that is executing (forward hooks on every module of the model and the perceptual encoder)."""
+
+    def __init__(self, roots):
+        import torch
+        import torch.nn.functional as F
+        self.torch, self.F = torch, F
+        self.stack = []
+        self.depth = 0
+        self.cur = None
+        self.records = []
+        self.handles = []
+        seen = set()
+        for prefix, root in roots:
+            for name, mod in root.named_modules():
+                if id(mod) in seen:
+                    continue
+                seen.add(id(mod))
+                full = (prefix + "." + name).strip(".") if prefix else name
+                self.handles.append(mod.register_forward_pre_hook(lambda m, a, full=full: self.stack.append(full)))
+                self.handles.append(mod.register_forward_hook(lambda m, a, o: (self.stack.pop(), None)[1]))
+        self.saved = {k: getattr(F, k) for k in ("relu", "leaky_relu", "max_pool2d", "max_pool1d")}
+        rec = self
+
+        # (a tensor subclass - the fp64-widened run has some - makes the original function re-dispatch through the PATCHED name: `depth`
+        # keeps such a nested call from being recorded twice)
+        def relu(input, inplace=False):
+            if rec.depth == 0:
+                rec._act(input)
+            rec.depth += 1
+            try:
+                return rec.saved["relu"](input, inplace=inplace)
+            finally:
+                rec.depth -= 1
+
+        def leaky_relu(input, negative_slope=0.01, inplace=False):
+            if rec.depth == 0:
+                rec._act(input)
+            rec.depth += 1
+            try:
+                return rec.saved["leaky_relu"](input, negative_slope, inplace)
+            finally:
+                rec.depth -= 1
+
+        def max_pool2d(input, kernel_size, stride=None, padding=0, dilation=1, ceil_mode=False, return_indices=False):
+            rec.depth += 1
+            try:
+                out, idx = rec.saved["max_pool2d"](input, kernel_size, stride, padding, dilation, ceil_mode=ceil_mode, return_indices=True)
+            finally:
+                rec.depth -= 1
+            if rec.depth == 0:
+                rec._pool(input, out, idx, kernel_size, stride, padding)
+            return (out, idx) if return_indices else out
+
+        def max_pool1d(input, kernel_size, stride=None, padding=0, dilation=1, ceil_mode=False, return_indices=False):
+            rec.depth += 1
+            try:
+                out, idx = rec.saved["max_pool1d"](input, kernel_size, stride, padding, dilation, ceil_mode=ceil_mode, return_indices=True)
+            finally:
+                rec.depth -= 1
+            if rec.depth == 0:
+                k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+                s = k if stride is None else (stride if isinstance(stride, int) else stride[0])
+                p = padding if isinstance(padding, int) else padding[0]
+                rec._pool(input.unsqueeze(2), out.unsqueeze(2), idx.unsqueeze(2), (1, k), (1, s), (0, p))
+            return (out, idx) if return_indices else out
+        F.relu, F.leaky_relu, F.max_pool2d, F.max_pool1d = relu, leaky_relu, max_pool2d, max_pool1d
+
+    def remove(self):
+        for k, f in self.saved.items():
+            setattr(self.F, k, f)
+        for h in self.handles:
+            h.remove()
+
+    def begin(self, key):
+        self.cur, self.records = key, []
+
+    def end(self):
+        recs, self.cur, self.records = self.records, None, []
+        return recs
+
+    def _name(self):
+        return self.stack[-1] if self.stack else "trainer"       # (the hinge losses' relu, trainer :797-806: outside every module)
+
+    def _act(self, x):
+        if self.cur is None:
+            return
+        t = x.detach()
+        N = t.shape[0]
+        pre = np.array(t.reshape(N, -1).double().numpy(), copy=True)      # (inplace activations overwrite their input)
+        self.records.append({"name": self._name(), "kind": "act", "dec": (pre > 0).astype(np.uint8), "pre": pre})
+
+    def _pool(self, x, out, idx, kernel, stride, padding):
+        if self.cur is None:
+            return
+        kh, kw = (kernel, kernel) if isinstance(kernel, int) else kernel
+        stride = (kh, kw) if stride is None else stride
+        sh, sw = (stride, stride) if isinstance(stride, int) else stride
+        ph, pw = (padding, padding) if isinstance(padding, int) else padding
+        N, C, H, W = x.shape
+        P, Q = out.shape[2], out.shape[3]
+        torch = self.torch
+        ih, iw = idx // W, idx % W
+        oh = torch.arange(P).view(1, 1, P, 1) * sh - ph
+        ow = torch.arange(Q).view(1, 1, 1, Q) * sw - pw
+        winner = (ih - oh) * kw + (iw - ow)
+        live = out.detach() > 0
+        self.records.append({"name": self._name(), "kind": "pool", "dec": pool_codes(winner.reshape(N, -1).numpy(), live.reshape(N, -1).numpy()), "pre": None})

@@ -2,6 +2,7 @@
 UNMODIFIED reference trainer produced on the same seeded weights, synthetic batches and RNG streams
 (tests/golden/trainer_cycle.json, made by tools/gen_golden_trainer.py)."""
 import json
+import math
 import os
 import random
 
@@ -336,3 +337,48 @@ def test_masked_stash_holds_zeros_outside_its_mask(cuda):
     s4 = flat.stash(); flat.touched[:] = False
     check(s4, want)
     torch.cuda.synchronize()
+
+
+def test_taped_lessons_run_at_a_batch_above_the_banked_backward_limit(cuda, tmp_path):
+    """the style MLP chain / AdaIN affine bank hold at most 16 rows in their BACKWARD kernels. A taped generator forward runs under
+    no_grad, which used to look like a forward-only call and put the banked ops on the tape at B = 17 - the batched backward then raised.
+    With 17 lines per batch the balanced (taped) gen / auto lessons must train, on the per-layer path, with finite losses and gradients."""
+    from handwriting_line_generation_amd import rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    rng.set_mode("device", seed=11)
+    torch.manual_seed(3); np.random.seed(3); random.seed(3)
+    trainer, _ = build_gan_trainer("iam_gan", 17, 1, width=128, label_len=6, workdir=str(tmp_path), curriculum=[["no-step", "gen"], ["auto", "auto-gen"]])
+    assert trainer._batch_gen_backward and trainer.balance_loss
+    for it in range(2):
+        log = trainer._train_iteration(it)
+        assert all(math.isfinite(float(v)) for v in log.values()), log
+    torch.cuda.synchronize()
+    g = trainer.flat.flat_grad
+    assert bool(torch.isfinite(g).all())
+    gen = trainer.model.generator
+    assert all(p.grad is not None and float(p.grad.abs().sum()) > 0 for m in gen.style_emb if hasattr(m, "weight") for p in (m.weight,))
+
+
+def test_discriminator_applied_twice_in_one_pass_deferred_equals_eager(cuda, tmp_path):
+    """a lesson with both 'disc' and 'gen' applies the discriminator twice inside ONE backward pass, so every spectral-norm layer's
+    deferred sigma-path backward is queued twice with the same destination; entries of one hwg_spectral_bwd_multi launch are added with plain
+    read-modify-writes, so the two must go to consecutive launches. Deferred vs eager from the same seeds: bit-identical losses and weights."""
+    from handwriting_line_generation_amd import ops, rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    outs = []
+    for defer in (False, True):
+        rng.set_mode("device", seed=11)
+        torch.manual_seed(3); np.random.seed(3); random.seed(3)
+        trainer, _ = build_gan_trainer("iam_gan", 2, 2, width=256, label_len=12, workdir=str(tmp_path / ("d%d" % defer)), curriculum=[["disc", "gen"]])
+        trainer._defer_reduce = defer
+        torch.manual_seed(5); np.random.seed(5); random.seed(5)
+        sn_before = ops._defer["sn_launches"]
+        logs = [trainer._train_iteration(it) for it in range(3)]
+        torch.cuda.synchronize()
+        outs.append((logs, {k: v.detach().clone() for k, v in trainer.model.state_dict().items()}, ops._defer["sn_launches"] - sn_before))
+    (la, sa, sna), (lb, sb, snb) = outs
+    assert sna == 0 and snb >= 6, (sna, snb)       # two passes (one per application of the discriminator) per flush
+    for it, (a, b) in enumerate(zip(la, lb)):
+        assert a == b, "iteration %d: %s vs %s" % (it, a, b)
+    for k, v in sa.items():
+        assert torch.equal(v, sb[k]), "%s differs with the deferred reduce" % k

@@ -17,6 +17,8 @@ Cases
 
 Recorded per iteration (fp32 run and fp64 run with identical draws, as tools/gen_golden_lessons.py): losses, fingerprints of every
 pre-clip gradient / stashed set / parameter update, the discriminator's inputs, and the per-tensor gradient RMS used for the moments.
+Round 5: the fp64 run also records every DISCRETE decision of the iteration (ReLU / LeakyReLU signs, max-pool winners; oracle/gates.py) as
+block hashes + the near-zero pre-activations -> tests/golden/<case>_gates.npz, with the reference's own fp32-vs-fp64 flip count per gate.
 
 Build container only:   python tools/gen_golden_tf.py [case ...]
 """
@@ -193,6 +195,13 @@ def run_units(case, wide, out_path, rms_path):
     model.discriminator.register_forward_pre_hook(lambda mod, args: d_calls.append([list(args[0].shape)] + fingerprint(args[0], 0)))
     if c["warm"]:
         base_sd, base_prev = trained_sd(model, os.path.join(GOLD, "%s_state.npz" % case), wide)
+    # the discrete decisions of every iteration (oracle/gates.py): the fp32 run leaves its decisions in /tmp, the fp64 run counts how many of
+    # them its own differ in (the reference's own flip count) and writes the compact fp64 record the HIP run is compared with
+    from oracle import gates
+    gate_rec = gates.RefRecorder([("", model), ("encoder", trainer.encoder)])
+    gate_dir = "/tmp/hwg_tf_%s_gates32" % case
+    os.makedirs(gate_dir, exist_ok=True)
+    gate_file = gates.GateFile()
     units = []
     for u, positions in enumerate(UNITS):
         if c["warm"]:
@@ -215,7 +224,22 @@ def run_units(case, wide, out_path, rms_path):
             cur["key"] = "%d:%d" % (u, pos)
             snap = [p.detach().clone() for p in plist]
             del d_calls[:]
+            gate_rec.begin(cur["key"])
             log = trainer._train_iteration(it)
+            recs = gate_rec.end()
+            gpath = os.path.join(gate_dir, "%d_%d.npz" % (u, pos))
+            if not wide:
+                np.savez(gpath, names=np.array([r["name"] + "|" + r["kind"] for r in recs]), **{"d%d" % i: r["dec"] for i, r in enumerate(recs)})
+            else:
+                z32 = np.load(gpath)
+                n32 = list(z32["names"])
+                same_seq = n32 == [r["name"] + "|" + r["kind"] for r in recs]
+                for i, r in enumerate(recs):
+                    d32 = z32["d%d" % i] if same_seq else None
+                    flips = int((d32 != r["dec"]).sum()) if d32 is not None and d32.shape == r["dec"].shape else -1
+                    nzi, nzv = gates.near_zero(r["pre"].reshape(-1)) if r["kind"] == "act" else (np.full(gates.NZ, -1, np.int64), np.zeros(gates.NZ))
+                    gate_file.add(cur["key"], r["name"], r["kind"], r["dec"].shape[1], gates.block_hashes(r["dec"]), nzi, nzv, flips)
+            del recs
             upd = [fingerprint(p.detach() - s, k) for k, (p, s) in enumerate(zip(plist, snap))]
             stashes = [[fingerprint(R, k) if R is not None else None for k, R in enumerate(sg)] for sg in getattr(trainer, "saved_grads", [])]
             its.append({"iteration": it, "position": pos, "lesson": trainer.curriculum.getLesson(it), "log": {k: float(v) for k, v in log.items()},
@@ -223,9 +247,12 @@ def run_units(case, wide, out_path, rms_path):
                         "update": [x if x[1] != 0.0 else None for x in upd], "stashes": stashes, "d_inputs": [list(x) for x in d_calls]})
             print(case, "fp64" if wide else "fp32", "unit", u, "it", it, its[-1]["lesson"], its[-1]["log"], flush=True)
         units.append(its)
+    gate_rec.remove()
     if not wide:
         with open(rms_path, "w") as f:
             json.dump(rms_at_clip, f)
+    else:
+        gate_file.save(out_path[:-5] + "_gates.npz")
     with open(out_path, "w") as f:
         json.dump({"names": names, "units": units}, f)
 
@@ -264,6 +291,10 @@ def main():
         with open(path, "w") as f:
             json.dump(out, f, separators=(",", ":"))
         print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+        import shutil
+        gpath = os.path.join(GOLD, "%s_gates.npz" % case)
+        shutil.copyfile("/tmp/hwg_tf_%s_1_gates.npz" % case, gpath)
+        print("wrote", gpath, os.path.getsize(gpath) // 1024, "KiB")
 
 
 if __name__ == "__main__":

@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--random-init-aux", action="store_true",
                     help="allow a RANDOM-INIT perceptual encoder / recogniser when trainer.encoder_weights / model.pretrained_hwr do not exist "
                          "(the reference fails there); implied by --synthetic")
+    ap.add_argument("--reference-gradients", action="store_true",
+                    help="also compute the parameter gradients the reference computes and nothing reads (the frozen recogniser's; the "
+                         "discriminator's in gen / auto lessons): the reference's launches, same weights and losses to the bit, ~20 %% slower")
     args = ap.parse_args()
 
     resume = args.resume
@@ -58,6 +61,9 @@ def main():
         config["gpu"] = args.gpu
     if args.iterations is not None:
         config["trainer"]["iterations"] = args.iterations
+    # dead-gradient elimination is the drop-in's default: losses, updates and every weight are bit-identical to the loop
+    # that computes them (tests/test_trainer_gpu.py::test_skip_unused_grads_changes_no_weight_and_no_loss); a config key or the flag decide otherwise
+    config["trainer"].setdefault("skip_unused_grads", 0 if args.reference_gradients else 1)
 
     # Random streams: one base seed per run (config["seed"] or drawn here and shared by all ranks), rank r draws from stream
     # (base, r): generator noise and Dropout2d masks differ between data-parallel ranks and between runs. The Philox offset is
