@@ -441,9 +441,9 @@ def main():
             g[0] += flops; g[1] += dt; g[2] += 1
         if os.environ.get("HWG_CONV_DUMP"):
             with open(os.environ["HWG_CONV_DUMP"], "w") as fh:
-                fh.write("# per-shape MFMA conv launches in the profiled cycles after the timed region (%d steps): time_ms  launches  avg_us  TFLOP/s  kind  shape(N,H,W,C,K,R,S,stride,pad,dil,mode)\n" % prof_steps)
+                fh.write("# per-shape MFMA conv launches in the profiled cycles after the timed region (%d steps): time_ms  launches  avg_us  TFLOP/s  kind  shape(N,H,W,C,K,R,S,stride,pad,dil,mode,network)  work (FLOPs; bytes for the reduce kinds)\n" % prof_steps)
                 for (kind, shape), (fl, sec, n) in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
-                    fh.write("%9.3f %6d %9.1f %7.1f  %s %s\n" % (sec * 1e3, n, sec / n * 1e6, fl / sec / 1e12 if sec > 0 else 0, kind, shape))
+                    fh.write("%9.3f %6d %9.1f %7.1f  %s %s  %.6e\n" % (sec * 1e3, n, sec / n * 1e6, fl / sec / 1e12 if sec > 0 else 0, kind, shape, fl))
         # the north-star target is stated on the G+D conv stack: every conv kernel (MFMA, direct, their reduce passes) launched by the
         # generator's or the discriminator's layers, forward and backward, algorithmic FLOPs / kernel time
         gd = {"G": [0.0, 0.0], "D": [0.0, 0.0]}
@@ -483,9 +483,10 @@ def main():
                     v["mfma_issued_frac"] = round(v["achieved"] / 2.25 / PEAK_FP32_MFMA_TFLOPS, 4)
             gfl, gsec = gd["G"][0] + gd["D"][0], gd["G"][1] + gd["D"][1]
             if gsec > 0:
-                # FLOPs are those of the launches this implementation makes ("minimum-necessary": the discriminator's weight gradients are not
-                # computed in gen / auto lessons, where the reference computes and discards them - SURVEY 8d counts 231.9 GFLOP/step "as
-                # executed" by the reference against the ~207 counted here); 3x3 layers on the Winograd kernels count their direct-form FLOPs
+                # FLOPs are those of the launches made in the profiled cycles = the reference's launches, as executed (231.9 GFLOP per
+                # step at 8 lines; the discriminator's weight gradients of gen / auto lessons are computed here as there). 3x3 layers on the
+                # Winograd kernels count their direct-form FLOPs; time = every conv kernel of the two networks incl. their reduce passes.
+                # tools/prof_summary.py gd <HWG_CONV_DUMP file> recomputes these figures from the per-shape dump of the same run.
                 roofline["gd_conv_stack"] = {"flop_variant": "as executed by this implementation (the reference's launches, discriminator weight gradients of gen / auto lessons included)",
                                              "achieved": round(gfl / gsec / 1e12, 3), "frac": round(gfl / gsec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                              "gflop_per_step": round(gfl / 1e9 / max(prof_steps, 1), 1), "ms_per_step": round(gsec * 1e3 / max(prof_steps, 1), 3),
@@ -496,7 +497,7 @@ def main():
         if roofline:
             # HBM bytes per launch of the dominant kernel: PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately with rocprofv3 on this
             # same command and corrected per MI355X_MICROARCH.md) are committed under profiles/; they cannot be collected from inside bench.py
-            for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", name)))
                     if pm.get("workload") == args.workload and dom in pm["kernels"]:
@@ -509,7 +510,7 @@ def main():
             # ... and per layer shape (tools/pmc_shapes.py replays the step's top conv shapes under the same counters): measured HBM bytes against
             # the one-pass operand bytes 4*(input + weights + output), weighted by this run's launch counts
             try:
-                shapes_file = next((f for f in ("r04_pmc_shapes.json", "r03_pmc_shapes.json", "r02_pmc_shapes.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r02_pmc_shapes.json")
+                shapes_file = next((f for f in ("r05_pmc_shapes.json", "r04_pmc_shapes.json", "r03_pmc_shapes.json", "r02_pmc_shapes.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r02_pmc_shapes.json")
                 ps = json.load(open(os.path.join(ROOT, "profiles", shapes_file)))
                 launches = {(k, repr(sh)): v[2] for (k, sh), v in by_shape.items()}
                 tot = {}

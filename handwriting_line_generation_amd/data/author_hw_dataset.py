@@ -67,12 +67,15 @@ def _resize(img, percent):
 
 
 def affine_trans(img, skew, strech):
-    """horizontal stretch + shear around the mid-line (augmentation.affine_trans): x' = strech*x + tan(skew)*(y - h/2), white border"""
+    """horizontal stretch + shear around the mid-line (augmentation.affine_trans): x' = strech*x + tan(skew)*(y - h/2), white border.
+    cv2.warpAffine maps pixel INDICES (dst(x', y') = src(M^-1 (x', y'))); PIL evaluates its destination -> source map at pixel CENTRES
+    (x' + 0.5, y' + 0.5) and takes 0.5 off the result, so the constant term is moved by 0.5 (1 - A - B) to sample the same source positions."""
     from PIL import Image
     m = math.tan(skew)
     h = img.shape[0] / 2
     size = (int(img.shape[1] * strech), img.shape[0])
-    coeffs = (1.0 / strech, -m / strech, h * m / strech, 0.0, 1.0, 0.0)      # PIL wants the destination -> source map
+    A, B, C = 1.0 / strech, -m / strech, h * m / strech      # PIL wants the destination -> source map (index convention so far)
+    coeffs = (A, B, C + 0.5 * (1.0 - A - B), 0.0, 1.0, 0.0)
     return np.asarray(Image.fromarray(img).transform(size, Image.AFFINE, coeffs, resample=Image.BILINEAR, fillcolor=255))
 
 

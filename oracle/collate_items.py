@@ -60,6 +60,34 @@ def rimes_xml(n_pages=4, seed=9):
     return RIMES_XML % "\n".join(pages)
 
 
+def rng_fingerprint():
+    """numpy's global RNG state as [position, sum of the key words, the next uniform draw a copy of the state would give]"""
+    st = np.random.get_state()
+    rs = np.random.RandomState()
+    rs.set_state(st)
+    return [int(st[2]), int(np.asarray(st[1], dtype=np.uint64).sum()), float(rs.random_sample())]
+
+
+def fake_rimes(root, n_pages=4, seed=1):
+    """fabricated RIMES directory in the reference's layout: `images_gray/page%03d.png` (dark strokes everywhere on white paper, so every line
+    crop has ink) + the two annotation files of rimes_xml()"""
+    import os
+    from PIL import Image, ImageDraw
+    os.makedirs(os.path.join(root, "images_gray"), exist_ok=True)
+    text = rimes_xml(n_pages)
+    for fn in ("lines_training_2011.xml", "lines_eval_2011_annotated.xml"):
+        with open(os.path.join(root, fn), "w") as f:
+            f.write(text)
+    rs = np.random.RandomState(seed)
+    for p in range(n_pages):
+        img = Image.new("L", (1000, 420), 255)
+        dr = ImageDraw.Draw(img)
+        for _ in range(300):
+            x, y = int(rs.randint(0, 980)), int(rs.randint(0, 400))
+            dr.rectangle([x, y, x + int(rs.randint(3, 18)), y + int(rs.randint(6, 30))], fill=int(rs.randint(10, 120)))
+        img.save(os.path.join(root, "images_gray", "page%03d.png" % p))
+
+
 IAM_TEXTS = ["the quick brown", "fox jumps", "over a lazy dog", "pack my box", "with five dozen", "liquor jugs", "sphinx of black quartz",
              "he said &quot;no&quot;", "Tom &amp; Co.", "a", "judge my vow", "it&apos;s 4 o&apos;clock"]
 
