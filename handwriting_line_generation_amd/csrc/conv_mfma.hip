@@ -27,6 +27,12 @@ struct ConvK {
   int ntm_pad;     // ntm rounded up to a multiple of 8 (XCD remap)
   int nsplit;      // split-K: the taps x channel-steps loop is cut into nsplit ranges, one workgroup each (blockIdx.y % nsplit)
   float* part;     // nsplit > 1: partial outputs [nsplit][N*P*Q*K] in y's layout, summed (+bias) by conv_split_reduce_kernel
+  int dbg;         // ABL kernel only (HWG_CONV_DBG, timing ablations of the 128 x 128 tile - results are garbage): 1 no global loads in the loop, 2 no LDS
+                   // stores, 4 no barrier, 8 no MFMAs / fragment reads, 16 no fragment reads (MFMAs on stale registers), 32 nothing (the ABL build itself).
+                   // Round 5 (tools/probes/probe_r5_abl7.txt, warm clocks, 4x66x1026x64->128 4x4 stride 2): 147.6 us as shipped; MFMAs alone 130 us
+                   // (132 TFLOP/s - the ceiling of this tiling at the clock the chip sustains, 0.84 of the nominal peak); the shipped kernel runs at
+                   // 0.88 of that ceiling. A single-basic-block rolled pipeline (burst interleaved with the MFMAs, barrier behind the last fragment
+                   // read) and a start offset between co-resident workgroups both measured +-1 % and were removed again.
 };
 
 // PF = register prefetch depth in K steps. 1: the loads of step t+1 are issued before the MFMAs of step t and consumed right after them
@@ -36,7 +42,7 @@ struct ConvK {
 // s_waitcnt for most of every step.
 // WK > 1: WK wavefronts share every (M, N) sub-tile and split each K step between them (their partial sums meet in LDS once, at the end):
 // a second wavefront per SIMD for layers whose grid is one small workgroup per CU, without a second launch to add partial images.
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int PF = 1, int WK = 1>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int PF = 1, int WK = 1, bool ABL = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(ConvK a) {
   constexpr int NT = 64 * WAVES_M * WAVES_N * WK;  // 4, 8 or 16 wavefronts per workgroup
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -203,6 +209,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
     constexpr int NSG = BK / 8 / WK;        // groups of 8 k values of this wavefront's share of the step
     static_assert(NSG >= 1, "K step too short for the K-split wavefronts");
     float4 af[2][MI], bf[2][NI];
+    if constexpr (ABL) {
+      for (int s_ = 0; s_ < 2; ++s_) {
+        for (int mi = 0; mi < MI; ++mi) af[s_][mi] = make_float4(lane * 1e-3f, 1.f, 2.f, 3.f);
+        for (int ni = 0; ni < NI; ++ni) bf[s_][ni] = make_float4(1.f, lane * 1e-3f, 2.f, 3.f);
+      }
+    }
     auto frag = [&](int sg, int slot) {
       const int koff = 4 * (2 * (wk * NSG + sg) + lhi);
 #pragma unroll
@@ -210,10 +222,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) bf[slot][ni] = *reinterpret_cast<const float4*>(Bb + (wn0 + ni * 32 + l31) * LD + koff);
     };
-    frag(0, 0);
+    if (!ABL || !(a.dbg & 16)) frag(0, 0);
 #pragma unroll
     for (int sg = 0; sg < NSG; ++sg) {
-      if (sg + 1 < NSG) frag(sg + 1, (sg + 1) & 1);
+      if (sg + 1 < NSG && (!ABL || !(a.dbg & 16))) frag(sg + 1, (sg + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -256,10 +268,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
     if (T > 1) load_tile(ra[0], rb[0], ma[0]);
     __syncthreads();
     for (int t = 0; t < T; ++t) {
-      if (t + 1 < T) store_tile((t + 1) & 1, ra[0], rb[0], ma[0]);
-      if (t + 2 < T) load_tile(ra[0], rb[0], ma[0]);
-      compute(t & 1);
-      __syncthreads();
+      if (t + 1 < T && (!ABL || !(a.dbg & 2))) store_tile((t + 1) & 1, ra[0], rb[0], ma[0]);
+      if (t + 2 < T && (!ABL || !(a.dbg & 1))) load_tile(ra[0], rb[0], ma[0]);
+      if (!ABL || !(a.dbg & 8)) compute(t & 1);
+      if (!ABL || !(a.dbg & 4)) __syncthreads();
     }
   } else {
     // register set (t & 1) carries tile t between its loads (issued during step t-2) and its LDS store (after the MFMAs of step t-1);
@@ -1045,7 +1057,10 @@ void launch_conv(const ConvK& k, dim3 grid, hipStream_t st, int pf) {
       return;
     }
   }
-  if (pf == 3) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 3>), grid, dim3(64 * WM_ * WN_), 0, st, k);
+  if constexpr (BM == 128 && BN == 128 && BK == 32) {
+    if (k.dbg) { hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 3, 1, true>), grid, dim3(64 * WM_ * WN_), 0, st, k); return; }
+  }
+  if (pf >= 3) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 3>), grid, dim3(64 * WM_ * WN_), 0, st, k);
   else if (pf == 2) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 2>), grid, dim3(64 * WM_ * WN_), 0, st, k);
   else hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM_, WN_, 1>), grid, dim3(64 * WM_ * WN_), 0, st, k);
 }
@@ -1300,6 +1315,7 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
   k.accumulate = accumulate;
   k.nsplit = p.nsplit;
   k.part = (float*)workspace;
+  k.dbg = hwg_tune().conv_dbg;
   const int bm = p.bm, bn = p.bn, bk = p.bk;
   k.ntm = hwg_cdiv(p.Mc, bm);
   k.ntm_pad = (k.ntm + 7) / 8 * 8;

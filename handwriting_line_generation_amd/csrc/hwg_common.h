@@ -67,6 +67,7 @@ struct HwgTune {
   int wwg_debug;         // HWG_WWG_DEBUG
   int conv_pf;           // HWG_CONV_PF: register prefetch depth of the implicit-GEMM conv kernel (1 or 2)
   int conv_wk;           // HWG_CONV_WK: 2 (default) = K-split wavefront pairs on the 64 x 64 direct conv tile (8 wavefronts), 1 = four wavefronts
+  int conv_dbg;          // HWG_CONV_DBG: timing ablations of the 128 x 128 direct conv kernel (garbage results), 0 default
   int c1_mfma;           // HWG_C1_MFMA: 0 = single-input-channel forward convs on the VALU kernel (A/B timing), 1 default = taps-as-K on the matrix cores
   int to1_lanes;         // HWG_TO1_LANES: 0 = one wave per output pixel whenever taps x channel groups > 16 (A/B timing), 1 default = lanes cover one tap's channel groups
   int conv_lds;          // HWG_CONV_LDS: 0 keeps strided layers on the per-tap gather kernel (A/B timing), 1 default

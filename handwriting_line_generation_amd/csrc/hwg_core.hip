@@ -51,6 +51,7 @@ const HwgTune& hwg_tune() {
     t->wgrad_reduce_rows = tune_int("HWG_WGRAD_REDUCE_ROWS", 1);
     t->conv_wk = tune_int("HWG_CONV_WK", 2);
     t->c1_mfma = tune_int("HWG_C1_MFMA", 1);
+    t->conv_dbg = tune_int("HWG_CONV_DBG", 0);
     tune_str(t->wino_force, sizeof(t->wino_force), "HWG_WINO_FORCE");
     tune_str(t->conv_force, sizeof(t->conv_force), "HWG_CONV_FORCE");
     tune_str(t->wgrad_force, sizeof(t->wgrad_force), "HWG_WGRAD_FORCE");

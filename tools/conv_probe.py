@@ -8,7 +8,7 @@ dev = torch.device('cuda:0')
 st = torch.cuda.current_stream().cuda_stream
 
 
-def bench(fn, iters=30):
+def bench(fn, iters=int(os.environ.get('PROBE_ITERS', '60'))):
     for _ in range(5): fn()
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -19,6 +19,25 @@ def bench(fn, iters=30):
 
 
 lines = [l for l in (sys.argv[1:] or os.environ.get("PROBE", "").split(";")) if l.strip()]
+
+
+def warm_clocks(ms=400.0):
+    """the first ~50 ms of MFMA work after idle run at a lower clock (a probe line is only ~6 ms long): keep the matrix cores busy first"""
+    N, H, W, C, K = 8, 32, 256, 256, 256
+    x = torch.randn(N, H, W, C, device=dev); y = torch.empty(N, H, W, K, device=dev); wp = torch.randn(9, K, C, device=dev) * 0.05
+    d = ops._desc(N, H, W, C, K, 3, 3, (1, 1), (1, 1), (1, 1), H, W, 0)
+    need = L.query("hwg_conv_fwd_workspace", d.ptr); ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    t = 0.0
+    while t < ms:
+        e0.record()
+        for _ in range(50): L.call("hwg_conv_fwd", d.ptr, x, wp, None, y, 0, ws, ws.numel(), st)
+        e1.record(); torch.cuda.synchronize()
+        t += e0.elapsed_time(e1)
+
+
+if not os.environ.get("PROBE_NO_WARM"):
+    warm_clocks()
 for line in lines:
     parts = line.split()
     v = [int(t) for t in parts[0].split(",")]
