@@ -14,7 +14,9 @@ A record = one gated tensor of one call, in the reference's element order (sampl
   kind      "act" (decision = pre-activation > 0) | "pool" (decision = 1 + winner position inside the window, 0 for a window whose maximum is <= 0)
   N, M      samples, decisions per sample
   hashes    uint64 [N][ceil(M / bs)]: one hash per block of `bs` consecutive decisions of a sample (bs = block_size(M))
-  nz        the NZ smallest |pre-activation| of the record: flat index into [N][M] and the value ("act" only)
+  nz        the NZ decisions of the record that are closest to flipping: flat index into [N][M], the margin (act: the pre-activation itself;
+            pool: maximum minus runner-up of a live window) and the reference's decision code there - enough to LOCATE a flip inside a block
+            whose hash differs, and to impose the reference's decision on the other side (tests: gate forcing)
 Blocks are per SAMPLE so that a record can be matched sample by sample, whatever batch composition or call order the other side uses.
 """
 import json
@@ -80,9 +82,10 @@ class GateFile:
         self.hashes = []
         self.nz_idx = []
         self.nz_val = []
+        self.nz_code = []
         self._off = 0
 
-    def add(self, key, name, kind, M, hashes, nz_idx, nz_val, ref32_flips):
+    def add(self, key, name, kind, M, hashes, nz_idx, nz_val, ref32_flips, nz_code=None):
         N, nblk = hashes.shape
         assert nblk == (M + block_size(M) - 1) // block_size(M)
         self.meta.setdefault(key, []).append([name, kind, int(N), int(M), self._off, ref32_flips, len(self.nz_idx)])
@@ -90,12 +93,14 @@ class GateFile:
         self._off += hashes.size
         self.nz_idx.append(nz_idx)
         self.nz_val.append(nz_val)
+        self.nz_code.append(np.asarray(nz_code, dtype=np.uint8) if nz_code is not None else (np.asarray(nz_val) > 0).astype(np.uint8))
 
     def save(self, path):
         np.savez_compressed(path, meta=np.frombuffer(json.dumps(self.meta, separators=(",", ":")).encode(), dtype=np.uint8),
                             hashes=np.concatenate(self.hashes) if self.hashes else np.zeros(0, np.uint64),
                             nz_idx=np.stack(self.nz_idx) if self.nz_idx else np.zeros((0, NZ), np.int64),
-                            nz_val=np.stack(self.nz_val).astype(np.float32) if self.nz_val else np.zeros((0, NZ), np.float32))
+                            nz_val=np.stack(self.nz_val).astype(np.float32) if self.nz_val else np.zeros((0, NZ), np.float32),
+                            nz_code=np.stack(self.nz_code) if self.nz_code else np.zeros((0, NZ), np.uint8))
 
 
 def load(path):
@@ -103,6 +108,7 @@ def load(path):
     z = np.load(path)
     meta = json.loads(bytes(z["meta"]).decode())
     hashes, nz_idx, nz_val = z["hashes"], z["nz_idx"], z["nz_val"]
+    nz_code = z["nz_code"] if "nz_code" in z.files else (nz_val > 0).astype(np.uint8)
     out = {}
     for key, recs in meta.items():
         lst = []
@@ -110,7 +116,7 @@ def load(path):
             bs = block_size(M)
             nblk = (M + bs - 1) // bs
             lst.append({"name": name, "kind": kind, "N": N, "M": M, "hashes": hashes[off:off + N * nblk].reshape(N, nblk),
-                        "nz_idx": nz_idx[row], "nz_val": nz_val[row], "ref32_flips": flips})
+                        "nz_idx": nz_idx[row], "nz_val": nz_val[row], "nz_code": nz_code[row], "ref32_flips": flips})
         out[key] = lst
     return out
 
@@ -145,10 +151,14 @@ class Matcher:
         self.flips = {}            # record name -> decisions that differ (lower bound: >= 1 per differing block, exact where the near-zero list covers them)
         self.blocks = {}           # record name -> (differing blocks, compared blocks)
         self.unmatched_other = 0
+        self.feed_seq = 0          # feed() calls so far (the other side's gated tensors, in its own order)
+        self.sites = []            # flips located through the near-zero lists: (record name, feed_seq, other side's sample, index in the sample, fp64 margin, fp64 decision code)
 
     def feed(self, kind, dec, optional=False):
         """dec: uint8 [N][M] decisions of one gated tensor of the other implementation"""
         N, M = dec.shape
+        seq = self.feed_seq
+        self.feed_seq += 1
         cands = self.by_size.get((kind, M), [])
         if not cands:
             self.unmatched_other += 0 if optional else N
@@ -174,11 +184,14 @@ class Matcher:
             r = self.records[ri]
             differ = nblk - best_score
             exact = 0
-            if kind == "act" and differ:
+            if differ:
                 lo, hi = j * M, (j + 1) * M
-                for i, v in zip(r["nz_idx"], r["nz_val"]):
-                    if lo <= i < hi and bool(dec[n, i - lo]) != bool(v > 0):
+                codes = r.get("nz_code")
+                for q, (i, v) in enumerate(zip(r["nz_idx"], r["nz_val"])):
+                    code = int(codes[q]) if codes is not None else int(v > 0)
+                    if lo <= i < hi and int(dec[n, i - lo]) != code:
                         exact += 1
+                        self.sites.append((r["name"], seq, n, int(i - lo), float(v), code))
             name = r["name"]
             self.flips[name] = self.flips.get(name, 0) + max(differ, exact)
             b = self.blocks.get(name, (0, 0))
@@ -316,4 +329,14 @@ class RefRecorder:
         ow = torch.arange(Q).view(1, 1, 1, Q) * sw - pw
         winner = (ih - oh) * kw + (iw - ow)
         live = out.detach() > 0
-        self.records.append({"name": self._name(), "kind": "pool", "dec": pool_codes(winner.reshape(N, -1).numpy(), live.reshape(N, -1).numpy()), "pre": None})
+        dec = pool_codes(winner.reshape(N, -1).numpy(), live.reshape(N, -1).numpy())
+        # margin of every live window: maximum minus runner-up (the winner masked out, pooled again)
+        x2 = x.detach().clone()
+        x2.view(N, C, -1).scatter_(2, idx.reshape(N, C, -1), float("-inf"))
+        self.depth += 1          # (a tensor subclass re-dispatches through the patched name: not a gate of the model)
+        try:
+            second = self.saved["max_pool2d"](x2, (kh, kw), (sh, sw), (ph, pw))
+        finally:
+            self.depth -= 1
+        margin = torch.where(live, (out.detach() - second).double(), torch.full_like(out.detach(), 1e30).double())
+        self.records.append({"name": self._name(), "kind": "pool", "dec": dec, "pre": None, "margin": margin.reshape(N, -1).numpy()})

@@ -337,6 +337,9 @@ def _tf_collect(kind, tag, names, got, ref32, ref64, bad, rows, skipped, fps=Non
         rows.append((tag, kind, n.split(".")[0], n, e_hip, e_ref, nrm, l1))
 
 
+GATE_FORCED = [0]      # elements nudged by the gate-forcing passes (diagnostic)
+
+
 class _GateRecorder:
     """Records every discrete decision of a training iteration - the sign behind every ReLU / LeakyReLU (elementwise, fused into a norm, the
     generator's noise + LeakyReLU epilogue), the winner of every max-pool window with a positive maximum, the style extractor's arg-max map -
@@ -352,6 +355,7 @@ class _GateRecorder:
         self.saved = {c: c.forward for c in (ops._BiasAct, ops._Norm, ops._MaxPool, ops._AdaIN, ops._MLPChain, expert_bank._GroupedGN)}
         self.store, self.counts, self.cur, self.keep, self.pos, self.total = {}, {}, None, True, 0, {}
         self.matcher = None       # oracle.gates.Matcher over the REFERENCE's fp64 decisions of the current iteration (judged run only)
+        self.force = {}           # gate forcing: feed sequence number of a gated tensor -> [(sample, index in the sample, fp64 margin, fp64 decision code)]
 
     def _feed64(self, kind, t, live=None, geom=None, optional=False):
         """the decisions of one gated tensor, in the reference's element order [sample][channel][spatial], to the fp64 matcher"""
@@ -390,6 +394,27 @@ class _GateRecorder:
                 c["pool"] += int(((a != b) & lv).sum()); t["pool"] += int(lv.sum())
         self.pos += 1
 
+    def _sites(self, ahead=0):
+        """the gate sites to force in the tensor whose decisions will be fed `ahead` feeds from now: [(sample, index in the sample, margin, code)]"""
+        if self.matcher is None or not self.force:
+            return ()
+        return self.force.get(self.matcher.feed_seq + ahead, ())
+
+    @staticmethod
+    def _nudge_sign(x, sites, scale=None):
+        """x [N, ..., C]: put the listed elements (reference order: channel-major inside a sample) on the side of zero the reference's fp64 run had
+        them on - by 1e-5 (relative to the element, at least absolute) at ONE element per site: nothing for any smooth quantity, but the gate
+        then takes the reference's branch. `scale` [N, C]: d(pre-activation) / d(x) where the gate does not look at x itself (norm + activation)."""
+        N, C = x.shape[0], x.shape[-1]
+        xv = x.view(N, -1, C)
+        for n, idx, margin, code in sites:
+            hw, c = idx % xv.shape[1], idx // xv.shape[1]
+            d = 1e-5 * max(1.0, abs(float(xv[n, hw, c])))
+            if scale is not None:
+                d = d / float(scale[n, c])
+            xv[n, hw, c] += d if code else -d
+            GATE_FORCED[0] += 1
+
     def install(self):
         ops, rec = self.ops, self
 
@@ -397,26 +422,62 @@ class _GateRecorder:
             f = rec.saved[cls]
 
             def fwd(ctx, *a):
+                gated = a[act_index] in (ops.ACT_RELU, ops.ACT_LRELU)
+                sites = rec._sites() if gated else ()
+                if sites and cls is ops._BiasAct:
+                    rec._nudge_sign(a[0], sites)                 # pre-activation = mask * (x + bias), mask >= 0
+                running = [t.clone() for t in (a[9], a[10])] if (sites and cls is ops._Norm and a[9] is not None) else None
                 y = f(ctx, *a)
-                if a[act_index] in (ops.ACT_RELU, ops.ACT_LRELU):
+                if sites and cls is ops._Norm:
+                    # pre-activation = gamma * (x - mean) * rstd + beta: a second pass with x moved by 1e-5 / (gamma * rstd) at the listed elements
+                    # (a BatchNorm's running statistics are put back first: they are to be updated once)
+                    if running is not None:
+                        a[9].copy_(running[0]); a[10].copy_(running[1])
+                    saved = ctx.to_save if hasattr(ctx, "to_save") else ctx.saved_tensors
+                    rstd, gamma = saved[5], a[1]
+                    scale = rstd if gamma is None else rstd * (gamma if gamma.dim() == 2 else gamma.view(1, -1))
+                    rec._nudge_sign(a[0], sites, scale)
+                    y = f(ctx, *a)
+                if gated:
                     rec._put("act", y > 0)
                     rec._feed64("act", y)
                 return y
             return staticmethod(fwd)
 
         def fwd_pool(ctx, *a):
+            x = a[0]
+            N, H, W, C = x.shape
+            (kh, kw), (sh, sw), (ph, pw) = a[1], a[2], a[3]
+            s_act, s_pool = rec._sites(0), rec._sites(1)
+            if s_act:
+                rec._nudge_sign(x, s_act)
             y = rec.saved[ops._MaxPool](ctx, *a)
+            if s_pool:
+                # a live window whose winner differs: lift the element the reference's fp64 run picked just above the window's present maximum
+                P, Q = y.shape[1], y.shape[2]
+                for n, idx, margin, code in s_pool:
+                    if code == 0:
+                        continue                                  # (the reference's window has no positive maximum: a sign site, not a winner site)
+                    c, pq = idx // (P * Q), idx % (P * Q)
+                    p_, q_ = pq // Q, pq % Q
+                    h, w = p_ * sh - ph + (code - 1) // kw, q_ * sw - pw + (code - 1) % kw
+                    if 0 <= h < H and 0 <= w < W:
+                        top = float(y[n, p_, q_, c])
+                        x[n, h, w, c] = top + 1e-5 * max(1.0, abs(top))
+                        GATE_FORCED[0] += 1
+                y = rec.saved[ops._MaxPool](ctx, *a)
             idx = ctx.to_save[0] if hasattr(ctx, "to_save") else ctx.saved_tensors[0]
             rec._put("pool", idx.clone(), y > 0)
             # the recogniser applies its ReLU behind the pool (relu(max) == max(relu)): the sign map the reference's ReLU in FRONT of the pool
             # saw is the sign of the pool's input (optional: where a ReLU already ran in front of the pool this is a second look at its record)
-            rec._feed64("act", a[0], optional=True)
-            N, H, W, C = a[0].shape
-            (kh, kw), (sh, sw), (ph, pw) = a[1], a[2], a[3]
+            rec._feed64("act", x, optional=True)
             rec._feed64("pool", idx, live=y > 0, geom=(H, W, kh, kw, sh, sw, ph, pw, y.shape[1], y.shape[2]))
             return y
 
         def fwd_adain(ctx, *a):
+            sites = rec._sites()
+            if sites:
+                rec._nudge_sign(a[0], sites)                     # pre-activation = x + w * noise
             y = rec.saved[ops._AdaIN](ctx, *a)
             u = (ctx.to_save if hasattr(ctx, "to_save") else ctx.saved_tensors)[0]
             rec._put("act", u > 0)
@@ -490,6 +551,7 @@ def test_lessons_teacher_forced(cuda, tmp_path, case):
     names = gold["names"]
     index = {n: k for k, n in enumerate(names)}
     rng.set_mode("host")
+    GATE_FORCED[0] = 0
     try:
         import handwriting_line_generation_amd.harness as harness
         orig = harness.synthetic_gan_config
@@ -532,10 +594,16 @@ def test_lessons_teacher_forced(cuda, tmp_path, case):
         gpath = os.path.join(GOLD, "%s_gates.npz" % case)
         ref_gates = gate_records.load(gpath)          # the reference's fp64 decisions per iteration ("unit:position"), tools/gen_golden_tf.py
         flips64 = {}          # tag -> {"iter": {network: HIP-vs-fp64 flips in this iteration}, "unit": the same summed over the unit so far, ...}
-        for variant in ("alt", "judged"):
+        forced = ([], [], {})
+        force_map, flips64_forced = {}, {}     # tag -> {feed sequence number: sites} found by the judged run; tag -> flips left in the forced run
+        for variant in ("alt", "judged", "forced"):
             # "alt": the same units on another valid schedule of the same kernels (ALT_TUNING) - only its fingerprints are kept, as the
             # yardstick of how far two correct fp32 evaluations of THIS implementation are apart (see SELF_SLACK)
-            bad, rows, skipped = ([], [], {}) if variant == "alt" else judged
+            # "forced": the judged schedule once more with every LOCATED flip (near-zero pre-activations, near-tie pool windows of the reference's
+            # record) nudged onto the reference's fp64 side - the intervention that shows what the flips cost: a flip-labelled group whose gates
+            # are all back on the reference's branches must be within its arithmetic bound
+            bad, rows, skipped = ([], [], {}) if variant == "alt" else judged if variant == "judged" else forced
+            fps.setdefault(variant, {})
             with _ops.tuning(**(ALT_TUNING if variant == "alt" else {})):
                 for u, unit in enumerate(gold["units"]):
                     sd, prev = _tf_state(gold, host_model, u)
@@ -557,11 +625,19 @@ def test_lessons_teacher_forced(cuda, tmp_path, case):
                         snap = {n: p.detach().clone() for n, p in trainer.model.named_parameters()}
                         del d_calls[:]
                         gates.enc.last_argmax = None
-                        gates.begin((u, it), keep=(variant == "alt"), ref_records=ref_gates["%d:%d" % (u, ref["position"])] if variant == "judged" else None)
+                        gates.force = force_map.get(tag, {}) if variant == "forced" else {}
+                        gates.begin((u, it), keep=(variant != "judged"), ref_records=ref_gates["%d:%d" % (u, ref["position"])] if variant != "alt" else None)
                         log = trainer._train_iteration(it)
                         cnt = gates.end()
                         m64 = gates.end64()
-                        if m64 is not None:
+                        gates.force = {}
+                        if m64 is not None and variant == "forced":
+                            flips64_forced[tag] = m64.flips_by_network()
+                        if m64 is not None and variant == "judged":
+                            fm = force_map.setdefault(tag, {})
+                            for name_, seq_, n_, idx_, v_, code_ in m64.sites:
+                                fm.setdefault(seq_, []).append((n_, idx_, v_, code_))
+                        if m64 is not None and variant == "judged":
                             by_net = m64.flips_by_network()
                             prev64 = [v for k, v in flips64.items() if k.startswith("u%d." % u)]
                             unit = dict(prev64[-1]["unit"]) if prev64 else {}
@@ -600,12 +676,23 @@ def test_lessons_teacher_forced(cuda, tmp_path, case):
                         for j, (mine, a, b) in enumerate(zip(trainer.saved_grads, ref["stashes"], ref["stashes64"])):
                             _tf_collect("stash%d" % j, tag, names, _stash_fingerprints(trainer, mine, names, index), a, b, bad, rows, skipped, fps[variant])
         gates.remove()
+        bad, rows, skipped = judged
         groups = {}
         for tag, kind, top, n, eh, er, nrm, l1 in rows:
             ga, gb = fps["judged"][(tag, kind, n)], fps["alt"].get((tag, kind, n))
             es = max(abs(ga[3] - gb[3]) / nrm, abs(ga[1] - gb[1]) / l1) if gb is not None else 0.0     # judged vs alternative schedule
             groups.setdefault((tag, kind, top), []).append((n, eh, er, es))
-        lines, floor, worst_bound, flips = [], 0, 0.0, 0
+        groups_f = {}
+        for tag, kind, top, n, eh, er, nrm, l1 in forced[1]:
+            groups_f.setdefault((tag, kind, top), []).append(eh)
+        forced_unit, run = {}, {}
+        for tag_ in flips64:                      # flips left in the forced run, summed over the unit so far (tags are in run order)
+            u_ = tag_.split(".")[0]
+            acc_ = dict(run.get(u_, {}))
+            for net, c in flips64_forced.get(tag_, {}).items():
+                acc_[net] = acc_.get(net, 0) + c
+            run[u_] = forced_unit[tag_] = acc_
+        lines, floor, worst_bound, flips, collapsed = [], 0, 0.0, 0, 0
         for key, items in sorted(groups.items()):
             rms_h = math.sqrt(sum(e[1] ** 2 for e in items) / len(items))
             rms_r = math.sqrt(sum(e[2] ** 2 for e in items) / len(items))
@@ -630,8 +717,18 @@ def test_lessons_teacher_forced(cuda, tmp_path, case):
                 # recorded decision differs between them in this unit so far: then the "flip" explanation does not hold for this group
                 bad.append("%s %s %s: labelled flip (%.2e > bound %.2e, schedules apart %.2e) but no recorded decision differs between the schedules" % (
                     key[0], key[1], key[2], rms_h, bound, rms_s))
-            lines.append("   %-22s %-7s %-16s %5d  %.2e  %.2e  %.2e  %.2e  %4d%s" % (key[0], key[1], key[2], len(items), rms_h, rms_r, bound, rms_s, upstream,
-                                                                                    "  flip" if flip else "  FAIL" if rms_h > bound else ""))
+            note = ""
+            if flip and key in groups_f:
+                # the same group with the located flips forced onto the reference's fp64 branches
+                rms_f = math.sqrt(sum(e ** 2 for e in groups_f[key]) / len(groups_f[key]))
+                left = sum(c for net, c in forced_unit.get(key[0], {}).items() if net in gate_records.DOWNSTREAM.get(key[2], ()))
+                collapsed += int(rms_f <= bound)
+                note = "   forced: %.2e%s, %d flips left" % (rms_f, " (within the bound)" if rms_f <= bound else "", left)
+                if left == 0 and rms_f > bound:
+                    bad.append("%s %s %s: every gate downstream of the group is on the reference's fp64 branch in the forced run, yet the group is %.2e from "
+                               "fp64 (bound %.2e): the excess is not a gate flip" % (key[0], key[1], key[2], rms_f, bound))
+            lines.append("   %-22s %-7s %-16s %5d  %.2e  %.2e  %.2e  %.2e  %4d%s%s" % (key[0], key[1], key[2], len(items), rms_h, rms_r, bound, rms_s, upstream,
+                                                                                      "  flip" if flip else "  FAIL" if rms_h > bound else "", note))
             if rms_h > limit:
                 bad.append("%s %s %s: pooled error %.2e over %d tensors > %.2e (reference fp32-vs-fp64 %.2e, two HIP schedules apart %.2e)" % (
                     key[0], key[1], key[2], rms_h, len(items), limit, rms_r, rms_s))
@@ -656,6 +753,17 @@ def test_lessons_teacher_forced(cuda, tmp_path, case):
         for tag_, c in flipped.items():
             excl.append("      %-22s signs %d, max-pool winners %d, arg-max columns %d [%d]%s" % (
                 tag_, c["act"], c["pool"], c.get("argmax", 0), c["unit_so_far"], "  (op sequences differed: %d)" % c["mismatch"] if c["mismatch"] else ""))
+        f_tol = f_bound = 0
+        for key_, errs_ in groups_f.items():
+            if key_ in groups:
+                rf_ = math.sqrt(sum(e ** 2 for e in errs_) / len(errs_))
+                rr_ = math.sqrt(sum(e[2] ** 2 for e in groups[key_]) / len(groups[key_]))
+                f_tol += int(rf_ <= TOL); f_bound += int(rf_ <= min(max(TOL, TF_SLACK * rr_), CAP))
+        excl.append("   forced pass, all %d groups: %d within %.0e of the reference's fp64 values, %d within their arithmetic bound (no flip allowance)" % (
+            len(groups_f), f_tol, TOL, f_bound))
+        excl.append("   gate forcing: %d element(s) nudged by 1e-5 onto the reference's fp64 side of their gate in a third pass; %d of the %d flip-labelled groups are within "
+                    "their arithmetic bound there (a group with flips LEFT keeps gates the near-zero / near-tie lists of the record could not locate)" % (
+                        GATE_FORCED[0], collapsed, flips))
         excl.append("   HIP-vs-fp64 decisions (the judged run against the reference's fp64 record, tests/golden/%s_gates.npz), per iteration and network; in brackets "
                     "what the reference's OWN fp32 run flips against its fp64 run:" % case)
         for tag_, f in flips64.items():
@@ -674,8 +782,111 @@ def test_lessons_teacher_forced(cuda, tmp_path, case):
         text = "\n".join([head] + lines + excl)
         print("\n" + text)
         if os.environ.get("HWG_PARITY_SUMMARY"):
+            os.makedirs(os.path.dirname(os.path.abspath(os.environ["HWG_PARITY_SUMMARY"])), exist_ok=True)
             with open(os.environ["HWG_PARITY_SUMMARY"], "a") as fh:
                 fh.write(text + "\n\n")
         assert not bad, "%d mismatches: %s" % (len(bad), "; ".join(bad[:12]))
     finally:
+        rng.set_mode("device")
+
+
+def test_forcing_the_counted_generator_flip_restores_the_adversarial_gradients(cuda, tmp_path):
+    """`tf_trained u3.no-step+gen stash1 generator` sits 1.8e-3 from the reference's fp64 values on BOTH kernel schedules
+    (they agree to 3e-7) while the reference's own fp32 run is 1.5e-6 away. The fp64 gate record names the cause: in that iteration exactly one
+    generator gate differs from the reference's fp64 run - one LeakyReLU sign in block 0 (`generator.conv.0.lrelu2`), whose pre-activation lies
+    within rounding of zero; the block's conv2 bias / noise-weight gradients, which sum that layer's 4 x T' gradient field, carry the error.
+    Proof by intervention: the same iteration from the same state with that ONE pre-activation nudged (by 1e-5) onto the side of zero the
+    reference's fp64 run recorded. The adversarial gradient set of the generator must then be within 1e-4 of the reference's fp64 values -
+    i.e. the kernels' arithmetic is exact to the tolerance and the whole excess of the group is that one gate."""
+    from handwriting_line_generation_amd import rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer, load_config
+    from handwriting_line_generation_amd.model import Autoencoder, HWWithStyle
+    from oracle import gates as gate_records
+    from oracle import tf_state
+    case, u = "tf_trained", 3
+    gold = json.load(open(os.path.join(GOLD, "%s.json" % case)))
+    ref_gates = gate_records.load(os.path.join(GOLD, "%s_gates.npz" % case))
+    cfg_model = dict(load_config(gold["config"])["model"], pretrained_hwr=None)
+    cfg_model.update(gold["reduced"])
+    esd = torch_ref.seeded_state_dict(Autoencoder({"type": "2tight", "hwr": cfg_model["num_class"]}), gold["wseed_enc"])
+    names = gold["names"]
+    index = {n: k for k, n in enumerate(names)}
+    rng.set_mode("host")
+    gates = None
+    try:
+        import handwriting_line_generation_amd.harness as harness
+        orig = harness.synthetic_gan_config
+
+        def patched(*a, **k):
+            cfg, wd = orig(*a, **k)
+            cfg["model"].update(gold["reduced"])
+            return cfg, wd
+        harness.synthetic_gan_config = patched
+        try:
+            trainer, cfg = build_gan_trainer(gold["config"], gold["batch_size"], gold["a_batch_size"], width=gold["W"], label_len=gold["label_len"],
+                                             workdir=str(tmp_path), encoder_state=esd)
+        finally:
+            harness.synthetic_gan_config = orig
+        host_model = HWWithStyle(cfg_model)
+        ref = gold["units"][u][0]
+        assert ref["lesson"] == ["no-step", "gen"]
+        gates = _GateRecorder()
+        gates.install()
+
+        def run(force):
+            sd, prev = _tf_state(gold, host_model, u)
+            trainer.model.load_state_dict(sd)
+            for opt in (trainer.optimizer, trainer.optimizer_discriminator):
+                opt.reset_state()
+            trainer.prev_styles = [t.to(trainer.gpu) for t in prev]
+            for s_ in trainer.saved_grads:
+                trainer.flat.release(s_)
+            trainer.saved_grads = []
+            trainer.flat.flat_grad.zero_()
+            trainer.flat.touched[:] = False
+            trainer.data_loader_iter = _iter_from(trainer.data_loader.dataset, 10 * u)
+            torch.manual_seed(500 + u); np.random.seed(500 + u); random.seed(500 + u)
+            gates.force = force
+            gates.begin((u, ref["iteration"]), keep=True, ref_records=ref_gates["%d:%d" % (u, ref["position"])])
+            trainer._train_iteration(ref["iteration"])
+            gates.end()
+            m = gates.end64()
+            rows, bad, skipped = [], [], {}
+            _tf_collect("stash1", "u3", names, _stash_fingerprints(trainer, trainer.saved_grads[1], names, index), ref["stashes"][1], ref["stashes64"][1], bad, rows, skipped)
+            assert not bad, bad
+            gen = [r for r in rows if r[2] == "generator"]
+            rms_h = math.sqrt(sum(r[4] ** 2 for r in gen) / len(gen))
+            rms_r = math.sqrt(sum(r[5] ** 2 for r in gen) / len(gen))
+            return m, rms_h, rms_r, sorted(gen, key=lambda r: -r[4])[:3]
+        m0, e0, er, worst0 = run({})
+        gen_sites = [s_ for s_ in m0.sites if s_[0].startswith("generator.")]
+        gen_flips = {k: v for k, v in m0.flips.items() if k.startswith("generator.") and v}
+        disc_flips = {k: v for k, v in m0.flips.items() if k.startswith("discriminator.") and v}
+        text = ["[flip forcing, %s u%d %s] generator adversarial set (stash1): HIP %.2e from the reference's fp64 values, the reference's fp32 run %.2e" % (
+            case, u, "+".join(ref["lesson"]), e0, er),
+            "   gates that differ from the reference's fp64 record: generator %s, discriminator %s" % (gen_flips, disc_flips),
+            "   worst tensors: %s" % ", ".join("%s %.2e" % (r[3], r[4]) for r in worst0)]
+        if e0 <= TOL:
+            text.append("   (this build takes the reference's branch at every generator gate of the iteration: nothing to force)")
+        else:
+            # every generator flip of the iteration must have been located through the near-zero lists (else it cannot be forced)
+            assert sum(gen_flips.values()) == len(gen_sites) > 0, (gen_flips, gen_sites)
+            force = {}
+            for name, seq, n, idx, v64, code in gen_sites:
+                force.setdefault(seq, []).append((n, idx, v64, code))
+            m1, e1, _, worst1 = run(force)
+            left = {k: v for k, v in m1.flips.items() if k.startswith("generator.") and v}
+            text += ["   forced %d pre-activation(s) onto the reference's side of zero: %s" % (len(gen_sites), ", ".join("%s %+.2e" % (s_[0], s_[4]) for s_ in gen_sites)),
+                     "   -> HIP %.2e from the reference's fp64 values; generator gates still differing: %s; worst tensors: %s" % (
+                         e1, left, ", ".join("%s %.2e" % (r[3], r[4]) for r in worst1))]
+            assert not left, left
+            assert e1 <= max(TOL, TF_SLACK * er), "with the counted flip forced the group is still %.2e from fp64 (reference %.2e)" % (e1, er)
+        print("\n" + "\n".join(text))
+        if os.environ.get("HWG_PARITY_SUMMARY"):
+            os.makedirs(os.path.dirname(os.path.abspath(os.environ["HWG_PARITY_SUMMARY"])), exist_ok=True)
+            with open(os.environ["HWG_PARITY_SUMMARY"], "a") as fh:
+                fh.write("\n".join(text) + "\n\n")
+    finally:
+        if gates is not None:
+            gates.remove()
         rng.set_mode("device")

@@ -237,8 +237,11 @@ def run_units(case, wide, out_path, rms_path):
                 for i, r in enumerate(recs):
                     d32 = z32["d%d" % i] if same_seq else None
                     flips = int((d32 != r["dec"]).sum()) if d32 is not None and d32.shape == r["dec"].shape else -1
-                    nzi, nzv = gates.near_zero(r["pre"].reshape(-1)) if r["kind"] == "act" else (np.full(gates.NZ, -1, np.int64), np.zeros(gates.NZ))
-                    gate_file.add(cur["key"], r["name"], r["kind"], r["dec"].shape[1], gates.block_hashes(r["dec"]), nzi, nzv, flips)
+                    nzi, nzv = gates.near_zero((r["pre"] if r["kind"] == "act" else r["margin"]).reshape(-1))
+                    if r["kind"] == "pool":          # windows without a positive maximum carry the margin 1e30: not near-ties
+                        nzi = np.where(nzv < 1e29, nzi, -1)
+                    codes = np.where(nzi >= 0, r["dec"].reshape(-1)[np.maximum(nzi, 0)], 0)
+                    gate_file.add(cur["key"], r["name"], r["kind"], r["dec"].shape[1], gates.block_hashes(r["dec"]), nzi, np.where(nzi >= 0, nzv, 0.0), flips, codes)
             del recs
             upd = [fingerprint(p.detach() - s, k) for k, (p, s) in enumerate(zip(plist, snap))]
             stashes = [[fingerprint(R, k) if R is not None else None for k, R in enumerate(sg)] for sg in getattr(trainer, "saved_grads", [])]
