@@ -121,8 +121,18 @@ def _ctypes_entry(fn):
     # (descriptors travel as addresses - ConvDesc.ptr - like every other pointer: typed struct pointers become void*)
     fn.argtypes = [ctypes.c_void_p if (isinstance(t, type) and issubclass(t, ctypes._Pointer)) else t for t in (fn.argtypes or [])]
 
+    # the same range checks the thunks make in C: ctypes would wrap an out-of-range Python int into the C type silently
+    limits = [(-(1 << 31), (1 << 31) - 1) if t is ctypes.c_int else (0, (1 << 64) - 1) if t in (ctypes.c_size_t, ctypes.c_ulonglong)
+              else (-(1 << 63), (1 << 63) - 1) if t is ctypes.c_longlong else None for t in fn.argtypes]
+
     def call(*args):
-        return fn(*[a.data_ptr() if hasattr(a, "data_ptr") else a for a in args])
+        conv = []
+        for a, lim in zip(args, limits):
+            a = a.data_ptr() if hasattr(a, "data_ptr") else a
+            if lim is not None and isinstance(a, int) and not (lim[0] <= a <= lim[1]):
+                raise OverflowError("%s: integer argument %d does not fit the C type" % (getattr(fn, "__name__", "hwg call"), a))
+            conv.append(a)
+        return fn(*conv)
     return call
 
 

@@ -803,6 +803,7 @@ __global__ __launch_bounds__(512) void wino_conv_ws_kernel(WinoK a) {
 #ifndef HWG_W64D_SCHED
 #define HWG_W64D_SCHED 6
 #endif
+template <int ABL>
 __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
   constexpr int NT = 512, TM = 64, TN = 64;
   constexpr int PSV = TM * 16 + 8, PSU = TN * 16 + 8;
@@ -902,6 +903,13 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
       }
   };
   auto col_transform = [&]() {
+    if constexpr (ABL & 1) {          // timing ablation (HWG_CONV_DBG=512): no patch transform - what a kernel fed with pre-transformed patches would save
+#pragma unroll
+      for (int it = 0; it < XI; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tr[it][r] = raw[it][r];
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < XI; ++it) {
       float4 d[4];
@@ -924,10 +932,14 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
       const float sa = (x_b[it] == 3) ? -1.f : 1.f;
       const float sb = (x_b[it] & 1) ? 1.f : -1.f;
       float4 o;
-      o.x = sa * v.x + sb * quad_partner(v.x);
-      o.y = sa * v.y + sb * quad_partner(v.y);
-      o.z = sa * v.z + sb * quad_partner(v.z);
-      o.w = sa * v.w + sb * quad_partner(v.w);
+      if constexpr (ABL & 1) {
+        o = v;
+      } else {
+        o.x = sa * v.x + sb * quad_partner(v.x);
+        o.y = sa * v.y + sb * quad_partner(v.y);
+        o.z = sa * v.z + sb * quad_partner(v.z);
+        o.w = sa * v.w + sb * quad_partner(v.w);
+      }
       *reinterpret_cast<float4*>(Vb + x_b[it] * PSV + swz(x_row[it], x_c4[it])) = o;
     }
   };
@@ -1473,7 +1485,8 @@ extern "C" int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const f
   else if (p.cfg == 2) hipLaunchKernelGGL((wino_conv_kernel<8, 1>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 7) hipLaunchKernelGGL((wino_conv_kernel<2, 2>), grid, dim3(256), 0, st, k);
   else if (p.cfg == 5) hipLaunchKernelGGL(wino_conv_big_kernel, grid, dim3(768), 0, st, k);
-  else if (p.cfg == 6 && !hwg_tune().w64_nodma) hipLaunchKernelGGL(wino_conv64d_kernel, grid, dim3(512), 0, st, k);
+  else if (p.cfg == 6 && !hwg_tune().w64_nodma && (hwg_tune().conv_dbg & 512)) hipLaunchKernelGGL(wino_conv64d_kernel<1>, grid, dim3(512), 0, st, k);
+  else if (p.cfg == 6 && !hwg_tune().w64_nodma) hipLaunchKernelGGL(wino_conv64d_kernel<0>, grid, dim3(512), 0, st, k);
   else if (p.cfg == 6) hipLaunchKernelGGL(wino_conv64_kernel, grid, dim3(512), 0, st, k);
   else hipLaunchKernelGGL((wino_conv_ws_kernel<1, 4>), grid, dim3(512), 0, st, k);
   hwg_prof_close(prof, st);

@@ -196,12 +196,8 @@ class HWWithStyle(BaseModel):
     def extract_style(self, image, label, a_batch_size=None):
         if self.style_tape_mode and torch.is_grad_enabled() and self.pred is None and not image.requires_grad:
             tape = ops.Tape()
-            ops.TAPE = tape
-            try:
-                with torch.no_grad():
-                    style = self._extract_style(image, label, a_batch_size)
-            finally:
-                ops.TAPE = None
+            with ops.taping(tape), torch.no_grad():
+                style = self._extract_style(image, label, a_batch_size)
             tape._adopt_views([style])          # (the last op's result may come back as a reshape of the taped tensor)
             if id(style) in tape.live:          # (nothing on the path requires a gradient otherwise: frozen everything)
                 style.requires_grad_(True)

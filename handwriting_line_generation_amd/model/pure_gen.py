@@ -187,12 +187,8 @@ class SpacedGenerator(nn.Module):
             raise ops.L.HwgError("taped generator forward: the content rows carry no gradient in any lesson")
         tape = ops.Tape()
         s_in = tape.watch(style.detach())
-        ops.TAPE = tape
-        try:
-            with torch.no_grad():
-                y = self._forward(content, s_in)
-        finally:
-            ops.TAPE = None
+        with ops.taping(tape), torch.no_grad():
+            y = self._forward(content, s_in)
         y.requires_grad_(True)          # a leaf: the losses' backward passes stop here and leave their gradient in y.grad
         self.open_tapes.append(GenTape(tape, y, s_in, style if style.requires_grad else None))
         return y

@@ -202,6 +202,55 @@ class Tape:
         return out
 
 
+# ---- debug guard for taped forwards (HWG_TAPE_CHECK=1) ---------------------------------------------------------------------------------
+# A taped forward runs under no_grad and tracks only Function calls plus contiguous whole-memory reshapes of their results. Any OTHER
+# torch-level op on a taped tensor (arithmetic, torch.cat, indexing, a norm in eval mode ...) would produce a tensor the tape does not
+# know, and the gradient path through it would be dropped without an error. With the check on, every torch-level call made while a tape is
+# recording is inspected: an argument that is (a view of) a taped tensor is only allowed in the shape / view / bookkeeping calls below.
+TAPE_CHECK = bool(int(os.environ.get("HWG_TAPE_CHECK", "0") or 0))
+_TAPE_SAFE = {"view", "reshape", "contiguous", "flatten", "size", "dim", "numel", "data_ptr", "is_contiguous", "stride", "detach", "requires_grad_",
+              "__get__", "__len__", "__repr__", "storage_offset", "element_size", "untyped_storage", "is_floating_point", "get_device", "_is_view",
+              "__set__", "__bool__", "is_leaf", "__format__", "__str__", "type", "nelement", "ndimension", "__hash__", "__reduce_ex__"}
+
+
+class _TapeGuard(torch.overrides.TorchFunctionMode):
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        tape = TAPE
+        if tape is not None:                       # (None inside an op's own forward: ops allocate and launch freely there)
+            name = getattr(func, "__name__", str(func))
+            if name not in _TAPE_SAFE:
+                stack = list(args) + list((kwargs or {}).values())
+                while stack:
+                    a = stack.pop()
+                    if isinstance(a, (list, tuple)):
+                        stack.extend(a)
+                    elif isinstance(a, torch.Tensor) and (id(a) in tape.live or (a._base is not None and id(a._base) in tape.live)):
+                        raise L.HwgError("taped forward: torch-level op %r on a taped tensor (shape %s) - its result would be unknown to the tape and the "
+                                         "gradient through it silently dropped; route it through an ops.Function" % (name, tuple(a.shape)))
+        return func(*args, **(kwargs or {}))
+
+
+class taping:
+    """`with ops.taping(tape):` - Function.apply records on `tape` instead of autograd's graph (no_grad is the caller's business)"""
+
+    def __init__(self, tape):
+        self.tape, self.guard = tape, (_TapeGuard() if TAPE_CHECK else None)
+
+    def __enter__(self):
+        global TAPE
+        TAPE = self.tape
+        if self.guard is not None:
+            self.guard.__enter__()
+        return self.tape
+
+    def __exit__(self, *exc):
+        global TAPE
+        if self.guard is not None:
+            self.guard.__exit__(*exc)
+        TAPE = None
+        return False
+
+
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 NORM_IN, NORM_GN, NORM_BN = 0, 1, 2
 
@@ -213,6 +262,8 @@ _get_device = getattr(torch._C, "_cuda_getDevice", None)
 def _stream():
     # raw hipStream_t of torch's current stream (the Python Stream object is ~20 us to build, torch.cuda.current_device() re-checks the lazy
     # initialisation on every call: ~1 us; the two C entry points together ~0.3 us - this runs ~430 times per training step)
+    if _raw_stream is None or _get_device is None:       # a torch build without the private entry points: the public (slower) API
+        return torch.cuda.current_stream().cuda_stream
     return _raw_stream(_get_device())
 
 

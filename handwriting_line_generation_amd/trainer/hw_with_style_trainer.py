@@ -1,4 +1,3 @@
-import collections
 """GAN / recogniser training step on HIP kernels (reference: trainer/hw_with_style_trainer.py:21-1023).
 
 `_train_iteration` keeps the reference's control flow - curriculum lesson, loss weighting, the up-to-three backward
@@ -10,6 +9,7 @@ Data parallelism (absent from the reference): with torch.distributed initialised
 its own author shard; gradient sets are averaged with one all-reduce (RCCL over xGMI) at the points where the reference
 reads them (before balancing / clipping), and the `None`-gradient masks are OR-ed so all ranks update the same tensors.
 """
+import collections
 import os
 import json
 import random

@@ -103,6 +103,7 @@ def test_module_parity(cuda, name):
             bad.append("d%s vs golden: HIP %.2e, reference %.2e" % (k, eh, eg))
     params = dict(m.named_parameters())
     gmax = max(float(v.abs().max()) for v in g64.values() if v is not None)
+    realised = []          # (parameter, HIP error vs fp64, fp32 oracle's error, fp64 sensitivity, bound) - written to the parity summary
     for k in pnames:
         g = params[k].grad
         og, od = sd2[k].grad, g64[k]
@@ -119,6 +120,7 @@ def test_module_parity(cuda, name):
             bad.append("missing gradient for %s" % k)
             continue
         eh, eo = l2(g, od), l2(og, od)
+        realised.append((k, eh, eo, cond[k], max(TOL, 2 * eo, 3 * cond[k])))
         if eh > max(TOL, 2 * eo, 3 * cond[k]):
             bad.append("grad %s: error vs fp64 %.2e (fp32 oracle %.2e, sensitivity %.2e)" % (k, eh, eo, cond[k]))
     if cases.kind(name) == "discriminator":  # spectral-norm u vectors mutate identically
@@ -130,6 +132,19 @@ def test_module_parity(cuda, name):
             if "running_mean" in k and rel(v.cpu(), gold["post_" + k.replace(".", "__")]) >= TOL:
                 bad.append("post-forward %s: %.2e" % (k, rel(v.cpu(), gold["post_" + k.replace(".", "__")])))
     rng.set_mode("device")
+    if realised:
+        import math
+        n_tol = sum(1 for r in realised if r[4] == TOL)
+        worst = max(realised, key=lambda r: r[4])
+        rms = lambda j: math.sqrt(sum(r[j] ** 2 for r in realised) / len(realised))      # noqa: E731
+        line = ("[module parity, %s] %d parameter gradients vs fp64: HIP rms error %.2e (worst %.2e), fp32 oracle rms %.2e; %d held at %.0e, largest realised "
+                "bound %.2e (%s: HIP %.2e, oracle %.2e, fp64 sensitivity to 1e-6 perturbations %.2e)" % (
+                    name, len(realised), rms(1), max(r[1] for r in realised), rms(2), n_tol, TOL, worst[4], worst[0], worst[1], worst[2], worst[3]))
+        print("\n" + line)
+        if os.environ.get("HWG_PARITY_SUMMARY"):
+            os.makedirs(os.path.dirname(os.path.abspath(os.environ["HWG_PARITY_SUMMARY"])), exist_ok=True)
+            with open(os.environ["HWG_PARITY_SUMMARY"], "a") as fh:
+                fh.write(line + "\n")
     assert not bad, "%s: %d mismatches: %s" % (name, len(bad), "; ".join(bad[:12]))
 
 

@@ -1102,3 +1102,26 @@ def test_spectral_backward_of_several_layers_in_two_launches_is_bit_identical(cu
         sg = l["sigma"].double()
         want = l["dst0"].double() + l["dwsn"].double() / sg - (l["dwsn"].double() * l["wbar"].double()).sum() / sg ** 2 * torch.outer(l["u"].double(), l["v"].double())
         assert float((b.double() - want).abs().max()) < 2e-5 * float(want.abs().max())
+
+
+def test_tape_guard_rejects_torch_level_ops_on_taped_tensors(cuda, monkeypatch):
+    """a taped forward tracks Function calls and whole-memory reshapes only; with HWG_TAPE_CHECK on, any other torch-level op on a
+    taped tensor raises instead of silently dropping the gradient path through its result"""
+    from handwriting_line_generation_amd import ops
+    from handwriting_line_generation_amd._lib import HwgError
+    monkeypatch.setattr(ops, "TAPE_CHECK", True)
+    x = torch.randn(2, 4, 4, 16, device=cuda)
+    tape = ops.Tape()
+    xin = tape.watch(x)
+    with ops.taping(tape), torch.no_grad():
+        y = ops.relu(xin)
+        z = y.view(2, -1)                          # a reshape of a taped tensor: adopted by the next op
+        assert z.shape == (2, 256) and y.is_contiguous() and y.dim() == 4
+        w = torch.empty(3, device=cuda) * 2.0      # torch-level work on tensors the tape does not know is none of its business
+        with pytest.raises(HwgError, match="torch-level op"):
+            y * 2.0
+        with pytest.raises(HwgError, match="torch-level op"):
+            torch.cat([y, y], dim=0)
+        with pytest.raises(HwgError, match="torch-level op"):
+            z[:, :4].sum()
+    assert ops.TAPE is None and len(tape.nodes) == 1 and w.shape == (3,)
