@@ -1,0 +1,11 @@
+#!/bin/bash
+# launch census of the default bench workload: rocprofv3 kernel trace -> launches / average / time per step by kernel   (GPU box)
+set -u
+OUT=$GRAFT_REPO_ROOT/${1:-gpurun_out/census}
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+HWG_BENCH_NO_MINNEC=1 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -f csv -- python3 bench.py --steps 28 --warmup 7 --no-cpu-baseline --no-gen > $OUT/kt.log 2>&1
+find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+python tools/launch_census.py $OUT/kernel_stats.csv $OUT/kt.log > $OUT/launch_census.txt 2>&1
+rm -rf $OUT/kt
+head -100 $OUT/launch_census.txt | cut -c1-150

@@ -39,7 +39,7 @@ def bench(fn, iters=20):
 def read(path, top):
     rows = {}
     for line in open(path):
-        m = re.match(r"\s*([\d.]+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+(\S+)\s+(\(.*\))\s*$", line)
+        m = re.match(r"\s*([\d.]+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+(\S+)\s+(\(.*\))(?:\s+[\d.eE+-]+)?\s*$", line)
         if not m:
             continue
         ms, n, avg, tf, kind, shape = m.groups()

@@ -29,7 +29,7 @@ def read_shapes(path):
     for line in open(path):
         if line.startswith("#"):
             continue
-        m = re.match(r"\s*([\d.]+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+(\S+)\s+(\(.*\))\s*$", line)
+        m = re.match(r"\s*([\d.]+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+(\S+)\s+(\(.*\))(?:\s+[\d.eE+-]+)?\s*$", line)
         if not m:
             continue
         ms, n, avg, tf, kind, shape = m.groups()
