@@ -758,7 +758,13 @@ def test_lessons_teacher_forced(cuda, tmp_path, case):
             if key_ in groups:
                 rf_ = math.sqrt(sum(e ** 2 for e in errs_) / len(errs_))
                 rr_ = math.sqrt(sum(e[2] ** 2 for e in groups[key_]) / len(groups[key_]))
-                f_tol += int(rf_ <= TOL); f_bound += int(rf_ <= min(max(TOL, TF_SLACK * rr_), CAP))
+                b_ = min(max(TOL, TF_SLACK * rr_), CAP)
+                f_tol += int(rf_ <= TOL); f_bound += int(rf_ <= b_)
+                left_ = sum(c for net, c in forced_unit.get(key_[0], {}).items() if net in gate_records.DOWNSTREAM.get(key_[2], ()))
+                if rf_ > b_ and left_ == 0:
+                    # the forced pass is the strict form of the bar: with every gate downstream of a group on the reference's fp64 branch NO
+                    # group - flip-labelled in the judged pass or not - may be outside its arithmetic bound
+                    bad.append("%s %s %s: forced pass %.2e > bound %.2e with no flip left downstream" % (key_[0], key_[1], key_[2], rf_, b_))
         excl.append("   forced pass, all %d groups: %d within %.0e of the reference's fp64 values, %d within their arithmetic bound (no flip allowance)" % (
             len(groups_f), f_tol, TOL, f_bound))
         excl.append("   gate forcing: %d element(s) nudged by 1e-5 onto the reference's fp64 side of their gate in a third pass; %d of the %d flip-labelled groups are within "
