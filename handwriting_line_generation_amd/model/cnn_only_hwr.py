@@ -71,6 +71,13 @@ class CNNOnlyHWR(nn.Module):
     logit_offset = None
 
     def forward(self, input, style=None):
+        from .. import replay
+        if replay.ENABLED:
+            # one C-side replay of the recorded launch list instead of ~45 + ~70 Python -> torch -> C-ABI round trips (replay.py); None = not
+            # eligible / not recorded yet / rejected by its self-check: the eager path below
+            out = replay.hwr_forward(self, input)
+            if out is not None:
+                return out
         with ops.scope("HWR"):
             return self._forward(input, style)
 

@@ -699,10 +699,14 @@ WINOGRAD = bool(int(os.environ.get("HWG_WINO", "1") or 1))
 _wino_choice = {}
 
 
+TUNE_EPOCH = 0      # bumped by tuning_reload(): anything derived from the library's plans (recorded launch lists, replay.py) is keyed by it
+
+
 def tuning_reload():
     """The library plans every geometry once and reads its tuning knobs (HWG_WINO, HWG_WINO_FORCE, HWG_CONV_FORCE, ...) at plan time; the
     per-geometry choices are cached here as well. Call this after changing such a variable in a running process."""
-    global WINOGRAD
+    global WINOGRAD, TUNE_EPOCH
+    TUNE_EPOCH += 1
     WINOGRAD = bool(int(os.environ.get("HWG_WINO", "1") or 1))
     _wino_choice.clear(); _wino_wgrad_choice.clear(); _conv_plans.clear(); _wgrad_plans.clear(); _wgrad_sets_ok.clear(); _wgrad_sets_ws.clear()
     L.call("hwg_tuning_reload")

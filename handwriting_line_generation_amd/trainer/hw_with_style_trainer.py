@@ -125,6 +125,9 @@ class HWWithStyleTrainer(BaseTrainer):
         self._pending_log = collections.deque()
         self.pre_clip_hook = None
         self._defer_reduce = bool(int(tr.get("defer_wgrad_reduce", os.environ.get("HWG_DEFER_REDUCE", "1")) or 0))
+        # launch-list replay of the frozen recogniser (replay.py): the switches its backward passes run under
+        from .. import replay as _replay
+        _replay.BACKWARD_FLAGS = {(self._defer_reduce, False), (self._defer_reduce, True)}
         # the two or three gradients a balanced lesson sends through the generator go through it in one pass (see _generator_backward)
         self._batch_gen_backward = bool(int(tr.get("batch_gen_backward", os.environ.get("HWG_BATCH_GEN_BWD", "1")) or 0))
         # recogniser-on-real-lines + style extractor on a tape as well: each loss group's pass through them runs on a stream of its own

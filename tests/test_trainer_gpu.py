@@ -398,3 +398,36 @@ def test_taped_lessons_make_no_untracked_torch_ops(cuda, tmp_path, monkeypatch):
         log = trainer._train_iteration(it)
         assert all(math.isfinite(float(v)) for v in log.values()), log
     torch.cuda.synchronize()
+
+
+def test_recogniser_replay_trains_to_the_same_bits(cuda, tmp_path):
+    """replay.py: the frozen recogniser's forward / backward as recorded launch lists replayed by ONE C call per pass. Two curriculum cycles +
+    with it on and off from the same seeds: every logged loss and every parameter / buffer BIT-identical (the recorded programs passed their
+    own bit-exact self-check, the trainer's gradient-set redirects, deferred sums, side stream and style tapes run through them), and the
+    replay must really have carried the passes."""
+    from handwriting_line_generation_amd import ops, replay, rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    outs = []
+    for on in (False, True):
+        replay.reset()
+        replay.ENABLED = on
+        after, replay.RECORD_AFTER, replay.RECORD_AFTER_DX = (replay.RECORD_AFTER, replay.RECORD_AFTER_DX), 2, 2
+        for k in replay.STATS:
+            replay.STATS[k] = 0
+        try:
+            rng.set_mode("device", seed=11)
+            torch.manual_seed(3); np.random.seed(3); random.seed(3)
+            trainer, _ = build_gan_trainer("iam_gan", 2, 2, width=256, label_len=12, workdir=str(tmp_path / ("r%d" % on)))
+            torch.manual_seed(5); np.random.seed(5); random.seed(5)
+            logs = [trainer._train_iteration(it) for it in range(21)]
+            torch.cuda.synchronize()
+            outs.append((logs, {k: v.detach().clone() for k, v in trainer.model.state_dict().items()}, dict(replay.STATS)))
+        finally:
+            replay.ENABLED = False
+            replay.RECORD_AFTER, replay.RECORD_AFTER_DX = after
+    (la, sa, st_off), (lb, sb, st_on) = outs
+    assert st_off["fwd"] == 0 and st_on["captures"] >= 1 and st_on["fwd"] >= 10 and st_on["bwd"] >= 10 and st_on["rejected"] == 0, st_on
+    for it, (a, b) in enumerate(zip(la, lb)):
+        assert a == b, "iteration %d: %s vs %s" % (it, a, b)
+    for k, v in sa.items():
+        assert torch.equal(v, sb[k]), "%s differs with the recogniser replayed" % k

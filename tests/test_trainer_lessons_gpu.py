@@ -417,6 +417,8 @@ class _GateRecorder:
 
     def install(self):
         ops, rec = self.ops, self
+        from handwriting_line_generation_amd import replay
+        self._replay_was, replay.ENABLED = replay.ENABLED, False      # (a replayed recogniser pass runs no op forward: nothing to record)
 
         def wrap_act(cls, act_index):
             f = rec.saved[cls]
@@ -503,6 +505,8 @@ class _GateRecorder:
         rec.eb._GroupedGN.forward = staticmethod(fwd_ggn)
 
     def remove(self):
+        from handwriting_line_generation_amd import replay
+        replay.ENABLED = getattr(self, "_replay_was", False)
         for c, f in self.saved.items():
             c.forward = f
 

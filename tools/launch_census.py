@@ -4,7 +4,7 @@ import csv, json, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 line = [l for l in open(sys.argv[2]) if l.startswith('{"metric"')][-1]
 j = json.loads(line)
-extra = int(sys.argv[3]) if len(sys.argv) > 3 else j["roofline"].get("profiled_steps", 0)
+extra = int(sys.argv[3]) if len(sys.argv) > 3 else (j.get("roofline") or {}).get("profiled_steps", 0)
 steps = j["steps"] + j["warmup"] + extra
 tot_calls = sum(int(r["Calls"]) for r in rows)
 tot_ns = sum(float(r["TotalDurationNs"]) for r in rows)

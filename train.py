@@ -64,6 +64,9 @@ def main():
     # dead-gradient elimination is the drop-in's default: losses, updates and every weight are bit-identical to the loop
     # that computes them (tests/test_trainer_gpu.py::test_skip_unused_grads_changes_no_weight_and_no_loss); a config key or the flag decide otherwise
     config["trainer"].setdefault("skip_unused_grads", 0 if args.reference_gradients else 1)
+    # the frozen recogniser's passes as recorded launch lists (replay.py; bit-identical, self-checked; HWG_REPLAY=0 turns it off)
+    from handwriting_line_generation_amd import replay as _replay
+    _replay.enable()
 
     # Random streams: one base seed per run (config["seed"] or drawn here and shared by all ranks), rank r draws from stream
     # (base, r): generator noise and Dropout2d masks differ between data-parallel ranks and between runs. The Philox offset is
