@@ -126,6 +126,21 @@ class CharStyleEncoder(nn.Module):
         with ops.scope("StyleEx"):
             return self._forward(x, recog)
 
+    def _trunk_eager(self, feat):
+        for blk in self.down:
+            feat = blk(feat)
+        return feat
+
+    def _trunk(self, feat):
+        """the seven replicate-padded conv blocks: a pure function of the image geometry (no random draws, no host decisions), so its passes
+        can be replayed from a recorded launch list (replay.py) - the experts behind it depend on the arg-max map and stay eager"""
+        from .. import replay
+        if replay.ENABLED:
+            out = replay.forward(self.down, self._trunk_eager, "StyleEx", feat)
+            if out is not None:
+                return out
+        return self._trunk_eager(feat)
+
     def _forward(self, x, recog):
         """x: NCHW [B',1,64,Wc] author image; recog: [B',n_class,Tc] log-probs (channel major, as the reference passes) or NHWC [B',1,Tc,n_class]"""
         B = x.shape[0]
@@ -136,8 +151,7 @@ class CharStyleEncoder(nn.Module):
         T0 = recog.shape[2]
         pred_fetch = ops.AsyncFetch(ops.argmax_rows(recog.reshape(B * T0, self.n_class)))
         feat = ops.to_nhwc(x)
-        for blk in self.down:
-            feat = blk(feat)
+        feat = self._trunk(feat)
         if feat.shape[1] != 1:
             raise ValueError("style extractor expects 64-pixel-high lines (feature height %d != 1)" % feat.shape[1])
         feat, recog = self._align(feat, recog)

@@ -334,7 +334,7 @@ class _ReplayNet(ops.Function):
         return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
-# ---- the recogniser ------------------------------------------------------------------------------------------------------------------------
+# ---- recording and dispatch ---------------------------------------------------------------------------------------------------------------
 _programs = {}      # key -> sightings so far | Program | None (rejected: eager for the rest of the process)
 BACKWARD_FLAGS = set()   # (DEFER_REDUCE, SIDE_WGRAD) settings the owner of the network runs backward passes under (the trainers say; else the current ones)
 
@@ -360,7 +360,7 @@ def _static_ptrs(net):
     return ptrs, keep
 
 
-def _record(net, x, needs_dx, params):
+def _record(net, fn, scope, x, needs_dx, params):
     """-> Program, or raises _Reject. Leaves no trace: gradients go to scratch sets, BatchNorm statistics, counters and the trainer's switches
     are put back."""
     flat = params[0]._hwg_flat[0]
@@ -405,8 +405,8 @@ def _record(net, x, needs_dx, params):
             with _Recorder(prog, static, params, dev) as rec:
                 rec.inputs[xc.untyped_storage().data_ptr()] = S_X
                 rec.phase = "fwd"
-                with ops.scope("HWR"):
-                    y = net._forward(xc)
+                with ops.scope(scope):
+                    y = fn(xc)
                 rec.phase = None
                 # the upstream gradient of the recording: uploaded by a stream-ordered copy (not a C-ABI call, so not part of the program)
                 g = torch.randn(y.shape, generator=torch.Generator().manual_seed(5), dtype=torch.float32).pin_memory().to(dev, non_blocking=True)
@@ -452,12 +452,12 @@ def _record(net, x, needs_dx, params):
     return prog
 
 
-def hwr_forward(net, x):
-    """the recogniser's forward through a recorded program, or None (caller runs the eager path)"""
-    if not (ENABLED and _FUNCS and net.training and net.logit_offset is None and ops.PROF_SHAPES is None and x.is_cuda and x.dtype == torch.float32):
+def forward(net, fn, scope, x, eligible=True):
+    """`fn(x)` - the forward of the sub-network whose parameters and buffers `net` (an nn.Module) holds - through a recorded program, or None
+    (the caller runs the eager path). The sub-network must be a pure function of x's geometry: no random draws, no host decisions."""
+    if not (ENABLED and eligible and _FUNCS and net.training and ops.PROF_SHAPES is None and x.is_cuda and x.dtype == torch.float32):
         return None
-    grad_ctx = ops.TAPE is not None or torch.is_grad_enabled()
-    if not grad_ctx:
+    if not (ops.TAPE is not None or torch.is_grad_enabled()):
         return None
     params = [p for p in net.parameters()]
     if not params or any(getattr(p, "_hwg_flat", None) is None for p in params):
@@ -478,11 +478,11 @@ def hwr_forward(net, x):
         if ops._defer["count"] or ops._sn_defer or ops._side_dirty or ops.DEFER_KEEP_ARENA:
             return None                   # queued work of the surrounding pass: record at a quieter moment
         try:
-            prog = _record(net, x, needs_dx, params)
+            prog = _record(net, fn, scope, x, needs_dx, params)
             STATS["captures"] += 1
         except Exception as e:  # noqa: BLE001 - _Reject, or anything a recording trips over: the eager path is always there, in-process
             import warnings
-            warnings.warn("handwriting_line_generation_amd.replay: recogniser pass %s stays on the eager path (%s: %s)" % (tuple(x.shape), type(e).__name__, e))
+            warnings.warn("handwriting_line_generation_amd.replay: %s pass %s stays on the eager path (%s: %s)" % (scope, tuple(x.shape), type(e).__name__, e))
             prog = None
             STATS["rejected"] += 1
         _programs[key] = prog
@@ -493,11 +493,16 @@ def hwr_forward(net, x):
         prog.verdict = True
         if not ok:
             import warnings
-            warnings.warn("handwriting_line_generation_amd.replay: recogniser pass %s stays on the eager path (the replayed pass does not reproduce "
-                          "the recorded one bit for bit)" % (tuple(x.shape),))
+            warnings.warn("handwriting_line_generation_amd.replay: %s pass %s stays on the eager path (the replayed pass does not reproduce the "
+                          "recorded one bit for bit)" % (scope, tuple(x.shape)))
             prog.pools.clear()
             _programs[key] = None
             STATS["rejected"] += 1
             STATS["captures"] -= 1
             return None
     return _ReplayNet.apply(x, prog, *params)
+
+
+def hwr_forward(net, x):
+    """the recogniser (model/cnn_only_hwr.py): frozen weights, BatchNorm in train mode, no random draws"""
+    return forward(net, net._forward, "HWR", x, eligible=net.logit_offset is None)
