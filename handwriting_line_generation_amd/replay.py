@@ -166,21 +166,21 @@ class _Recorder:
                 kind, val = 0, int(a)
             elif k == "f":
                 kind, val = 1, int(np.array([float(a)], dtype=np.float64).view(np.int64)[0])
+            elif k == "s":                         # a parameter the header declares as a stream: re-pointed at the streams of the replaying pass
+                a = 0 if a is None else int(a)
+                if a == self.main_stream:
+                    kind, val = 3, S_STREAM
+                elif self.side_stream is not None and a == self.side_stream:
+                    kind, val = 3, S_SIDE
+                    ph.uses_side = True
+                else:
+                    raise _Reject("%s runs on a stream that is neither the pass's main nor its side stream" % name)
             elif a is None:
                 kind, val = 2, 0
             elif isinstance(a, torch.Tensor):
                 kind, val, off = self._tensor(a, ph)
             else:
-                a = int(a)
-                if a == self.main_stream and (a != 0 or name.startswith("hwg_stream_")):
-                    kind, val = 3, S_STREAM
-                elif self.side_stream is not None and a == self.side_stream:
-                    kind, val = 3, S_SIDE
-                    ph.uses_side = True
-                elif a == 0:
-                    kind, val = 3, S_STREAM        # (the null stream is only ever passed where a stream is meant; null pointers travel as None)
-                else:
-                    kind, val = 2, a               # a host-side address with static lifetime (geometry descriptors of the plan caches)
+                kind, val = 2, int(a)              # a host-side address with static lifetime (geometry descriptors of the plan caches), or 0
             ph.kinds.append(kind); ph.vals.append(val); ph.offs.append(off)
 
     def _tensor(self, t, ph):

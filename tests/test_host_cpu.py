@@ -121,3 +121,24 @@ def test_call_thunks_refuse_values_that_do_not_fit_the_c_types():
         L.call("hwg_prof_start", 1 << 40)                       # int capacity
     with pytest.raises(OverflowError):
         L.call("hwg_conv_pack_weight", None, None, 1 << 33, *([1] * 9), None)   # int A (13 arguments: checked before the call is made)
+
+
+def test_replay_executor_runs_a_call_list_and_classifies_stream_parameters():
+    """the C launch-list executor behind replay.py (csrc/hwg_pycall.c, generated): a list of status-returning entry points runs in one call, stops at
+    the first non-zero status and reports its index; malformed lists are refused before anything is called; the table it is driven by marks every
+    parameter hwg.h names *stream as a stream (the recorder re-points exactly those at the replaying pass's streams, nothing else)"""
+    from handwriting_line_generation_amd import _lib as L
+    funcs = L._hwgcall.replay_functions()
+    assert funcs["hwg_stream_fork"][1] == "ss" and funcs["hwg_stream_join"][1] == "ss"
+    header = open(os.path.join(os.path.dirname(__file__), "..", "include", "hwg.h")).read()
+    assert sum(k.count("s") for _, k in funcs.values()) == header.count("void* stream") + 4     # + fork / join's two each
+    for name, (fid, kinds) in funcs.items():
+        assert set(kinds) <= set("psif"), (name, kinds)
+    reload_id, abi_id = funcs["hwg_tuning_reload"][0], funcs["hwg_abi_version"][0]
+    empty64, table = np.zeros(1, np.int64), np.zeros(1, np.uint64)
+    run = lambda recs: L._hwgcall.replay(np.asarray(recs, np.int32).reshape(-1, 3), np.zeros(0, np.uint8), empty64, empty64, table)
+    assert run([(reload_id, 0, 0), (reload_id, 0, 0)]) == (0, -1)
+    assert run([(reload_id, 0, 0), (abi_id, 0, 0), (reload_id, 0, 0)]) == (L._FN["hwg_abi_version"](), 1)      # a non-zero status stops the list
+    assert run([(len(funcs), 0, 0)])[0] == -1002 and run([(funcs["hwg_prof_start"][0], 0, 0)])[0] == -1002   # unknown id; wrong argument count
+    recs = np.asarray([(funcs["hwg_prof_start"][0], 0, 1)], np.int32)
+    assert L._hwgcall.replay(recs, np.asarray([3], np.uint8), np.asarray([5], np.int64), empty64, table)[0] == -1003   # table slot out of range
