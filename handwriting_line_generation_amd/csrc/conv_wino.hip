@@ -32,6 +32,8 @@ struct WinoK {
   float* part;         // [nsplit][N*P*Q*K]
   int mt, nt;          // workgroup tiles along M and K
   int xcd_order;       // 1: every XCD owns a contiguous run of the (split, n-tile, m-tile) sequence, 0: plain launch order
+  int bal;             // > 0 (64 x 64 DMA kernel only): the tiles from `bal_tile0` on are scheduled BALANCED on `bal` workgroups - their (tile, chunk)
+  int bal_tile0;       //   unit sequence in equal runs, launched behind the whole-tile workgroups of the tiles before (a multiple of 256 of them)
 };
 
 // Work item of this workgroup. The dispatcher places block b on XCD b % 8 and every XCD has its own 4 MiB L2: with the plain order all
@@ -55,6 +57,21 @@ __device__ __forceinline__ bool wino_work_item(const WinoK& a, int& mtile, int& 
   split = r / a.nt;
   return true;
 }
+
+// block -> position in the work order of a launch of `total` work items (same XCD-contiguous order as above)
+__device__ __forceinline__ bool wino_block(const WinoK& a, int block, int total, int& w) {
+  w = block;
+  if (a.xcd_order) {
+    const int xcd = w & 7, slot = w >> 3;
+    const int lo = (int)((long long)xcd * total >> 3), hi = (int)((long long)(xcd + 1) * total >> 3);
+    w = lo + slot;
+    return w < hi;
+  }
+  return w < total;
+}
+// balanced schedule: workgroup g of G owns the units [U g / G, U (g + 1) / G); the owner of unit u is the largest g with U g / G <= u
+// (32-bit arithmetic: wino_balance keeps U * G below 2^31)
+__host__ __device__ __forceinline__ int wino_bal_owner(int G, int U, int u) { return (int)(((unsigned)(u + 1) * (unsigned)G - 1u) / (unsigned)U); }
 
 __device__ __forceinline__ float quad_partner(float v) {
   // lane b of every quad receives the value of lane {2,2,1,1}[b]  (DPP quad_perm)
@@ -803,7 +820,7 @@ __global__ __launch_bounds__(512) void wino_conv_ws_kernel(WinoK a) {
 #ifndef HWG_W64D_SCHED
 #define HWG_W64D_SCHED 6
 #endif
-template <int ABL>
+template <int ABL, bool BAL>
 __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
   constexpr int NT = 512, TM = 64, TN = 64;
   constexpr int PSV = TM * 16 + 8, PSU = TN * 16 + 8;
@@ -821,13 +838,44 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int bq = wid & 3, nh = wid >> 2;
-  int mtile, ntile, split;
-  if (!wino_work_item(a, mtile, ntile, split)) return;
+  const int T_all = a.C >> 4;
+  // Work of this workgroup: one (tile, chunk range) item of the uniform split - or, in a balanced launch (a.bal > 0), either one whole tile
+  // of the leading region or its G-th of the (tile, chunk) unit sequence of the tail region, which may end one tile and begin the next:
+  // every tile it touches is one SEGMENT of the loop below. A tile cut by workgroup boundaries is written as numbered pieces into `part`
+  // (piece = workgroup - first workgroup of the tile) and summed by wino_bal_reduce_kernel; a tile inside one workgroup is written directly.
+  int mtile, ntile, split = 0, wg = 0;
+  int unit = 0, unit_end = 0;               // units of the balanced region, relative to its first tile (32-bit: the planner keeps units * G < 2^31)
+  const int U_bal = (a.mt * a.nt - a.bal_tile0) * T_all;
+  bool whole = false;                        // balanced launch, whole-tile workgroup of the leading region
+  if constexpr (BAL) {
+    if ((int)blockIdx.x < a.bal_tile0) {
+      if (!wino_block(a, blockIdx.x, a.bal_tile0, wg)) return;
+      whole = true;
+      mtile = wg % a.mt;
+      ntile = wg / a.mt;
+    } else {
+      if (!wino_block(a, blockIdx.x - a.bal_tile0, a.bal, wg)) return;
+      unit = (int)((long long)U_bal * wg / a.bal);
+      unit_end = (int)((long long)U_bal * (wg + 1) / a.bal);
+      if (unit >= unit_end) return;
+    }
+  } else if (!wino_work_item(a, mtile, ntile, split)) {
+    return;
+  }
+  for (;;) {
+  int t0, t1;
+  if (BAL && !whole) {
+    const int rel = unit / T_all, tile = a.bal_tile0 + rel;
+    t0 = unit - rel * T_all;
+    t1 = unit_end - unit < T_all - t0 ? t0 + (unit_end - unit) : T_all;
+    mtile = tile % a.mt;
+    ntile = tile / a.mt;
+  } else {
+    t0 = (int)((long long)T_all * split / a.nsplit);
+    t1 = (int)((long long)T_all * (split + 1) / a.nsplit);
+  }
   const int m0 = mtile * TM;
   const int n0 = ntile * TN;
-  const int T_all = a.C >> 4;
-  const int t0 = (int)((long long)T_all * split / a.nsplit);
-  const int t1 = (int)((long long)T_all * (split + 1) / a.nsplit);
 
   int x_off[XI], x_ok[XI], x_row[XI], x_c4[XI], x_b[XI];
   const int row_stride = a.W * a.C;
@@ -1042,8 +1090,15 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
   __syncthreads();
   const int kk = tid & 63;
   const int k = n0 + kk;
-  const bool direct = a.nsplit == 1;
-  float* yg = direct ? a.y : a.part + (long long)split * ((long long)a.N * a.P * a.Q * a.K);
+  bool direct = a.nsplit == 1;
+  int piece = split;
+  if (BAL && !whole) {
+    const int rel = unit / T_all;
+    const int g_first = wino_bal_owner(a.bal, U_bal, rel * T_all), g_last = wino_bal_owner(a.bal, U_bal, rel * T_all + T_all - 1);
+    direct = g_first == g_last;
+    piece = wg - g_first;
+  }
+  float* yg = direct ? a.y : a.part + (long long)piece * ((long long)a.N * a.P * a.Q * a.K);
   const float bv = (direct && a.bias && k < a.K) ? a.bias[k] : 0.f;
   const bool accum = direct && a.accumulate;
 #pragma unroll 2
@@ -1071,6 +1126,11 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
         yg[o] = v;
       }
     }
+  }
+  if (!BAL || whole) break;
+  unit += t1 - t0;
+  if (unit >= unit_end) break;
+  __syncthreads();      // the exchange image has been read: the next segment's prologue may overwrite the operand buffers it aliases
   }
 }
 
@@ -1347,15 +1407,81 @@ __global__ __launch_bounds__(256) void wino_pack_weight_kernel(const float* src,
     wino_pack_one(src, dst, i, A, Apad, B, Bpad, sa, sb, sr, ss, flip);
 }
 
+// Balanced schedule (wino_conv64d_kernel, a.bal > 0): sums the numbered pieces of every tile the workgroup boundaries cut (+ bias, + the
+// accumulate operand) into y; tiles written directly (whole-tile region, or inside one workgroup's run) are left alone.
+template <int VEC>
+__global__ __launch_bounds__(256) void wino_bal_reduce_kernel(WinoK a, int T_all) {
+  const int KV = a.K / VEC;
+  const int total = a.N * a.P * a.Q * KV;
+  const long long plane = (long long)a.N * a.P * a.Q * a.K;
+  const int U_bal = (a.mt * a.nt - a.bal_tile0) * T_all;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int k = (i % KV) * VEC, pix = i / KV;
+    const int q = pix % a.Q, t = pix / a.Q, p = t % a.P, n = t / a.P;
+    const int m = (n * a.TP + (p >> 1)) * a.TQ + (q >> 1);
+    const int rel = (m >> 6) + a.mt * (k >> 6) - a.bal_tile0;
+    if (rel < 0) continue;
+    const int g_first = wino_bal_owner(a.bal, U_bal, rel * T_all), g_last = wino_bal_owner(a.bal, U_bal, rel * T_all + T_all - 1);
+    if (g_first == g_last) continue;
+    const long long o = (long long)pix * a.K + k;
+    float s[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s[v] = 0.f;
+    for (int j = 0; j <= g_last - g_first; ++j) {
+      if constexpr (VEC == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(a.part + j * plane + o);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      } else {
+        s[0] += a.part[j * plane + o];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      if (a.bias) s[v] += a.bias[k + v];
+      if (a.accumulate) s[v] += a.y[o + v];
+    }
+    if constexpr (VEC == 4) *reinterpret_cast<float4*>(a.y + o) = make_float4(s[0], s[1], s[2], s[3]);
+    else a.y[o] = s[0];
+  }
+}
+
 struct WinoPlan {
   int cfg;      // 0: 64 tiles x 32 k, 1: 32 x 64, 2: 128 x 16 (all-purpose kernel); 4: 32 x 64 (wave-specialised kernel); 5: 64 x 64 (12 waves);
                 // 6: 64 x 64 with register-level operand reuse (wino_conv64_kernel); 3 unused
   int tm, tn, nsplit;
+  int bal, bal_tile0, bal_pieces;   // cfg 6 only, bal > 0: balanced schedule (WinoK.bal / bal_tile0), at most bal_pieces partial images
+  int bal_segs, bal_cut, bal_cut_pieces;
   double model_s;   // modelled duration of the chosen schedule (seconds)
 };
 static void wino_cfg(WinoPlan& p, int cfg) {
   static const int tms[8] = {64, 32, 128, 64, 32, 64, 64, 32}, tns[8] = {32, 64, 16, 32, 64, 64, 64, 32};
   p.cfg = cfg; p.tm = tms[cfg]; p.tn = tns[cfg];
+  p.bal = p.bal_tile0 = p.bal_pieces = p.bal_segs = p.bal_cut = p.bal_cut_pieces = 0;
+}
+// Balanced schedule of the 64 x 64 DMA kernel for `tiles` workgroup tiles of `chunks` channel chunks: the first floor(tiles / 256) * 256 tiles
+// run as whole-tile workgroups (full rounds of the chip), the rest - the round that would be partly filled - is cut into G equal runs of
+// (tile, chunk) units. Returns false where that cannot help (nothing left over, or the chip is filled anyway). bal_segs = most tiles one
+// workgroup touches, bal_cut = tiles that are cut, bal_cut_pieces = their pieces in total (the reduce pass reads those and writes bal_cut tiles).
+static bool wino_balance(WinoPlan& p, long long tiles, int chunks, int g_force = 0, int a_force = -1) {
+  const long long lead = a_force >= 0 ? (long long)a_force : tiles / 256 * 256;
+  const long long rem = tiles - lead;
+  if (lead % 256 || rem <= 0 || (g_force <= 0 && rem >= 240)) return false;
+  const long long units = rem * chunks;
+  long long G = g_force > 0 ? g_force : (units < 256 ? units : 256);
+  if (G > units) G = units;
+  if (G < 1 || (g_force <= 0 && G <= rem) || units * G >= (1ll << 31) || units >= (1ll << 24)) return false;
+  p.bal = (int)G; p.bal_tile0 = (int)lead; p.nsplit = 1;
+  p.bal_pieces = 1; p.bal_segs = 1; p.bal_cut = 0; p.bal_cut_pieces = 0;
+  for (long long t = 0; t < rem; ++t) {
+    const int n = wino_bal_owner((int)G, (int)units, (int)(t * chunks + chunks - 1)) - wino_bal_owner((int)G, (int)units, (int)(t * chunks)) + 1;
+    if (n > p.bal_pieces) p.bal_pieces = n;
+    if (n > 1) { ++p.bal_cut; p.bal_cut_pieces += n; }
+  }
+  for (long long g = 0; g < G; ++g) {
+    const long long u0 = units * g / G, u1 = units * (g + 1) / G;
+    if (u1 > u0) p.bal_segs = std::max(p.bal_segs, (int)((u1 - 1) / chunks - u0 / chunks + 1));
+  }
+  return true;
 }
 // Schedule = (kernel variant, channel split) with the smallest modelled time. Model (fitted to tools/wino_check.py sweeps on MI355X,
 // profiles/r02_wino_shapes.txt): one workgroup per CU at a time, so the launch takes ceil(workgroups / 256) rounds of
@@ -1400,10 +1526,30 @@ static WinoPlan plan_wino_model(const hwg_conv_desc* d) {
       if (t < best_t) { best_t = t; best = p; best.nsplit = ns; }
     }
   }
+  // balanced schedule of the 64 x 64 DMA kernel (wino_balance): whole-tile rounds + the leftover tiles cut into equal unit runs, the cut tiles
+  // summed by one pass over their pieces
+  const int bal_mode = hwg_tune().wino_bal[0] ? atoi(hwg_tune().wino_bal) : 0;      // HWG_WINO_BAL: -1 never, 0 by model, "G[,lead tiles]" forced
+  if (d->K > 48 && bal_mode >= 0 && !hwg_tune().w64_nodma && !(hwg_tune().conv_dbg & 512) && (long long)d->N * d->P * d->Q * d->K < (1ll << 31)) {
+    WinoPlan p;
+    wino_cfg(p, 6);
+    const long long tiles = (long long)hwg_cdiv(M, 64) * hwg_cdiv(d->K, 64);
+    int gf = 0, af = -1;
+    if (bal_mode > 0) sscanf(hwg_tune().wino_bal, "%d,%d", &gf, &af);
+    if (wino_balance(p, tiles, chunks, gf, af)) {
+      // fitted on tools/probes/probe_r5_bal.txt (profiles/r05_probe_bal.txt): a tail workgroup starts while the last whole-tile ones drain
+      // (4 us of its fixed cost hidden), every further tile it touches costs 5 us (output transform + prologue)
+      const long long units = (tiles - p.bal_tile0) * chunks;
+      const long long c = hwg_cdiv(units, (long long)p.bal);
+      double t = (p.bal_tile0 / 256) * (cost6.fixed_us + 4.0 * chunks * cost6.step_us) * 1e-6;
+      t += (double)hwg_cdiv((long long)p.bal, 256ll) * (cost6.fixed_us - 4.0 + (p.bal_segs - 1) * 5.0 + 4.0 * c * cost6.step_us) * 1e-6;
+      if (p.bal_cut) t += (p.bal_cut_pieces + p.bal_cut) * (out_bytes / tiles) / 3.0e12 + out_bytes / 2.0e13 + 6e-6;
+      if (bal_mode > 0 || t < 0.97 * best_t) { best = p; best_t = t; }
+    }
+  }
   if (const char* f = hwg_tune().wino_force; *f) {   // tuning aid: "cfg[,nsplit]"
     int fc = -1, fs = 0;
     const int n = sscanf(f, "%d,%d", &fc, &fs);
-    if (n >= 1 && fc >= 0 && fc <= 7 && fc != 3 && fc != 4 && (fc == 2 || d->K > 16)) wino_cfg(best, fc);
+    if (n >= 1 && fc >= 0 && fc <= 7 && fc != 3 && fc != 4 && (fc == 2 || d->K > 16)) { const int ns = best.nsplit; wino_cfg(best, fc); best.nsplit = ns; }
     if (n >= 2 && fs >= 1) best.nsplit = fs > chunks ? chunks : fs;
   }
   best.model_s = best_t;
@@ -1450,6 +1596,7 @@ extern "C" int hwg_wino_pack_weight(const float* src, float* dst, int A, int B, 
 extern "C" size_t hwg_wino_conv_workspace(const hwg_conv_desc* d) {
   if (!hwg_wino_supported(d)) return 0;
   const WinoPlan p = plan_wino(d);
+  if (p.bal > 0) return p.bal_pieces > 1 ? (size_t)p.bal_pieces * d->N * d->P * d->Q * d->K * sizeof(float) : 0;
   if (p.nsplit <= 1) return 0;
   return (size_t)p.nsplit * d->N * d->P * d->Q * d->K * sizeof(float);
 }
@@ -1478,21 +1625,33 @@ extern "C" int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const f
   k.part = (float*)workspace;
   k.mt = hwg_cdiv(k.M, p.tm); k.nt = hwg_cdiv(d->K, p.tn);
   k.xcd_order = hwg_tune().wino_order;
-  dim3 grid((k.mt * k.nt * p.nsplit + 7) / 8 * 8);
+  k.bal = p.bal; k.bal_tile0 = p.bal_tile0;
+  dim3 grid(p.bal > 0 ? p.bal_tile0 + (p.bal + 7) / 8 * 8 : (k.mt * k.nt * p.nsplit + 7) / 8 * 8);
   const int prof = hwg_prof_open(HWG_PROF_CONV_WINO, 2.0 * d->N * d->P * d->Q * (double)d->K * d->C * 9.0, st);
   if (p.cfg == 0) hipLaunchKernelGGL((wino_conv_kernel<4, 2>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 1) hipLaunchKernelGGL((wino_conv_kernel<2, 4>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 2) hipLaunchKernelGGL((wino_conv_kernel<8, 1>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 7) hipLaunchKernelGGL((wino_conv_kernel<2, 2>), grid, dim3(256), 0, st, k);
   else if (p.cfg == 5) hipLaunchKernelGGL(wino_conv_big_kernel, grid, dim3(768), 0, st, k);
-  else if (p.cfg == 6 && !hwg_tune().w64_nodma && (hwg_tune().conv_dbg & 512)) hipLaunchKernelGGL(wino_conv64d_kernel<1>, grid, dim3(512), 0, st, k);
-  else if (p.cfg == 6 && !hwg_tune().w64_nodma) hipLaunchKernelGGL(wino_conv64d_kernel<0>, grid, dim3(512), 0, st, k);
+  else if (p.cfg == 6 && !hwg_tune().w64_nodma && (hwg_tune().conv_dbg & 512)) hipLaunchKernelGGL((wino_conv64d_kernel<1, false>), grid, dim3(512), 0, st, k);
+  else if (p.cfg == 6 && !hwg_tune().w64_nodma && p.bal > 0) hipLaunchKernelGGL((wino_conv64d_kernel<0, true>), grid, dim3(512), 0, st, k);
+  else if (p.cfg == 6 && !hwg_tune().w64_nodma) hipLaunchKernelGGL((wino_conv64d_kernel<0, false>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 6) hipLaunchKernelGGL(wino_conv64_kernel, grid, dim3(512), 0, st, k);
   else hipLaunchKernelGGL((wino_conv_ws_kernel<1, 4>), grid, dim3(512), 0, st, k);
   hwg_prof_close(prof, st);
-  hwg_note_plan(HWG_PROF_CONV_WINO, p.cfg, p.nsplit);
+  hwg_note_plan(HWG_PROF_CONV_WINO, p.cfg, p.bal > 0 ? -p.bal : p.nsplit);
   HWG_LAUNCH_CHECK("wino_conv_fwd");
-  if (p.nsplit > 1) {
+  if (p.bal > 0 && p.bal_pieces > 1) {
+    const long long total = (long long)d->N * d->P * d->Q * d->K;
+    const double cut = (double)(k.mt * k.nt - p.bal_tile0) / (k.mt * k.nt);
+    const int prof2 = hwg_prof_open(HWG_PROF_CONV_REDUCE, 4.0 * total * cut * (p.bal_pieces + 1), st);
+    const int vec = d->K % 4 == 0 ? 4 : 1;
+    const dim3 rgrid(hwg_stream_grid(total / vec, 256));
+    if (vec == 4) hipLaunchKernelGGL(wino_bal_reduce_kernel<4>, rgrid, dim3(256), 0, st, k, d->C / 16);
+    else hipLaunchKernelGGL(wino_bal_reduce_kernel<1>, rgrid, dim3(256), 0, st, k, d->C / 16);
+    hwg_prof_close(prof2, st);
+    HWG_LAUNCH_CHECK("wino_bal_reduce");
+  } else if (p.nsplit > 1) {
     const long long total = (long long)d->N * d->P * d->Q * d->K;
     const int prof2 = hwg_prof_open(HWG_PROF_CONV_REDUCE, 4.0 * total * (p.nsplit + 1), st);
     const int rc = hwg_conv_split_reduce_launch((const float*)workspace, bias, y, total, d->K, p.nsplit, accumulate, st);

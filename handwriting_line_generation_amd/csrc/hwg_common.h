@@ -73,6 +73,7 @@ struct HwgTune {
   int conv_lds;          // HWG_CONV_LDS: 0 keeps strided layers on the per-tap gather kernel (A/B timing), 1 default
   int wgrad_reduce_rows; // HWG_WGRAD_REDUCE_ROWS: 0 = tap-at-a-time partial-image reduce (A/B timing), 1 default = row-contiguous stores
   char wino_force[32];   // HWG_WINO_FORCE  "cfg[,nsplit]"
+  char wino_bal[32];     // HWG_WINO_BAL    balanced schedule of the 64 x 64 Winograd kernel: -1 never, unset / 0 by model, "G[,lead tiles]" forced
   char conv_force[48];   // HWG_CONV_FORCE  "bm,bn,bk[,nsplit]"
   char wgrad_force[32];  // HWG_WGRAD_FORCE "cfg,target_blocks"
   char wino_cost6[48];   // HWG_WINO_COST6  "fixed_us,step_us"

@@ -53,6 +53,7 @@ const HwgTune& hwg_tune() {
     t->c1_mfma = tune_int("HWG_C1_MFMA", 1);
     t->conv_dbg = tune_int("HWG_CONV_DBG", 0);
     tune_str(t->wino_force, sizeof(t->wino_force), "HWG_WINO_FORCE");
+    tune_str(t->wino_bal, sizeof(t->wino_bal), "HWG_WINO_BAL");
     tune_str(t->conv_force, sizeof(t->conv_force), "HWG_CONV_FORCE");
     tune_str(t->wgrad_force, sizeof(t->wgrad_force), "HWG_WGRAD_FORCE");
     tune_str(t->wino_cost6, sizeof(t->wino_cost6), "HWG_WINO_COST6");

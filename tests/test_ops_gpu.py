@@ -317,6 +317,41 @@ def test_winograd_forced_schedules_vs_cpu(cuda, cfg, nsplit):
     assert ran >= 2
 
 
+# The balanced schedule of the 64 x 64 DMA kernel (whole-tile rounds + the leftover tiles cut into equal runs of (tile, chunk) units, pieces
+# summed by wino_bal_reduce_kernel): forced workgroup counts that cut tiles into 1, 2 and 3+ pieces, runs that span several tiles, a leading
+# whole-tile region, ragged channel counts, with bias - against torch's CPU convolution, and bit-repeatable.
+WINO_BAL_CASES = [((2, 13, 37, 64, 80, 1, 1), "3"), ((2, 13, 37, 64, 80, 1, 1), "7"), ((2, 13, 37, 64, 80, 1, 1), "40"), ((1, 9, 66, 48, 208, 0, 1), "5"),
+                  ((1, 9, 66, 48, 208, 0, 1), "11"), ((2, 5, 19, 96, 64, 0, 0), "4"), ((2, 5, 19, 96, 64, 0, 0), "6"), ((8, 66, 130, 32, 64, 1, 1), "9,256"),
+                  ((8, 66, 130, 32, 64, 1, 1), "26,256"), ((8, 66, 130, 32, 64, 1, 1), "64,0"), ((2, 8, 129, 512, 256, 1, 1), "256")]
+
+
+@pytest.mark.parametrize("case", WINO_BAL_CASES, ids=lambda c: "x".join(map(str, c[0])) + "_G" + c[1].replace(",", "_lead"))
+def test_winograd_balanced_schedule_vs_cpu(cuda, case):
+    from handwriting_line_generation_amd import ops
+    (N, H, W, C, K, ph, pw), force = case
+    g = torch.Generator().manual_seed(57)
+    x = torch.randn(N, C, H, W, generator=g); w = torch.randn(K, C, 3, 3, generator=g) / (3 * C ** 0.5); b = torch.randn(K, generator=g)
+    yr = F.conv2d(x, w, b, 1, (ph, pw))
+    gy = torch.randn(yr.shape, generator=g)
+    dxr = torch.nn.grad.conv2d_input(x.shape, w, gy, 1, (ph, pw))
+    with ops.tuning(HWG_WINO="2", HWG_WINO_BAL=force, HWG_WINO_WGRAD="0"):
+        xg, wg, bg = nhwc(x).to(cuda), w.to(cuda), b.to(cuda)
+        y = ops.conv2d(xg, wg, bg, 1, (ph, pw))
+        assert ops.last_plan() == (6, 6, -int(force.split(",")[0])), ops.last_plan()
+        y2 = ops.conv2d(xg, wg, bg, 1, (ph, pw))
+        assert torch.equal(y, y2)
+        _close(nchw(y), yr, "balanced %s %s y" % (force, case[0]), tol=2e-5)
+        if K % 16 == 0:
+            dx = ops.conv2d(nhwc(gy).to(cuda), wg.flip(2, 3).transpose(0, 1).contiguous(), None, 1, (2 - ph, 2 - pw))
+            lp = ops.last_plan()
+            assert lp[0] == 6 and (lp[1] == 6 and lp[2] < 0) == (C > 48), lp      # (the 64 x 64 kernel needs > 48 output channels)
+            _close(nchw(dx), dxr, "balanced %s %s dx" % (force, case[0]), tol=2e-5)
+    with ops.tuning(HWG_WINO="2", HWG_WINO_FORCE="6,1", HWG_WINO_BAL="-1", HWG_WINO_WGRAD="0"):
+        y1 = ops.conv2d(xg, wg, bg, 1, (ph, pw))
+        assert ops.last_plan() == (6, 6, 1)
+    assert float((y - y1).abs().max()) < 2e-5 * float(yr.abs().max())
+
+
 # One full-size layer per network (the bench step's own geometries), every engine, against torch's CPU convolution in fp64: the kernels that
 # carry the headline number are compared with the oracle directly, not only with each other.
 FULL_SIZE_LAYERS = [("D convs1.0", (16, 58, 512, 64, 64, 0, 1)), ("HWR conv5", (8, 8, 129, 512, 512, 0, 0)), ("style down.2", (4, 32, 514, 128, 128, 0, 0))]
