@@ -21,7 +21,13 @@ struct ConvK {
   const float* bias;
   float* y;
   int N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, P, Q;
-  int mode;        // 0: convolution gather, 1: fractionally strided (transposed, stride>1) by parity class
+  int mode;        // 0: convolution gather, 1: fractionally strided (transposed, stride>1) by parity class, 2: fractionally strided with the parity
+                   // classes MERGED into the GEMM's N dimension (R % sh == 0, S % sw == 0: every class has R/sh x S/sw taps, and - with each class's
+                   // block grid shifted by floor((class + pad) / stride) - they all read the SAME input pixels: one stride-1 (R/sh x S/sw)-tap
+                   // convolution to classes * K channels, written depth-to-space. The operand is read once instead of once per class and a
+                   // 64-channel layer fills 128 x 128 tiles)
+  int KN;          // extent of the GEMM's N dimension: K, in mode 2 classes * K
+  int Pm, Qm;      // mode 2: rows / columns of the shared block grid
   int accumulate;
   int ntm;         // M tiles of the largest parity class
   int ntm_pad;     // ntm rounded up to a multiple of 8 (XCD remap)
@@ -77,6 +83,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
   if (a.mode == 0) {
     ah = a.sh; bh = -a.ph; ch = a.dh;
     aw = a.sw; bw = -a.pw; cw = a.dw;
+  } else if (a.mode == 2) {
+    Pc = a.Pm; Qc = a.Qm;
+    tr = a.sh; ts = a.sw;
+    nr = a.R / a.sh; ns = a.S / a.sw;
+    ah = 1; bh = 0; ch = -1;
+    aw = 1; bw = 0; cw = -1;
   } else {
     const int cls = blockIdx.z;
     cp = cls / a.sw; cq = cls % a.sw;
@@ -115,14 +127,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
     a_wb[it] = aw * qi + bw;
     a_nb[it] = n * a.H * a.W;
   }
-  int b_row[B_IT], b_chk[B_IT];
+  int b_row[B_IT], b_chk[B_IT], b_base[B_IT];     // b_base: row of the [tap][K][C] filter image this B row reads at the class's first tap
   bool b_ok[B_IT];
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
     const int f = tid + it * NT;
     b_row[it] = f / KC;
     b_chk[it] = f % KC;
-    b_ok[it] = (f < B_F4) && (n0 + b_row[it] < a.K);
+    const int col = n0 + b_row[it];
+    b_ok[it] = (f < B_F4) && (col < a.KN);
+    if (a.mode == 2) {
+      const int cls = col / a.K, kk = col - cls * a.K;
+      const int rc = (cls / a.sw + a.ph) % a.sh, sc = (cls % a.sw + a.pw) % a.sw;
+      b_base[it] = (rc * a.S + sc) * a.K + kk;
+    } else {
+      b_base[it] = (r0 * a.S + s0) * a.K + col;
+    }
   }
 
   const int csteps = a.C / BK;
@@ -149,8 +169,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
   const float* __restrict__ wg = a.w;
 
   auto load_tile = [&](float4* ra, float4* rb, bool* ma) {
-    const int r = r0 + tr * jr, s = s0 + ts * js;
-    const int tap = r * a.S + s;
+    const int tap = tr * jr * a.S + ts * js;      // tap offset from the class's first tap (which b_base holds)
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int ih = a_hb[it] + ch * jr;
@@ -164,7 +183,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const long long off = b_ok[it] ? ((long long)tap * a.K + n0 + b_row[it]) * a.C + c0 + b_chk[it] * 4 : 0;
+      const long long off = b_ok[it] ? ((long long)tap * a.K + b_base[it]) * a.C + c0 + b_chk[it] * 4 : 0;
       rb[it] = *reinterpret_cast<const float4*>(wg + off);
     }
     // advance to the next tile
@@ -318,10 +337,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
   }
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   float bv[NI];
+  int ck[NI], c_p[NI], c_q[NI], c_bh[NI], c_bw[NI];     // mode 2: channel, parity class and block shift of this lane's columns
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int col = n0 + wn0 + ni * 32 + l31;
-    bv[ni] = (a.bias && a.nsplit == 1 && col < a.K) ? a.bias[col] : 0.f;
+    ck[ni] = col; c_p[ni] = c_q[ni] = c_bh[ni] = c_bw[ni] = 0;
+    if (a.mode == 2) {
+      const int cls = col / a.K;
+      ck[ni] = col - cls * a.K;
+      c_p[ni] = cls / a.sw; c_q[ni] = cls % a.sw;
+      c_bh[ni] = (c_p[ni] + a.ph) / a.sh; c_bw[ni] = (c_q[ni] + a.pw) / a.sw;
+    }
+    bv[ni] = (a.bias && a.nsplit == 1 && col < a.KN) ? a.bias[ck[ni]] : 0.f;
   }
   float* __restrict__ yg = a.nsplit == 1 ? a.y : a.part + (long long)split * ((long long)a.N * a.P * a.Q * a.K);
   const bool accum = a.accumulate && a.nsplit == 1;
@@ -332,6 +359,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
       const int row = wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
       const int m = m0 + row;
       if (m >= Mc) continue;
+      if (a.mode == 2) {
+        const int qi = m % Qc;
+        const int t2 = m / Qc;
+        const int pi = t2 % Pc;
+        const int n = t2 / Pc;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int col = n0 + wn0 + ni * 32 + l31;
+          const int p = a.sh * (pi - c_bh[ni]) + c_p[ni], q = a.sw * (qi - c_bw[ni]) + c_q[ni];
+          if (col < a.KN && pi >= c_bh[ni] && p < a.P && qi >= c_bw[ni] && q < a.Q) {
+            const long long o = (((long long)n * a.P + p) * a.Q + q) * a.K + ck[ni];
+            float v = acc[mi][ni][e] + bv[ni];
+            if (accum) v += yg[o];
+            yg[o] = v;
+          }
+        }
+        continue;
+      }
       long long obase;
       if (a.mode == 0) {
         obase = (long long)m * a.K;
@@ -1202,6 +1247,7 @@ struct ConvPlan {
   bool mfma;
   int bm, bn, bk, nsplit, classes;
   long long Mc;
+  int merged, KN, Pm, Qm;   // transposed with R % sh == 0 and S % sw == 0: parity classes merged into the GEMM's N dimension (ConvK.mode 2)
   double model_s;   // modelled duration of the chosen schedule (seconds)
 };
 static ConvPlan plan_conv_model(const hwg_conv_desc* d);
@@ -1215,6 +1261,18 @@ static ConvPlan plan_conv_model(const hwg_conv_desc* d) {
   p.classes = d->transposed ? d->stride_h * d->stride_w : 1;
   p.Mc = (long long)d->N * d->P * d->Q;
   if (d->transposed) p.Mc = (long long)d->N * hwg_cdiv(d->P, d->stride_h) * hwg_cdiv(d->Q, d->stride_w);
+  p.merged = 0; p.KN = d->K; p.Pm = p.Qm = 0;
+  // Measured (tools/probes/probe_r5_merge.txt, profiles/r05_probe_merge.txt): the merged form only pays where a class alone cannot fill the narrowest
+  // tile - 8x32x244x32->16 (the generator's last up-convolution) 48.8 -> 25.4 us; at K >= 32 it is equal (style extractor's 4x4 stride-2 data
+  // gradients 214 vs 216 us: those launches are bound by their 2.07 rounds of workgroups, not by the operand re-reads) or slower where the
+  // class grid had the better tile count (8x8x61x128->64 20.5 -> 35 us). HWG_CONV_MERGE: 0 never, 1 (default) K < 32, 2 always (tests).
+  if (d->transposed && p.classes > 1 && d->R % d->stride_h == 0 && d->S % d->stride_w == 0 &&
+      (hwg_tune().conv_merge == 2 || (hwg_tune().conv_merge == 1 && d->K < 32))) {
+    // block grid shared by all classes: class c's blocks are shifted by floor((c + pad) / stride)
+    for (int c = 0; c < d->stride_h; ++c) p.Pm = std::max(p.Pm, hwg_cdiv(d->P - c, d->stride_h) + (c + d->pad_h) / d->stride_h);
+    for (int c = 0; c < d->stride_w; ++c) p.Qm = std::max(p.Qm, hwg_cdiv(d->Q - c, d->stride_w) + (c + d->pad_w) / d->stride_w);
+    p.merged = 1; p.KN = p.classes * d->K; p.Mc = (long long)d->N * p.Pm * p.Qm; p.classes = 1;
+  }
   // Schedule = (tile, split-K factor) with the smallest modelled time. The model (fitted to tools/conv_sweep.py measurements):
   //  * a CU retires one workgroup "quantum" at a time (co-resident workgroups share its matrix cores) and every XCD (32 CUs) owns
   //    a fixed 1/8 of the M tiles, so the makespan is ceil(blocks_per_XCD / 32) quanta (beyond 8 quanta the tail evens out);
@@ -1222,7 +1280,7 @@ static ConvPlan plan_conv_model(const hwg_conv_desc* d) {
   //  * split-K adds one pass that reads the nsplit partial images and writes the output.
   const int bk = (d->C % 32 == 0) ? 32 : 16;
   const int taps_total = d->R * d->S;
-  const double taps_per_class = (double)taps_total / p.classes;
+  const double taps_per_class = (double)taps_total / (d->transposed ? d->stride_h * d->stride_w : 1);
   const double T_total = taps_per_class * (d->C / bk);
   const int min_taps = d->transposed ? (d->R / d->stride_h) * (d->S / d->stride_w) : taps_total;
   const int min_steps = (min_taps > 0 ? min_taps : 1) * (d->C / bk);
@@ -1234,9 +1292,9 @@ static ConvPlan plan_conv_model(const hwg_conv_desc* d) {
   double best = 1e30;
   for (int ti = 0; ti < 4; ++ti) {
     const Tile& t = tiles[ti];
-    if (d->K <= 32 ? t.bn != 32 : (t.bn == 32 || (t.bn == 128 && d->K < 96))) continue;
+    if (p.KN <= 32 ? t.bn != 32 : (t.bn == 32 || (t.bn == 128 && p.KN < 96))) continue;
     const double step_s = 2.0 * t.bm * t.bn * bk / (t.tflops * 1e12 / 256.0);
-    const double per_xcd = (double)hwg_cdiv(hwg_cdiv(p.Mc, t.bm), 8) * hwg_cdiv(d->K, t.bn) * p.classes;
+    const double per_xcd = (double)hwg_cdiv(hwg_cdiv(p.Mc, t.bm), 8) * hwg_cdiv(p.KN, t.bn) * p.classes;
     for (int si = 0; si < 8; ++si) {
       const int n = splits[si];
       if (n > 1 && (min_steps / n < 3 || out_bytes * n > 1.5e9)) break;
@@ -1311,7 +1369,8 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
   k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.R = d->R; k.S = d->S;
   k.sh = d->stride_h; k.sw = d->stride_w; k.ph = d->pad_h; k.pw = d->pad_w; k.dh = d->dil_h; k.dw = d->dil_w;
   k.P = d->P; k.Q = d->Q;
-  k.mode = d->transposed ? 1 : 0;
+  k.mode = d->transposed ? (p.merged ? 2 : 1) : 0;
+  k.KN = p.KN; k.Pm = p.Pm; k.Qm = p.Qm;
   k.accumulate = accumulate;
   k.nsplit = p.nsplit;
   k.part = (float*)workspace;
@@ -1319,7 +1378,7 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
   const int bm = p.bm, bn = p.bn, bk = p.bk;
   k.ntm = hwg_cdiv(p.Mc, bm);
   k.ntm_pad = (k.ntm + 7) / 8 * 8;
-  dim3 grid(k.ntm_pad, hwg_cdiv(d->K, bn) * p.nsplit, p.classes);
+  dim3 grid(k.ntm_pad, hwg_cdiv(p.KN, bn) * p.nsplit, p.classes);
   // algorithmic work: every output pixel x K x C x taps (transposed: every input pixel feeds RxS outputs)
   const double pix = d->transposed ? (double)d->N * d->H * d->W : (double)d->N * d->P * d->Q;
   const int prof = hwg_prof_open(HWG_PROF_CONV, 2.0 * pix * d->K * d->C * d->R * d->S, st);
@@ -1338,7 +1397,7 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
   { hwg_set_error("conv_fwd: no tile config for bm=%d bn=%d", bm, bn); return HWG_ERR_ARG; }
 #undef HWG_CONV_CASE
   hwg_prof_close(prof, st);
-  hwg_note_plan(HWG_PROF_CONV, bm * 1000 + bn, p.nsplit);
+  hwg_note_plan(HWG_PROF_CONV, bm * 1000 + bn + (p.merged ? 1000000 : 0), p.nsplit);      // (+ 1000000: merged parity classes)
   HWG_LAUNCH_CHECK("conv_fwd");
   if (p.nsplit > 1) {
     const long long total = (long long)d->N * d->P * d->Q * d->K;

@@ -63,6 +63,7 @@ struct HwgTune {
   int wgrad_narrow;      // HWG_WGRAD_NARROW: 0 never, 2 also 2 / 4 channel blocks, 1 default
   int w64_nodma;         // HWG_W64_NODMA: register-staged filter stream in the 64x64 Winograd kernel (A/B timing)
   int wino_order;        // HWG_WINO_ORDER: 1 (default) XCD-contiguous work order
+  int conv_merge;        // HWG_CONV_MERGE: transposed convolutions with R % sh == 0, S % sw == 0 with merged parity classes: 0 never, 1 (default) K < 32, 2 always
   int wino_wgrad_split;  // HWG_WINO_WGRAD_SPLIT: forced pixel-range count of the Winograd weight gradient (0 = model)
   int wwg_debug;         // HWG_WWG_DEBUG
   int conv_pf;           // HWG_CONV_PF: register prefetch depth of the implicit-GEMM conv kernel (1 or 2)

@@ -140,6 +140,55 @@ def _conv_case(cuda, ops, case, expect_fwd_engine=None, expect_wgrad_cfg=None):
     _close(bg.grad, br.grad, name + ".db")
 
 
+# Fractionally strided convolutions whose kernel is a multiple of the stride run with their parity classes merged into the GEMM's N dimension
+# (ConvK.mode 2: one stride-1 (R/sh x S/sw)-tap convolution to classes * K channels, written depth-to-space). Every geometry family the
+# networks have - 4x4 stride 2 with padding 0 / 1, stride (2, 1), 6x3 stride (3, 1), output_padding, ragged channel counts, one input row -
+# merged vs by-class vs torch's CPU transposed convolution, with bias, also with the K loop split.
+MERGE_CASES = [(2, 8, 20, 64, 32, 4, 4, (2, 2), (1, 1), (0, 0)), (2, 7, 19, 32, 64, 4, 4, (2, 2), (0, 0), (0, 0)), (3, 5, 33, 48, 80, 4, 4, (2, 1), (0, 0), (0, 0)),
+               (2, 5, 21, 32, 24, 4, 4, (2, 2), (1, 1), (1, 1)), (2, 1, 30, 64, 40, 6, 3, (3, 1), (0, 1), (0, 0)), (1, 9, 17, 16, 16, 2, 2, (2, 2), (0, 0), (0, 0)),
+               (2, 6, 40, 128, 64, 4, 4, (2, 2), (0, 0), (1, 0)), (2, 4, 12, 32, 48, 4, 6, (2, 3), (1, 2), (0, 0)), (4, 1, 62, 256, 256, 4, 4, (2, 1), (0, 0), (0, 0))]
+
+
+@pytest.mark.parametrize("force", ["", "128,128,32,2", "64,64,32,3"])
+@pytest.mark.parametrize("case", MERGE_CASES, ids=lambda c: "x".join(str(v) for v in c[:7]) + "_s%d%d_p%d%d_o%d%d" % (c[7] + c[8] + c[9]))
+def test_transposed_conv_merged_classes(cuda, case, force):
+    from handwriting_line_generation_amd import ops
+    N, H, W, C, K, R, S, stride, pad, opad = case
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(N, C, H, W, generator=g); w = torch.randn(C, K, R, S, generator=g) / (C * R * S / (stride[0] * stride[1])) ** 0.5; b = torch.randn(K, generator=g)
+    yr = F.conv_transpose2d(x, w, b, stride=stride, padding=pad, output_padding=opad)
+    outs = {}
+    for merge in ("2", "0"):
+        env = dict(HWG_CONV_MERGE=merge)
+        if force:
+            env["HWG_CONV_FORCE"] = force
+        with ops.tuning(**env):
+            y = ops.conv_transpose2d(nhwc(x).to(cuda), w.to(cuda), b.to(cuda), stride=stride, padding=pad, output_padding=opad)
+            lp = ops.last_plan()
+            assert lp[0] == 0 and (lp[1] >= 1000000) == (merge == "2"), lp
+            outs[merge] = y
+    _close(nchw(outs["2"]), yr, "merged classes %s %s" % (case, force), tol=2e-5)
+    _close(nchw(outs["0"]), yr, "by class %s %s" % (case, force), tol=2e-5)
+    with ops.tuning(HWG_CONV_MERGE="2"):          # and as a layer: the gradients of a transposed layer / of the stride-2 convolution whose data gradient it is
+        xg, wg, bg = nhwc(x).to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        gy = torch.randn(yr.shape, generator=g)
+        F.conv_transpose2d(xr, wr, br, stride=stride, padding=pad, output_padding=opad).backward(gy)
+        ops.conv_transpose2d(xg, wg, bg, stride=stride, padding=pad, output_padding=opad).backward(nhwc(gy).to(cuda))
+        _close(nchw(xg.grad), xr.grad, "merged layer dx %s" % (case,), tol=2e-5)
+        _close(wg.grad, wr.grad, "merged layer dw %s" % (case,), tol=2e-5)
+        if opad == (0, 0):
+            xc = torch.randn(yr.shape, generator=g).requires_grad_(True)
+            wc = w.clone()                           # F.conv2d(x [.,K,..], weight [C, K, R, S]) -> C channels
+            yc = F.conv2d(xc, wc, None, stride=stride, padding=pad)
+            if yc.shape[2:] == x.shape[2:]:
+                gc = torch.randn(yc.shape, generator=g)
+                yc.backward(gc)
+                xcg = nhwc(xc.detach()).to(cuda).requires_grad_(True)
+                ops.conv2d(xcg, wc.to(cuda), None, stride, pad).backward(nhwc(gc).to(cuda))
+                _close(nchw(xcg.grad), xc.grad, "stride-s conv dx through merged classes %s" % (case,), tol=2e-5)
+
+
 def test_winograd_agrees_with_direct_engine(cuda):
     """the same 3x3 layer through the F(2x2,3x3) kernels and through the direct implicit-GEMM kernels"""
     from handwriting_line_generation_amd import ops
