@@ -935,7 +935,7 @@ struct PackEntry {
   float* dst;
   int A, B, Bpad, R, S, flip;
   long long sa, sb, sr, ss, total, first_block;
-  int mode, Apad;   // mode 1: Winograd filter transform (conv_wino.hip), total = Apad*Bpad threads
+  int mode, Apad;   // mode 1: Winograd filter transform (conv_wino.hip), total = Apad*Bpad threads; mode 2: the F(3x3,2x2) image of a 4x4 stride-2 layer
 };
 
 constexpr int PACK_PER_BLOCK = 1024;
@@ -953,6 +953,10 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackEntry*
     if (i >= e.total) break;
     if (e.mode == 1) {
       wino_pack_one(e.src, e.dst, i, e.A, e.Apad, e.B, e.Bpad, e.sa, e.sb, e.sr, e.ss, e.flip);
+      continue;
+    }
+    if (e.mode == 2) {      // F(3x3,2x2) image of a 4x4 stride-2 layer: A / B = the convolution's output / input channels, flip = data-gradient image
+      wino_s2_pack_one(e.src, e.dst, i, e.A, e.B, e.sa, e.sb, e.flip);
       continue;
     }
     const int b = (int)(i % e.Bpad);
@@ -991,6 +995,10 @@ __global__ __launch_bounds__(256) void pack_weight_multi_scaled_kernel(const Pac
     if (i >= e.total) break;
     if (e.mode == 1) {
       wino_pack_one(e.src, dst, i, e.A, e.Apad, e.B, e.Bpad, e.sa, e.sb, e.sr, e.ss, e.flip, sc);
+      continue;
+    }
+    if (e.mode == 2) {
+      wino_s2_pack_one(e.src, dst, i, e.A, e.B, e.sa, e.sb, e.flip, sc);
       continue;
     }
     const int b = (int)(i % e.Bpad);

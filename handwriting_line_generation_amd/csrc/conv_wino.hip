@@ -34,6 +34,12 @@ struct WinoK {
   int xcd_order;       // 1: every XCD owns a contiguous run of the (split, n-tile, m-tile) sequence, 0: plain launch order
   int bal;             // > 0 (64 x 64 DMA kernel only): the tiles from `bal_tile0` on are scheduled BALANCED on `bal` workgroups - their (tile, chunk)
   int bal_tile0;       //   unit sequence in equal runs, launched behind the whole-tile workgroups of the tiles before (a multiple of 256 of them)
+  // F(3x3,2x2) launches (wino_conv64d_kernel<.., 3>) and wino_bal_reduce_kernel address the images through strides. N, H, W, C, K, P, Q then describe
+  // the VIRTUAL stride-1 two-tap convolution; element (n, h, w, channel chunk t) of its input lies at
+  //   x + n x_img + h x_row + w x_pix + (t / x_tc) x_run + (t % x_tc) 16,   output (n, p, q, k) at  y + n y_img + p y_row + q y_pix + (k / y_kc) y_run + k % y_kc
+  int mt_edge;         // 2 or 3
+  int x_img, x_row, x_pix, x_tc, x_run;
+  int y_img, y_row, y_pix, y_kc, y_run;
 };
 
 // Work item of this workgroup. The dispatcher places block b on XCD b % 8 and every XCD has its own 4 MiB L2: with the plain order all
@@ -820,7 +826,7 @@ __global__ __launch_bounds__(512) void wino_conv_ws_kernel(WinoK a) {
 #ifndef HWG_W64D_SCHED
 #define HWG_W64D_SCHED 6
 #endif
-template <int ABL, bool BAL>
+template <int ABL, bool BAL, int MT = 2>
 __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
   constexpr int NT = 512, TM = 64, TN = 64;
   constexpr int PSV = TM * 16 + 8, PSU = TN * 16 + 8;
@@ -877,8 +883,12 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
   const int m0 = mtile * TM;
   const int n0 = ntile * TN;
 
+  // MT = output tile edge: 2 = F(2x2,3x3) on a plain NHWC image; 3 = F(3x3,2x2) (two-tap layers: the 4x4 stride-2 convolutions and their data
+  // gradients as stride-1 2x2 convolutions on the space-to-depth image). Same 4x4 patches, same input transform (the sign of the fourth
+  // position is folded into the packed filters), hence the same main loop; the image is addressed through the strides of WinoK (rows of the
+  // virtual image may be row PAIRS of the real one, its channels split in runs that lie a real row apart).
   int x_off[XI], x_ok[XI], x_row[XI], x_c4[XI], x_b[XI];
-  const int row_stride = a.W * a.C;
+  const int row_stride = MT == 2 ? a.W * a.C : a.x_row;
 #pragma unroll
   for (int it = 0; it < XI; ++it) {
     const int id = tid + it * NT;
@@ -891,10 +901,11 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
     const int t2 = mm / a.TQ;
     const int ti = t2 % a.TP;
     const int n = t2 / a.TP;
-    const int w = 2 * tj - a.pw + b;
+    const int w = MT * tj - a.pw + b;
     const bool wok = mok && w >= 0 && w < a.W;
-    const int h0 = 2 * ti - a.ph;
-    x_off[it] = ((n * a.H + h0) * a.W + (wok ? w : 0)) * a.C + c4 * 4;
+    const int h0 = MT * ti - a.ph;
+    if constexpr (MT == 2) x_off[it] = ((n * a.H + h0) * a.W + (wok ? w : 0)) * a.C + c4 * 4;
+    else x_off[it] = n * a.x_img + h0 * a.x_row + (wok ? w : 0) * a.x_pix + c4 * 4;
     int okm = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -946,7 +957,7 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
     for (int it = 0; it < XI; ++it)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int off = (x_ok[it] >> r) & 1 ? x_off[it] + r * row_stride + t * 16 : 0;
+        const int off = (x_ok[it] >> r) & 1 ? x_off[it] + r * row_stride + (MT == 2 ? t * 16 : (t / a.x_tc) * a.x_run + (t % a.x_tc) * 16) : 0;
         raw[it][r] = *reinterpret_cast<const float4*>(a.x + off);
       }
   };
@@ -1072,6 +1083,15 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
   // have landed before the exchange image below reuses their LDS arrays
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  bool direct = a.nsplit == 1;
+  int piece = split;
+  if (BAL && !whole) {
+    const int rel = unit / T_all;
+    const int g_first = wino_bal_owner(a.bal, U_bal, rel * T_all), g_last = wino_bal_owner(a.bal, U_bal, rel * T_all + T_all - 1);
+    direct = g_first == g_last;
+    piece = wg - g_first;
+  }
+  if constexpr (MT == 2) {
   // ---- output transform: over the rows a in registers (s0 = m0+m1+m2, s1 = m1-m2-m3), over the columns b through LDS ----------------
   // exchange image X[b][i][tile][channel]; C/D layout of a block: channel = lane & 15, tile = (lane >> 4) * 4 + e
   auto xplane = [&](int pl) -> float* { return pl < 4 ? smem + pl * XP : pl == 4 ? U0 : pl == 5 ? U1 : pl == 6 ? U2 : U3; };
@@ -1090,14 +1110,6 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
   __syncthreads();
   const int kk = tid & 63;
   const int k = n0 + kk;
-  bool direct = a.nsplit == 1;
-  int piece = split;
-  if (BAL && !whole) {
-    const int rel = unit / T_all;
-    const int g_first = wino_bal_owner(a.bal, U_bal, rel * T_all), g_last = wino_bal_owner(a.bal, U_bal, rel * T_all + T_all - 1);
-    direct = g_first == g_last;
-    piece = wg - g_first;
-  }
   float* yg = direct ? a.y : a.part + (long long)piece * ((long long)a.N * a.P * a.Q * a.K);
   const float bv = (direct && a.bias && k < a.K) ? a.bias[k] : 0.f;
   const bool accum = direct && a.accumulate;
@@ -1124,6 +1136,64 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
         float v = (j == 0 ? y0 : y1) + bv;
         if (accum) v += yg[o];
         yg[o] = v;
+      }
+    }
+  }
+  } else {
+    // F(3x3,2x2): A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,1]] - three output rows per tile, so twelve (b, i) planes: the exchange runs in two
+    // passes of 32 tiles (planes of 32 x LDK floats: eight in smem, two in each filter array)
+    constexpr int XH = 32 * LDK;
+    auto xplane3 = [&](int pl) -> float* {
+      return pl < 8 ? smem + pl * XH : pl < 10 ? U0 + (pl - 8) * XH : pl < 12 ? U1 + (pl - 10) * XH : pl < 14 ? U2 + (pl - 12) * XH : U3 + (pl - 14) * XH;
+    };
+    const int kk = tid & 63;
+    const int k = n0 + kk;
+    float* yg = direct ? a.y : a.part + (long long)piece * ((long long)a.N * a.P * a.Q * a.K);
+    const float bv = (direct && a.bias && k < a.K) ? a.bias[k] : 0.f;
+    const bool accum = direct && a.accumulate;
+    const long long kch = (long long)(k / a.y_kc) * a.y_run + (k % a.y_kc);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (half) __syncthreads();
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int m = half * 2 + mh;
+            const float a0 = acc[0][m][n][e], a1 = acc[1][m][n][e], a2 = acc[2][m][n][e], a3 = acc[3][m][n][e];
+            const int tile = mh * 16 + (lane >> 4) * 4 + e, kc = (nh * 2 + n) * 16 + (lane & 15);
+            xplane3(bq * 3 + 0)[tile * LDK + kc] = a0 + a1 + a2;
+            xplane3(bq * 3 + 1)[tile * LDK + kc] = a1 - a2;
+            xplane3(bq * 3 + 2)[tile * LDK + kc] = a1 + a2 + a3;
+          }
+      __syncthreads();
+#pragma unroll 2
+      for (int tl = tid >> 6; tl < 32; tl += 8) {
+        const int m = m0 + half * 32 + tl;
+        if (m >= a.M || k >= a.K) continue;
+        const int tj = m % a.TQ;
+        const int t2 = m / a.TQ;
+        const int ti = t2 % a.TP;
+        const int n = t2 / a.TP;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int p = 3 * ti + i;
+          if (p >= a.P) continue;
+          const float r0 = xplane3(0 * 3 + i)[tl * LDK + kk], r1 = xplane3(1 * 3 + i)[tl * LDK + kk];
+          const float r2 = xplane3(2 * 3 + i)[tl * LDK + kk], r3 = xplane3(3 * 3 + i)[tl * LDK + kk];
+          const float yv[3] = {r0 + r1 + r2, r1 - r2, r1 + r2 + r3};
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const int q = 3 * tj + j;
+            if (q >= a.Q) continue;
+            const long long o = (long long)n * a.y_img + (long long)p * a.y_row + (long long)q * a.y_pix + kch;
+            float v = yv[j] + bv;
+            if (accum) v += yg[o];
+            yg[o] = v;
+          }
+        }
       }
     }
   }
@@ -1415,15 +1485,16 @@ __global__ __launch_bounds__(256) void wino_bal_reduce_kernel(WinoK a, int T_all
   const int total = a.N * a.P * a.Q * KV;
   const long long plane = (long long)a.N * a.P * a.Q * a.K;
   const int U_bal = (a.mt * a.nt - a.bal_tile0) * T_all;
+  const int e = a.mt_edge;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int k = (i % KV) * VEC, pix = i / KV;
     const int q = pix % a.Q, t = pix / a.Q, p = t % a.P, n = t / a.P;
-    const int m = (n * a.TP + (p >> 1)) * a.TQ + (q >> 1);
+    const int m = (n * a.TP + p / e) * a.TQ + q / e;
     const int rel = (m >> 6) + a.mt * (k >> 6) - a.bal_tile0;
     if (rel < 0) continue;
     const int g_first = wino_bal_owner(a.bal, U_bal, rel * T_all), g_last = wino_bal_owner(a.bal, U_bal, rel * T_all + T_all - 1);
     if (g_first == g_last) continue;
-    const long long o = (long long)pix * a.K + k;
+    const long long o = (long long)n * a.y_img + (long long)p * a.y_row + (long long)q * a.y_pix + (long long)(k / a.y_kc) * a.y_run + k % a.y_kc;
     float s[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) s[v] = 0.f;
@@ -1626,6 +1697,9 @@ extern "C" int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const f
   k.mt = hwg_cdiv(k.M, p.tm); k.nt = hwg_cdiv(d->K, p.tn);
   k.xcd_order = hwg_tune().wino_order;
   k.bal = p.bal; k.bal_tile0 = p.bal_tile0;
+  k.mt_edge = 2;
+  k.x_img = k.x_row = k.x_pix = k.x_tc = k.x_run = 0;      // (the F(2x2,3x3) kernels address the plain NHWC image themselves)
+  k.y_img = d->P * d->Q * d->K; k.y_row = d->Q * d->K; k.y_pix = d->K; k.y_kc = d->K; k.y_run = 0;
   dim3 grid(p.bal > 0 ? p.bal_tile0 + (p.bal + 7) / 8 * 8 : (k.mt * k.nt * p.nsplit + 7) / 8 * 8);
   const int prof = hwg_prof_open(HWG_PROF_CONV_WINO, 2.0 * d->N * d->P * d->Q * (double)d->K * d->C * 9.0, st);
   if (p.cfg == 0) hipLaunchKernelGGL((wino_conv_kernel<4, 2>), grid, dim3(512), 0, st, k);
@@ -1653,6 +1727,183 @@ extern "C" int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const f
     HWG_LAUNCH_CHECK("wino_bal_reduce");
   } else if (p.nsplit > 1) {
     const long long total = (long long)d->N * d->P * d->Q * d->K;
+    const int prof2 = hwg_prof_open(HWG_PROF_CONV_REDUCE, 4.0 * total * (p.nsplit + 1), st);
+    const int rc = hwg_conv_split_reduce_launch((const float*)workspace, bias, y, total, d->K, p.nsplit, accumulate, st);
+    hwg_prof_close(prof2, st);
+    if (rc) return rc;
+  }
+  return HWG_OK;
+}
+
+
+// ---- F(3x3,2x2): 4x4 stride-2 pad-0 convolutions and their data gradients ---------------------------------------------------------------------
+// y[p,q] = sum_{r,s<4} x[2p+r, 2q+s] w[r,s]; with r = 2u+a, s = 2v+b this is a stride-1 2x2-tap convolution (u, v) over the space-to-depth image
+// x'[i, j, (a,b,c)] = x[2i+a, 2j+b, c] - no copy: a row of x' is a row PAIR of x, its channels two runs of 2C floats one row apart. The data
+// gradient is the 2x2-tap full correlation of dy to the 4C channels (a,b,c) of dx's 2x2 blocks, written depth-to-space. Two taps per axis
+// take F(3x3,2x2): 16 multiplies per 9 outputs x 4 taps = the same 2.25 x as F(2x2,3x3), on the same 4x4 patches with the same input
+// transform, so it is the 64 x 64 DMA kernel with MT = 3 (output transform A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,1]]; filters G g G^T with
+// G = [[1,0],[.5,.5],[.5,-.5],[0,1]], the sign of the fourth position folded in because the kernel's input transform is F(2x2,3x3)'s).
+namespace {
+
+struct S2Geom {
+  int N, Hv, Wv, Cv, Kv, Pv, Qv, pad;
+  int x_img, x_row, x_pix, x_tc, x_run, y_img, y_row, y_pix, y_kc, y_run;
+  double flops;
+};
+
+bool s2_geom(const hwg_conv_desc* d, S2Geom& g) {
+  if (!d || d->R != 4 || d->S != 4 || d->stride_h != 2 || d->stride_w != 2 || d->pad_h || d->pad_w || d->dil_h != 1 || d->dil_w != 1) return false;
+  if (d->C % 16 || d->K % 4 || d->N < 1 || d->H < 1 || d->W < 1) return false;
+  const long long in_e = (long long)d->N * d->H * d->W * d->C, out_e = (long long)d->N * d->P * d->Q * d->K;
+  if (in_e >= (1ll << 31) || out_e >= (1ll << 31)) return false;
+  g.N = d->N;
+  if (!d->transposed) {
+    if (d->H < 4 || d->W < 4 || d->P != (d->H - 4) / 2 + 1 || d->Q != (d->W - 4) / 2 + 1) return false;
+    g.Hv = d->P + 1; g.Wv = d->Q + 1; g.Cv = 4 * d->C; g.Kv = d->K; g.Pv = d->P; g.Qv = d->Q; g.pad = 0;
+    g.x_img = d->H * d->W * d->C; g.x_row = 2 * d->W * d->C; g.x_pix = 2 * d->C; g.x_tc = 2 * d->C / 16; g.x_run = d->W * d->C;
+    g.y_img = d->P * d->Q * d->K; g.y_row = d->Q * d->K; g.y_pix = d->K; g.y_kc = d->K; g.y_run = 0;
+    g.flops = 2.0 * d->N * d->P * d->Q * (double)d->K * d->C * 16.0;
+  } else {
+    if (d->P != 2 * d->H + 2 || d->Q != 2 * d->W + 2) return false;      // (an odd image would keep a last row / column the blocks never write)
+    g.Hv = d->H; g.Wv = d->W; g.Cv = d->C; g.Kv = 4 * d->K; g.Pv = d->H + 1; g.Qv = d->W + 1; g.pad = 1;
+    g.x_img = d->H * d->W * d->C; g.x_row = d->W * d->C; g.x_pix = d->C; g.x_tc = d->C / 16; g.x_run = 0;
+    g.y_img = d->P * d->Q * d->K; g.y_row = 2 * d->Q * d->K; g.y_pix = 2 * d->K; g.y_kc = 2 * d->K; g.y_run = d->Q * d->K;
+    g.flops = 2.0 * d->N * d->H * d->W * (double)d->K * d->C * 16.0;
+  }
+  return g.Kv > 48;
+}
+
+WinoPlan plan_wino_s2_model(const hwg_conv_desc* d) {
+  WinoPlan best;
+  wino_cfg(best, 6);
+  best.nsplit = 1;
+  best.model_s = 1e30;
+  S2Geom g;
+  if (!s2_geom(d, g)) return best;
+  const long long M = (long long)g.N * hwg_cdiv(g.Pv, 3) * hwg_cdiv(g.Qv, 3);
+  const int chunks = g.Cv / 16;
+  const double out_bytes = 4.0 * g.N * g.Pv * g.Qv * g.Kv;
+  const WinoCost wc = kWinoCost[4];
+  const long long tiles = (long long)hwg_cdiv(M, 64) * hwg_cdiv(g.Kv, 64);
+  double best_t = 1e30;
+  for (int ns = 1; ns <= 8 && ns * 2 <= (chunks > 1 ? chunks : 2); ns *= 2) {
+    if (ns > 1 && (chunks / ns < 2 || out_bytes * ns > 1.5e9)) break;
+    const double q = (double)(tiles * ns) / 256.0;
+    const double rounds = q <= 3.0 ? (double)hwg_cdiv(tiles * ns, 256) : q + 0.5;
+    double t = rounds * (wc.fixed_us + 4.0 * hwg_cdiv(chunks, ns) * wc.step_us) * 1e-6;
+    if (ns > 1) t += (ns + 1) * out_bytes / 3.0e12 + 6e-6;
+    if (t < best_t) { best_t = t; best.nsplit = ns; }
+  }
+  const int bal_mode = hwg_tune().wino_bal[0] ? atoi(hwg_tune().wino_bal) : 0;
+  if (bal_mode >= 0) {
+    WinoPlan p;
+    wino_cfg(p, 6);
+    int gf = 0, af = -1;
+    if (bal_mode > 0) sscanf(hwg_tune().wino_bal, "%d,%d", &gf, &af);
+    if (wino_balance(p, tiles, chunks, gf, af)) {
+      const long long units = (tiles - p.bal_tile0) * chunks;
+      const long long c = hwg_cdiv(units, (long long)p.bal);
+      double t = (p.bal_tile0 / 256) * (wc.fixed_us + 4.0 * chunks * wc.step_us) * 1e-6;
+      t += (double)hwg_cdiv((long long)p.bal, 256ll) * (wc.fixed_us - 4.0 + (p.bal_segs - 1) * 5.0 + 4.0 * c * wc.step_us) * 1e-6;
+      if (p.bal_cut) t += (p.bal_cut_pieces + p.bal_cut) * (out_bytes / tiles) / 3.0e12 + out_bytes / 2.0e13 + 6e-6;
+      if (bal_mode > 0 || t < 0.97 * best_t) { best = p; best_t = t; }
+    }
+  }
+  if (const char* f = hwg_tune().wino_force; *f) {   // "cfg[,nsplit]": only the split applies here
+    int fc = -1, fs = 0;
+    if (sscanf(f, "%d,%d", &fc, &fs) >= 2 && fs >= 1) { const int keep = fs > chunks ? chunks : fs; wino_cfg(best, 6); best.nsplit = keep; }
+  }
+  best.model_s = best_t;
+  return best;
+}
+WinoPlan plan_wino_s2(const hwg_conv_desc* d) {
+  static thread_local HwgPlanCache<WinoPlan> cache;
+  return cache.get(d, plan_wino_s2_model);
+}
+
+__global__ __launch_bounds__(256) void wino_s2_pack_kernel(const float* src, float* dst, int Kc, int Cc, long long sk, long long sc, int dgrad, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    wino_s2_pack_one(src, dst, i, Kc, Cc, sk, sc, dgrad);
+}
+
+}  // namespace
+
+extern "C" int hwg_wino_s2_supported(const hwg_conv_desc* d) {
+  S2Geom g;
+  return hwg_tune().wino_s2 != 0 && !hwg_tune().w64_nodma && s2_geom(d, g) ? 1 : 0;
+}
+
+extern "C" int hwg_wino_s2_preferred(const hwg_conv_desc* d) {
+  if (!hwg_wino_s2_supported(d)) return 0;
+  if (hwg_tune().wino_s2 == 2) return 1;
+  const WinoPlan p = plan_wino_s2(d);
+  return p.model_s < 0.9 * hwg_conv_direct_model_seconds(d) ? 1 : 0;
+}
+
+extern "C" size_t hwg_wino_s2_weight_floats(int Kc, int Cc, int dgrad) {
+  const size_t A = dgrad ? 4 * (size_t)Cc : (size_t)Kc, B = dgrad ? (size_t)Kc : 4 * (size_t)Cc;
+  return 16 * ((A + 15) / 16 * 16) * ((B + 15) / 16 * 16);
+}
+
+extern "C" int hwg_wino_s2_pack_weight(const float* src, float* dst, int Kc, int Cc, long long sk, long long sc, int dgrad, void* stream) {
+  HWG_REQUIRE(src && dst && Kc > 0 && Cc > 0, "wino_s2_pack_weight: bad arguments");
+  const long long total = (long long)hwg_wino_s2_weight_floats(Kc, Cc, dgrad) / 16;
+  hipLaunchKernelGGL(wino_s2_pack_kernel, dim3(hwg_stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, Kc, Cc, sk, sc, dgrad, total);
+  HWG_LAUNCH_CHECK("wino_s2_pack_weight");
+  return HWG_OK;
+}
+
+extern "C" size_t hwg_wino_s2_workspace(const hwg_conv_desc* d) {
+  if (!hwg_wino_s2_supported(d)) return 0;
+  const WinoPlan p = plan_wino_s2(d);
+  const size_t out = (size_t)d->N * d->P * d->Q * d->K * sizeof(float);
+  if (p.bal > 0) return p.bal_pieces > 1 ? p.bal_pieces * out : 0;
+  return p.nsplit > 1 ? p.nsplit * out : 0;
+}
+
+extern "C" int hwg_wino_s2_conv(const hwg_conv_desc* d, const float* x, const float* u, const float* bias, float* y, int accumulate,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  HWG_REQUIRE(d && x && u && y, "wino_s2_conv: null pointer");
+  S2Geom g;
+  HWG_REQUIRE(hwg_wino_s2_supported(d) && s2_geom(d, g), "wino_s2_conv: needs a 4x4 stride-2 pad-0 convolution (or its data gradient) with C %% 16 == 0");
+  HWG_REQUIRE(!(d->transposed && bias), "wino_s2_conv: the data-gradient form takes no bias");
+  hipStream_t st = (hipStream_t)stream;
+  const WinoPlan p = plan_wino_s2(d);
+  const size_t need = hwg_wino_s2_workspace(d);
+  if (need && (!workspace || workspace_bytes < need)) {
+    hwg_set_error("wino_s2_conv: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return HWG_ERR_WORKSPACE;
+  }
+  WinoK k;
+  k.x = x; k.u = u; k.bias = bias; k.y = y;
+  k.N = g.N; k.H = g.Hv; k.W = g.Wv; k.C = g.Cv; k.K = g.Kv; k.Kpad = (g.Kv + 15) / 16 * 16;
+  k.P = g.Pv; k.Q = g.Qv; k.ph = g.pad; k.pw = g.pad;
+  k.TP = hwg_cdiv(g.Pv, 3); k.TQ = hwg_cdiv(g.Qv, 3);
+  k.M = g.N * k.TP * k.TQ;
+  k.accumulate = accumulate;
+  k.nsplit = p.nsplit;
+  k.part = (float*)workspace;
+  k.mt = hwg_cdiv(k.M, 64); k.nt = hwg_cdiv(g.Kv, 64);
+  k.xcd_order = hwg_tune().wino_order;
+  k.bal = p.bal; k.bal_tile0 = p.bal_tile0;
+  k.mt_edge = 3;
+  k.x_img = g.x_img; k.x_row = g.x_row; k.x_pix = g.x_pix; k.x_tc = g.x_tc; k.x_run = g.x_run;
+  k.y_img = g.y_img; k.y_row = g.y_row; k.y_pix = g.y_pix; k.y_kc = g.y_kc; k.y_run = g.y_run;
+  dim3 grid(p.bal > 0 ? p.bal_tile0 + (p.bal + 7) / 8 * 8 : (k.mt * k.nt * p.nsplit + 7) / 8 * 8);
+  const int prof = hwg_prof_open(HWG_PROF_CONV_WINO, g.flops, st);
+  if (p.bal > 0) hipLaunchKernelGGL((wino_conv64d_kernel<0, true, 3>), grid, dim3(512), 0, st, k);
+  else hipLaunchKernelGGL((wino_conv64d_kernel<0, false, 3>), grid, dim3(512), 0, st, k);
+  hwg_prof_close(prof, st);
+  hwg_note_plan(HWG_PROF_CONV_WINO, 36, p.bal > 0 ? -p.bal : p.nsplit);      // (schedule id 36: F(3x3,2x2) on the 64 x 64 DMA kernel)
+  HWG_LAUNCH_CHECK("wino_s2_conv");
+  const long long total = (long long)d->N * d->P * d->Q * d->K;
+  if (p.bal > 0 && p.bal_pieces > 1) {
+    const double cut = (double)(k.mt * k.nt - p.bal_tile0) / (k.mt * k.nt);
+    const int prof2 = hwg_prof_open(HWG_PROF_CONV_REDUCE, 4.0 * total * cut * (p.bal_pieces + 1), st);
+    hipLaunchKernelGGL(wino_bal_reduce_kernel<4>, dim3(hwg_stream_grid(total / 4, 256)), dim3(256), 0, st, k, g.Cv / 16);
+    hwg_prof_close(prof2, st);
+    HWG_LAUNCH_CHECK("wino_bal_reduce");
+  } else if (p.bal <= 0 && p.nsplit > 1) {
     const int prof2 = hwg_prof_open(HWG_PROF_CONV_REDUCE, 4.0 * total * (p.nsplit + 1), st);
     const int rc = hwg_conv_split_reduce_launch((const float*)workspace, bias, y, total, d->K, p.nsplit, accumulate, st);
     hwg_prof_close(prof2, st);

@@ -63,6 +63,7 @@ struct HwgTune {
   int wgrad_narrow;      // HWG_WGRAD_NARROW: 0 never, 2 also 2 / 4 channel blocks, 1 default
   int w64_nodma;         // HWG_W64_NODMA: register-staged filter stream in the 64x64 Winograd kernel (A/B timing)
   int wino_order;        // HWG_WINO_ORDER: 1 (default) XCD-contiguous work order
+  int wino_s2;           // HWG_WINO_S2: F(3x3,2x2) for 4x4 stride-2 pad-0 layers: 0 never, 2 always, 1 (default) by cost model
   int conv_merge;        // HWG_CONV_MERGE: transposed convolutions with R % sh == 0, S % sw == 0 with merged parity classes: 0 never, 1 (default) K < 32, 2 always
   int wino_wgrad_split;  // HWG_WINO_WGRAD_SPLIT: forced pixel-range count of the Winograd weight gradient (0 = model)
   int wwg_debug;         // HWG_WWG_DEBUG

@@ -44,6 +44,7 @@ const HwgTune& hwg_tune() {
     t->w64_nodma = tune_int("HWG_W64_NODMA", 0);
     t->wino_order = tune_int("HWG_WINO_ORDER", 1);
     t->conv_merge = tune_int("HWG_CONV_MERGE", 1);
+    t->wino_s2 = tune_int("HWG_WINO_S2", 1);
     t->wino_wgrad_split = tune_int("HWG_WINO_WGRAD_SPLIT", 0);
     t->wwg_debug = tune_int("HWG_WWG_DEBUG", 0);
     t->conv_pf = tune_int("HWG_CONV_PF", 3);

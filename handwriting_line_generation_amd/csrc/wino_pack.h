@@ -42,3 +42,40 @@ static __device__ __forceinline__ void wino_pack_one(const float* src, float* ds
   for (int p = 0; p < 16; ++p) dst[base + (long long)p * Apad * 16] = U[p >> 2][p & 3];
 }
 
+
+// F(3x3,2x2) image of a 4x4 stride-2 convolution's weight (conv_wino.hip, hwg_wino_s2_*): pair i = (A index aa, B index b) of the product -
+// forward: A = output channels, B = the 4 Cc space-to-depth channels (a, b, c); data gradient: A = the 4 Cc block channels, B = Kc, taps
+// mirrored. g[u][v] = w[kc, cc, 2u+a, 2v+b] at src[kc*sk + cc*sc + r*4 + s]; U = G g G^T with G = [[1,0],[.5,.5],[.5,-.5],[0,1]], the entries
+// with exactly one index equal to 3 negated (the kernel's input transform is F(2x2,3x3)'s, whose fourth row is the negative of F(3x3,2x2)'s).
+static __device__ __forceinline__ void wino_s2_pack_one(const float* src, float* dst, long long i, int Kc, int Cc, long long sk, long long sc, int dgrad,
+                                                 float scale = 1.f) {
+  const int A = dgrad ? 4 * Cc : Kc, B = dgrad ? Kc : 4 * Cc;
+  const int Apad = (A + 15) / 16 * 16, Bpad = (B + 15) / 16 * 16;
+  const int b = (int)(i % Bpad), aa = (int)(i / Bpad);
+  const bool ok = aa < A && b < B;
+  const int comp = dgrad ? aa : b, ab = ok ? comp / Cc : 0, cc = ok ? comp % Cc : 0, kc = ok ? (dgrad ? b : aa) : 0;
+  const int pa = ab >> 1, pb = ab & 1;
+  float g[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int uu = dgrad ? 1 - u : u, vv = dgrad ? 1 - v : v;
+      g[u][v] = ok ? __fmul_rn(src[kc * sk + cc * sc + (2 * uu + pa) * 4 + (2 * vv + pb)], scale) : 0.f;
+    }
+  float t[4][2], U[4][4];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    t[0][v] = g[0][v]; t[1][v] = 0.5f * (g[0][v] + g[1][v]); t[2][v] = 0.5f * (g[0][v] - g[1][v]); t[3][v] = g[1][v];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    U[r][0] = t[r][0]; U[r][1] = 0.5f * (t[r][0] + t[r][1]); U[r][2] = 0.5f * (t[r][0] - t[r][1]); U[r][3] = t[r][1];
+  }
+  const long long base = ((long long)(b >> 4) * 16 * Apad + aa) * 16 + (b & 15);
+#pragma unroll
+  for (int ps = 0; ps < 16; ++ps) {
+    const bool neg = ((ps >> 2) == 3) != ((ps & 3) == 3);
+    dst[base + (long long)ps * Apad * 16] = neg ? -U[ps >> 2][ps & 3] : U[ps >> 2][ps & 3];
+  }
+}

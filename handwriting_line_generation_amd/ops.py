@@ -540,13 +540,17 @@ def _pack(weight, A, B, R, S, sa, sb, flip, Bpad=None, wino=False):
     """engine image of a weight: [tap][A][Bpad], or (wino) the Winograd-domain filters U = G g G^T as [Bpad/16][16][Apad][16]"""
     Bpad = B if Bpad is None else Bpad
     Apad = (A + 15) // 16 * 16 if wino else A
-    if wino:
+    if wino == 2:
+        # F(3x3,2x2) image of a 4x4 stride-2 convolution's weight (hwg_wino_s2_pack_weight): A = the convolution's output channels, B = its input
+        # channels, sa / sb their strides, flip = 1: the image of the data-gradient product ((a,b,c) block channels x K)
+        Apad, Bpad = ((4 * B + 15) // 16 * 16, (A + 15) // 16 * 16) if flip else ((A + 15) // 16 * 16, (4 * B + 15) // 16 * 16)
+    elif wino:
         Bpad = (B + 15) // 16 * 16
     pre = getattr(weight, "_hwg_prepack", None)
     if pre is not None:
         # a spectral-norm layer's W_bar / sigma: its images were written by the network's one scaled multi-pack launch (SpectralBank.update);
         # an image nobody asked for before is packed here, from the tensor itself, and joins the launch from the next forward pass on
-        variant = (A, B, Bpad, R, S, sa, sb, int(flip), int(bool(wino)), Apad)
+        variant = (A, B, Bpad, R, S, sa, sb, int(flip), int(wino), Apad)
         img = pre.images.get(variant)
         if img is not None:
             return img
@@ -558,7 +562,7 @@ def _pack(weight, A, B, R, S, sa, sb, flip, Bpad=None, wino=False):
     if isinstance(weight, torch.nn.Parameter):
         group = getattr(weight, "_hwg_group", None)
         epoch = WEIGHT_EPOCH.get(group, 0)
-        key = (id(weight), weight.data_ptr(), A, B, Bpad, sa, sb, int(flip), bool(wino))
+        key = (id(weight), weight.data_ptr(), A, B, Bpad, sa, sb, int(flip), int(wino))
         hit = _pack_cache.get(key)
         if hit is not None and hit[0] == weight._version and hit[1] == epoch:
             return hit[2]
@@ -568,12 +572,14 @@ def _pack(weight, A, B, R, S, sa, sb, flip, Bpad=None, wino=False):
         out = torch.empty((Bpad // 16, 16, Apad, 16), dtype=torch.float32, device=weight.device)
     else:
         out = torch.empty((R * S, A, Bpad), dtype=torch.float32, device=weight.device)
-    if wino:
+    if wino == 2:
+        L.call("hwg_wino_s2_pack_weight", weight, out, A, B, sa, sb, int(flip), _stream())
+    elif wino:
         L.call("hwg_wino_pack_weight", weight, out, A, B, sa, sb, S, 1, int(flip), _stream())
     else:
         L.call("hwg_conv_pack_weight", weight, out, A, B, Bpad, R, S, sa, sb, S, 1, int(flip), _stream())
     if key is not None:
-        _pack_cache[key] = [weight._version, epoch, out, weight, (A, B, Bpad, R, S, sa, sb, int(flip), int(bool(wino)), Apad), group]
+        _pack_cache[key] = [weight._version, epoch, out, weight, (A, B, Bpad, R, S, sa, sb, int(flip), int(wino), Apad), group]
     return out
 
 
@@ -682,12 +688,12 @@ def _run_conv(x, wp, bias, N, H, W, C, K, R, S, stride, pad, dil, P, Q, transpos
     plan = _conv_plans.get(key)
     if plan is None:
         d = _desc(N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed)
-        plan = _conv_plans[key] = (d, L.query("hwg_wino_conv_workspace" if wino else "hwg_conv_fwd_workspace", d.ptr), d.ptr)
+        plan = _conv_plans[key] = (d, L.query(("hwg_conv_fwd_workspace", "hwg_wino_conv_workspace", "hwg_wino_s2_workspace")[int(wino)], d.ptr), d.ptr)
     d, need, dptr = plan
     if PROF_SHAPES is not None:
         _prof_tag((N, H, W, C, K, R, S, stride, pad, dil, transposed, _RUN_SCOPE[0]))
     ws = workspace(need, x.device) if need else None
-    L.call("hwg_wino_conv_fwd" if wino else "hwg_conv_fwd", dptr, x, wp, bias, y, 0, ws, need, _stream())
+    L.call(("hwg_conv_fwd", "hwg_wino_conv_fwd", "hwg_wino_s2_conv")[int(wino)], dptr, x, wp, bias, y, 0, ws, need, _stream())
     return y
 
 
@@ -756,6 +762,19 @@ def _wino_ok(N, H, W, C, K, R, S, stride, pad, dil, P, Q):
     if hit is None:
         d = _desc(N, H, W, C, K, 3, 3, (1, 1), pad, (1, 1), P, Q, 0)
         hit = _wino_choice[key] = bool(L.query("hwg_wino_preferred", d.ptr))
+    return hit
+
+
+def _wino_s2_ok(N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed):
+    """4x4 stride-2 pad-0 layers (transposed = 1: their data gradient, described as the fractionally strided product) in the Winograd domain
+    F(3x3,2x2) on the space-to-depth image (csrc/conv_wino.hip, hwg_wino_s2_*) - the library's cost models decide per geometry"""
+    if not (WINOGRAD and R == 4 and S == 4 and stride == (2, 2) and pad == (0, 0) and dil == (1, 1) and C % 16 == 0):
+        return False
+    key = (N, H, W, C, K, "s2", transposed)
+    hit = _wino_choice.get(key)
+    if hit is None:
+        d = _desc(N, H, W, C, K, 4, 4, (2, 2), (0, 0), (1, 1), P, Q, transposed)
+        hit = _wino_choice[key] = bool(L.query("hwg_wino_s2_preferred", d.ptr))
     return hit
 
 
@@ -844,9 +863,13 @@ class _Conv2d(Function):
             Q = (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
             Cp = _cpad(C, K)
             xin = _pad_channels(x, Cp) if Cp != C else x
-            wino = _wino_ok(N, H, W, Cp, K, R, S, (sh, sw), (ph, pw), (dh, dw), P, Q)
-            wp = _pack(weight, K, C, R, S, C * R * S, R * S, flip=0, Bpad=Cp, wino=wino)
-            y = _run_conv(xin, wp, bias, N, H, W, Cp, K, R, S, (sh, sw), (ph, pw), (dh, dw), P, Q, 0, wino)
+            if Cp == C and _wino_s2_ok(N, H, W, C, K, R, S, (sh, sw), (ph, pw), (dh, dw), P, Q, 0):
+                wp = _pack(weight, K, C, 4, 4, C * 16, 16, flip=0, wino=2)
+                y = _run_conv(x, wp, bias, N, H, W, C, K, 4, 4, (2, 2), (0, 0), (1, 1), P, Q, 0, 2)
+            else:
+                wino = _wino_ok(N, H, W, Cp, K, R, S, (sh, sw), (ph, pw), (dh, dw), P, Q)
+                wp = _pack(weight, K, C, R, S, C * R * S, R * S, flip=0, Bpad=Cp, wino=wino)
+                y = _run_conv(xin, wp, bias, N, H, W, Cp, K, R, S, (sh, sw), (ph, pw), (dh, dw), P, Q, 0, wino)
         else:
             K = weight.shape[1]
             assert weight.shape[0] == C, "conv_transpose: weight expects %d input channels, got %d" % (weight.shape[0], C)
@@ -1033,6 +1056,9 @@ class _Conv2d(Function):
                     wino = _wino_ok(N, P, Q, Kp, C, R, S, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), H, W)
                     wp = _pack(weight, C, K, R, S, R * S, C * R * S, flip=1, Bpad=Kp, wino=wino)
                     dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (1, 1), (dh * (R - 1) - ph, dw * (S - 1) - pw), (dh, dw), H, W, 0, wino)
+                elif Kp == K and _wino_s2_ok(N, P, Q, K, C, R, S, (sh, sw), (ph, pw), (dh, dw), H, W, 1):
+                    wp = _pack(weight, K, C, 4, 4, C * 16, 16, flip=1, wino=2)
+                    dx = _run_conv(dy, wp, None, N, P, Q, K, C, 4, 4, (2, 2), (0, 0), (1, 1), H, W, 1, 2)
                 else:
                     assert dh == 1 and dw == 1, "strided conv backward needs dilation 1"
                     wp = _pack(weight, C, K, R, S, R * S, C * R * S, flip=0, Bpad=Kp)

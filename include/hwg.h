@@ -90,7 +90,8 @@ int hwg_conv_pack_weight(const float* src, float* dst, int A, int B, int Bpad, i
 /* The same re-layout for many weights in one launch (after an optimizer step). table: device array of n_entries records
  * { const float* src; float* dst; int A, B, Bpad, R, S, flip; long long sa, sb, sr, ss, total, first_block; int mode, Apad; }
  * (96 bytes) where total = R*S*A*Bpad and first_block = running sum of ceil(total/1024); total_blocks = that sum over all entries.
- * mode 1 = the Winograd filter transform of hwg_wino_pack_weight (then Apad = ceil16(A), Bpad = ceil16(B), total = Apad*Bpad). */
+ * mode 1 = the Winograd filter transform of hwg_wino_pack_weight (then Apad = ceil16(A), Bpad = ceil16(B), total = Apad*Bpad);
+ * mode 2 = hwg_wino_s2_pack_weight (A = Kc, B = Cc, sa = sk, sb = sc, flip = dgrad; Apad / Bpad = the image's padded extents, total = Apad*Bpad). */
 int hwg_conv_pack_weight_multi(const void* table, int n_entries, long long total_blocks, void* stream);
 /* ... and for weights that are a device-side scalar multiple of a stored tensor: the spectral-norm layers' W_bar / sigma
  * (model/discriminator_ap.py:31-32, recomputed on every forward pass). Records of 112 bytes: the 96-byte record above followed by
@@ -169,6 +170,20 @@ int hwg_wino_pack_weight(const float* src, float* dst, int A, int B, long long s
 size_t hwg_wino_conv_workspace(const hwg_conv_desc* d);
 int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const float* u, const float* bias, float* y,
                       int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* 4x4 stride-2 pad-0 dilation-1 convolutions (d->transposed = 0; reference: the style extractor's down-sampling convolutions,
+ * model/char_style.py:154 Conv2dBlock(dim, 2*dim, 4, 2, 1): a pad layer followed by nn.Conv2d(.., 4, 2), :69-71) and their data gradients (d->transposed = 1, described like the
+ * fractionally strided product of hwg_conv_fwd: input = dy [N,H,W,C], output = dx [N,P,Q,K] with P = 2H + 2, Q = 2W + 2) as stride-1 two-tap
+ * convolutions on the space-to-depth image in the Winograd domain F(3x3, 2x2) (conv_wino.hip). The filter image (hwg_wino_s2_weight_floats
+ * floats) is packed from the CONVOLUTION's weight: element (output channel kc, input channel cc, r, s) at src[kc*sk + cc*sc + r*4 + s];
+ * dgrad = 1 packs the image of the data-gradient product. hwg_wino_s2_preferred: 1 when the cost models put it ahead of the direct kernels. */
+int hwg_wino_s2_supported(const hwg_conv_desc* d);
+int hwg_wino_s2_preferred(const hwg_conv_desc* d);
+size_t hwg_wino_s2_weight_floats(int Kc, int Cc, int dgrad);
+int hwg_wino_s2_pack_weight(const float* src, float* dst, int Kc, int Cc, long long sk, long long sc, int dgrad, void* stream);
+size_t hwg_wino_s2_workspace(const hwg_conv_desc* d);
+int hwg_wino_s2_conv(const hwg_conv_desc* d, const float* x, const float* u, const float* bias, float* y,
+                     int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Weight gradient of a 3x3 stride-1 dilation-1 convolution in the Winograd domain F(3x3, 2x2) (conv_wino_wgrad.hip): same operands and weight
  * strides as hwg_conv_wgrad (dy = anchor [N,P,Q,K], x = gathered [N,H,W,C]; reference: the weight gradients autograd produces for

@@ -401,6 +401,71 @@ def test_winograd_balanced_schedule_vs_cpu(cuda, case):
     assert float((y - y1).abs().max()) < 2e-5 * float(yr.abs().max())
 
 
+# F(3x3,2x2) for the 4x4 stride-2 pad-0 layers (conv_wino.hip, hwg_wino_s2_*): forward through the space-to-depth gather, data gradient through
+# the depth-to-space scatter, through the C-ABI directly - ragged tile counts (outputs not multiples of 3), channel counts off the 64-wide
+# tiles, bias, uniform channel splits and the balanced schedule - against torch's CPU convolution.
+WINO_S2_CASES = [(2, 12, 20, 16, 64, ""), (1, 10, 38, 32, 80, ""), (3, 8, 26, 64, 128, "HWG_WINO_FORCE=6,2"), (2, 14, 44, 48, 64, "HWG_WINO_BAL=7"),
+                 (2, 6, 130, 128, 96, "HWG_WINO_FORCE=6,4"), (1, 16, 64, 32, 256, "HWG_WINO_BAL=40,0"), (4, 66, 130, 64, 128, "")]
+
+
+@pytest.mark.parametrize("case", WINO_S2_CASES, ids=lambda c: "x".join(map(str, c[:5])) + ("_" + c[5].replace("HWG_WINO_", "").replace("=", "").replace(",", "_") if c[5] else ""))
+def test_winograd_two_tap_kernel_for_4x4_stride2_layers(cuda, case):
+    from handwriting_line_generation_amd import ops, _lib as L
+    N, H, W, C, K, env = case
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(N, C, H, W, generator=g); w = torch.randn(K, C, 4, 4, generator=g) / (4 * C ** 0.5); b = torch.randn(K, generator=g)
+    yr = F.conv2d(x, w, b, stride=2)
+    P, Q = yr.shape[2:]
+    gy = torch.randn(yr.shape, generator=g)
+    dxr = F.conv_transpose2d(gy, w, None, stride=2)
+    assert dxr.shape[2:] == (H, W)
+    st = torch.cuda.current_stream().cuda_stream
+    with ops.tuning(HWG_WINO_S2="2", **dict(kv.split("=") for kv in env.split())):
+        wd = w.to(cuda)
+        # forward
+        d = ops._desc(N, H, W, C, K, 4, 4, (2, 2), (0, 0), (1, 1), P, Q, 0)
+        assert L.query("hwg_wino_s2_supported", d.ptr) == 1
+        u = torch.empty(L.query("hwg_wino_s2_weight_floats", K, C, 0), device=cuda)
+        L.call("hwg_wino_s2_pack_weight", wd, u, K, C, C * 16, 16, 0, st)
+        need = L.query("hwg_wino_s2_workspace", d.ptr); ws = torch.empty(max(need, 16), dtype=torch.uint8, device=cuda)
+        xg = nhwc(x).to(cuda); y = torch.full((N, P, Q, K), float("nan"), device=cuda)
+        L.call("hwg_wino_s2_conv", d.ptr, xg, u, b.to(cuda), y, 0, ws, ws.numel(), st)
+        lp = ops.last_plan()
+        assert lp[:2] == (6, 36), lp
+        _close(nchw(y), yr, "two-tap winograd forward %s" % (case,), tol=2e-5)
+        y2 = torch.ones_like(y)
+        L.call("hwg_wino_s2_conv", d.ptr, xg, u, None, y2, 1, ws, ws.numel(), st)          # accumulate, no bias
+        _close(nchw(y2), yr - b.view(1, -1, 1, 1) + 1.0, "two-tap winograd forward accumulate %s" % (case,), tol=2e-5)
+        # data gradient (described as the fractionally strided product: input dy, output dx)
+        dd = ops._desc(N, P, Q, K, C, 4, 4, (2, 2), (0, 0), (1, 1), H, W, 1)
+        if H == 2 * P + 2 and W == 2 * Q + 2 and K % 16 == 0 and 4 * C > 48:
+            assert L.query("hwg_wino_s2_supported", dd.ptr) == 1
+            ud = torch.empty(L.query("hwg_wino_s2_weight_floats", K, C, 1), device=cuda)
+            L.call("hwg_wino_s2_pack_weight", wd, ud, K, C, C * 16, 16, 1, st)
+            need = L.query("hwg_wino_s2_workspace", dd.ptr); ws = torch.empty(max(need, 16), dtype=torch.uint8, device=cuda)
+            dx = torch.full((N, H, W, C), float("nan"), device=cuda)
+            L.call("hwg_wino_s2_conv", dd.ptr, nhwc(gy).to(cuda), ud, None, dx, 0, ws, ws.numel(), st)
+            assert ops.last_plan()[:2] == (6, 36)
+            _close(nchw(dx), dxr, "two-tap winograd data gradient %s" % (case,), tol=2e-5)
+        else:
+            assert L.query("hwg_wino_s2_supported", dd.ptr) == 0
+        # and as a layer (ops.conv2d: forward, data gradient, weight / bias gradients; a second pass after an in-place weight update must see it)
+        xl, wl, bl = nhwc(x).to(cuda).requires_grad_(True), torch.nn.Parameter(w.to(cuda)), torch.nn.Parameter(b.to(cuda))
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        for rep in range(2):
+            yl = ops.conv2d(xl, wl, bl, 2, 0)
+            assert ops.last_plan()[:2] == (6, 36), ops.last_plan()
+            yrr = F.conv2d(xr, wr, br, stride=2)
+            _close(nchw(yl), yrr, "two-tap layer y (pass %d) %s" % (rep, case), tol=2e-5)
+            xl.grad = wl.grad = bl.grad = xr.grad = wr.grad = br.grad = None
+            yl.backward(nhwc(gy).to(cuda)); yrr.backward(gy)
+            _close(nchw(xl.grad), xr.grad, "two-tap layer dx %s" % (case,), tol=2e-5)
+            _close(wl.grad, wr.grad, "two-tap layer dw %s" % (case,), tol=2e-5)
+            _close(bl.grad, br.grad, "two-tap layer db %s" % (case,), tol=2e-5)
+            with torch.no_grad():
+                wl.mul_(0.5); wr.mul_(0.5)
+
+
 # One full-size layer per network (the bench step's own geometries), every engine, against torch's CPU convolution in fp64: the kernels that
 # carry the headline number are compared with the oracle directly, not only with each other.
 FULL_SIZE_LAYERS = [("D convs1.0", (16, 58, 512, 64, 64, 0, 1)), ("HWR conv5", (8, 8, 129, 512, 512, 0, 0)), ("style down.2", (4, 32, 514, 128, 128, 0, 0))]

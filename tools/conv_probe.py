@@ -46,6 +46,7 @@ for line in lines:
     env = dict(kv.split("=", 1) for kv in parts[1:])
     wino = env.pop("WINO", None)
     wgrad = env.pop("WGRAD", None)
+    s2 = env.pop("S2", None)
     if tr:
         P = (H - 1) * sh - 2 * ph + R; Q = (W - 1) * sw - 2 * pw + S; pix = N * H * W
     else:
@@ -60,6 +61,11 @@ for line in lines:
             fn = "hwg_wino_wgrad" if use_wino else "hwg_conv_wgrad"
             need = L.query(fn + "_workspace", d.ptr); ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
             t = bench(lambda: L.call(fn, d.ptr, dy, x, dw, C * R * S, R * S, S, 1, 0, db, 0, ws, ws.numel(), st))
+        elif s2:           # F(3x3,2x2) path of the 4x4 stride-2 pad-0 layers (forward, or tr = 1: their data gradient)
+            Kc, Cc = (C, K) if tr else (K, C)
+            wp = torch.randn(L.query("hwg_wino_s2_weight_floats", Kc, Cc, tr), device=dev) * 0.05
+            need = L.query("hwg_wino_s2_workspace", d.ptr); ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+            t = bench(lambda: L.call("hwg_wino_s2_conv", d.ptr, x, wp, None, y, 0, ws, ws.numel(), st))
         elif wino:
             wp = torch.randn((C + 15) // 16, 16, (K + 15) // 16 * 16, 16, device=dev) * 0.05
             need = L.query("hwg_wino_conv_workspace", d.ptr); ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
