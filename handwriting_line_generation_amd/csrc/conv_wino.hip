@@ -1606,7 +1606,7 @@ static WinoPlan plan_wino_model(const hwg_conv_desc* d) {
     const long long tiles = (long long)hwg_cdiv(M, 64) * hwg_cdiv(d->K, 64);
     int gf = 0, af = -1;
     if (bal_mode > 0) sscanf(hwg_tune().wino_bal, "%d,%d", &gf, &af);
-    if (wino_balance(p, tiles, chunks, gf, af)) {
+    if (wino_balance(p, tiles, chunks, gf, af) && (p.bal_pieces <= 1 || (double)p.bal_pieces * out_bytes <= 1.5e9)) {
       // fitted on tools/probes/probe_r5_bal.txt (profiles/r05_probe_bal.txt): a tail workgroup starts while the last whole-tile ones drain
       // (4 us of its fixed cost hidden), every further tile it touches costs 5 us (output transform + prologue)
       const long long units = (tiles - p.bal_tile0) * chunks;
@@ -1800,7 +1800,7 @@ WinoPlan plan_wino_s2_model(const hwg_conv_desc* d) {
     wino_cfg(p, 6);
     int gf = 0, af = -1;
     if (bal_mode > 0) sscanf(hwg_tune().wino_bal, "%d,%d", &gf, &af);
-    if (wino_balance(p, tiles, chunks, gf, af)) {
+    if (wino_balance(p, tiles, chunks, gf, af) && (p.bal_pieces <= 1 || (double)p.bal_pieces * out_bytes <= 1.5e9)) {
       const long long units = (tiles - p.bal_tile0) * chunks;
       const long long c = hwg_cdiv(units, (long long)p.bal);
       double t = (p.bal_tile0 / 256) * (wc.fixed_us + 4.0 * chunks * wc.step_us) * 1e-6;

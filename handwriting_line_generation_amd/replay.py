@@ -99,8 +99,7 @@ class _Recorder:
         self.inputs = {}                    # storage address -> table slot (S_X / S_DY)
         self.pidx = {id(p): i for i, p in enumerate(params)}
         self.main_stream = ops._stream()
-        side = ops._side_streams.get(device.index if device.index is not None else torch.cuda.current_device())
-        self.side_stream = side[1] if side else None
+        self.side_stream = ops._side_stream(device)[1]      # (created here if no pass has forked yet: the recording's backward variants may)
 
     def _ph(self):
         if isinstance(self.phase, tuple):
