@@ -513,6 +513,50 @@ def test_full_size_layers_vs_fp64(cuda, layer, engine):
 _FULL_REF = {}
 
 
+@pytest.mark.parametrize("engine", ["model", "wino_s2", "direct"])
+def test_full_size_stride2_layer_vs_fp64(cuda, engine):
+    """the style extractor's first down-sampling convolution at the bench step's size (4 x 66 x 1026, 64 -> 128, 4x4 stride 2: the layer the
+    F(3x3,2x2) kernel was built for), forward / data gradient / weight gradient against torch's CPU convolution in fp64, both engines"""
+    from handwriting_line_generation_amd import ops
+    N, H, W, C, K = 4, 66, 1026, 64, 128
+    g = torch.Generator().manual_seed(47)
+    x = torch.randn(N, C, H, W, generator=g); w = torch.randn(K, C, 4, 4, generator=g) / (4 * C ** 0.5); b = torch.randn(K, generator=g)
+    key = ("s2", N, H, W, C, K)
+    if key not in _FULL_REF:
+        xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+        torch.set_num_threads(max(torch.get_num_threads(), min(16, os.cpu_count() or 1)))
+        yr = F.conv2d(xr, wr, br, 2)
+        gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(49))
+        yr.backward(gy.double())
+        _FULL_REF[key] = {"y": yr.detach(), "dx": xr.grad, "dw": wr.grad, "db": br.grad, "gy": gy}
+    ref = _FULL_REF[key]
+    env = {"model": {}, "wino_s2": dict(HWG_WINO_S2="2"), "direct": dict(HWG_WINO_S2="0")}[engine]
+    with ops.tuning(**env):
+        xg = nhwc(x).to(cuda).requires_grad_(True)
+        wg, bg = torch.nn.Parameter(w.to(cuda)), torch.nn.Parameter(b.to(cuda))
+        y = ops.conv2d(xg, wg, bg, 2, 0)
+        fwd_plan = ops.last_plan()
+        y.backward(nhwc(ref["gy"]).to(cuda))
+    if engine == "wino_s2":
+        assert fwd_plan[:2] == (6, 36), fwd_plan
+    elif engine == "direct":
+        assert fwd_plan[0] == 0, fwd_plan
+    rels = {}
+    for got, k in ((nchw(y), "y"), (nchw(xg.grad), "dx"), (wg.grad, "dw"), (bg.grad, "db")):
+        want = ref[k]
+        rel = float((got.detach().cpu().double() - want).norm() / want.norm())
+        mx = float((got.detach().cpu().double() - want).abs().max() / want.abs().max())
+        rels[k] = rel
+        assert rel < 3e-6 and mx < 1e-4, "4x4 stride-2 layer [%s, forward %s] %s: rel L2 %.2e, max/max %.2e vs fp64" % (engine, fwd_plan, k, rel, mx)
+    line = "style down 4x4s2 [%-7s] forward plan %s: rel L2 vs fp64  y %.2e  dx %.2e  dw %.2e  db %.2e" % (engine, fwd_plan, rels["y"], rels["dx"], rels["dw"], rels["db"])
+    print("\n" + line)
+    if os.environ.get("HWG_PARITY_SUMMARY"):
+        with open(os.environ["HWG_PARITY_SUMMARY"], "a") as fh:
+            fh.write("full-size layer " + line + "\n")
+
+
+
+
 def _full_size_reference(shape, x, w, b):
     """fp64 CPU autograd reference of a layer, computed once per layer (a few seconds each) and shared by the engine variants"""
     if shape not in _FULL_REF:
