@@ -783,9 +783,9 @@ _wino_wgrad_choice = {}
 
 def _wino_wgrad_ok(d):
     """weight gradient of a 3x3 stride-1 layer in the Winograd domain (conv_wino_wgrad.hip) - the library decides per geometry"""
-    if not WINOGRAD or d.R != 3 or d.S != 3:
-        return False
-    key = (d.N, d.H, d.W, d.C, d.K, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.dil_h, d.dil_w, d.P, d.Q)
+    if not WINOGRAD or not ((d.R == 3 and d.S == 3) or (d.R == 4 and d.S == 4 and d.stride_h == 2 and d.stride_w == 2 and not d.transposed)):
+        return False      # (4x4 stride 2 pad 0: the two-tap problem on the space-to-depth image, F(2x2 taps, 3x3 gradient tiles))
+    key = (d.N, d.H, d.W, d.C, d.K, d.R, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.dil_h, d.dil_w, d.P, d.Q)
     hit = _wino_wgrad_choice.get(key)
     if hit is None:
         hit = _wino_wgrad_choice[key] = bool(L.query("hwg_wino_wgrad_preferred", d.ptr))

@@ -459,6 +459,7 @@ def test_winograd_two_tap_kernel_for_4x4_stride2_layers(cuda, case):
             _close(nchw(yl), yrr, "two-tap layer y (pass %d) %s" % (rep, case), tol=2e-5)
             xl.grad = wl.grad = bl.grad = xr.grad = wr.grad = br.grad = None
             yl.backward(nhwc(gy).to(cuda)); yrr.backward(gy)
+            assert ops.last_plan()[:2] == (7, 36), ops.last_plan()      # the weight gradient: F(2x2 taps, 3x3 gradient tiles) on the Winograd weight-gradient kernel
             _close(nchw(xl.grad), xr.grad, "two-tap layer dx %s" % (case,), tol=2e-5)
             _close(wl.grad, wr.grad, "two-tap layer dw %s" % (case,), tol=2e-5)
             _close(bl.grad, br.grad, "two-tap layer db %s" % (case,), tol=2e-5)

@@ -57,7 +57,7 @@ for line in lines:
         d = ops._desc(N, H, W, C, K, R, S, (sh, sw), (ph, pw), (1, 1), P, Q, tr)
         if wgrad:          # weight gradient of the (non-transposed) layer: engine chosen like ops._make_wgrad_plan does
             dy = torch.randn(N, P, Q, K, device=dev); dw = torch.empty(K, C, R, S, device=dev); db = torch.empty(K, device=dev)
-            use_wino = R == 3 and S == 3 and bool(L.query("hwg_wino_wgrad_preferred", d.ptr))
+            use_wino = ((R == 3 and S == 3) or (R == 4 and S == 4 and (sh, sw) == (2, 2))) and bool(L.query("hwg_wino_wgrad_preferred", d.ptr))
             fn = "hwg_wino_wgrad" if use_wino else "hwg_conv_wgrad"
             need = L.query(fn + "_workspace", d.ptr); ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
             t = bench(lambda: L.call(fn, d.ptr, dy, x, dw, C * R * S, R * S, S, 1, 0, db, 0, ws, ws.numel(), st))
