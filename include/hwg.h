@@ -185,7 +185,10 @@ size_t hwg_wino_s2_workspace(const hwg_conv_desc* d);
 int hwg_wino_s2_conv(const hwg_conv_desc* d, const float* x, const float* u, const float* bias, float* y,
                      int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Weight gradient of a 3x3 stride-1 dilation-1 convolution in the Winograd domain F(3x3, 2x2) (conv_wino_wgrad.hip): same operands and weight
+/* (Their weight gradient goes through hwg_wino_wgrad* below, which accept these descriptors as well.) */
+
+/* Weight gradient of a 3x3 stride-1 dilation-1 convolution in the Winograd domain F(3x3, 2x2) - or of a 4x4 stride-2 pad-0 one as the two-tap
+ * problem on the space-to-depth image, F(2x2 taps, 3x3 gradient tiles) - (conv_wino_wgrad.hip): same operands and weight
  * strides as hwg_conv_wgrad (dy = anchor [N,P,Q,K], x = gathered [N,H,W,C]; reference: the weight gradients autograd produces for
  * model/pure_gen.py, model/discriminator_ap.py and model/cnn_only_hwr.py's 3x3 layers). dbias (or null): the bias gradient, column sums of dy,
  * taken from the dy tiles on their way through the kernel. */
