@@ -299,14 +299,24 @@ def main():
     barrier()
     tw = time.perf_counter()
     warm_done = 0
+    # ... and until the launch-list recorder (replay.py) has gone quiet: a pass is recorded at its 3rd / 24th sighting (a one-off eager run of
+    # every backward variant plus a self-check, 20-50 ms), i.e. around cycle 12 for the recogniser on generated lines - with a warm-up of 10-12
+    # cycles those recordings fell into the 1.5 s timed region on some boxes (r05_bench_line_slow_host.json: 65 / 75 where the same box then
+    # read 79 / 85). Warm until no program has been recorded for QUIET_CYCLES cycles, at least REPLAY_MIN_CYCLES and at most 40 cycles.
+    QUIET_CYCLES, REPLAY_MIN_CYCLES = 4, 14
+    quiet, recorded = 0, -1
     while True:
         for _ in range(cycle):
             trainer._train_iteration(it); it += 1
         warm_done += cycle
+        now = _replay.STATS["captures"] + _replay.STATS["rejected"]
+        quiet, recorded = (quiet + 1 if now == recorded else 0), now
         if warm_done < args.warmup:
             continue
         torch.cuda.synchronize()
-        if agree_max(time.perf_counter() - tw) >= WARM_SECONDS or warm_done >= 100 * cycle:
+        settled = (not _replay.ENABLED) or not gan or (quiet >= QUIET_CYCLES and warm_done >= REPLAY_MIN_CYCLES * cycle) or warm_done >= 40 * cycle
+        waiting = 0.0 if (time.perf_counter() - tw >= WARM_SECONDS and settled) else 1.0
+        if agree_max(waiting) == 0.0 or warm_done >= 100 * cycle:
             break
     # one more cycle, timed on its own, to size the timed region: at least the requested steps, MIN_CYCLES cycles and TIMED_SECONDS
     barrier()
