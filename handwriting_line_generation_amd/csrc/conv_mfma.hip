@@ -592,7 +592,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void wgrad_mfma_k
   const int wm0 = (wmn / WAVES_N) * WM;
   const int wn0 = (wmn % WAVES_N) * WN;
   const int kbeg = wk * (BKP / WAVES_K);
-  const int kend = kbeg + BKP / WAVES_K;
   const int l31 = lane & 31, lhi = lane >> 5;
 
   // bias gradient = column sums of u: taken by the workgroups of the first tap / first v tile from their LDS copy of the u tile

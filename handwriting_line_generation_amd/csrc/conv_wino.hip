@@ -831,7 +831,6 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
   constexpr int NT = 512, TM = 64, TN = 64;
   constexpr int PSV = TM * 16 + 8, PSU = TN * 16 + 8;
   constexpr int XI = TM * 16 / NT;                   // 2 x work items per thread: (tile, 4-channel group, patch column)
-  constexpr int UI = TN * 16 / NT;                   // 2 u work items per thread per round: (position, k, 4-channel group)
   constexpr int VBUF = 4 * PSV, UBUF = 4 * PSU;      // two patch buffers; ring of four filter rounds = the four rounds of a chunk, each its own array:
   // the compiler tracks pending LDS DMA per underlying object, so reading the array of round r does not force a wait for the DMA that is
   // filling the array of round r + 2 (one shared array costs a vmcnt(0) before every fragment read)
