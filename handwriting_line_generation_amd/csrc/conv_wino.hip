@@ -1910,3 +1910,30 @@ extern "C" int hwg_wino_s2_conv(const hwg_conv_desc* d, const float* x, const fl
   }
   return HWG_OK;
 }
+
+/* the schedule hwg_wino_conv_fwd (3x3 stride 1) / hwg_wino_s2_conv (4x4 stride 2 pad 0, either direction) would run for this product, without launching
+ * anything: out[8] = {tile config, uniform channel split, balanced tail workgroups (0 = uniform schedule), whole-tile lead workgroups, most
+ * pieces a cut tile is written in, workgroup tiles, channel chunks, most tiles one tail workgroup touches}; -1s when the product is not supported */
+extern "C" int hwg_wino_conv_describe(const hwg_conv_desc* d, int* out) {
+  HWG_REQUIRE(d && out, "wino_conv_describe: null pointer");
+  for (int i = 0; i < 8; ++i) out[i] = -1;
+  WinoPlan p;
+  long long tiles;
+  int chunks;
+  S2Geom g;
+  if (d->R == 4 && d->S == 4) {
+    if (!hwg_wino_s2_supported(d) || !s2_geom(d, g)) return HWG_OK;
+    p = plan_wino_s2(d);
+    tiles = (long long)hwg_cdiv((long long)g.N * hwg_cdiv(g.Pv, 3) * hwg_cdiv(g.Qv, 3), 64ll) * hwg_cdiv(g.Kv, 64);
+    chunks = g.Cv / 16;
+  } else {
+    if (!hwg_wino_supported(d)) return HWG_OK;
+    p = plan_wino(d);
+    tiles = (long long)hwg_cdiv((long long)d->N * hwg_cdiv(d->P, 2) * hwg_cdiv(d->Q, 2), (long long)p.tm) * hwg_cdiv(d->K, p.tn);
+    chunks = d->C / 16;
+  }
+  out[0] = p.cfg; out[1] = p.nsplit; out[2] = p.bal; out[3] = p.bal_tile0; out[4] = p.bal > 0 ? p.bal_pieces : (p.nsplit > 1 ? p.nsplit : 1);
+  out[5] = (int)tiles; out[6] = chunks; out[7] = p.bal > 0 ? p.bal_segs : 1;
+  return HWG_OK;
+}
+

@@ -187,6 +187,12 @@ int hwg_wino_s2_conv(const hwg_conv_desc* d, const float* x, const float* u, con
 
 /* (Their weight gradient goes through hwg_wino_wgrad* below, which accept these descriptors as well.) */
 
+/* Diagnostic, like hwg_last_plan: the schedule hwg_wino_conv_fwd (3x3 stride 1) / hwg_wino_s2_conv (4x4 stride 2 pad 0, either direction) would
+ * run for this product, without launching anything. out[8] = {tile config, uniform channel split, balanced tail workgroups (0 = uniform
+ * schedule), whole-tile lead workgroups, most pieces a cut tile is written in (= workspace images), workgroup tiles, channel chunks, most tiles
+ * one tail workgroup touches}; all -1 when the product is not supported. */
+int hwg_wino_conv_describe(const hwg_conv_desc* d, int* out);
+
 /* Weight gradient of a 3x3 stride-1 dilation-1 convolution in the Winograd domain F(3x3, 2x2) - or of a 4x4 stride-2 pad-0 one as the two-tap
  * problem on the space-to-depth image, F(2x2 taps, 3x3 gradient tiles) - (conv_wino_wgrad.hip): same operands and weight
  * strides as hwg_conv_wgrad (dy = anchor [N,P,Q,K], x = gathered [N,H,W,C]; reference: the weight gradients autograd produces for

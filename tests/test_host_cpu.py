@@ -142,3 +142,58 @@ def test_replay_executor_runs_a_call_list_and_classifies_stream_parameters():
     assert run([(len(funcs), 0, 0)])[0] == -1002 and run([(funcs["hwg_prof_start"][0], 0, 0)])[0] == -1002   # unknown id; wrong argument count
     recs = np.asarray([(funcs["hwg_prof_start"][0], 0, 1)], np.int32)
     assert L._hwgcall.replay(recs, np.asarray([3], np.uint8), np.asarray([5], np.int64), empty64, table)[0] == -1003   # table slot out of range
+
+
+def test_winograd_planner_balanced_schedule_bookkeeping():
+    """the balanced schedule of the 64 x 64 Winograd kernel (csrc/conv_wino.hip, wino_balance): the planner's bookkeeping - which tiles run
+    whole, how many workgroups share the rest, the most pieces a tile is cut into (= workspace images), the most tiles a workgroup touches -
+    against an independent recomputation, and the closed form the kernel and the reduce pass use to find a unit's owner against the runs
+    themselves (workgroup g owns units [U g / G, U (g + 1) / G)). No launch: hwg_wino_conv_describe only plans."""
+    from handwriting_line_generation_amd import ops, _lib as L
+
+    def describe(N, H, W, C, K, R, S, stride, pad, P, Q, tr=0):
+        d = ops._desc(N, H, W, C, K, R, S, stride, pad, (1, 1), P, Q, tr)
+        out = np.full(8, -7, dtype=np.int32)
+        L.call("hwg_wino_conv_describe", d.ptr, out.ctypes.data)
+        return [int(v) for v in out], d
+
+    def check(out, d, workspace_fn):
+        cfg, ns, G, lead, pieces, tiles, chunks, segs = out
+        assert cfg == 6 and G > 0 and lead % 256 == 0 and 0 <= lead < tiles, out
+        units = (tiles - lead) * chunks
+        owner = lambda u: ((u + 1) * G - 1) // units                      # noqa: E731 - the closed form of wino_bal_owner
+        runs = [(units * g // G, units * (g + 1) // G) for g in range(G)]
+        assert runs[0][0] == 0 and runs[-1][1] == units and all(a[1] == b[0] for a, b in zip(runs, runs[1:]))
+        for g, (u0, u1) in enumerate(runs):
+            assert all(owner(u) == g for u in (u0, u1 - 1) if u1 > u0), (g, u0, u1)
+        cut = [owner(t * chunks + chunks - 1) - owner(t * chunks) + 1 for t in range(tiles - lead)]
+        assert max(cut) == pieces, (max(cut), pieces)
+        assert max((u1 - 1) // chunks - u0 // chunks + 1 for u0, u1 in runs if u1 > u0) == segs
+        out_bytes = 4 * d.N * d.P * d.Q * d.K
+        assert L.query(workspace_fn, d.ptr) == (pieces * out_bytes if pieces > 1 else 0)
+
+    with ops.tuning(HWG_WINO="1", HWG_WINO_BAL=None, HWG_WINO_FORCE=None, HWG_WINO_S2="1"):
+        # the recogniser layer that used half the chip (132 tiles of 32 chunks): all of it balanced over 256 workgroups
+        out, d = describe(8, 8, 129, 512, 256, 3, 3, (1, 1), (1, 1), 8, 129)
+        assert out[:4] == [6, 1, 256, 0] and out[5:7] == [132, 32], out
+        check(out, d, "hwg_wino_conv_workspace")
+        # 260 tiles: one whole round of 256 + the 4 leftover tiles cut into single-chunk runs
+        out, d = describe(4, 13, 256, 256, 256, 3, 3, (1, 1), (2, 2), 15, 258)
+        assert out[2] > 0 and out[3] == 256 and out[5] == 260, out
+        check(out, d, "hwg_wino_conv_workspace")
+        # a layer that fills its rounds keeps the uniform schedule
+        out, d = describe(8, 16, 128, 256, 256, 3, 3, (1, 1), (1, 1), 16, 128)
+        assert out[0] == 6 and out[2] == 0 and out[5] == 256, out
+        # the style extractor's 4x4 stride-2 data gradient as a two-tap problem (described like the fractionally strided product)
+        out, d = describe(4, 15, 256, 256, 128, 4, 4, (2, 2), (0, 0), 32, 514, tr=1)
+        assert out[0] == 6 and out[6] == 16, out
+        if out[2] > 0:
+            check(out, d, "hwg_wino_s2_workspace")
+    for force in ("3", "7", "40", "64,0", "9,256"):
+        with ops.tuning(HWG_WINO="2", HWG_WINO_BAL=force):
+            out, d = describe(8, 66, 130, 32, 64, 3, 3, (1, 1), (1, 1), 66, 130)       # 269 tiles of 2 chunks
+            assert out[5] == 269 and out[6] == 2 and out[2] == min(int(force.split(",")[0]), (269 - out[3]) * 2), (force, out)
+            check(out, d, "hwg_wino_conv_workspace")
+    # a 4x4 stride-2 layer the two-tap path does not take (odd image: the data gradient's last row would never be written) reports -1s
+    out, _ = describe(4, 15, 256, 256, 128, 4, 4, (2, 2), (0, 0), 33, 514, tr=1)
+    assert out == [-1] * 8
