@@ -38,6 +38,8 @@ struct WinoK {
   // the VIRTUAL stride-1 two-tap convolution; element (n, h, w, channel chunk t) of its input lies at
   //   x + n x_img + h x_row + w x_pix + (t / x_tc) x_run + (t % x_tc) 16,   output (n, p, q, k) at  y + n y_img + p y_row + q y_pix + (k / y_kc) y_run + k % y_kc
   int mt_edge;         // 2 or 3
+  int dbg;             // timing ablations of the ABL build of wino_conv64d_kernel (HWG_CONV_DBG, results are garbage): 1024 no global stores in the
+                       // epilogue, 2048 no output transform at all (one dependent store per lane keeps the accumulators alive), 4096 patch loads of chunk 0 only
   int x_img, x_row, x_pix, x_tc, x_run;
   int y_img, y_row, y_pix, y_kc, y_run;
 };
@@ -839,6 +841,10 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
   static_assert(XP >= UBUF && 4 * XP >= 2 * VBUF, "exchange planes alias the operand buffers");
   __shared__ __attribute__((aligned(16))) float smem[4 * XP];
   __shared__ __attribute__((aligned(16))) float U0[XP], U1[XP], U2[XP], U3[XP];
+  // output coordinates of the workgroup's 64 tiles, decoded ONCE (by 64 lanes) instead of by every lane for each of its 8 tiles: the three
+  // integer divisions per tile (~120 VALU instructions) made the output loop 5.5 us of a 31 us workgroup on 4-chunk layers
+  // (tools/probes/probe_r5_wino_fixed.txt: HWG_CONV_DBG 512 vs 2560)
+  __shared__ int tile_out[64], tile_ext[64], tile_w0[64];
   float* const Vs = smem;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -888,21 +894,29 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
   // virtual image may be row PAIRS of the real one, its channels split in runs that lie a real row apart).
   int x_off[XI], x_ok[XI], x_row[XI], x_c4[XI], x_b[XI];
   const int row_stride = MT == 2 ? a.W * a.C : a.x_row;
-#pragma unroll
-  for (int it = 0; it < XI; ++it) {
-    const int id = tid + it * NT;
-    const int b = id & 3, c4 = (id >> 2) & 3, row = id >> 4;
-    x_b[it] = b; x_c4[it] = c4; x_row[it] = row;
-    const int m = m0 + row;
+  // patch origins of the 64 tiles, decoded once per workgroup (three integer divisions per tile) and shared through LDS
+  if (tid < 64) {
+    const int m = m0 + tid;
     const bool mok = m < a.M;
     const int mm = mok ? m : 0;
     const int tj = mm % a.TQ;
     const int t2 = mm / a.TQ;
     const int ti = t2 % a.TP;
-    const int n = t2 / a.TP;
-    const int w = MT * tj - a.pw + b;
+    tile_out[tid] = mok ? t2 / a.TP : -1;       // sample, -1: no such tile
+    tile_ext[tid] = MT * ti - a.ph;
+    tile_w0[tid] = MT * tj - a.pw;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < XI; ++it) {
+    const int id = tid + it * NT;
+    const int b = id & 3, c4 = (id >> 2) & 3, row = id >> 4;
+    x_b[it] = b; x_c4[it] = c4; x_row[it] = row;
+    const int n = max(tile_out[row], 0);
+    const bool mok = tile_out[row] >= 0;
+    const int w = tile_w0[row] + b;
     const bool wok = mok && w >= 0 && w < a.W;
-    const int h0 = MT * ti - a.ph;
+    const int h0 = tile_ext[row];
     if constexpr (MT == 2) x_off[it] = ((n * a.H + h0) * a.W + (wok ? w : 0)) * a.C + c4 * 4;
     else x_off[it] = n * a.x_img + h0 * a.x_row + (wok ? w : 0) * a.x_pix + c4 * 4;
     int okm = 0;
@@ -1030,7 +1044,7 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
       // (the last chunk re-fetches itself, so the counts below are the same in every round)
       if (r == 3) { col_transform(); __builtin_amdgcn_sched_barrier(0); }   // needs the patch loads of round 1: before this round's DMA joins the queue behind them
       dma_u(R + 2, r == 0 ? U2 : r == 1 ? U3 : r == 2 ? U0 : U1);
-      if (r == 1) load_x(t + 1 < t1 ? t + 1 : t);
+      if (r == 1) load_x((ABL & 1) && (a.dbg & 4096) ? t0 : (t + 1 < t1 ? t + 1 : t));      // (4096: timing ablation, every chunk re-reads the first one's patches)
       const float* Vb = Vs + cur * VBUF;
       const float* Ub = r == 0 ? U0 : r == 1 ? U1 : r == 2 ? U2 : U3;
       float4 af[4], bf[2];
@@ -1090,10 +1104,40 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
     direct = g_first == g_last;
     piece = wg - g_first;
   }
+  if constexpr ((ABL & 1) != 0) {
+    if (a.dbg & 2048) {      // timing ablation: no output transform (the accumulators stay alive through one store that never happens)
+      float keep = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) keep += acc[r][m][n][0] + acc[r][m][n][1] + acc[r][m][n][2] + acc[r][m][n][3];
+      if (keep == 123456.789f) a.y[tid] = keep;
+      if (!BAL || whole) break;
+      unit += t1 - t0;
+      if (unit >= unit_end) break;
+      __syncthreads();
+      continue;
+    }
+  }
   if constexpr (MT == 2) {
   // ---- output transform: over the rows a in registers (s0 = m0+m1+m2, s1 = m1-m2-m3), over the columns b through LDS ----------------
   // exchange image X[b][i][tile][channel]; C/D layout of a block: channel = lane & 15, tile = (lane >> 4) * 4 + e
   auto xplane = [&](int pl) -> float* { return pl < 4 ? smem + pl * XP : pl == 4 ? U0 : pl == 5 ? U1 : pl == 6 ? U2 : U3; };
+  if (tid < 64) {
+    const int m = m0 + tid;
+    int base = -1, ext = 0;
+    if (m < a.M) {
+      const int tj = m % a.TQ;
+      const int t2 = m / a.TQ;
+      const int ti = t2 % a.TP;
+      const int n = t2 / a.TP;
+      base = (n * a.P + 2 * ti) * a.Q + 2 * tj;                         // pixel index of the tile's first output (the planner keeps N P Q K < 2^31)
+      ext = (2 * ti + 1 < a.P ? 1 : 0) | (2 * tj + 1 < a.Q ? 2 : 0);    // second output row / column inside the image
+    }
+    tile_out[tid] = base; tile_ext[tid] = ext;
+  }
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -1114,26 +1158,21 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
   const bool accum = direct && a.accumulate;
 #pragma unroll 2
   for (int tile = tid >> 6; tile < 64; tile += 8) {
-    const int m = m0 + tile;
-    if (m >= a.M || k >= a.K) continue;
-    const int tj = m % a.TQ;
-    const int t2 = m / a.TQ;
-    const int ti = t2 % a.TP;
-    const int n = t2 / a.TP;
+    const int base = tile_out[tile], ext = tile_ext[tile];
+    if (base < 0 || k >= a.K) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const float r0 = xplane(0 * 2 + i)[tile * LDK + kk], r1 = xplane(1 * 2 + i)[tile * LDK + kk];
       const float r2 = xplane(2 * 2 + i)[tile * LDK + kk], r3 = xplane(3 * 2 + i)[tile * LDK + kk];
-      const int p = 2 * ti + i;
-      if (p >= a.P) continue;
+      if (i && !(ext & 1)) continue;
       const float y0 = r0 + r1 + r2, y1 = r1 - r2 - r3;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int q = 2 * tj + j;
-        if (q >= a.Q) continue;
-        const long long o = (((long long)n * a.P + p) * a.Q + q) * a.K + k;
+        if (j && !(ext & 2)) continue;
+        const long long o = ((long long)base + i * a.Q + j) * a.K + k;
         float v = (j == 0 ? y0 : y1) + bv;
         if (accum) v += yg[o];
+        if constexpr ((ABL & 1) != 0) { if ((a.dbg & 1024) && v != 123456.789f) continue; }      // timing ablation: no global stores
         yg[o] = v;
       }
     }
@@ -1151,6 +1190,19 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
     const float bv = (direct && a.bias && k < a.K) ? a.bias[k] : 0.f;
     const bool accum = direct && a.accumulate;
     const long long kch = (long long)(k / a.y_kc) * a.y_run + (k % a.y_kc);
+    if (tid < 64) {
+      const int m = m0 + tid;
+      int base = -1, ext = 0;
+      if (m < a.M) {
+        const int tj = m % a.TQ;
+        const int t2 = m / a.TQ;
+        const int ti = t2 % a.TP;
+        const int n = t2 / a.TP;
+        base = n * a.y_img + 3 * ti * a.y_row + 3 * tj * a.y_pix;                 // element offset of the tile's first output (images < 2^31 elements)
+        ext = min(3, a.P - 3 * ti) | (min(3, a.Q - 3 * tj) << 2);               // output rows / columns of the tile inside the image
+      }
+      tile_out[tid] = base; tile_ext[tid] = ext;
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       if (half) __syncthreads();
@@ -1170,24 +1222,18 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
       __syncthreads();
 #pragma unroll 2
       for (int tl = tid >> 6; tl < 32; tl += 8) {
-        const int m = m0 + half * 32 + tl;
-        if (m >= a.M || k >= a.K) continue;
-        const int tj = m % a.TQ;
-        const int t2 = m / a.TQ;
-        const int ti = t2 % a.TP;
-        const int n = t2 / a.TP;
+        const int base = tile_out[half * 32 + tl], ext = tile_ext[half * 32 + tl];
+        if (base < 0 || k >= a.K) continue;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          const int p = 3 * ti + i;
-          if (p >= a.P) continue;
+          if (i >= (ext & 3)) continue;
           const float r0 = xplane3(0 * 3 + i)[tl * LDK + kk], r1 = xplane3(1 * 3 + i)[tl * LDK + kk];
           const float r2 = xplane3(2 * 3 + i)[tl * LDK + kk], r3 = xplane3(3 * 3 + i)[tl * LDK + kk];
           const float yv[3] = {r0 + r1 + r2, r1 - r2, r1 + r2 + r3};
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
-            const int q = 3 * tj + j;
-            if (q >= a.Q) continue;
-            const long long o = (long long)n * a.y_img + (long long)p * a.y_row + (long long)q * a.y_pix + kch;
+            if (j >= (ext >> 2)) continue;
+            const long long o = (long long)base + (long long)i * a.y_row + (long long)j * a.y_pix + kch;
             float v = yv[j] + bv;
             if (accum) v += yg[o];
             yg[o] = v;
@@ -1696,7 +1742,7 @@ extern "C" int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const f
   k.mt = hwg_cdiv(k.M, p.tm); k.nt = hwg_cdiv(d->K, p.tn);
   k.xcd_order = hwg_tune().wino_order;
   k.bal = p.bal; k.bal_tile0 = p.bal_tile0;
-  k.mt_edge = 2;
+  k.mt_edge = 2; k.dbg = hwg_tune().conv_dbg;
   k.x_img = k.x_row = k.x_pix = k.x_tc = k.x_run = 0;      // (the F(2x2,3x3) kernels address the plain NHWC image themselves)
   k.y_img = d->P * d->Q * d->K; k.y_row = d->Q * d->K; k.y_pix = d->K; k.y_kc = d->K; k.y_run = 0;
   dim3 grid(p.bal > 0 ? p.bal_tile0 + (p.bal + 7) / 8 * 8 : (k.mt * k.nt * p.nsplit + 7) / 8 * 8);
@@ -1885,7 +1931,7 @@ extern "C" int hwg_wino_s2_conv(const hwg_conv_desc* d, const float* x, const fl
   k.mt = hwg_cdiv(k.M, 64); k.nt = hwg_cdiv(g.Kv, 64);
   k.xcd_order = hwg_tune().wino_order;
   k.bal = p.bal; k.bal_tile0 = p.bal_tile0;
-  k.mt_edge = 3;
+  k.mt_edge = 3; k.dbg = 0;
   k.x_img = g.x_img; k.x_row = g.x_row; k.x_pix = g.x_pix; k.x_tc = g.x_tc; k.x_run = g.x_run;
   k.y_img = g.y_img; k.y_row = g.y_row; k.y_pix = g.y_pix; k.y_kc = g.y_kc; k.y_run = g.y_run;
   dim3 grid(p.bal > 0 ? p.bal_tile0 + (p.bal + 7) / 8 * 8 : (k.mt * k.nt * p.nsplit + 7) / 8 * 8);
