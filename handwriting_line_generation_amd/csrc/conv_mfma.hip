@@ -60,6 +60,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
   constexpr int A_IT = (A_F4 + NT - 1) / NT, B_IT = (B_F4 + NT - 1) / NT;
 
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LD];
+  // fractionally strided modes: (sample, block row, block column) of the tile's BM rows, decoded once per workgroup for the epilogue (every lane
+  // used to decode each of its 16 x MI rows itself: three divisions by run-time values per row)
+  __shared__ int row_n[BM], row_p[BM], row_q[BM];
   float* As = smem;
   float* Bs = smem + 2 * BM * LD;
 
@@ -312,6 +315,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
     }
   }
 
+  if (a.mode != 0) {
+    for (int r = tid; r < BM; r += NT) {
+      const int m = m0 + r;
+      int n = -1, pi = 0, qi = 0;
+      if (m < Mc) {
+        qi = m % Qc;
+        const int t2 = m / Qc;
+        pi = t2 % Pc;
+        n = t2 / Pc;
+      }
+      row_n[r] = n; row_p[r] = pi; row_q[r] = qi;
+    }
+    if constexpr (WK == 1) __syncthreads();      // (WK > 1: the barrier of the partial-sum exchange below orders it)
+  }
   if constexpr (WK > 1) {
     // the K-split wavefronts' partial sums meet in LDS (the tile buffers are free after the loop's last barrier); wavefront group 0 adds
     // them in group order and writes the output
@@ -360,10 +377,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
       const int m = m0 + row;
       if (m >= Mc) continue;
       if (a.mode == 2) {
-        const int qi = m % Qc;
-        const int t2 = m / Qc;
-        const int pi = t2 % Pc;
-        const int n = t2 / Pc;
+        const int qi = row_q[row], pi = row_p[row], n = row_n[row];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           const int col = n0 + wn0 + ni * 32 + l31;
@@ -381,10 +395,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
       if (a.mode == 0) {
         obase = (long long)m * a.K;
       } else {
-        const int qi = m % Qc;
-        const int t2 = m / Qc;
-        const int pi = t2 % Pc;
-        const int n = t2 / Pc;
+        const int qi = row_q[row], pi = row_p[row], n = row_n[row];
         obase = (((long long)n * a.P + (cp + a.sh * pi)) * a.Q + (cq + a.sw * qi)) * a.K;
       }
 #pragma unroll
