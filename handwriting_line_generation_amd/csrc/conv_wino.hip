@@ -1160,6 +1160,7 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
   for (int tile = tid >> 6; tile < 64; tile += 8) {
     const int base = tile_out[tile], ext = tile_ext[tile];
     if (base < 0 || k >= a.K) continue;
+    const long long ob = (long long)base * a.K + k;      // one 64-bit product per tile; the four outputs are 32-bit steps from it
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const float r0 = xplane(0 * 2 + i)[tile * LDK + kk], r1 = xplane(1 * 2 + i)[tile * LDK + kk];
@@ -1169,7 +1170,7 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (j && !(ext & 2)) continue;
-        const long long o = ((long long)base + i * a.Q + j) * a.K + k;
+        const long long o = ob + (i * a.Q + j) * a.K;
         float v = (j == 0 ? y0 : y1) + bv;
         if (accum) v += yg[o];
         if constexpr ((ABL & 1) != 0) { if ((a.dbg & 1024) && v != 123456.789f) continue; }      // timing ablation: no global stores
