@@ -252,6 +252,17 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgK a_in) {
   // C/D layout of a 16x16 block: column (c) = lane & 15, row (k) = (lane >> 4) * 4 + e
   float* X = smem;
   float* out = a.part + (long long)split_all * a.pstride;
+  if constexpr ((DBG & 4) != 0) {          // timing ablation (HWG_WWG_DEBUG=4, garbage results): no output transform, no partial-image stores
+    float keep = 0.f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) keep += acc[p][i][j][0] + acc[p][i][j][1] + acc[p][i][j][2] + acc[p][i][j][3];
+    if (keep == 123456.789f) out[tid] = keep;
+    return;
+  }
   if (a.bias_on && c0 == 0) {              // the four dy wavefronts saw every dy element of this k-tile and pixel range exactly once
     float* bs = smem + XCH;
     __syncthreads();
@@ -429,6 +440,7 @@ static int wino_wgrad_run(const hwg_conv_desc* d, const float* dy, const float* 
   if (s2) hipLaunchKernelGGL((wino_wgrad_kernel<0, 3>), dim3((total + 7) / 8 * 8), dim3(512), 0, st, k);
   else if (dbg == 1) hipLaunchKernelGGL(wino_wgrad_kernel<1>, dim3((total + 7) / 8 * 8), dim3(512), 0, st, k);
   else if (dbg == 2) hipLaunchKernelGGL(wino_wgrad_kernel<2>, dim3((total + 7) / 8 * 8), dim3(512), 0, st, k);
+  else if (dbg == 4) hipLaunchKernelGGL(wino_wgrad_kernel<4>, dim3((total + 7) / 8 * 8), dim3(512), 0, st, k);
   else hipLaunchKernelGGL(wino_wgrad_kernel<0>, dim3((total + 7) / 8 * 8), dim3(512), 0, st, k);
   hwg_prof_close(prof, st);
   hwg_note_plan(HWG_PROF_WGRAD_WINO, s2 ? 36 : 0, p.nsplit);

@@ -47,7 +47,7 @@ for wl in iam_gan_b1a1_w512 rimes_gan_b4a2_w256_1024 iam_auto_b28_w512; do
 done
 rm -rf $OUT/kt
 python tools/norm_bw.py > $OUT/norm_bw.txt 2>&1
-for pf in abl7 direct wino_wgrad wino_abl narrow bal s2 merge tdir dlayers wino_fixed; do
+for pf in abl7 direct wino_wgrad wino_abl narrow bal s2 merge tdir dlayers wino_fixed wwg_fixed; do
   PROBE="$(grep -v "^#" tools/probes/probe_r5_$pf.txt | tr "\n" ";")" timeout 300 python tools/conv_probe.py > $OUT/probe_$pf.txt 2>&1
 done
 # parity summary: teacher-forced trainer groups, pre-training trainers, measured gate flips, per-engine forward error
