@@ -239,6 +239,19 @@ __global__ void copy_channels_kernel(const float* src, int Cs, int soff, float* 
     *d = accumulate ? *d + v : v;
   }
 }
+// dst[row][0..Cpad) = src[row][0..C) followed by zeros; one 16-byte store per thread
+__global__ void pad_channels_kernel(const float* __restrict__ src, int C, float* __restrict__ dst, int Cpad, unsigned total4) {
+  const unsigned q = Cpad / 4;
+  GRID_STRIDE(i, total4) {
+    const unsigned row = (unsigned)i / q;
+    const int c = (int)((unsigned)i - row * q) * 4;
+    const float* s = src + (size_t)row * C + c;
+    float4 v;
+    v.x = c + 0 < C ? s[0] : 0.f; v.y = c + 1 < C ? s[1] : 0.f;
+    v.z = c + 2 < C ? s[2] : 0.f; v.w = c + 3 < C ? s[3] : 0.f;
+    reinterpret_cast<float4*>(dst)[i] = v;
+  }
+}
 // out[n][c] (+)= sum_hw src[n*HW + hw][soff + c]   (backward of the broadcast)
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* src, int Cs, int soff, float* out, int Cn, int HW, int accumulate) {
   __shared__ float red[256];
@@ -424,6 +437,15 @@ extern "C" int hwg_copy_channels(const float* src, int Cs, int soff, float* dst,
   hipLaunchKernelGGL(copy_channels_kernel, dim3(hwg_stream_grid(rows * Cn, 256)), dim3(256), 0, st, src, Cs, soff, dst, Cd, doff, Cn, rows, HW,
                      bcast, accumulate);
   HWG_LAUNCH_CHECK("copy_channels");
+  return HWG_OK;
+}
+extern "C" int hwg_pad_channels(const float* src, int C, float* dst, int Cpad, long long rows, void* stream) {
+  HWG_REQUIRE(src && dst && rows > 0 && C > 0 && Cpad >= C && Cpad % 4 == 0, "pad_channels: bad arguments");
+  HWG_REQUIRE(rows * (Cpad / 4) < (1ll << 31), "pad_channels: tensor too large for 32-bit element indices");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned total4 = (unsigned)(rows * (Cpad / 4));
+  hipLaunchKernelGGL(pad_channels_kernel, dim3(hwg_stream_grid(total4, 256)), dim3(256), 0, st, src, C, dst, Cpad, total4);
+  HWG_LAUNCH_CHECK("pad_channels");
   return HWG_OK;
 }
 extern "C" int hwg_reduce_rows(const float* src, int Cs, int soff, float* out, int Cn, int N, int HW, int accumulate, void* stream) {

@@ -6,9 +6,13 @@ word/cmp boxes), and `data/sets.json` = {"train": [pages], "valid": [...], "test
 working directory). One dataset item = `a_batch_size` lines of one author; `collate` pads `batch_size` such items to a common width
 (-1) and label length (0) - the instance dict `HWWithStyleTrainer.run_gen` consumes.
 
-Interpolation differs from cv2 in the last bits (PIL bicubic for the height normalisation, bilinear for the affine warp); everything
-downstream of the decoded pixels - normalisation 1 - p/128, padding, label encoding, grouping of an author's lines, the draw order of the
-augmentation parameters - follows the reference.
+The interpolation ARITHMETIC is PIL's, not OpenCV's, and is NOT pinned to the reference (cv2 is absent from the build image, so no reference
+pixel exists): PIL bicubic (a = -0.5, antialiased) for the height normalisation where cv2.INTER_CUBIC uses a = -0.75 without antialiasing,
+PIL bilinear for the affine warp. What IS pinned to the reference (tests/golden/getitem_calls.json): which pixels are decoded and cropped,
+the resize / warp geometry handed to the interpolator, output sizes, normalisation 1 - p/128, padding, label encoding, grouping of an
+author's lines and the draw order of the augmentation parameters. `fg_mask` (Otsu threshold + dilation through cv2 when `fg_masks_dir` is
+set, reference :407-420) is not produced: the key is absent from the items, as it is in the reference without `fg_masks_dir`; nothing on the
+loss path reads it (INTEGRATION.md lists the difference).
 """
 import json
 import math
@@ -138,6 +142,12 @@ class AuthorHWDataset(torch.utils.data.Dataset):
         with open(config["char_file"]) as f:
             self.char_to_idx = json.load(f)["char_to_idx"]
         self.augmentation = config.get("augmentation")
+        # the reference applies `affine_trans` when the string contains "affine" and, for ANY other non-None value, Tensmeyer brightness +
+        # grid-distortion warping (datasets/author_hw_dataset.py:427-433, author_rimeslines_dataset.py:428-434) - OpenCV code outside this
+        # package's scope: refuse instead of silently training un-augmented
+        if self.augmentation is not None and not (isinstance(self.augmentation, str) and "affine" in self.augmentation and "normalization" not in self.augmentation):
+            raise NotImplementedError("data option augmentation=%r: only None and 'affine' are implemented (the reference's 'warp' / brightness / "
+                                      "'normalization' augmentations are OpenCV code outside the hot-path scope)" % (self.augmentation,))
         self.max_strech = 0.4
         self.max_rot_rad = 45 / 180 * math.pi
         self._pages = {}

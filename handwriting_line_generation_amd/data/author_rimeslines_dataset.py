@@ -91,6 +91,12 @@ class AuthorRIMESLinesDataset(AuthorHWDataset):
         with open(config["char_file"]) as f:
             self.char_to_idx = json.load(f)["char_to_idx"]
         self.augmentation = config.get("augmentation")
+        # the reference applies `affine_trans` when the string contains "affine" and, for ANY other non-None value, Tensmeyer brightness +
+        # grid-distortion warping (datasets/author_hw_dataset.py:427-433, author_rimeslines_dataset.py:428-434) - OpenCV code outside this
+        # package's scope: refuse instead of silently training un-augmented
+        if self.augmentation is not None and not (isinstance(self.augmentation, str) and "affine" in self.augmentation and "normalization" not in self.augmentation):
+            raise NotImplementedError("data option augmentation=%r: only None and 'affine' are implemented (the reference's 'warp' / brightness / "
+                                      "'normalization' augmentations are OpenCV code outside the hot-path scope)" % (self.augmentation,))
         self.max_strech = 0.4
         self.max_rot_rad = 45 / 180 * math.pi
         self._pages = {}

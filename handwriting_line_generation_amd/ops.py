@@ -402,10 +402,18 @@ def _defer_workspace(nbytes, device):
 DEFER_KEEP_ARENA = False     # passes on several streams in flight: a flush must not hand the arena's start to the next pass (reset after the join)
 
 
+_FLUSH_LAUNCHES = None     # the flush's `int* launches` out-parameter: a module-lifetime host array (never a temporary: a call list that
+                            # recorded the address of a temporary would write through a dangling pointer on every replay)
+
+
 def flush_deferred_reduce():
     """sum every queued set of partial images on the current stream (call after the side stream has been joined)"""
+    global _FLUSH_LAUNCHES
     import numpy as np
-    n = np.zeros(1, dtype=np.int32)
+    if _FLUSH_LAUNCHES is None:
+        _FLUSH_LAUNCHES = np.zeros(1, dtype=np.int32)
+    n = _FLUSH_LAUNCHES
+    n[0] = 0
     L.call("hwg_wgrad_defer_flush", _stream(), n.ctypes.data)
     _defer["launches"] += int(n[0]); _defer["flushes"] += 1
     _defer["count"] = 0
@@ -614,8 +622,8 @@ def repack_group(group):
 
 def _pad_channels(x, Cpad):
     N, H, W, C = x.shape
-    out = torch.zeros((N, H, W, Cpad), dtype=x.dtype, device=x.device)
-    L.call("hwg_copy_channels", x, C, 0, out, Cpad, 0, C, N * H * W, 1, 0, 0, _stream())
+    out = torch.empty((N, H, W, Cpad), dtype=x.dtype, device=x.device)
+    L.call("hwg_pad_channels", x, C, out, Cpad, N * H * W, _stream())      # copy + zero lanes in one launch (and visible to replay.py's call log)
     return out
 
 
@@ -680,6 +688,14 @@ _RUN_SCOPE = [None]     # scope of the conv op currently being executed (forward
 
 
 _conv_plans = {}    # geometry -> (descriptor, workspace bytes): descriptors are built (and the library's schedule queried) once per geometry
+
+
+def static_host_ptrs():
+    """addresses of the host-side descriptors that live as long as the plan caches (what a recorded call list may hold as literal host
+    pointers - replay.py rejects every other host address: a temporary's address would dangle on replay)"""
+    out = {int(p[2]) for p in _conv_plans.values()}
+    out.update(int(p[0].ptr) for p in _wgrad_plans.values())
+    return out
 
 
 def _run_conv(x, wp, bias, N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed, wino=False):
@@ -770,7 +786,7 @@ def _wino_s2_ok(N, H, W, C, K, R, S, stride, pad, dil, P, Q, transposed):
     F(3x3,2x2) on the space-to-depth image (csrc/conv_wino.hip, hwg_wino_s2_*) - the library's cost models decide per geometry"""
     if not (WINOGRAD and R == 4 and S == 4 and stride == (2, 2) and pad == (0, 0) and dil == (1, 1) and C % 16 == 0):
         return False
-    key = (N, H, W, C, K, "s2", transposed)
+    key = (N, H, W, C, K, "s2", transposed, P, Q)     # (P, Q: the data gradient of an odd-width input is not the F(3x3,2x2) geometry)
     hit = _wino_choice.get(key)
     if hit is None:
         d = _desc(N, H, W, C, K, 4, 4, (2, 2), (0, 0), (1, 1), P, Q, transposed)

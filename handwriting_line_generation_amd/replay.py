@@ -98,6 +98,7 @@ class _Recorder:
         self.dynamic = {}                   # data_ptr of a tensor handed out by a helper -> (table slot, )
         self.inputs = {}                    # storage address -> table slot (S_X / S_DY)
         self.pidx = {id(p): i for i, p in enumerate(params)}
+        self.host_static = ops.static_host_ptrs()
         self.main_stream = ops._stream()
         self.side_stream = ops._side_stream(device)[1]      # (created here if no pass has forked yet: the recording's backward variants may)
 
@@ -179,7 +180,13 @@ class _Recorder:
             elif isinstance(a, torch.Tensor):
                 kind, val, off = self._tensor(a, ph)
             else:
-                kind, val = 2, int(a)              # a host-side address with static lifetime (geometry descriptors of the plan caches), or 0
+                # a host-side address: only the geometry descriptors of the plan caches have static lifetime. Anything else (the address of a
+                # temporary numpy array handed to an out-parameter or a host table) would dangle on replay
+                kind, val = 2, int(a)
+                if val != 0 and val not in self.host_static:
+                    self.host_static = ops.static_host_ptrs()       # (plans made during this recording)
+                    if val not in self.host_static:
+                        raise _Reject("%s takes a host pointer that is not a cached descriptor" % name)
             ph.kinds.append(kind); ph.vals.append(val); ph.offs.append(off)
 
     def _tensor(self, t, ph):
@@ -382,8 +389,11 @@ def _record(net, fn, scope, x, needs_dx, params):
     flags = (ops.DEFER_REDUCE, ops.SIDE_WGRAD)
     scratches = []
 
-    def backward_under(fl, y, g, xc):
-        """one backward pass under the switches `fl` into a scratch gradient set of its own -> (input gradient, the network's span of the set, mask)"""
+    def backward_under(fl, y, g, xc, rec=None):
+        """one backward pass under the switches `fl` into a scratch gradient set of its own -> (input gradient, the network's span of the set, mask).
+        The join behind the pass (side-stream join + the flush of the queued partial-image sums) is NOT part of the program: `rec` stops logging
+        before it. A replayed pass queues its sums like an eager one and the owner's join_side_stream() flushes them (what `_table` / `_side_hold`
+        are written for); a flush baked into the call list would also carry the address of the flush's host-side out-parameter."""
         scratch = torch.empty(total, dtype=torch.float32, device=dev)      # (only the network's own span is written, zeroed and compared)
         scratch[lo:hi].zero_()
         scratches.append(scratch)
@@ -393,6 +403,8 @@ def _record(net, fn, scope, x, needs_dx, params):
         with ops.grad_set((scratch, mask)):
             if y.requires_grad:
                 torch.autograd.backward(y, g, retain_graph=True)
+            if rec is not None:
+                rec.phase = None
             ops.join_side_stream()
         return xc.grad, scratch[lo:hi], mask
 
@@ -417,7 +429,7 @@ def _record(net, fn, scope, x, needs_dx, params):
                 for fl in variants:
                     rec.phase = ("bwd", fl)
                     rec._ph()
-                    dxe, span, mask = backward_under(fl, y, g, xc)
+                    dxe, span, mask = backward_under(fl, y, g, xc, rec)
                     rec.phase = None
                     if needs_dx:
                         hit = rec.slots.get(dxe.untyped_storage().data_ptr()) if dxe is not None else None
@@ -429,6 +441,15 @@ def _record(net, fn, scope, x, needs_dx, params):
             y0 = y.detach().clone()
             restore_bn()
             # ---- the self-check: the same input through the programs ------------------------------------------------------------------
+            # The recording's tensors are released first (a literal pointer into a recorded intermediate must not find its old bytes) and the
+            # replay runs in arenas filled with NaN bit patterns: a lane the program never writes (a torch-side fill that was not recorded)
+            # then shows up in the comparison instead of hiding behind a zero weight.
+            del y, dxe, span
+            rec.hold.clear(); rec.slots.clear(); rec.dynamic.clear()
+            st_key = ops._stream()
+            prog.pools.setdefault(("f", st_key), []).append(torch.full((max(prog.fwd.bytes, 256),), 0xFF, dtype=torch.uint8, device=dev))
+            for fl in variants:
+                prog.pools.setdefault(("b%d%d" % fl, st_key), []).append(torch.full((max(prog.bwds[fl].bytes, 256),), 0xFF, dtype=torch.uint8, device=dev))
             xr = x.detach().clone().requires_grad_(bool(needs_dx))
             y1 = _ReplayNet.apply(xr, prog, *params)
             ok = (y0 == y1).all()

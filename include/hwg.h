@@ -280,6 +280,10 @@ int hwg_pad2d_bwd(const float* dy, float* dx, int N, int H, int W, int C, int pt
 /* dst[row][doff+c] (+)= src[bcast ? row/HW : row][soff+c], c < Cn */
 int hwg_copy_channels(const float* src, int Cs, int soff, float* dst, int Cd, int doff, int Cn, long long rows, int HW, int bcast,
                       int accumulate, void* stream);
+/* dst[row][c] = c < C ? src[row][c] : 0 for c < Cpad (Cpad % 4 == 0): the zero-padded channel copy the MFMA paths take when a contraction
+ * side is not a multiple of their channel step (model/cnn_only_hwr.py:92: the RIMES recogniser's 78 classes) - copy and fill in ONE launch
+ * (it was a torch-side zero fill plus hwg_copy_channels; the fill was invisible to a recorded call list) */
+int hwg_pad_channels(const float* src, int C, float* dst, int Cpad, long long rows, void* stream);
 /* out[n][c] (+)= sum_hw src[n*HW+hw][soff+c] */
 int hwg_reduce_rows(const float* src, int Cs, int soff, float* out, int Cn, int N, int HW, int accumulate, void* stream);
 /* label [L][B] int32 -> out[b][l][doff + cls] one-hot rows of width ncls inside rows of width Cd (HWWithStyle.onehot, hw_with_style.py:333-337) */

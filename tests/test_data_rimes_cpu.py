@@ -95,3 +95,22 @@ def test_rimes_items_and_bucketed_loader(rimes_dir):
     tl, vl = getDataLoader(config, "train")
     inst = next(iter(tl))
     assert inst["image"].shape[3] % 128 == 0 and inst["a_batch_size"] == 2 and vl is not None and len(vl) > 0
+
+
+@pytest.mark.parametrize("aug", ["warp", True, "normalization affine", "brightness"])
+def test_unimplemented_augmentations_are_refused_not_ignored(rimes_dir, tmp_path, aug):
+    """the reference warps / re-lights every line for ANY non-None `augmentation` that is not 'affine' (datasets/author_rimeslines_dataset.py:428-434,
+    author_hw_dataset.py:427-433; cf_RIMESLines_hwr_cnnOnly_batchnorm_aug.json says "warp"): OpenCV code outside this package's scope, so both
+    dataset classes refuse at construction instead of silently training un-augmented"""
+    from handwriting_line_generation_amd.data.author_hw_dataset import AuthorHWDataset
+    from handwriting_line_generation_amd.data.author_rimeslines_dataset import AuthorRIMESLinesDataset
+    cfg = {"img_height": 64, "a_batch_size": 2, "char_file": CHAR_FILE, "max_width": 1300, "augmentation": aug}
+    with pytest.raises(NotImplementedError, match="augmentation"):
+        AuthorRIMESLinesDataset(rimes_dir, "train", cfg)
+    root = str(tmp_path / "iam")
+    os.makedirs(root)
+    collate_items.fake_iam(root, with_images=False)
+    with pytest.raises(NotImplementedError, match="augmentation"):
+        AuthorHWDataset(root, "train", dict(cfg, data_set_name="AuthorHWDataset"))
+    AuthorRIMESLinesDataset(rimes_dir, "train", dict(cfg, augmentation="affine"))      # the implemented ones still construct
+    AuthorRIMESLinesDataset(rimes_dir, "train", dict(cfg, augmentation=None))

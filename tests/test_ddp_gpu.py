@@ -277,3 +277,32 @@ def test_single_rank_rccl_exchange_is_the_identity(cuda, tmp_path):
     assert forced["comm"]["collectives"] > 20 and forced["comm"]["bytes"] > 500e6 and plain["comm"]["collectives"] == 0
     for k, v in plain["params"].items():
         assert torch.equal(v, forced["params"][k]), "%s differs after a cycle with the one-rank RCCL exchange" % k
+
+
+def test_bench_rank_sharded_path_with_two_gloo_ranks(cuda, tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (one process per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment),
+    here with HWG_DIST_BACKEND=gloo so that both ranks can share the one GPU of the lease: the rank-sharded path (per-rank author shards,
+    gradient-set all-reduces, max-over-ranks timing, rank 0's JSON line) must run and report a 2-rank job. Keeps SURVEY 8(e)'s N > 1 bench
+    path from rotting while no multi-GPU node is available to the build."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HWG_DIST_BACKEND="gloo",
+                   HWG_BENCH_NO_MINNEC="1", HWG_BENCH_PROF_CYCLES="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "0", "--no-cpu-baseline", "--no-gen"],
+                                      cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    assert outs[1][0].strip() == "", "only rank 0 prints"
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 7 and line["warmup"] == 0 and line["scaling"] == "weak"
+    assert line["data_parallel"]["world_size"] == 2 and line["data_parallel"]["backend"] == "gloo"
+    assert line["data_parallel"]["collectives_per_step"] > 0 and line["data_parallel"]["allreduce_mbytes_per_step"] > 0
+    assert line["value"] > 0 and line["value"] == line["value"] and line["value"] != float("inf")
+    assert abs(line["value"] - 2 * 7 / (line["ms_per_step"] * 7e-3)) < 0.01 * line["value"]      # whole-job aggregate: N x K / max-over-ranks time
+    assert line["other_workloads"] is None

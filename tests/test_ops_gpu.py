@@ -467,6 +467,34 @@ def test_winograd_two_tap_kernel_for_4x4_stride2_layers(cuda, case):
                 wl.mul_(0.5); wr.mul_(0.5)
 
 
+@pytest.mark.parametrize("first", ["even", "odd"])
+def test_two_tap_layer_choice_is_keyed_by_the_input_width_parity(cuda, first):
+    """4x4 stride-2 layers meet inputs of BOTH width parities at the same (N, P, Q) (the style extractor on real lines, width_bucket 0): width
+    2Q+2 has the F(3x3,2x2) data-gradient geometry, width 2Q+3 does not (its last column meets no tap). The per-geometry engine choice must
+    not leak from one to the other, whichever comes first (the cache key lacked P, Q)."""
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(17)
+    N, C, K, H = 2, 32, 64, 14
+    w = torch.randn(K, C, 4, 4, generator=g) / (4 * C ** 0.5); b = torch.randn(K, generator=g)
+    widths = (44, 45) if first == "even" else (45, 44)         # same Q = 21 for both
+    with ops.tuning(HWG_WINO_S2="2"):
+        wl, bl = torch.nn.Parameter(w.to(cuda)), torch.nn.Parameter(b.to(cuda))
+        for W in widths + widths:
+            x = torch.randn(N, C, H, W, generator=g)
+            xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            yr = F.conv2d(xr, wr, br, stride=2)
+            assert yr.shape[3] == 21
+            gy = torch.randn(yr.shape, generator=g)
+            xl = nhwc(x).to(cuda).requires_grad_(True)
+            wl.grad = bl.grad = None
+            yl = ops.conv2d(xl, wl, bl, 2, 0)
+            _close(nchw(yl), yr, "width %d forward" % W, tol=2e-5)
+            yl.backward(nhwc(gy).to(cuda)); yr.backward(gy)
+            _close(nchw(xl.grad), xr.grad, "width %d dx" % W, tol=2e-5)
+            _close(wl.grad, wr.grad, "width %d dw" % W, tol=2e-5)
+            _close(bl.grad, br.grad, "width %d db" % W, tol=2e-5)
+
+
 # One full-size layer per network (the bench step's own geometries), every engine, against torch's CPU convolution in fp64: the kernels that
 # carry the headline number are compared with the oracle directly, not only with each other.
 FULL_SIZE_LAYERS = [("D convs1.0", (16, 58, 512, 64, 64, 0, 1)), ("HWR conv5", (8, 8, 129, 512, 512, 0, 0)), ("style down.2", (4, 32, 514, 128, 128, 0, 0))]

@@ -5,11 +5,13 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 line = [l for l in open(sys.argv[2]) if l.startswith('{"metric"')][-1]
 j = json.loads(line)
 extra = int(sys.argv[3]) if len(sys.argv) > 3 else (j.get("roofline") or {}).get("profiled_steps", 0)
-steps = j["steps"] + j["warmup"] + extra
+pre = int(j.get("recorder_warmup_steps") or 0)                       # (round 6: the recorder warm-up and the whole-cycle secondary run in the traced process too)
+whole = int((j.get("whole_cycles") or {}).get("steps") or 0)
+steps = j["steps"] + j["warmup"] + extra + pre + whole
 tot_calls = sum(int(r["Calls"]) for r in rows)
 tot_ns = sum(float(r["TotalDurationNs"]) for r in rows)
-print("# %d steps in the traced run (%d timed + %d warm-up + %d profiled): %.1f launches and %.2f ms of kernel time per step"
-      % (steps, j["steps"], j["warmup"], extra, tot_calls / steps, tot_ns / steps / 1e6))
+print("# %d steps in the traced run (%d timed + %d warm-up + %d recorder warm-up + %d whole-cycle secondary + %d profiled): %.1f launches and %.2f ms of kernel time per step"
+      % (steps, j["steps"], j["warmup"], pre, whole, extra, tot_calls / steps, tot_ns / steps / 1e6))
 print("# launches/step   avg us   us/step   kernel")
 for r in sorted(rows, key=lambda r: -int(r["Calls"])):
     c = int(r["Calls"]) / steps

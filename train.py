@@ -63,7 +63,16 @@ def main():
         config["trainer"]["iterations"] = args.iterations
     # dead-gradient elimination is the drop-in's default: losses, updates and every weight are bit-identical to the loop
     # that computes them (tests/test_trainer_gpu.py::test_skip_unused_grads_changes_no_weight_and_no_loss); a config key or the flag decide otherwise
-    config["trainer"].setdefault("skip_unused_grads", 0 if args.reference_gradients else 1)
+    if args.reference_gradients:
+        if int(config["trainer"].get("skip_unused_grads", 0) or 0):
+            print("train.py: --reference-gradients overrides trainer.skip_unused_grads=%r of the config" % config["trainer"]["skip_unused_grads"], flush=True)
+        config["trainer"]["skip_unused_grads"] = 0          # the explicit flag wins over the config key
+    else:
+        config["trainer"].setdefault("skip_unused_grads", 1)
+    if rank == 0:
+        print("train.py: skip_unused_grads = %d (%s)" % (int(config["trainer"]["skip_unused_grads"] or 0),
+              "dead-gradient elimination: the reference's never-read parameter gradients are not computed; weights and losses bit-identical"
+              if int(config["trainer"]["skip_unused_grads"] or 0) else "the reference's launches, including the gradients nothing reads"), flush=True)
     # the frozen recogniser's passes as recorded launch lists (replay.py; bit-identical, self-checked; HWG_REPLAY=0 turns it off)
     from handwriting_line_generation_amd import replay as _replay
     _replay.enable()
