@@ -228,6 +228,103 @@ __global__ __launch_bounds__(256) void mt_adam_kernel(MtArgs a, const float* ste
   }
 }
 
+// The whole gradient-consumption tail of a stepping lesson in ONE launch (trainer/hw_with_style_trainer.py:379-391: clip_grad_value_ over every
+// parameter with a gradient, the per-parameter NaN asserts, optimizer.step()): tensors with a gradient and NO parameter entry (touched, but
+// owned by the optimizer that does not step in this lesson) are clipped only; tensors with a parameter entry are clipped and stepped, and
+// `flag` is raised when a freshly written parameter value is not finite (a parameter can only become NaN / inf where it is written).
+// The clipped gradient is stored back only where clipping changed it (the reference clips in place; almost no element is ever outside +-2).
+__global__ __launch_bounds__(256) void mt_clip_adam_kernel(MtArgs a, const float* step_size, const float* bc2_sqrt, float beta1, float beta2, float eps,
+                                                           float clip, int* flag) {
+  const int t = a.chunk_tensor[blockIdx.x];
+  float* g = reinterpret_cast<float*>(a.pb[t]);
+  if (!g) return;
+  float* p = reinterpret_cast<float*>(a.pa[t]);
+  const long long off = a.chunk_off[blockIdx.x];
+  const long long end = min(off + (long long)a.chunk, a.numel[t]);
+  if (!p) {      // clip only
+    const bool al = (reinterpret_cast<uintptr_t>(g + off) & 15) == 0;
+    const long long n4 = al ? (end - off) >> 2 : 0;
+    float4* g4 = reinterpret_cast<float4*>(g + off);
+    for (long long j0 = threadIdx.x; j0 < n4; j0 += MT_U * 256) {
+      float4 vv[MT_U];
+#pragma unroll
+      for (int u = 0; u < MT_U; ++u) vv[u] = g4[j0 + u * 256 < n4 ? j0 + u * 256 : j0];
+#pragma unroll
+      for (int u = 0; u < MT_U; ++u) {
+        const long long j = j0 + u * 256;
+        if (j >= n4) break;
+        const float4 v = vv[u];
+        const float4 c = make_float4(fminf(fmaxf(v.x, -clip), clip), fminf(fmaxf(v.y, -clip), clip), fminf(fmaxf(v.z, -clip), clip), fminf(fmaxf(v.w, -clip), clip));
+        if (c.x != v.x || c.y != v.y || c.z != v.z || c.w != v.w) g4[j] = c;      // (NaN: fminf / fmaxf return the bound, as the standalone clip pass did)
+      }
+    }
+    for (long long i = off + 4 * n4 + threadIdx.x; i < end; i += 256) {
+      const float v = g[i], c = fminf(fmaxf(v, -clip), clip);
+      if (c != v) g[i] = c;
+    }
+    return;
+  }
+  float* m = reinterpret_cast<float*>(a.pc[t]);
+  float* v = reinterpret_cast<float*>(a.pd[t]);
+  if (!m || !v) return;
+  const float ss = step_size[t], b2 = bc2_sqrt[t];
+  const bool al = ((reinterpret_cast<uintptr_t>(p + off) | reinterpret_cast<uintptr_t>(g + off) | reinterpret_cast<uintptr_t>(m + off) |
+                    reinterpret_cast<uintptr_t>(v + off)) & 15) == 0;
+  const long long n4 = al ? (end - off) >> 2 : 0;
+  float4* p4 = reinterpret_cast<float4*>(p + off);
+  float4* g4 = reinterpret_cast<float4*>(g + off);
+  float4* m4 = reinterpret_cast<float4*>(m + off);
+  float4* v4 = reinterpret_cast<float4*>(v + off);
+  bool bad = false;
+  constexpr int AU = 2;
+  for (long long j0 = threadIdx.x; j0 < n4; j0 += AU * 256) {
+    float4 gq[AU], mq[AU], vq[AU], pq[AU];
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+      const long long ju = j0 + u * 256 < n4 ? j0 + u * 256 : j0;
+      gq[u] = g4[ju]; mq[u] = m4[ju]; vq[u] = v4[ju]; pq[u] = p4[ju];
+    }
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+      const long long j = j0 + u * 256;
+      if (j >= n4) break;
+      float* gp = reinterpret_cast<float*>(&gq[u]); float* mp = reinterpret_cast<float*>(&mq[u]);
+      float* vp = reinterpret_cast<float*>(&vq[u]); float* pp = reinterpret_cast<float*>(&pq[u]);
+      bool changed = false;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float gi = gp[e];
+        const float gc = fminf(fmaxf(gi, -clip), clip);
+        changed |= gc != gi;
+        gi = gc;
+        gp[e] = gi;
+        const float mi = mp[e] + (gi - mp[e]) * (1.f - beta1);
+        const float vi = vp[e] * beta2 + (1.f - beta2) * gi * gi;
+        mp[e] = mi; vp[e] = vi;
+        const float denom = sqrtf(vi) / b2 + eps;
+        pp[e] = pp[e] - ss * (mi / denom);
+        bad |= !isfinite(pp[e]);
+      }
+      if (changed) g4[j] = gq[u];
+      m4[j] = mq[u]; v4[j] = vq[u]; p4[j] = pq[u];
+    }
+  }
+  for (long long i = off + 4 * n4 + threadIdx.x; i < end; i += 256) {
+    float gi = g[i];
+    const float gc = fminf(fmaxf(gi, -clip), clip);
+    if (gc != gi) g[i] = gc;
+    gi = gc;
+    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / b2 + eps;
+    const float pn = p[i] - ss * (mi / denom);
+    p[i] = pn;
+    bad |= !isfinite(pn);
+  }
+  if (bad && flag) atomicOr(flag, 1);
+}
+
 // ---------------- Philox4x32-10 (philox.h) ----------------
 __device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t (&out)[4]) { hwg_philox4(seed, ctr, out); }
 __device__ __forceinline__ float u01(uint32_t x) { return hwg_u01(x); }
@@ -250,6 +347,27 @@ __global__ void dropmask_kernel(float* out, long long n, float p, uint64_t seed,
     philox4(seed, offset + (uint64_t)i, r);
     for (int e = 0; e < 4; ++e)
       if (i * 4 + e < n) out[i * 4 + e] = (u01(r[e]) >= p) ? keep : 0.f;
+  }
+}
+
+// several feature-dropout masks of one network pass in ONE launch: segment j = elements [start_j, start_j+1) of `out` (starts are multiples
+// of 4) with its own drop probability; element i takes uniform i % 4 of Philox counter offset + i / 4 - the values consecutive
+// hwg_dropmask calls (each advancing the stream by n_j / 4 counters) would have written
+constexpr int DROP_SEG_MAX = 16;
+struct DropSegs { int n; long long end[DROP_SEG_MAX]; float p[DROP_SEG_MAX]; };
+__global__ void dropmask_multi_kernel(float* out, long long n, DropSegs sg, uint64_t seed, uint64_t offset) {
+  const long long n4 = n / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    int j = 0;
+    while (j + 1 < sg.n && i * 4 >= sg.end[j]) ++j;
+    const float p = sg.p[j];
+    const float keep = 1.f / (1.f - p);
+    uint32_t r[4];
+    philox4(seed, offset + (uint64_t)i, r);
+    float4 v;
+    v.x = (u01(r[0]) >= p) ? keep : 0.f; v.y = (u01(r[1]) >= p) ? keep : 0.f;
+    v.z = (u01(r[2]) >= p) ? keep : 0.f; v.w = (u01(r[3]) >= p) ? keep : 0.f;
+    reinterpret_cast<float4*>(out)[i] = v;
   }
 }
 
@@ -309,6 +427,17 @@ extern "C" int hwg_mt_adam(const void* ptrs_p, const void* ptrs_g, const void* p
   MtArgs a = make_mt(ptrs_p, ptrs_g, ptrs_m, ptrs_v, numel, chunk_tensor, chunk_off, chunk);
   hipLaunchKernelGGL(mt_adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a, step_size, bc2_sqrt, beta1, beta2, eps, clip);
   HWG_LAUNCH_CHECK("mt_adam");
+  return HWG_OK;
+}
+
+extern "C" int hwg_mt_clip_adam(const void* ptrs_p, const void* ptrs_g, const void* ptrs_m, const void* ptrs_v, const float* step_size,
+                                const float* bc2_sqrt, float beta1, float beta2, float eps, float clip, int* flag, const void* numel,
+                                const void* chunk_tensor, const void* chunk_off, int nchunks, int chunk, void* stream) {
+  HWG_REQUIRE(ptrs_p && ptrs_g && ptrs_m && ptrs_v && step_size && bc2_sqrt && numel && chunk_tensor && chunk_off && nchunks > 0 && chunk > 0 && clip > 0.f,
+              "mt_clip_adam: bad arguments");
+  MtArgs a = make_mt(ptrs_p, ptrs_g, ptrs_m, ptrs_v, numel, chunk_tensor, chunk_off, chunk);
+  hipLaunchKernelGGL(mt_clip_adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a, step_size, bc2_sqrt, beta1, beta2, eps, clip, flag);
+  HWG_LAUNCH_CHECK("mt_clip_adam");
   return HWG_OK;
 }
 
@@ -386,6 +515,22 @@ extern "C" int hwg_randn(float* out, long long n, unsigned long long seed, unsig
   HWG_REQUIRE(out && n > 0, "randn: bad arguments");
   hipLaunchKernelGGL(randn_kernel, dim3(hwg_stream_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n, (uint64_t)seed, (uint64_t)offset);
   HWG_LAUNCH_CHECK("randn");
+  return HWG_OK;
+}
+extern "C" int hwg_dropmask_multi(float* out, int nseg, const long long* seg_elems, const float* seg_p, unsigned long long seed,
+                                  unsigned long long offset, void* stream) {
+  HWG_REQUIRE(out && seg_elems && seg_p && nseg > 0 && nseg <= DROP_SEG_MAX, "dropmask_multi: bad arguments (at most %d segments)", DROP_SEG_MAX);
+  DropSegs sg;
+  sg.n = nseg;
+  long long total = 0;
+  for (int j = 0; j < nseg; ++j) {
+    HWG_REQUIRE(seg_elems[j] > 0 && seg_elems[j] % 4 == 0 && seg_p[j] >= 0.f && seg_p[j] < 1.f, "dropmask_multi: segment %d: element count must be a positive multiple of 4, 0 <= p < 1", j);
+    total += seg_elems[j];
+    sg.end[j] = total; sg.p[j] = seg_p[j];
+  }
+  hipLaunchKernelGGL(dropmask_multi_kernel, dim3(hwg_stream_grid(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, total, sg, (uint64_t)seed,
+                     (uint64_t)offset);
+  HWG_LAUNCH_CHECK("dropmask_multi");
   return HWG_OK;
 }
 extern "C" int hwg_dropmask(float* out, long long n, float p, unsigned long long seed, unsigned long long offset, void* stream) {

@@ -62,8 +62,73 @@ __global__ void avgpool_bwd_kernel(const float* dy, float* dx, int N, int H, int
   }
 }
 
-// ---------------- max pooling (general kernel/stride/padding), argmax saved as h*W+w ----------------
+// ---------------- activation + average pooling in one pass (model/discriminator_ap.py:84-131: SN conv -> Dropout2d -> LeakyReLU -> AvgPool2d) ------------
+// y = avgpool(act(mask[n][c] * x)): the full-resolution activation is never written (one read of x and a quarter-size write instead of
+// read + write + read + quarter write); the backward pass recomputes the gate from x: dx = mask * act'(mask * x) * dy[pooled] / (kh kw).
+// Every element goes through the same rounded operations, in the same order, as hwg_bias_act_fwd followed by hwg_avgpool_fwd (and their
+// backward kernels): bit-identical (explicitly rounded multiplies, so that no product is contracted into the window sum).
+__device__ __forceinline__ float act_rn(float v, int act, float slope) {
+  if (act == 1) return v > 0.f ? v : 0.f;
+  if (act == 2) return v > 0.f ? v : __fmul_rn(v, slope);
+  return v;
+}
 template <int V>
+__global__ void act_avgpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ y, int N, int H, int W, int C,
+                                       int kh, int kw, int P, int Q, int act, float slope) {
+  const int CV = C / V;
+  const long long total = (long long)N * P * Q * CV;
+  const float inv = 1.f / (kh * kw);
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % CV) * V; unsigned t = i / CV;
+    const int q = (int)(t % Q); t /= Q;
+    const int p = (int)(t % P); const int n = (int)(t / P);
+    VecT<V> k;
+    for (int e = 0; e < V; ++e) k.v[e] = 1.f;
+    if (mask) k = vload<V>(mask + (size_t)n * C + c);
+    VecT<V> acc = vzero<V>();
+    for (int a = 0; a < kh; ++a)
+      for (int b = 0; b < kw; ++b) {
+        const VecT<V> v = vload<V>(x + (((long long)n * H + p * kh + a) * W + q * kw + b) * C + c);
+        for (int e = 0; e < V; ++e) acc.v[e] = __fadd_rn(acc.v[e], act_rn(mask ? __fmul_rn(v.v[e], k.v[e]) : v.v[e], act, slope));
+      }
+    for (int e = 0; e < V; ++e) acc.v[e] = __fmul_rn(acc.v[e], inv);
+    vstore<V>(y + (size_t)i * V, acc);
+  }
+}
+template <int V>
+__global__ void act_avgpool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ dx,
+                                       int N, int H, int W, int C, int kh, int kw, int P, int Q, int act, float slope) {
+  const int CV = C / V;
+  const long long total = (long long)N * H * W * CV;
+  const float inv = 1.f / (kh * kw);
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % CV) * V; unsigned t = i / CV;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H); const int n = (int)(t / H);
+    const int p = h / kh, q = w / kw;
+    VecT<V> r = vzero<V>();
+    if (p < P && q < Q) {
+      r = vload<V>(dy + (((long long)n * P + p) * Q + q) * C + c);
+      const VecT<V> v = vload<V>(x + (size_t)i * V);
+      VecT<V> k;
+      for (int e = 0; e < V; ++e) k.v[e] = 1.f;
+      if (mask) k = vload<V>(mask + (size_t)n * C + c);
+      for (int e = 0; e < V; ++e) {
+        const float z = mask ? __fmul_rn(v.v[e], k.v[e]) : v.v[e];       // the forward pass's pre-activation: same sign as its output
+        float g = __fmul_rn(r.v[e], inv);
+        if (act == 1) g = z > 0.f ? g : __fmul_rn(g, 0.f);
+        if (act == 2) g = z > 0.f ? g : __fmul_rn(g, slope);
+        r.v[e] = mask ? __fmul_rn(g, k.v[e]) : g;
+      }
+    }
+    vstore<V>(dx + (size_t)i * V, r);
+  }
+}
+
+// ---------------- max pooling (general kernel/stride/padding), argmax saved as h*W+w ----------------
+// RELU: y = relu(max) and, backward, dy gated by y > 0 (model/cnn_only_hwr.py:31-43: conv -> ReLU -> MaxPool2d; relu(max(w)) == max(relu(w))
+// exactly, and a window whose maximum is <= 0 passes no gradient in either order) - the ReLU passes over the pooled tensor ride along
+template <int V, bool RELU>
 __global__ void maxpool_fwd_kernel(const float* x, float* y, int* idx, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
                                    int ph, int pw, int P, int Q) {
   const int CV = C / V;
@@ -86,12 +151,14 @@ __global__ void maxpool_fwd_kernel(const float* x, float* y, int* idx, int N, in
           if (v.v[e] > best.v[e] || v.v[e] != v.v[e] || bi[e] < 0) { best.v[e] = v.v[e]; bi[e] = h * W + w; }
       }
     }
+    if (RELU)
+      for (int e = 0; e < V; ++e) best.v[e] = best.v[e] > 0.f ? best.v[e] : 0.f;     // (act_apply's ReLU, as hwg_bias_act_fwd applies it)
     vstore<V>(y + (size_t)i * V, best);
     for (int e = 0; e < V; ++e) idx[(size_t)i * V + e] = bi[e];
   }
 }
-template <int V>
-__global__ void maxpool_bwd_kernel(const float* dy, const int* idx, float* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
+template <int V, bool RELU>
+__global__ void maxpool_bwd_kernel(const float* dy, const float* y, const int* idx, float* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
                                    int ph, int pw, int P, int Q) {
   const int CV = C / V;
   const long long total = (long long)N * H * W * CV;
@@ -110,7 +177,7 @@ __global__ void maxpool_bwd_kernel(const float* dy, const int* idx, float* dx, i
       for (int q = qmin; q <= qmax; ++q) {
         const long long o = (((long long)n * P + p) * Q + q) * C + c;
         for (int e = 0; e < V; ++e)
-          if (idx[o + e] == me) acc.v[e] += dy[o + e];
+          if (idx[o + e] == me) acc.v[e] += RELU ? __fmul_rn(dy[o + e], y[o + e] > 0.f ? 1.f : 0.f) : dy[o + e];
       }
     vstore<V>(dx + (size_t)i * V, acc);
   }
@@ -326,6 +393,12 @@ __global__ void fused_up_weight_bwd_kernel(const float* dw4, float* dw3, long lo
     else hipLaunchKernelGGL(kern<1>, dim3(hwg_stream_grid((total_of_v), 256)), dim3(256), 0, st, __VA_ARGS__);           \
   } while (0)
 
+#define LAUNCH_V2(kern, flag, total_of_v, C, ...)                                                                  \
+  do {                                                                                                               \
+    HWG_REQUIRE((long long)(total_of_v) < (1ll << 31), "tensor too large for the 32-bit indices of the resampling kernels"); \
+    if ((C) % 4 == 0) hipLaunchKernelGGL((kern<4, flag>), dim3(hwg_stream_grid((total_of_v) / 4, 256)), dim3(256), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((kern<1, flag>), dim3(hwg_stream_grid((total_of_v), 256)), dim3(256), 0, st, __VA_ARGS__);           \
+  } while (0)
 
 // Data gradient of a single-input-channel convolution (first layers), second half: dx[n,ih,iw] = sum_{r,s} t[n, ih+ph-r*dh, iw+pw-s*dw, r*S+s]
 // where t = dy x W^T is the per-pixel tap matrix produced by a 1x1 convolution on the matrix cores (stride 1). Taps are summed in
@@ -369,21 +442,59 @@ extern "C" int hwg_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, 
   return HWG_OK;
 }
 
+extern "C" int hwg_act_avgpool_fwd(const float* x, const float* chan_mask, float* y, int N, int H, int W, int C, int kh, int kw, int act, float slope,
+                                   void* stream) {
+  HWG_REQUIRE(x && y && N > 0 && H >= kh && W >= kw && C > 0 && kh > 0 && kw > 0, "act_avgpool_fwd: bad arguments");
+  HWG_REQUIRE(act == 0 || act == HWG_ACT_RELU || act == HWG_ACT_LRELU, "act_avgpool_fwd: activation must be none / relu / leaky relu");
+  hipStream_t st = (hipStream_t)stream;
+  const int P = H / kh, Q = W / kw;
+  LAUNCH_V(act_avgpool_fwd_kernel, (long long)N * P * Q * C, C, x, chan_mask, y, N, H, W, C, kh, kw, P, Q, act, slope);
+  HWG_LAUNCH_CHECK("act_avgpool_fwd");
+  return HWG_OK;
+}
+extern "C" int hwg_act_avgpool_bwd(const float* dy, const float* x, const float* chan_mask, float* dx, int N, int H, int W, int C, int kh, int kw,
+                                   int act, float slope, void* stream) {
+  HWG_REQUIRE(dy && x && dx && N > 0 && H >= kh && W >= kw && C > 0 && kh > 0 && kw > 0, "act_avgpool_bwd: bad arguments");
+  HWG_REQUIRE(act == 0 || act == HWG_ACT_RELU || act == HWG_ACT_LRELU, "act_avgpool_bwd: activation must be none / relu / leaky relu");
+  hipStream_t st = (hipStream_t)stream;
+  const int P = H / kh, Q = W / kw;
+  LAUNCH_V(act_avgpool_bwd_kernel, (long long)N * H * W * C, C, dy, x, chan_mask, dx, N, H, W, C, kh, kw, P, Q, act, slope);
+  HWG_LAUNCH_CHECK("act_avgpool_bwd");
+  return HWG_OK;
+}
+
 extern "C" int hwg_maxpool_fwd(const float* x, float* y, int* idx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                                int P, int Q, void* stream) {
   HWG_REQUIRE(x && y && idx && N > 0 && C > 0 && P > 0 && Q > 0, "maxpool_fwd: bad arguments");
   HWG_REQUIRE(P == (H + 2 * ph - kh) / sh + 1 && Q == (W + 2 * pw - kw) / sw + 1, "maxpool_fwd: inconsistent output size");
   hipStream_t st = (hipStream_t)stream;
-  LAUNCH_V(maxpool_fwd_kernel, (long long)N * P * Q * C, C, x, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q);
+  LAUNCH_V2(maxpool_fwd_kernel, false, (long long)N * P * Q * C, C, x, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q);
   HWG_LAUNCH_CHECK("maxpool_fwd");
+  return HWG_OK;
+}
+extern "C" int hwg_maxpool_relu_fwd(const float* x, float* y, int* idx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+                                    int P, int Q, void* stream) {
+  HWG_REQUIRE(x && y && idx && N > 0 && C > 0 && P > 0 && Q > 0, "maxpool_relu_fwd: bad arguments");
+  HWG_REQUIRE(P == (H + 2 * ph - kh) / sh + 1 && Q == (W + 2 * pw - kw) / sw + 1, "maxpool_relu_fwd: inconsistent output size");
+  hipStream_t st = (hipStream_t)stream;
+  LAUNCH_V2(maxpool_fwd_kernel, true, (long long)N * P * Q * C, C, x, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q);
+  HWG_LAUNCH_CHECK("maxpool_relu_fwd");
   return HWG_OK;
 }
 extern "C" int hwg_maxpool_bwd(const float* dy, const int* idx, float* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph,
                                int pw, int P, int Q, void* stream) {
   HWG_REQUIRE(dy && dx && idx && N > 0 && C > 0 && P > 0 && Q > 0, "maxpool_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  LAUNCH_V(maxpool_bwd_kernel, (long long)N * H * W * C, C, dy, idx, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q);
+  LAUNCH_V2(maxpool_bwd_kernel, false, (long long)N * H * W * C, C, dy, (const float*)nullptr, idx, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q);
   HWG_LAUNCH_CHECK("maxpool_bwd");
+  return HWG_OK;
+}
+extern "C" int hwg_maxpool_relu_bwd(const float* dy, const float* y, const int* idx, float* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
+                                    int ph, int pw, int P, int Q, void* stream) {
+  HWG_REQUIRE(dy && y && dx && idx && N > 0 && C > 0 && P > 0 && Q > 0, "maxpool_relu_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  LAUNCH_V2(maxpool_bwd_kernel, true, (long long)N * H * W * C, C, dy, y, idx, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q);
+  HWG_LAUNCH_CHECK("maxpool_relu_bwd");
   return HWG_OK;
 }
 

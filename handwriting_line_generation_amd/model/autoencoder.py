@@ -37,21 +37,25 @@ class Encoder2(nn.Module):
     def _forward(self, x):
         """x NCHW [N,1,64,W] -> (code [N,out,1,W/8-4], mid [N,64,16,W/4]) both NCHW like the reference"""
         d1, c1, d2, c2, d3 = self.down_conv1, self.conv1, self.down_conv2, self.conv2, self.down_conv3
+        # the four Dropout2d masks of this pass from one Philox launch
+        B = x.shape[0]
+        specs = [m.spec(B, c) for m, c in ((c1[3], 32), (c2[1], 64), (c2[5], 64), (d3[5], 128))]
+        mb = rng.MaskBlock([sp for sp in specs if sp is not None], x.device)
         h = ops.to_nhwc(x)
         h = d1[1](d1[0](h), "relu")
         h = d1[4](ops.avg_pool2d(h, 2))
         r = ops.relu(h)
-        h = c1[2](c1[1](r), "relu", 0.0, c1[3].mask_for_shape(r.shape[0], 32, r.device))
+        h = c1[2](c1[1](r), "relu", 0.0, c1[3].mask_for_shape(r.shape[0], 32, r.device, mb))
         h = ops.add(c1[5](h), r)
         h = d2[0](h, "relu")
         h = d2[3](ops.avg_pool2d(h, 2))
         res = h
-        h = c2[0](h, "relu", 0.0, c2[1].mask_for_shape(h.shape[0], 64, h.device))
-        h = c2[4](c2[3](h), "relu", 0.0, c2[5].mask_for_shape(h.shape[0], 64, h.device))
+        h = c2[0](h, "relu", 0.0, c2[1].mask_for_shape(h.shape[0], 64, h.device, mb))
+        h = c2[4](c2[3](h), "relu", 0.0, c2[5].mask_for_shape(h.shape[0], 64, h.device, mb))
         mid = ops.add(c2[7](h), res)
         h = d3[0](mid, "relu")
         h = d3[3](ops.avg_pool2d(h, 2))
-        h = d3[4](h, "relu", 0.0, d3[5].mask_for_shape(h.shape[0], 128, h.device))
+        h = d3[4](h, "relu", 0.0, d3[5].mask_for_shape(h.shape[0], 128, h.device, mb))
         code = d3[7](h)
         return ops.to_nchw(code), ops.to_nchw(mid)
 

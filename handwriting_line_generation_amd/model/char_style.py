@@ -163,8 +163,8 @@ class CharStyleEncoder(nn.Module):
         # arg-max map and builds the window lists
         xr = ops.cat_channels([ops.relu(feat), recog], (B, 1, Wf))
         p = self.prep
-        xr = ops.bias_act(ops.conv1d(xr, p[0].weight, p[0].bias, 1, 2, 1), None, None, ops.ACT_RELU)
-        xr = ops.max_pool2d(xr, (1, 2), (1, 2))
+        # (ReLU after the pool, riding along in the pooling kernels: relu(max(w)) == max(relu(w)) exactly, forward and backward)
+        xr = ops.max_pool2d(ops.conv1d(xr, p[0].weight, p[0].bias, 1, 2, 1), (1, 2), (1, 2), relu=True)
         xr = p[4](p[3](xr), "relu")
         xr = ops.bias_act(ops.conv1d(xr, p[6].weight, p[6].bias, 1, 1, 1), None, None, ops.ACT_RELU)
         xr = ops.avg_pool2d(xr, (1, xr.shape[2])).reshape(B, -1)

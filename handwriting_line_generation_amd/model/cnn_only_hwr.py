@@ -65,7 +65,7 @@ class CNNOnlyHWR(nn.Module):
             # ReLU after the pool instead of before it: max and ReLU are both monotone, relu(max(w)) == max(relu(w)) exactly, and the two
             # orders route the gradient to the same window element wherever it is not zero anyway (a window whose maximum is <= 0 passes
             # nothing back in either order) - same bits forward and backward, with the ReLU passes over a half / quarter of the pixels
-            h = ops.max_pool2d(h, *pool)
+            return ops.max_pool2d(h, *pool, relu=True)          # (the ReLU rides along in the pooling kernels: hwg_maxpool_relu_*)
         return ops.bias_act(h, None, None, ops.ACT_RELU)
 
     logit_offset = None

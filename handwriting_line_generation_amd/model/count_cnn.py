@@ -7,7 +7,7 @@ and ReLU that surround it.
 import torch
 from torch import nn
 
-from .. import ops
+from .. import ops, rng
 from .layers import Conv1d, Dropout2d, GroupNorm, Marker, group_count
 
 
@@ -40,8 +40,10 @@ class CountCNN(nn.Module):
         B, _, Lr, _ = input.shape
         c = self.cnn
         x = ops.cat_channels([input, style.contiguous()], (B, 1, Lr))
-        x = c[1](c[0](x), "relu", 0.0, c[2].mask_for_shape(B, c[1].num_channels, x.device))
-        x = c[5](c[4](x), "relu", 0.0, c[6].mask_for_shape(B, c[5].num_channels, x.device))
+        specs = [m.spec(B, n.num_channels) for m, n in ((c[2], c[1]), (c[6], c[5]))]
+        mb = rng.MaskBlock([sp for sp in specs if sp is not None], x.device)        # both Dropout2d masks from one Philox launch
+        x = c[1](c[0](x), "relu", 0.0, c[2].mask_for_shape(B, c[1].num_channels, x.device, mb))
+        x = c[5](c[4](x), "relu", 0.0, c[6].mask_for_shape(B, c[5].num_channels, x.device, mb))
         x = c[9](c[8](x), "relu")
         x = c[11](x)                                   # [B,1,L,n_out]
         y = ops.channel_affine(x, self.std.view(-1), self.mean.view(-1))

@@ -7,7 +7,7 @@ and run one power iteration on every forward, train or eval, mutating u and v (d
 import torch
 from torch import nn
 
-from .. import ops
+from .. import ops, rng
 from .layers import Conv2d, Dropout2d, GroupNorm, Marker, group_count
 
 
@@ -42,6 +42,8 @@ class SpectralConv2d(nn.Module):
 
 
 class DiscriminatorAP(nn.Module):
+    _masks = None
+
     def __init__(self, dim=64, use_low=False, use_med=True, small=False):
         super().__init__()
         if small:
@@ -66,19 +68,20 @@ class DiscriminatorAP(nn.Module):
                 SpectralConv2d(4 * dim, 4 * dim, (1, 3), (0, 1)), Dropout2d(0.025), Marker("lrelu"),
                 SpectralConv2d(4 * dim, 1, 1, (0, 0)))
 
-    def _sn_act(self, conv, x, drop=None):
-        """SN conv (+bias in its epilogue, so the bias gradient comes out of the weight-gradient kernel) -> Dropout2d mask, LeakyReLU"""
+    def _sn_act(self, conv, x, drop=None, pool=None):
+        """SN conv (+bias in its epilogue, so the bias gradient comes out of the weight-gradient kernel) -> Dropout2d mask, LeakyReLU
+        (-> AvgPool2d `pool`, fused into the activation pass: the full-resolution activation is never written)"""
         h = conv(x, with_bias=True)
-        mask = drop.mask_for(h) if drop is not None else None
+        mask = drop.mask_for(h, self._masks) if drop is not None else None
+        if pool is not None:
+            return ops.act_avg_pool2d(h, pool, mask, ops.ACT_LRELU, self.leak)
         return ops.bias_act(h, None, mask, ops.ACT_LRELU, self.leak)
 
     def _low_head(self, mL):
         c = self.convs4
-        h = self._sn_act(c[0], mL, c[1])
-        h = ops.avg_pool2d(h, (1, 2))
+        h = self._sn_act(c[0], mL, c[1], pool=(1, 2))
         h = self._sn_act(c[4], h, c[5])
-        h = self._sn_act(c[7], h, c[8])
-        h = ops.avg_pool2d(h, (1, 2))
+        h = self._sn_act(c[7], h, c[8], pool=(1, 2))
         h = self._sn_act(c[11], h, c[12])
         return c[14](h)
 
@@ -107,14 +110,19 @@ class DiscriminatorAP(nn.Module):
         if x.is_cuda:
             self._power_iterations(return_features)
         batch = x.shape[0]
+        # the Dropout2d masks of this pass (two in the trunk, four in the low head) from one Philox launch
+        dim = self.in_conv[0].out_channels
+        drops = [(self.convs1[4], 2 * dim), (self.convs3[5], 4 * dim)]
+        if self.use_low or return_features:
+            drops += [(self.convs4[1], 2 * dim), (self.convs4[5], 4 * dim), (self.convs4[8], 4 * dim), (self.convs4[12], 4 * dim)]
+        specs = [d.spec(batch, c) for d, c in drops]
+        self._masks = rng.MaskBlock([sp for sp in specs if sp is not None], x.device)
         h = ops.to_nhwc(x)
         h = self.in_conv[0](h)
         h = self.in_conv[1](h, "lrelu", self.leak)
-        h = self._sn_act(self.convs1[0], h)
-        h = ops.avg_pool2d(h, 2)
+        h = self._sn_act(self.convs1[0], h, pool=2)
         h = self._sn_act(self.convs1[3], h, self.convs1[4])
-        h = self._sn_act(self.convs2[0], h)
-        h = ops.avg_pool2d(h, 2)
+        h = self._sn_act(self.convs2[0], h, pool=2)
         h = self.convs3[0](h)
         h = self.convs3[1](h, "lrelu", self.leak)
         h = ops.avg_pool2d(h, 2)

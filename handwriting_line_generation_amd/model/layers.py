@@ -87,13 +87,20 @@ class Dropout2d(nn.Module):
         super().__init__()
         self.p = p
 
-    def mask_for(self, x):
-        return self.mask_for_shape(x.shape[0], x.shape[-1], x.device)
+    def mask_for(self, x, block=None):
+        return self.mask_for_shape(x.shape[0], x.shape[-1], x.device, block)
 
-    def mask_for_shape(self, N, C, device):
+    def mask_for_shape(self, N, C, device, block=None):
+        """block: the pass's rng.MaskBlock (all Dropout2d masks of a network pass from one launch) or None (a draw of its own)"""
         if not self.training or self.p == 0:
             return None
+        if block is not None:
+            return block.next(N, C, self.p)
         return rng.channel_mask(N, C, self.p, device)
+
+    def spec(self, N, C):
+        """this layer's entry in a rng.MaskBlock plan, or None when it draws nothing (eval mode)"""
+        return (N, C, self.p) if (self.training and self.p != 0) else None
 
     def forward(self, x):
         m = self.mask_for(x)

@@ -1517,9 +1517,38 @@ def avg_pool2d(x, kernel):
     return _AvgPool.apply(x, kh, kw)
 
 
+class _ActAvgPool(Function):
+    """avg_pool2d(act(mask * x)) as one kernel per direction (hwg_act_avgpool_*): bit-identical to bias_act + avg_pool2d, without writing and
+    re-reading the full-resolution activation (forward) and its gradient (backward); the gate is recomputed from x"""
+
+    @staticmethod
+    def forward(ctx, x, mask, act, slope, kh, kw):
+        _chk(x, "act_avgpool input"); _chk(mask, "channel mask")
+        N, H, W, C = x.shape
+        y = torch.empty((N, H // kh, W // kw, C), dtype=torch.float32, device=x.device)
+        L.call("hwg_act_avgpool_fwd", x, mask, y, N, H, W, C, kh, kw, act, slope, _stream())
+        ctx.save_for_backward(x, mask)
+        ctx.cfg = (N, H, W, C, kh, kw, act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mask = ctx.saved_tensors
+        N, H, W, C, kh, kw, act, slope = ctx.cfg
+        dx = torch.empty_like(x)
+        L.call("hwg_act_avgpool_bwd", dy.contiguous(), x, mask, dx, N, H, W, C, kh, kw, act, slope, _stream())
+        return dx, None, None, None, None, None
+
+
+def act_avg_pool2d(x, kernel, mask=None, act=ACT_NONE, slope=0.0):
+    """avg_pool2d(bias_act(x, None, mask, act, slope), kernel) in one pass"""
+    kh, kw = _pair(kernel)
+    return _ActAvgPool.apply(x, mask, act, slope, kh, kw)
+
+
 class _MaxPool(Function):
     @staticmethod
-    def forward(ctx, x, kernel, stride, padding):
+    def forward(ctx, x, kernel, stride, padding, relu):
         _chk(x, "maxpool input")
         N, H, W, C = x.shape
         kh, kw = kernel; sh, sw = stride; ph, pw = padding
@@ -1527,24 +1556,32 @@ class _MaxPool(Function):
         Q = (W + 2 * pw - kw) // sw + 1
         y = torch.empty((N, P, Q, C), dtype=torch.float32, device=x.device)
         idx = torch.empty((N, P, Q, C), dtype=torch.int32, device=x.device)
-        L.call("hwg_maxpool_fwd", x, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q, _stream())
-        ctx.save_for_backward(idx)
-        ctx.cfg = (N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q)
+        L.call("hwg_maxpool_relu_fwd" if relu else "hwg_maxpool_fwd", x, y, idx, N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q, _stream())
+        if relu:
+            ctx.save_for_backward(idx, y)
+        else:
+            ctx.save_for_backward(idx)
+        ctx.cfg = (N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q, relu)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (idx,) = ctx.saved_tensors
-        N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q = ctx.cfg
+        N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q, relu = ctx.cfg
         dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
-        L.call("hwg_maxpool_bwd", dy.contiguous(), idx, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q, _stream())
-        return dx, None, None, None
+        if relu:
+            idx, y = ctx.saved_tensors
+            L.call("hwg_maxpool_relu_bwd", dy.contiguous(), y, idx, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q, _stream())
+        else:
+            (idx,) = ctx.saved_tensors
+            L.call("hwg_maxpool_bwd", dy.contiguous(), idx, dx, N, H, W, C, kh, kw, sh, sw, ph, pw, P, Q, _stream())
+        return dx, None, None, None, None
 
 
-def max_pool2d(x, kernel, stride=None, padding=0):
+def max_pool2d(x, kernel, stride=None, padding=0, relu=False):
+    """relu=True: relu(max_pool2d(x)) (== max_pool2d(relu(x)) exactly) with the ReLU riding along in the pooling kernels, both directions"""
     kernel = _pair(kernel)
     stride = kernel if stride is None else _pair(stride)
-    return _MaxPool.apply(x, kernel, stride, _pair(padding))
+    return _MaxPool.apply(x, kernel, stride, _pair(padding), bool(relu))
 
 
 class _Upsample(Function):
@@ -2158,6 +2195,21 @@ class DeviceRNG:
         L.call("hwg_dropmask", out, n, float(p), self.seed, self.offset, _stream())
         self.offset += (n + 3) // 4
         return out
+
+
+    def dropmask_multi(self, counts, ps, device):
+        """the feature-dropout masks of one network pass from ONE launch: counts[j] elements (multiples of 4) with drop probability ps[j], back
+        to back in one buffer -> list of flat views; the values (and the stream position afterwards) are those of consecutive dropmask calls"""
+        import numpy as np
+        total = int(sum(counts))
+        out = torch.empty((total,), dtype=torch.float32, device=device)
+        ne = np.asarray(counts, dtype=np.int64); pp = np.asarray(ps, dtype=np.float32)
+        L.call("hwg_dropmask_multi", out, len(counts), ne.ctypes.data, pp.ctypes.data, self.seed, self.offset, _stream())
+        self.offset += total // 4
+        views, off = [], 0
+        for n in counts:
+            views.append(out[off: off + n]); off += n
+        return views
 
 
 # ----------------------------------------------------------------------------------------------

@@ -123,6 +123,25 @@ def channel_mask(N, C, p, device):
     return _dev_rng().dropmask((N, C), p, device)
 
 
+class MaskBlock:
+    """the Dropout2d masks of one network pass. Device mode: ONE Philox launch for all of them when the first is asked for (they were one
+    3 us launch each, up to six per discriminator pass), later requests are views; the values and the stream position afterwards are those
+    of the single draws. Host mode (parity tests), or a request off the plan: single draws, in the reference's order."""
+
+    def __init__(self, specs, device):
+        self.specs, self.device, self.views, self.k = [(int(n), int(c), float(p)) for n, c, p in specs], device, None, 0
+
+    def next(self, N, C, p):
+        if _state["mode"] == "host" or self.k >= len(self.specs) or self.specs[self.k] != (int(N), int(C), float(p)) or any((n * c) % 4 for n, c, _ in self.specs):
+            self.k = len(self.specs)
+            return channel_mask(N, C, p, self.device)
+        if self.views is None:
+            self.views = _dev_rng().dropmask_multi([n * c for n, c, _ in self.specs], [q for _, _, q in self.specs], self.device)
+        out = self.views[self.k].view(N, C)
+        self.k += 1
+        return out
+
+
 def randn_host_shaped(shape, device):
     if _state["mode"] == "host":
         return torch.randn(*shape).to(device)

@@ -79,6 +79,8 @@ class FlatParams:
         self._param_ptrs = np.array([self.params[i].data_ptr() for i in order], dtype=np.int64)
         self.d_param_ptrs = torch.from_numpy(self._param_ptrs).to(self.device)
         self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._scanned = False
+        self._zero_all = bool(int(os.environ.get("HWG_ZERO_ALL", "0") or 0))     # 1: zero_grad fills the whole group slice (the pre-round-6 behaviour; A/B, debugging)
         self._stash_pool = []
         # segments: maximal runs of flat positions that belong to one sub-network (or, without names, one optimizer group)
         label = [(names[pi].split(".")[0] if names is not None else None) for pi in order]
@@ -136,8 +138,18 @@ class FlatParams:
     # -- the reference's gradient bookkeeping, vectorised ------------------------------------------------
     def zero_grad(self, group):
         """optimizer.zero_grad() of torch >= 2.0 (set_to_none): gradients of that optimizer's parameters become None"""
-        self.group_slice(self.flat_grad, group).zero_()
         a, b = self.group_range[group]
+        tm = np.zeros(self.nt, dtype=bool)
+        tm[a:b] = self.touched[a:b]
+        if self.flat_grad.is_cuda and not self._zero_all:
+            # only the tensors that HAVE a gradient hold anything but zeros (the buffer starts zeroed, a stash moves-and-zeroes, untouched
+            # tensors are never written): one masked multi-tensor pass over those instead of a 143 MB fill per iteration - and nothing at
+            # all in the lessons that come right after a stash or that never touched this group
+            if tm.any():
+                L.call("hwg_mt_unary", self.masked_ptrs(self.flat_grad, tm), None, 0, 0.0, None, self.d_numel, self.d_chunk_tensor, self.d_chunk_off,
+                       self.nchunks, CHUNK, self._st())
+        else:
+            self.group_slice(self.flat_grad, group).zero_()
         self.touched[a:b] = False
 
     def stash(self):
@@ -208,8 +220,10 @@ class FlatParams:
                self.d_chunk_off, self.nchunks, CHUNK, self._st())
 
     def params_nonfinite_flag(self):
-        """device flag (int32[1]) set when any parameter holds NaN/inf - the reference asserts per tensor with a host sync each"""
-        self._flag.zero_()
+        """device flag (int32[1]) set when any parameter holds NaN/inf - the reference asserts per tensor with a host sync each. STICKY: never
+        cleared (training aborts on the first non-zero read). The full scan runs once per FlatParams (weights as loaded); afterwards
+        HipAdam.step(clip=...) raises the flag where it writes a non-finite parameter value - the only way one can appear."""
+        self._scanned = True
         L.call("hwg_mt_unary", self.d_param_ptrs, None, 2, 0.0, self._flag, self.d_numel, self.d_chunk_tensor, self.d_chunk_off, self.nchunks, CHUNK,
                self._st())
         return self._flag
@@ -415,10 +429,14 @@ class HipAdam:
     def zero_grad(self):
         self.flat.zero_grad(self.group)
 
-    def step(self):
+    def step(self, clip=None):
+        """clip = None: optimizer.step() on the gradients as they are. clip = v: the trainer's whole gradient-consumption tail in ONE launch
+        (hwg_mt_clip_adam): clip_grad_value_(v) over EVERY touched tensor (also those of the optimizer that does not step now), this
+        optimizer's Adam update, and the non-finite check of the parameters it writes (FlatParams._flag, sticky) - it replaces a clip pass
+        over the gradients, a scan over all 47 M parameters and the Adam launch (and their uploads) per stepping lesson."""
         f = self.flat
         active = self.mask & f.touched
-        if not active.any():
+        if not active.any() and clip is None:
             return
         ops.join_side_stream()
         self.steps[active] += 1
@@ -427,15 +445,26 @@ class HipAdam:
         t = np.maximum(self.steps, 1).astype(np.float64)
         step_size = (lr / (1.0 - b1 ** t)).astype(np.float32)
         bc2 = np.sqrt(1.0 - b2 ** t).astype(np.float32)
-        d_ss = ops.h2d(step_size, f.device)
-        d_bc = ops.h2d(bc2, f.device)
         am = active.astype(np.int64)
-        tab = np.stack([f._param_ptrs * am, f.base_ptrs(f.flat_grad) * am, f.base_ptrs(self.exp_avg) * am, f.base_ptrs(self.exp_avg_sq) * am])
-        d_tab = ops.h2d(tab, f.device)
-        L.call("hwg_mt_adam", d_tab[0], d_tab[1], d_tab[2], d_tab[3], d_ss, d_bc, float(b1), float(b2), float(self.eps), 0.0, f.d_numel,
-               f.d_chunk_tensor, f.d_chunk_off, f.nchunks, CHUNK, f._st())
-        ops.bump_weight_epoch((id(f), self.group))   # parameters changed behind torch's version counters
-        ops.repack_group((id(f), self.group))        # ... and their cached packed images are refreshed in one launch
+        gm = am if clip is None else f.touched.astype(np.int64)
+        nt = f.nt
+        # ONE upload: the four pointer rows (int64) followed by the two per-tensor scalars (float32)
+        host = np.empty(4 * nt * 8 + 2 * nt * 4, dtype=np.uint8)
+        host[:4 * nt * 8].view(np.int64).reshape(4, nt)[:] = np.stack([f._param_ptrs * am, f.base_ptrs(f.flat_grad) * gm, f.base_ptrs(self.exp_avg) * am,
+                                                                      f.base_ptrs(self.exp_avg_sq) * am])
+        host[4 * nt * 8:].view(np.float32).reshape(2, nt)[:] = np.stack([step_size, bc2])
+        dev = ops.h2d(host, f.device)
+        d_tab = dev[:4 * nt * 8].view(torch.int64).view(4, nt)
+        d_sc = dev[4 * nt * 8:].view(torch.float32).view(2, nt)
+        if clip is None:
+            L.call("hwg_mt_adam", d_tab[0], d_tab[1], d_tab[2], d_tab[3], d_sc[0], d_sc[1], float(b1), float(b2), float(self.eps), 0.0, f.d_numel,
+                   f.d_chunk_tensor, f.d_chunk_off, f.nchunks, CHUNK, f._st())
+        else:
+            L.call("hwg_mt_clip_adam", d_tab[0], d_tab[1], d_tab[2], d_tab[3], d_sc[0], d_sc[1], float(b1), float(b2), float(self.eps), float(clip),
+                   f._flag, f.d_numel, f.d_chunk_tensor, f.d_chunk_off, f.nchunks, CHUNK, f._st())
+        if active.any():
+            ops.bump_weight_epoch((id(f), self.group))   # parameters changed behind torch's version counters
+            ops.repack_group((id(f), self.group))        # ... and their cached packed images are refreshed in one launch
 
     # checkpoint format of torch.optim.Adam (state keyed by parameter index within the group)
     def state_dict(self):

@@ -125,6 +125,8 @@ class HWWithStyleTrainer(BaseTrainer):
         self._pending_log = collections.deque()
         self.pre_clip_hook = None
         self._defer_reduce = bool(int(tr.get("defer_wgrad_reduce", os.environ.get("HWG_DEFER_REDUCE", "1")) or 0))
+        # clip + NaN check + Adam of a stepping lesson as ONE launch (HipAdam.step(clip)); 0 = the three separate passes (A/B timing, tests)
+        self._fused_step = bool(int(tr.get("fused_step", os.environ.get("HWG_FUSED_STEP", "1")) or 0)) and hasattr(self.optimizer, "flat")
         # launch-list replay of the frozen recogniser (replay.py): the switches its backward passes run under
         from .. import replay as _replay
         _replay.BACKWARD_FLAGS = {(self._defer_reduce, False), (self._defer_reduce, True)}
@@ -408,12 +410,20 @@ class HWWithStyleTrainer(BaseTrainer):
         if self.curriculum and "no-step" not in lesson:
             if self.pre_clip_hook is not None:    # parity tests read the balanced gradients here, where the reference clips them (:381)
                 self.pre_clip_hook(iteration)
-            f.clip_(2)
-            flag = f.params_nonfinite_flag()
-            if "disc" in lesson or "auto-disc" in lesson:
-                self.optimizer_discriminator.step()
+            # clip to +-2, NaN check and the Adam update in ONE launch (HipAdam.step(clip): every touched gradient is clipped, the stepping
+            # optimizer's tensors are updated, the sticky flag is raised where a written parameter is not finite); the parameters as
+            # loaded are scanned once, at this trainer's first stepping lesson
+            if self._fused_step:
+                flag = f._flag if getattr(f, "_scanned", False) else f.params_nonfinite_flag()
+                opt = self.optimizer_discriminator if ("disc" in lesson or "auto-disc" in lesson) else self.optimizer
+                opt.step(clip=2)
             else:
-                self.optimizer.step()
+                f.clip_(2)
+                flag = f.params_nonfinite_flag()
+                if "disc" in lesson or "auto-disc" in lesson:
+                    self.optimizer_discriminator.step()
+                else:
+                    self.optimizer.step()
         elif not self.curriculum:
             if self.pre_clip_hook is not None:
                 self.pre_clip_hook(iteration)

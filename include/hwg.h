@@ -267,10 +267,23 @@ int hwg_bias_act_bwd(const float* dy, const float* y, const float* chan_mask, fl
  * ------------------------------------------------------------------------------------------ */
 int hwg_avgpool_fwd(const float* x, float* y, int N, int H, int W, int C, int kh, int kw, void* stream);
 int hwg_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, int C, int kh, int kw, void* stream);
+/* y = avgpool(act(chan_mask[n][c] * x)) in one pass, and its backward (gate recomputed from x): model/discriminator_ap.py:84-131, the
+ * SN conv -> Dropout2d -> LeakyReLU -> AvgPool2d runs of the discriminator; bit-identical to hwg_bias_act_fwd + hwg_avgpool_fwd (resp. their
+ * backward kernels) without the full-resolution activation / gradient round trips. act: none / relu / leaky relu; chan_mask may be NULL */
+int hwg_act_avgpool_fwd(const float* x, const float* chan_mask, float* y, int N, int H, int W, int C, int kh, int kw, int act, float slope,
+                        void* stream);
+int hwg_act_avgpool_bwd(const float* dy, const float* x, const float* chan_mask, float* dx, int N, int H, int W, int C, int kh, int kw,
+                        int act, float slope, void* stream);
 int hwg_maxpool_fwd(const float* x, float* y, int* idx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                     int P, int Q, void* stream);
 int hwg_maxpool_bwd(const float* dy, const int* idx, float* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph,
                     int pw, int P, int Q, void* stream);
+/* max-pool with the ReLU that precedes it in the reference riding along (model/cnn_only_hwr.py:31-43: conv -> ReLU -> MaxPool2d):
+ * y = relu(maxpool(x)) == maxpool(relu(x)) exactly; backward: dx = scatter(dy * [y > 0]) - same bits as the separate ReLU passes */
+int hwg_maxpool_relu_fwd(const float* x, float* y, int* idx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+                         int P, int Q, void* stream);
+int hwg_maxpool_relu_bwd(const float* dy, const float* y, const int* idx, float* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
+                         int ph, int pw, int P, int Q, void* stream);
 int hwg_upsample_nearest_fwd(const float* x, float* y, int N, int H, int W, int C, int fh, int fw, void* stream);
 int hwg_upsample_nearest_bwd(const float* dy, float* dx, int N, int H, int W, int C, int fh, int fw, void* stream);
 int hwg_blur3(const float* x, float* y, int N, int H, int W, int C, void* stream);
@@ -423,8 +436,20 @@ int hwg_mt_unary(const void* ptrs_a, const void* ptrs_b, int op, float c, int* f
 int hwg_mt_adam(const void* ptrs_p, const void* ptrs_g, const void* ptrs_m, const void* ptrs_v, const float* step_size,
                 const float* bc2_sqrt, float beta1, float beta2, float eps, float clip, const void* numel, const void* chunk_tensor,
                 const void* chunk_off, int nchunks, int chunk, void* stream);
+/* clip_grad_value_(clip) + the NaN asserts + Adam of one stepping lesson in ONE launch (trainer/hw_with_style_trainer.py:379-391): a tensor with a
+ * gradient entry and a NULL parameter entry is clipped only (touched, but not stepped in this lesson); a tensor with both is clipped and
+ * stepped, *flag |= 1 when a freshly written parameter is not finite (flag is sticky: never cleared here). Gradients are stored back only
+ * where clipping changed them. Same arithmetic per element as hwg_mt_unary(op 1) followed by hwg_mt_adam. */
+int hwg_mt_clip_adam(const void* ptrs_p, const void* ptrs_g, const void* ptrs_m, const void* ptrs_v, const float* step_size,
+                     const float* bc2_sqrt, float beta1, float beta2, float eps, float clip, int* flag, const void* numel,
+                     const void* chunk_tensor, const void* chunk_off, int nchunks, int chunk, void* stream);
 int hwg_randn(float* out, long long n, unsigned long long seed, unsigned long long offset, void* stream);
 int hwg_dropmask(float* out, long long n, float p, unsigned long long seed, unsigned long long offset, void* stream);
+/* the Dropout2d masks of one network pass in ONE launch (model/discriminator_ap.py:84-131 has up to six, model/autoencoder.py:341-410 four):
+ * nseg (<= 16) segments of seg_elems[j] floats (multiples of 4; HOST arrays, read during the call) laid out back to back in `out`, segment
+ * j with drop probability seg_p[j]. Same values as nseg consecutive hwg_dropmask calls at offsets offset + sum_{i<j} seg_elems[i] / 4. */
+int hwg_dropmask_multi(float* out, int nseg, const long long* seg_elems, const float* seg_p, unsigned long long seed,
+                       unsigned long long offset, void* stream);
 
 /* `insert_spaces` (model/hw_with_style.py:302-328) with the device generator: plan = per character of every line the number of blank columns
  * before it and of repeats, drawn as round(N(count, count_std)) / round(N(duplicates, dup_std)) (half to even, negative -> 0) from Philox block

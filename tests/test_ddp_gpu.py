@@ -298,8 +298,9 @@ def test_bench_rank_sharded_path_with_two_gloo_ranks(cuda, tmp_path):
     outs = [p.communicate(timeout=900) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-2000:]
-    assert outs[1][0].strip() == "", "only rank 0 prints"
-    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    lines = [[l for l in so.splitlines() if l.startswith('{"metric"')] for so, _ in outs]      # (gloo itself chats on stdout)
+    assert len(lines[0]) == 1 and lines[1] == [], "ONE JSON line, from rank 0"
+    line = json.loads(lines[0][0])
     assert line["n_gpus"] == 2 and line["steps"] == 7 and line["warmup"] == 0 and line["scaling"] == "weak"
     assert line["data_parallel"]["world_size"] == 2 and line["data_parallel"]["backend"] == "gloo"
     assert line["data_parallel"]["collectives_per_step"] > 0 and line["data_parallel"]["allreduce_mbytes_per_step"] > 0

@@ -775,6 +775,44 @@ def test_pools_resample(cuda):
     check(lambda t: F.max_pool2d(t, 2, 2), lambda t: ops.max_pool2d(t, 2, 2), "maxpool_c1", x1)
 
 
+def test_fused_activation_pools_are_bit_identical_to_the_separate_passes(cuda):
+    """hwg_act_avgpool_* (discriminator: SN conv -> Dropout2d -> LeakyReLU -> AvgPool2d, model/discriminator_ap.py:84-131) and hwg_maxpool_relu_*
+    (recogniser: conv -> ReLU -> MaxPool2d, model/cnn_only_hwr.py:31-43) against the separate kernels they replace - same bits, forward and
+    backward - and against torch on the CPU (fp32, tolerance 1e-5)."""
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(81)
+    for (N, C, H, W, k) in ((3, 32, 11, 23, (2, 2)), (2, 64, 1, 37, (1, 2)), (2, 6, 9, 10, (2, 2))):
+        x = torch.randn(N, C, H, W, generator=g)
+        mask = (torch.rand(N, C, generator=g) > 0.2).float() / 0.8
+        for m in (None, mask):
+            xa = nhwc(x).to(cuda).requires_grad_(True); xb = nhwc(x).to(cuda).requires_grad_(True)
+            md = None if m is None else m.to(cuda)
+            ya = ops.avg_pool2d(ops.bias_act(xa, None, md, ops.ACT_LRELU, 0.1), k)
+            yb = ops.act_avg_pool2d(xb, k, md, ops.ACT_LRELU, 0.1)
+            assert torch.equal(ya, yb)
+            gy = torch.randn(ya.shape, generator=g).to(cuda)
+            ya.backward(gy); yb.backward(gy)
+            assert torch.equal(xa.grad, xb.grad)
+            xr = x.clone().requires_grad_(True)
+            yr = F.avg_pool2d(F.leaky_relu(xr * (1.0 if m is None else m[:, :, None, None]), 0.1), k)
+            yr.backward(nchw(gy.cpu()))
+            _close(nchw(yb), yr, "act_avgpool.y", tol=1e-5); _close(nchw(xb.grad), xr.grad, "act_avgpool.dx", tol=1e-5)
+    for (N, C, H, W, args) in ((2, 32, 12, 22, (2, 2)), (2, 64, 8, 21, ((2, 2), (2, 1), (0, 1))), (3, 16, 1, 30, ((1, 2), (1, 2))), (2, 1, 8, 14, (2, 2))):
+        x = torch.randn(N, C, H, W, generator=g)
+        x[0, :, :2, :4] = -x[0, :, :2, :4].abs()          # whole windows <= 0: nothing may flow back through them
+        xa = nhwc(x).to(cuda).requires_grad_(True); xb = nhwc(x).to(cuda).requires_grad_(True)
+        ya = ops.bias_act(ops.max_pool2d(xa, *args), None, None, ops.ACT_RELU)
+        yb = ops.max_pool2d(xb, *args, relu=True)
+        assert torch.equal(ya, yb)
+        gy = torch.randn(ya.shape, generator=g).to(cuda)
+        ya.backward(gy); yb.backward(gy)
+        assert torch.equal(xa.grad, xb.grad)
+        xr = x.clone().requires_grad_(True)
+        yr = F.max_pool2d(F.relu(xr), *args)               # the reference's order: ReLU first
+        yr.backward(nchw(gy.cpu()))
+        _close(nchw(yb), yr, "maxpool_relu.y", tol=1e-6); _close(nchw(xb.grad), xr.grad, "maxpool_relu.dx", tol=1e-6)
+
+
 def test_cat_onehot_layout(cuda):
     from handwriting_line_generation_amd import ops
     g = torch.Generator().manual_seed(9)

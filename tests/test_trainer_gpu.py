@@ -113,6 +113,44 @@ def test_deferred_reduce_and_eager_reduce_train_to_the_same_bits(cuda, tmp_path)
         assert torch.equal(v, sb[k]), "%s differs with the deferred reduce" % k
 
 
+def test_fused_step_and_masked_zero_grad_train_to_the_same_bits(cuda, tmp_path):
+    """Round 6: (i) clip_grad_value_ + the NaN check + Adam of a stepping lesson as ONE launch (HipAdam.step(clip): hwg_mt_clip_adam) against the
+    three separate passes (trainer.fused_step = 0); (ii) zero_grad as a masked multi-tensor pass over the tensors that have a gradient against
+    the fill of the whole group slice (FlatParams._zero_all). Two curriculum cycles each way from the same seeds: every logged loss, every
+    parameter / buffer, every gradient left in the flat buffer and both Adam moments BIT-identical (trainer/hw_with_style_trainer.py:379-391);
+    and after zero_grad of both optimizers nothing but zeros is left outside the 'rest' group (no writer bypasses the touched marks)."""
+    from handwriting_line_generation_amd import rng
+    from handwriting_line_generation_amd.harness import build_gan_trainer
+    outs = []
+    for new in (False, True):
+        rng.set_mode("device", seed=11)
+        torch.manual_seed(3); np.random.seed(3); random.seed(3)
+        trainer, _ = build_gan_trainer("iam_gan", 2, 2, width=256, label_len=12, workdir=str(tmp_path / ("f%d" % new)))
+        trainer._fused_step = new
+        trainer.flat._zero_all = not new
+        torch.manual_seed(5); np.random.seed(5); random.seed(5)
+        logs = [trainer._train_iteration(it) for it in range(14)]
+        torch.cuda.synchronize()
+        f = trainer.flat
+        state = {k: v.detach().clone() for k, v in trainer.model.state_dict().items()}
+        extra = {"grad": f.flat_grad.clone(), "m": trainer.optimizer.exp_avg.clone(), "v": trainer.optimizer.exp_avg_sq.clone(),
+                 "md": trainer.optimizer_discriminator.exp_avg.clone(), "vd": trainer.optimizer_discriminator.exp_avg_sq.clone(),
+                 "flag": f._flag.clone()}
+        trainer.optimizer.zero_grad(); trainer.optimizer_discriminator.zero_grad()
+        a, b = f.group_range["rest"]
+        end = int(f.offsets[a]) if b > a else f.total
+        extra["left"] = float(f.flat_grad[:end].abs().max())
+        outs.append((logs, state, extra))
+    (la, sa, ea), (lb, sb, eb) = outs
+    for it, (a, b) in enumerate(zip(la, lb)):
+        assert a == b, "iteration %d: %s vs %s" % (it, a, b)
+    for k, v in sa.items():
+        assert torch.equal(v, sb[k]), "%s differs with the fused step" % k
+    for k in ("grad", "m", "v", "md", "vd", "flag"):
+        assert torch.equal(ea[k], eb[k]), k
+    assert ea["left"] == 0.0 and eb["left"] == 0.0 and int(eb["flag"]) == 0
+
+
 def test_pipelined_logging_returns_the_same_losses_n_iterations_later(cuda, tmp_path):
     """trainer.async_log = n: iteration i returns the losses of iteration i - n (the host may run n iterations ahead of the GPU), flush_log()
     resolves what is outstanding. Against synchronous logging from the same seeds: the same log dictionaries, shifted by n; the same weights."""
