@@ -218,7 +218,9 @@ def test_allocator_trim_changes_nothing_but_the_cache(cuda, tmp_path):
         trainer, _ = build_gan_trainer("iam_gan", 2, 2, width=256, label_len=12, workdir=str(tmp_path / ("t%d" % every)))
         trainer._trim_every = every
         torch.manual_seed(5); np.random.seed(5); random.seed(5)
-        hog = torch.empty(16 << 30, dtype=torch.uint8, device=trainer.gpu)      # a block that is free (cached) by the time of the first trim
+        # a block that is free (cached) by the time of the first trim; sized against what earlier tests of this process still hold (module-level
+        # caches keep their trainers alive): the trim fires when the cache exceeds twice the peak in use
+        hog = torch.empty((16 << 30) + 3 * torch.cuda.memory_allocated(), dtype=torch.uint8, device=trainer.gpu)
         del hog
         torch.cuda.reset_peak_memory_stats()
         logs = [trainer._train_iteration(it) for it in range(15)]
