@@ -1022,42 +1022,51 @@ __global__ __launch_bounds__(256) void pack_weight_multi_scaled_kernel(const Pac
 }
 
 // column sums: x[rows][C] -> part[chunks][C]  (single chunk: straight into out)
-// V = 4: block = 16 float4 column groups (64 columns) x 16 row lanes, 256-byte coalesced row segments; V = 1: 64 columns x 4 row lanes
+// V = 4: block = cgn float4 column groups x (256 / cgn) row lanes, cgn = min(16, C / 4): with fewer than 64 columns (the generator's 16 / 32
+// channel bias gradients on 250 k rows: 19 us at 0.8 TB/s when 3/4 of the block idled on 128 blocks) the spare threads become row lanes;
+// four rows per lane in flight. V = 1: 64 columns x 4 row lanes
 template <int V>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, long long rows, int C, float* part, long long rows_per_chunk,
                                                              float* direct_out, int accumulate) {
-  constexpr int CG = 64 / V;        // column groups per block
-  constexpr int RL = 256 / CG;      // row lanes
-  __shared__ double red[RL][64];
-  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+  __shared__ double red[256][V];
+  const int cleft = C - (int)blockIdx.y * 64;                          // columns this block column covers (<= 64 of them)
+  const int cgn = V == 4 ? min(16, (cleft + 3) / 4) : min(64, cleft);  // column groups per block
+  const int RL = 256 / cgn;                                            // row lanes
+  const int cg = threadIdx.x % cgn, rl = threadIdx.x / cgn;
   const int c = blockIdx.y * 64 + cg * V;
   const long long rb = blockIdx.x * rows_per_chunk;
   const long long re = min(rb + rows_per_chunk, rows);
   double s[V];        // fp64: column sums feed bias gradients, which are small differences of large sums
 #pragma unroll
   for (int e = 0; e < V; ++e) s[e] = 0.0;
-  if (c < C) {
-    for (long long rr = rb + rl; rr < re; rr += RL) {
-      if (V == 4) {
-        const float4 v = *reinterpret_cast<const float4*>(x + rr * C + c);
-        s[0] += (double)v.x; s[1 % V] += (double)v.y; s[2 % V] += (double)v.z; s[3 % V] += (double)v.w;
-      } else {
-        s[0] += (double)x[rr * C + c];
+  if (rl < RL && c < C) {
+    if (V == 4) {
+      for (long long rr = rb + rl; rr < re; rr += 4ll * RL) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long long r2 = rr + (long long)u * RL;
+          v[u] = *reinterpret_cast<const float4*>(x + (r2 < re ? r2 : rr) * C + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (rr + (long long)u * RL >= re) break;
+          s[0] += (double)v[u].x; s[1 % V] += (double)v[u].y; s[2 % V] += (double)v[u].z; s[3 % V] += (double)v[u].w;
+        }
       }
+    } else {
+      for (long long rr = rb + rl; rr < re; rr += RL) s[0] += (double)x[rr * C + c];
     }
   }
 #pragma unroll
-  for (int e = 0; e < V; ++e) red[rl][cg * V + e] = s[e];
+  for (int e = 0; e < V; ++e) red[threadIdx.x][e] = s[e];
   __syncthreads();
-  if (threadIdx.x < 64) {
+  if ((int)threadIdx.x < min(64, cleft)) {
     const int cc = blockIdx.y * 64 + threadIdx.x;
-    if (cc < C) {
-      double v = 0.0;
-#pragma unroll
-      for (int r = 0; r < RL; ++r) v += red[r][threadIdx.x];
-      if (direct_out) direct_out[cc] = accumulate ? direct_out[cc] + (float)v : (float)v;
-      else part[(long long)blockIdx.x * C + cc] = (float)v;
-    }
+    double v = 0.0;
+    for (int r = 0; r < RL; ++r) v += red[r * cgn + (int)threadIdx.x / V][threadIdx.x % V];
+    if (direct_out) direct_out[cc] = accumulate ? direct_out[cc] + (float)v : (float)v;
+    else part[(long long)blockIdx.x * C + cc] = (float)v;
   }
 }
 // C <= 8 (bias gradients of the 1- and 2-channel heads): the kernel above would keep 4 of its 256 threads busy. Here every thread owns whole
@@ -1571,6 +1580,90 @@ __global__ __launch_bounds__(512) void wgrad_narrow_kernel(WgK a, int kbn, int c
     if (a.bias_on && cb == 0 && lane < 16 && kb * 16 + lane < a.K) pout[(long long)NT * a.K * a.C + kb * 16 + lane] = bsum;
   }
 }
+// ---- single gathered channel, 64 anchor channels (the first layers: recogniser 3x3, style extractor 5x5, discriminator 7x7) --------------
+// dw[k][tap] = sum_pix dy[pix][k] * x[pix + tap]: 2 * taps FLOP per 4 bytes of dy - memory bound by a wide margin (one pass over dy, x is
+// a single-channel image that lives in L2). The taps-as-N MFMA kernel stages an im2col tile per 32 pixels through LDS for 7.7-40 TFLOP/s,
+// i.e. 3x the time of one pass over dy. Here a wavefront owns 64-pixel groups: lane = channel k for the dy loads (256 contiguous bytes
+// per pixel), lane = pixel for the gather of the group's R x S tap values (coalesced along the image row); the walk over the group's pixels
+// broadcasts each tap value with v_readlane (uniform pixel index) into an FMA on the lane's R x S accumulators. Partial images
+// [split][tap][K] (+K bias sums) as every other weight-gradient kernel writes them; fixed-order sum over the workgroup's four wavefronts.
+template <int R, int S>
+__global__ __launch_bounds__(256) void wgrad_c1_kernel(WgK a) {
+  constexpr int T = R * S, NW = 4, DEPTH = 8;
+  __shared__ float red[NW][(T + 1) * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int set = a.sets > 1 ? (int)blockIdx.x / a.gx : 0;
+  const float* __restrict__ au = a.u + (a.set_on_v ? 0ll : (long long)set * a.Mtot * 64);
+  const float* __restrict__ av = a.v + (a.set_on_v ? (long long)set * a.N * a.H * a.W : 0ll);
+  const long long G = ((long long)a.Mtot + 63) >> 6;
+  const long long w = (long long)((int)blockIdx.x - set * a.gx) * NW + wid, Wt = (long long)a.gx * NW;
+  const long long g0 = G * w / Wt, g1 = G * (w + 1) / Wt;
+  float acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = 0.f;
+  float bsum = 0.f;
+  const int PQ = a.P * a.Q;
+  for (long long g = g0; g < g1; ++g) {
+    const int pix0 = (int)(g << 6);
+    // this lane's pixel of the group: its R x S tap values (zero outside the image / past the last pixel)
+    float xv[T];
+    {
+      const int mp = pix0 + lane;
+      const bool mv = mp < a.Mtot;
+      const int mc = mv ? mp : a.Mtot - 1;
+      const int n = mc / PQ, rem = mc - n * PQ;
+      const int pp = rem / a.Q, qq = rem - pp * a.Q;
+      const int ih0 = pp * a.sh - a.ph, iw0 = qq * a.sw - a.pw;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int ih = ih0 + r * a.dh;
+        const bool rok = mv && ih >= 0 && ih < a.H;
+        const int rbase = (n * a.H + min(max(ih, 0), a.H - 1)) * a.W;
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) {
+          const int iw = iw0 + s2 * a.dw;
+          const float x = av[rbase + min(max(iw, 0), a.W - 1)];
+          xv[r * S + s2] = (rok && iw >= 0 && iw < a.W) ? x : 0.f;
+        }
+      }
+    }
+    const int npix = min(64, a.Mtot - pix0);
+    for (int j0 = 0; j0 < npix; j0 += DEPTH) {
+      float d[DEPTH];
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        const int j = j0 + u < npix ? j0 + u : j0;
+        d[u] = au[(long long)(pix0 + j) * 64 + lane];
+      }
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        const int j = j0 + u;                     // wave-uniform
+        if (j >= npix) break;
+        const float dv = d[u];
+        bsum += dv;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          acc[t] = fmaf(dv, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[t]), j)), acc[t]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) red[wid][t * 64 + lane] = acc[t];
+  red[wid][T * 64 + lane] = bsum;
+  __syncthreads();
+  float* pout = a.part + (long long)blockIdx.x * a.pstride;
+  for (int i = tid; i < (T + 1) * 64; i += 256) {
+    const float sres = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+    if (i < T * 64) pout[i] = sres;                        // [tap][K = 64][C = 1]
+    else if (a.bias_on) pout[i] = sres;                    // K bias sums behind the image
+  }
+}
+static bool wgrad_is_c1_valu(const hwg_conv_desc* d) {
+  static const int on = [] { const char* e = getenv("HWG_WGRAD_C1"); return e && *e ? atoi(e) : 1; }();      // 0: the taps-as-N MFMA kernel (A/B timing)
+  return on && d->C == 1 && d->K == 64 && d->R == d->S && (d->R == 3 || d->R == 5 || d->R == 7) &&
+         (long long)d->N * d->P * d->Q >= 4096 && (long long)d->N * d->P * d->Q * 64 < (1ll << 40) && (long long)d->N * d->H * d->W < (1ll << 31);
+}
 static bool wgrad_is_narrow(const hwg_conv_desc* d) {
   const int mode = hwg_tune().wgrad_narrow;               // 0: never, 2: also layers with 2 / 4 channel blocks (tests)
   const bool off = mode == 0, all = mode == 2;
@@ -1595,6 +1688,11 @@ static WgPlan plan_wgrad_tapn(const hwg_conv_desc* d) {
   WgPlan p;
   p.cfg = 3; p.bmu = 64; p.bnv = 64; p.bkp = 32;
   p.tiles_u = hwg_cdiv(d->K, 64); p.tiles_v = 1;
+  if (wgrad_is_c1_valu(d)) {      // wgrad_c1_kernel: one partial image per workgroup of four wavefronts, three workgroups per CU
+    p.cfg = 4;
+    wg_split(p, (long long)d->N * d->P * d->Q, 768);
+    return p;
+  }
   wg_split(p, (long long)d->N * d->P * d->Q, hwg_cdiv(1024, p.tiles_u));
   return p;
 }
@@ -1804,6 +1902,9 @@ static int conv_wgrad_run(const hwg_conv_desc* d, const float* u, const float* v
   else if (p.cfg == 0) hipLaunchKernelGGL((wgrad_mfma_kernel<128, 128, 32, 4, 4, 1>), grid, dim3(1024), 0, st, k);
   // 64x64: two wave groups split every 32-pixel K step between them (8 waves; 5..10 % over 4 waves on every measured shape)
   else if (p.cfg == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<64, 64, 32, 2, 2, 2>), grid, dim3(512), 0, st, k);
+  else if (p.cfg == 4 && d->R == 3) hipLaunchKernelGGL((wgrad_c1_kernel<3, 3>), dim3(gx), dim3(256), 0, st, k);
+  else if (p.cfg == 4 && d->R == 5) hipLaunchKernelGGL((wgrad_c1_kernel<5, 5>), dim3(gx), dim3(256), 0, st, k);
+  else if (p.cfg == 4) hipLaunchKernelGGL((wgrad_c1_kernel<7, 7>), dim3(gx), dim3(256), 0, st, k);
   else if (p.cfg == 3) hipLaunchKernelGGL((wgrad_mfma_kernel<64, 64, 32, 2, 2, 2, true>), grid, dim3(512), 0, st, k);
   else hipLaunchKernelGGL((wgrad_mfma_kernel<32, 32, 32, 1, 1, 4>), grid, dim3(256), 0, st, k);
   hwg_prof_close(prof, st);
@@ -1847,9 +1948,10 @@ extern "C" int hwg_conv_wgrad_sets(const hwg_conv_desc* d, const float* u, const
 }
 
 static long long colsum_chunks(long long rows) {
-  // ~16 rows per thread (16 row lanes per block); keep the second stage short (<= 128 partials per column)
+  // ~16 rows per thread (16 row lanes per block); keep the second stage short (<= 512 partials per column; 128 until round 6: a quarter of
+  // the chip on the generator's 250 k-row tensors)
   long long chunks = (rows + 255) / 256;
-  if (chunks > 128) chunks = 128;
+  if (chunks > 512) chunks = 512;
   if (chunks < 1) chunks = 1;
   return chunks;
 }

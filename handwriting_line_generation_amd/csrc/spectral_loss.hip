@@ -248,6 +248,24 @@ __global__ void axpby_kernel(const float* x, float a, const float* y, float b, f
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     out[i] = a * x[i] + (y ? b * y[i] : 0.f);
 }
+// weighted sum of up to 16 loss scalars (trainer/hw_with_style_trainer.py:280-298: `loss += losses[name] * lossWeights[name]`): scaled[i] = w_i * x_i
+// (x_i itself where w_i == 1, as ops.scale skips that product) and their left-to-right sum, every operation rounded like the chain of
+// hwg_axpby launches it replaces; backward: g_i = w_i * gout
+struct WSum { int n; const float* x[16]; float w[16]; };
+__global__ void weighted_sum_kernel(WSum a, float* scaled, float* sum) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float acc = 0.f;
+  for (int i = 0; i < a.n; ++i) {
+    const float v = a.w[i] == 1.f ? *a.x[i] : __fmul_rn(*a.x[i], a.w[i]);
+    scaled[i] = v;
+    acc = i == 0 ? v : __fadd_rn(acc, v);
+  }
+  *sum = acc;
+}
+__global__ void scale_scalars_kernel(const float* gout, WSum a, float* out) {
+  const int i = threadIdx.x;
+  if (i < a.n) out[i] = a.w[i] == 1.f ? *gout : __fmul_rn(*gout, a.w[i]);
+}
 __global__ void tanh_fwd_kernel(const float* x, float* y, long long n) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = tanhf(x[i]);
 }
@@ -420,6 +438,22 @@ extern "C" int hwg_axpby(const float* x, float a, const float* y, float b, float
   HWG_REQUIRE(x && out && n > 0, "axpby: bad arguments");
   hipLaunchKernelGGL(axpby_kernel, dim3(hwg_stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, a, y, b, out, n);
   HWG_LAUNCH_CHECK("axpby");
+  return HWG_OK;
+}
+extern "C" int hwg_weighted_sum(const void* x_ptrs, const float* weights, int n, float* scaled, float* sum, void* stream) {
+  HWG_REQUIRE(x_ptrs && weights && scaled && sum && n > 0 && n <= 16, "weighted_sum: bad arguments (1..16 terms)");
+  WSum a; a.n = n;
+  for (int i = 0; i < n; ++i) { a.x[i] = reinterpret_cast<const float*>(((const long long*)x_ptrs)[i]); a.w[i] = weights[i]; HWG_REQUIRE(a.x[i], "weighted_sum: null term"); }
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, scaled, sum);
+  HWG_LAUNCH_CHECK("weighted_sum");
+  return HWG_OK;
+}
+extern "C" int hwg_weighted_sum_bwd(const float* grad_out, const float* weights, int n, float* grads, void* stream) {
+  HWG_REQUIRE(grad_out && weights && grads && n > 0 && n <= 16, "weighted_sum_bwd: bad arguments (1..16 terms)");
+  WSum a; a.n = n;
+  for (int i = 0; i < n; ++i) { a.x[i] = nullptr; a.w[i] = weights[i]; }
+  hipLaunchKernelGGL(scale_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, grad_out, a, grads);
+  HWG_LAUNCH_CHECK("weighted_sum_bwd");
   return HWG_OK;
 }
 extern "C" int hwg_tanh_fwd(const float* x, float* y, long long n, void* stream) {

@@ -370,6 +370,83 @@ __global__ __launch_bounds__(1024) void mlp_chain_bwd_kernel(const float* __rest
     for (int t = tid; t < B * DD; t += 1024) dx[t] = dpre[t];
 }
 
+// The same backward pass as two launches (hwg_mlp_chain_bwd_split). The single-workgroup kernel above spends 69 us per call on ONE compute unit:
+// per layer 512 LDS reads per thread (half of them for the parameter gradients) and 192 KB of weight / gradient traffic through one CU's
+// memory port. Only the chain of data gradients is sequential: (1) one workgroup walks it (delta_l = (delta_{l+1} W_{l+1}) * lrelu') and leaves
+// every delta_l in `deltas` [L][BM][D]; (2) L x D*D/1024 workgroups add dW_l = delta_l^T h_l and db_l into the tables' buffers in parallel.
+// Every sum runs over the same terms in the same order as in the kernel above: bit-identical results.
+template <int DD, int BM, int LMAX>
+__global__ __launch_bounds__(1024) void mlp_chain_delta_kernel(const float* __restrict__ dout, const float* __restrict__ acts, const long long* wptr,
+                                                               int L, int B, float slope, float* __restrict__ deltas, float* __restrict__ dx) {
+  constexpr int PER = DD * DD / 1024;
+  __shared__ float dpre[BM * DD];
+  __shared__ float dnew[BM * DD];
+  __shared__ float ws[DD * DD];
+  const int tid = threadIdx.x;
+  float wn[PER];
+  auto prefetch = [&](int l) {
+    const float* W = reinterpret_cast<const float*>(wptr[l]);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) wn[u] = W[tid + u * 1024];
+  };
+  prefetch(L - 1);
+  for (int t = tid; t < BM * DD; t += 1024) dpre[t] = t < B * DD ? dout[t] : 0.f;
+  for (int l = L - 1; l >= 0; --l) {
+    __syncthreads();
+    for (int t = tid; t < BM * DD; t += 1024) {
+      const float h = t < B * DD ? acts[(long long)(l + 1) * B * DD + t] : 0.f;
+      const float d = dpre[t] * (h > 0.f ? 1.f : slope);
+      dpre[t] = d;
+      deltas[(long long)l * BM * DD + t] = d;
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) ws[tid + u * 1024] = wn[u];
+    if (l > 0) prefetch(l - 1);
+    __syncthreads();
+    for (int p = tid; p < BM * DD; p += 1024) {
+      const int b = p / DD, ii = p % DD;
+      float a = 0.f;
+#pragma unroll 8
+      for (int o = 0; o < DD; ++o) a += dpre[b * DD + o] * ws[o * DD + ii];
+      dnew[p] = a;
+    }
+    __syncthreads();
+    for (int t = tid; t < BM * DD; t += 1024) dpre[t] = dnew[t];
+  }
+  __syncthreads();
+  if (dx)
+    for (int t = tid; t < B * DD; t += 1024) dx[t] = dpre[t];
+}
+template <int DD, int BM>
+__global__ __launch_bounds__(1024) void mlp_chain_pgrad_kernel(const float* __restrict__ deltas, const float* __restrict__ acts, const long long* gwptr,
+                                                               const long long* gbptr, int B) {
+  __shared__ float dl[BM * DD];
+  __shared__ float hl[BM * DD];
+  const int l = blockIdx.y, tid = threadIdx.x;
+  float* gW = gwptr[l] ? reinterpret_cast<float*>(gwptr[l]) : nullptr;
+  float* gb = (gbptr && gbptr[l]) ? reinterpret_cast<float*>(gbptr[l]) : nullptr;
+  if (!gW && !gb) return;
+  for (int t = tid; t < BM * DD; t += 1024) {
+    dl[t] = deltas[(long long)l * BM * DD + t];
+    hl[t] = t < B * DD ? acts[(long long)l * B * DD + t] : 0.f;
+  }
+  __syncthreads();
+  const int t = blockIdx.x * 1024 + tid;            // element of dW_l [o][i]
+  if (gW) {
+    const int ii = t % DD, o = t / DD;
+    float a = 0.f;
+#pragma unroll
+    for (int b = 0; b < BM; ++b) a += dl[b * DD + o] * hl[b * DD + ii];
+    gW[t] = gW[t] + a;
+  }
+  if (gb && blockIdx.x == 0 && tid < DD) {
+    float a = 0.f;
+#pragma unroll
+    for (int b = 0; b < BM; ++b) a += dl[b * DD + tid];
+    gb[tid] += a;
+  }
+}
+
 }  // namespace
 
 extern "C" int hwg_gather_windows(const float* x, int B, int Wx, int C, const int* idx_b, const int* idx_pos, int n, int window, float* patches,
@@ -484,5 +561,27 @@ extern "C" int hwg_mlp_chain_bwd(const float* dout, const float* acts, const voi
   else HWG_MC_BWD(64, 16);
 #undef HWG_MC_BWD
   HWG_LAUNCH_CHECK("mlp_chain_bwd");
+  return HWG_OK;
+}
+extern "C" size_t hwg_mlp_chain_bwd_workspace(int L, int B, int D) { return (size_t)(L > 0 ? L : 0) * 16 * (D > 0 ? D : 0) * sizeof(float); }
+extern "C" int hwg_mlp_chain_bwd_split(const float* dout, const float* acts, const void* wptr, const void* gwptr, const void* gbptr, int L, int B,
+                                       int D, float slope, float* dx, void* workspace, size_t workspace_bytes, void* stream) {
+  HWG_REQUIRE(dout && acts && wptr && gwptr && L > 0 && L <= 8 && B > 0 && B <= MC_MAXB && (D == 64 || D == 128),
+              "mlp_chain_bwd_split: bad arguments (L <= 8, B <= %d, D 64 or 128)", MC_MAXB);
+  if (!workspace || workspace_bytes < hwg_mlp_chain_bwd_workspace(L, B, D)) { hwg_set_error("mlp_chain_bwd_split: workspace too small"); return HWG_ERR_WORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  float* deltas = (float*)workspace;
+#define HWG_MC_SPLIT(DD_, BM_)                                                                                                              \
+  do {                                                                                                                                      \
+    hipLaunchKernelGGL((mlp_chain_delta_kernel<DD_, BM_, 8>), dim3(1), dim3(1024), 0, st, dout, acts, (const long long*)wptr, L, B, slope, deltas, dx); \
+    hipLaunchKernelGGL((mlp_chain_pgrad_kernel<DD_, BM_>), dim3(DD_ * DD_ / 1024, L), dim3(1024), 0, st, (const float*)deltas, acts,         \
+                       (const long long*)gwptr, (const long long*)gbptr, B);                                                                 \
+  } while (0)
+  if (D == 128 && B <= 8) HWG_MC_SPLIT(128, 8);
+  else if (D == 128) HWG_MC_SPLIT(128, 16);
+  else if (B <= 8) HWG_MC_SPLIT(64, 8);
+  else HWG_MC_SPLIT(64, 16);
+#undef HWG_MC_SPLIT
+  HWG_LAUNCH_CHECK("mlp_chain_bwd_split");
   return HWG_OK;
 }

@@ -256,17 +256,31 @@ class HWWithStyleTrainer(BaseTrainer):
         if losses is None:
             return None
 
-        loss = recogLoss = autoGenLoss = 0
-        scaled = {}
+        # weight the losses and sum them per balancing group (trainer :280-298): one launch per group (ops.weighted_sum: products and partial
+        # sums rounded like the reference's `loss += losses[name] * lossWeights[name]` chain) instead of a scale and an add launch per loss,
+        # forward and backward; `scaled` (what is logged) holds views of the groups' scaled-term vectors
+        groups = {"loss": [], "recog": [], "autogen": []}
         for name in losses:
-            v = ops.scale(losses[name], self.lossWeights[name[:-4]])
-            scaled[name] = v
             if self.balance_loss and "generator" in name and "auto-gen" in lesson:
-                autoGenLoss = v if isinstance(autoGenLoss, int) else ops.add(autoGenLoss, v)
+                groups["autogen"].append(name)
             elif self.balance_loss and "Recog" in name:
-                recogLoss = v if isinstance(recogLoss, int) else ops.add(recogLoss, v)
+                groups["recog"].append(name)
             else:
-                loss = v if isinstance(loss, int) else ops.add(loss, v)
+                groups["loss"].append(name)
+        scaled, sums = {}, {}
+        for gname, names in groups.items():
+            if not names:
+                sums[gname] = 0
+                continue
+            if len(names) == 1 and float(self.lossWeights[names[0][:-4]]) == 1.0:      # nothing to multiply, nothing to add: no launch
+                sums[gname] = scaled[names[0]] = losses[names[0]]
+                continue
+            total, vec = ops.weighted_sum([losses[n] for n in names], [self.lossWeights[n[:-4]] for n in names])
+            sums[gname] = total
+            for i, n in enumerate(names):
+                scaled[n] = vec[i]
+        scaled = {n: scaled[n] for n in losses}          # (the reference's log order)
+        loss, recogLoss, autoGenLoss = sums["loss"], sums["recog"], sums["autogen"]
 
         lkey = tuple(lesson) if lesson else ()
         # the sums of the weight-gradient partial images of a backward pass are queued and made by one table-driven launch at the

@@ -358,6 +358,11 @@ int hwg_loss_bwd(const float* a, const float* b, long long n, int mode, float sc
                  int accumulate, void* stream);
 int hwg_pixelnorm_fwd(const float* x, float* y, int rows, int C, float eps, void* stream);
 int hwg_pixelnorm_bwd(const float* dy, const float* x, float* dx, int rows, int C, float eps, void* stream);
+/* scaled[i] = weights[i] * *x_i and *sum = their left-to-right sum (x_ptrs: HOST array of n <= 16 device addresses of scalars, weights: HOST
+ * array; both read during the call) - the trainer's weighted loss accumulation (trainer/hw_with_style_trainer.py:280-298) as one launch,
+ * rounded like the chain of hwg_axpby launches it replaces; _bwd: grads[i] = weights[i] * *grad_out */
+int hwg_weighted_sum(const void* x_ptrs, const float* weights, int n, float* scaled, float* sum, void* stream);
+int hwg_weighted_sum_bwd(const float* grad_out, const float* weights, int n, float* grads, void* stream);
 int hwg_axpby(const float* x, float a, const float* y, float b, float* out, long long n, void* stream);
 /* y = x*scale[c] + shift[c] on x[rows][C] (CountCNN output scaling, count_cnn.py:44); out = a*b elementwise */
 int hwg_channel_affine(const float* x, const float* scale, const float* shift, float* y, long long rows, int C, void* stream);
@@ -397,6 +402,11 @@ int hwg_linear_bank_bwd(const float* x, const void* dyptr, const void* wptr, con
 int hwg_mlp_chain_fwd(const float* x, const void* wptr, const void* bptr, int L, int B, int D, float slope, float* acts, void* stream);
 int hwg_mlp_chain_bwd(const float* dout, const float* acts, const void* wptr, const void* gwptr, const void* gbptr, int L, int B, int D,
                       float slope, float* dx, void* stream);
+/* the same backward pass as two launches: the sequential chain of data gradients on one workgroup (every delta_l kept in the workspace), then
+ * all layers' dW_l / db_l in parallel (L x D*D/1024 workgroups) - 69 -> ~25 us per call; bit-identical to hwg_mlp_chain_bwd */
+size_t hwg_mlp_chain_bwd_workspace(int L, int B, int D);
+int hwg_mlp_chain_bwd_split(const float* dout, const float* acts, const void* wptr, const void* gwptr, const void* gbptr, int L, int B, int D,
+                            float slope, float* dx, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Grouped "one expert per window" layers for the 79 character-style experts (model/char_style.py:84-124, 210-235).
  * x [n][R][Cin] -> y [n][R][Cout]; wptr/bptr are device tables (int64 addresses, one per expert) of weights in the Conv1d layout

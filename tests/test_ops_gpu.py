@@ -82,6 +82,12 @@ CONV_CASES = [
     ("narrow_16to32_4x4s2", 3, 128, 200, 16, 32, 4, 4, (2, 2), (1, 1), (1, 1), False),
     ("narrow_32x32_3x3_pad0", 2, 42, 258, 32, 32, 3, 3, (1, 1), (0, 0), (1, 1), False),
     ("narrow_c20_k24", 2, 64, 161, 20, 24, 3, 3, (1, 1), (1, 1), (1, 1), False),
+    # single-channel first layers with 64 filters and >= 4096 output pixels: the VALU weight-gradient kernel (wgrad_c1_kernel: lane = filter,
+    # tap values broadcast by v_readlane) - ragged last 64-pixel group, pad 0 / 1 / 3, stride and dilation, few and many pixel ranges
+    ("c1valu_3x3", 3, 40, 67, 1, 64, 3, 3, (1, 1), (1, 1), (1, 1), False),
+    ("c1valu_5x5_pad0", 2, 36, 131, 1, 64, 5, 5, (1, 1), (0, 0), (1, 1), False),
+    ("c1valu_7x7_dil2_s2", 2, 70, 150, 1, 64, 7, 7, (1, 2), (3, 6), (1, 2), False),
+    ("c1valu_3x3_big", 8, 64, 256, 1, 64, 3, 3, (1, 1), (1, 1), (1, 1), False),
     # RIMES (78 classes): channel counts that are not multiples of 4
     ("rimes_convT_lift_206", 2, 1, 20, 206, 64, 4, 3, (1, 1), (0, 1), (1, 1), True),
     ("rimes_conv1d_to78", 2, 1, 30, 64, 78, 1, 3, (1, 1), (0, 0), (1, 1), False),
@@ -97,6 +103,8 @@ def test_conv_fwd_bwd(cuda, case):
         # the library picks Winograd or the direct kernels per geometry from its cost models; these cases must run the Winograd kernels
         with ops.tuning(HWG_WINO="2"):
             return _conv_case(cuda, ops, case, expect_fwd_engine=6)
+    if name.startswith("c1valu_") or name == "c1_7x7_many_chunks":
+        return _conv_case(cuda, ops, case, expect_wgrad_cfg=14)
     if name.startswith("narrow_"):
         with ops.tuning(HWG_WGRAD_NARROW="2"):      # the all-taps narrow-layer weight-gradient kernel also for 2 / 4 channel blocks
             return _conv_case(cuda, ops, case, expect_wgrad_cfg=100 + case[6])
@@ -1131,6 +1139,23 @@ def test_linear_bank_and_mlp_chain(cuda):
     for k, (a, b) in enumerate(zip(dev_chain, ref_chain)):
         _close(a.weight.grad, b.weight.grad, "chain dW %d" % k)
         _close(a.bias.grad, b.bias.grad, "chain db %d" % k)
+    # the backward pass as two launches (hwg_mlp_chain_bwd_split, the default) against the single-workgroup kernel: same bits, twice in a row
+    # (the parameter gradients are ADDED into their buffers)
+    assert ops.MLP_CHAIN_SPLIT
+    got = {}
+    for split in (True, False):
+        ops.MLP_CHAIN_SPLIT = split
+        try:
+            for m in dev_chain:
+                m.weight.grad = m.bias.grad = None
+            zz = z.to(cuda).requires_grad_(True)
+            for _ in range(2):
+                (chain(zz) * wout.to(cuda)).sum().backward()
+            got[split] = [zz.grad.clone()] + [m.weight.grad.clone() for m in dev_chain] + [m.bias.grad.clone() for m in dev_chain]
+        finally:
+            ops.MLP_CHAIN_SPLIT = True
+    for a, b in zip(got[True], got[False]):
+        assert torch.equal(a, b)
 
 
 def _random_conv_cases(n=36, seed=2026):
