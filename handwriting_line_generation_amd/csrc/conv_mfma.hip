@@ -1581,12 +1581,12 @@ __global__ __launch_bounds__(512) void wgrad_narrow_kernel(WgK a, int kbn, int c
   }
 }
 // ---- single gathered channel, 64 anchor channels (the first layers: recogniser 3x3, style extractor 5x5, discriminator 7x7) --------------
-// dw[k][tap] = sum_pix dy[pix][k] * x[pix + tap]: 2 * taps FLOP per 4 bytes of dy - memory bound by a wide margin (one pass over dy, x is
-// a single-channel image that lives in L2). The taps-as-N MFMA kernel stages an im2col tile per 32 pixels through LDS for 7.7-40 TFLOP/s,
-// i.e. 3x the time of one pass over dy. Here a wavefront owns 64-pixel groups: lane = channel k for the dy loads (256 contiguous bytes
-// per pixel), lane = pixel for the gather of the group's R x S tap values (coalesced along the image row); the walk over the group's pixels
-// broadcasts each tap value with v_readlane (uniform pixel index) into an FMA on the lane's R x S accumulators. Partial images
-// [split][tap][K] (+K bias sums) as every other weight-gradient kernel writes them; fixed-order sum over the workgroup's four wavefronts.
+// dw[k][tap] = sum_pix dy[pix][k] * x[pix + tap] is memory bound on paper (2 * taps FLOP per 4 bytes of dy), so a VALU kernel that reads dy once
+// looked attractive next to the taps-as-N MFMA kernel (7.7-40 TFLOP/s). Built and MEASURED SLOWER in the training step (profiles/r06_census_c1.txt):
+// lane = channel k for the dy loads, lane = pixel for the gather of the group's R x S tap values, the walk over the group's 64 pixels broadcasts
+// each tap value with v_readlane into an FMA - 2 x taps VALU instructions of 4 cycles each per pixel and wavefront: 119 us for the
+// discriminator's 7x7 layer (MFMA kernel: 74), 65 us for the 5x5 (42-71), 34 us for the 3x3 (39). OFF by default (HWG_WGRAD_C1=1 runs it;
+// the parity cases c1valu_* keep it correct). Partial images [split][tap][K] (+K bias sums) as every other weight-gradient kernel writes them.
 template <int R, int S>
 __global__ __launch_bounds__(256) void wgrad_c1_kernel(WgK a) {
   constexpr int T = R * S, NW = 4, DEPTH = 8;
@@ -1660,8 +1660,7 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(WgK a) {
   }
 }
 static bool wgrad_is_c1_valu(const hwg_conv_desc* d) {
-  static const int on = [] { const char* e = getenv("HWG_WGRAD_C1"); return e && *e ? atoi(e) : 1; }();      // 0: the taps-as-N MFMA kernel (A/B timing)
-  return on && d->C == 1 && d->K == 64 && d->R == d->S && (d->R == 3 || d->R == 5 || d->R == 7) &&
+  return hwg_tune().wgrad_c1 && d->C == 1 && d->K == 64 && d->R == d->S && (d->R == 3 || d->R == 5 || d->R == 7) &&
          (long long)d->N * d->P * d->Q >= 4096 && (long long)d->N * d->P * d->Q * 64 < (1ll << 40) && (long long)d->N * d->H * d->W < (1ll << 31);
 }
 static bool wgrad_is_narrow(const hwg_conv_desc* d) {
@@ -1948,10 +1947,10 @@ extern "C" int hwg_conv_wgrad_sets(const hwg_conv_desc* d, const float* u, const
 }
 
 static long long colsum_chunks(long long rows) {
-  // ~16 rows per thread (16 row lanes per block); keep the second stage short (<= 512 partials per column; 128 until round 6: a quarter of
-  // the chip on the generator's 250 k-row tensors)
+  // ~16 rows per thread (16 row lanes per block); keep the second stage short (<= 256 partials per column; 128 until round 6: a quarter of
+  // the chip on the generator's 250 k-row tensors; 512 made the second stage slower than the first got faster)
   long long chunks = (rows + 255) / 256;
-  if (chunks > 512) chunks = 512;
+  if (chunks > 256) chunks = 256;
   if (chunks < 1) chunks = 1;
   return chunks;
 }

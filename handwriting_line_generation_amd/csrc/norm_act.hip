@@ -23,7 +23,7 @@ struct Geo {
 // 16 x 58 x 512 x 64) that is 256-1024 workgroups of 4 wavefronts: one or two wavefronts per SIMD, each with four 16-byte loads in flight -
 // a fraction of the ~16 MB the memory system needs in flight. Those tensors run 1024-thread workgroups (16 wavefronts per CU and chunk).
 static int norm_block_size(int HW, int C) {
-  static const int thresh = [] { const char* e = getenv("HWG_NORM_BIG"); return e && *e ? atoi(e) : 256; }();     // 0: never
+  const int thresh = hwg_tune().norm_big;     // 0: never
   const int L = C / 4, PP = 256 / L;
   return (thresh > 0 && L <= 256 && HW / (PP * NORM_PASSES) >= thresh) ? 1024 : 256;
 }

@@ -346,6 +346,21 @@ __global__ void onehot_kernel(const int* label, float* out, int L, int B, int nc
   }
 }
 
+// both layouts of the one-hot in one launch: blc[b][l][c] (what the networks read, NHWC [B,1,L,C]) and lbc[l][b][c] (the reference's
+// time-major [L,B,C], what HWWithStyle.onehot returns) - the model API hands the time-major tensor around and the generator / spacer
+// permuted it straight back: three launches per one-hot
+__global__ void onehot_both_kernel(const int* label, float* blc, float* lbc, int L, int B, int ncls) {
+  const long long total = (long long)B * L * ncls;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % ncls);
+    const unsigned t = i / ncls;
+    const int l = (int)(t % L), b = (int)(t / L);
+    const float v = (label[l * B + b] == c) ? 1.f : 0.f;
+    blc[i] = v;
+    lbc[((long long)l * B + b) * ncls + c] = v;
+  }
+}
+
 // generic strided 4-d permute copy: out[i0][i1][i2][i3] (contiguous) = in[i0*s0 + i1*s1 + i2*s2 + i3*s3]
 __global__ void permute4_kernel(const float* in, float* out, int d0, int d1, int d2, int d3, long long s0, long long s1, long long s2, long long s3) {
   const long long total = (long long)d0 * d1 * d2 * d3;
@@ -373,7 +388,7 @@ __global__ void fused_up_weight_fwd_kernel(const float* w3, float* w4, long long
     w4[i] = acc / 4.f;
   }
 }
-__global__ void fused_up_weight_bwd_kernel(const float* dw4, float* dw3, long long AB, float mult) {
+__global__ void fused_up_weight_bwd_kernel(const float* dw4, float* dw3, long long AB, float mult, int accumulate) {
   const long long total = AB * 9;
   GRID_STRIDE(i, total) {
     const int q = (int)(i % 3), p = (int)((i / 3) % 3);
@@ -382,7 +397,8 @@ __global__ void fused_up_weight_bwd_kernel(const float* dw4, float* dw3, long lo
     // w3[p][q] contributes to w4[r][s] with r = p+1-dr, s = q+1-ds
     for (int dr = 0; dr < 2; ++dr)
       for (int ds = 0; ds < 2; ++ds) acc += dw4[ab * 16 + (p + 1 - dr) * 4 + (q + 1 - ds)];
-    dw3[i] = acc * mult / 4.f;
+    const float v = acc * mult / 4.f;
+    dw3[i] = accumulate ? __fadd_rn(dw3[i], v) : v;
   }
 }
 
@@ -574,6 +590,14 @@ extern "C" int hwg_onehot(const int* label, float* out, int L, int B, int ncls, 
   HWG_LAUNCH_CHECK("onehot");
   return HWG_OK;
 }
+extern "C" int hwg_onehot_both(const int* label, float* out_blc, float* out_lbc, int L, int B, int ncls, void* stream) {
+  HWG_REQUIRE(label && out_blc && out_lbc && L > 0 && B > 0 && ncls > 0, "onehot_both: bad arguments");
+  HWG_REQUIRE((long long)((long long)B * L * ncls) < (1ll << 31), "tensor too large for 32-bit element indices");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(onehot_both_kernel, dim3(hwg_stream_grid((long long)B * L * ncls, 256)), dim3(256), 0, st, label, out_blc, out_lbc, L, B, ncls);
+  HWG_LAUNCH_CHECK("onehot_both");
+  return HWG_OK;
+}
 extern "C" int hwg_permute4(const float* in, float* out, int d0, int d1, int d2, int d3, long long s0, long long s1, long long s2, long long s3,
                             void* stream) {
   HWG_REQUIRE(in && out && d0 > 0 && d1 > 0 && d2 > 0 && d3 > 0, "permute4: bad arguments");
@@ -595,8 +619,15 @@ extern "C" int hwg_fused_upsample_weight_fwd(const float* w3, float* w4, long lo
 extern "C" int hwg_fused_upsample_weight_bwd(const float* dw4, float* dw3, long long AB, float mult, void* stream) {
   HWG_REQUIRE(dw4 && dw3 && AB > 0, "fused_upsample_weight_bwd: bad arguments");
   HWG_REQUIRE((long long)(AB * 9) < (1ll << 31), "tensor too large for 32-bit element indices");
-  hipLaunchKernelGGL(fused_up_weight_bwd_kernel, dim3(hwg_stream_grid(AB * 9, 256)), dim3(256), 0, (hipStream_t)stream, dw4, dw3, AB, mult);
+  hipLaunchKernelGGL(fused_up_weight_bwd_kernel, dim3(hwg_stream_grid(AB * 9, 256)), dim3(256), 0, (hipStream_t)stream, dw4, dw3, AB, mult, 0);
   HWG_LAUNCH_CHECK("fused_upsample_weight_bwd");
+  return HWG_OK;
+}
+extern "C" int hwg_fused_upsample_weight_bwd_acc(const float* dw4, float* dw3, long long AB, float mult, void* stream) {
+  HWG_REQUIRE(dw4 && dw3 && AB > 0, "fused_upsample_weight_bwd_acc: bad arguments");
+  HWG_REQUIRE((long long)(AB * 9) < (1ll << 31), "tensor too large for 32-bit element indices");
+  hipLaunchKernelGGL(fused_up_weight_bwd_kernel, dim3(hwg_stream_grid(AB * 9, 256)), dim3(256), 0, (hipStream_t)stream, dw4, dw3, AB, mult, 1);
+  HWG_LAUNCH_CHECK("fused_upsample_weight_bwd_acc");
   return HWG_OK;
 }
 

@@ -36,7 +36,8 @@ class CountCNN(nn.Module):
         """input [L,B,C] (time major) or NHWC [B,1,L,C]; style [B,S] -> [L,B,n_out]"""
         if input.dim() == 3:
             Lr, B, C = input.shape
-            input = ops.permute4(input.contiguous(), (B, 1, Lr, C), (C, 0, B * C, 1))
+            twin = ops.nhwc_of(input)
+            input = twin if twin is not None else ops.permute4(input.contiguous(), (B, 1, Lr, C), (C, 0, B * C, 1))
         B, _, Lr, _ = input.shape
         c = self.cnn
         x = ops.cat_channels([input, style.contiguous()], (B, 1, Lr))

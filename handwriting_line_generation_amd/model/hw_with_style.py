@@ -295,8 +295,7 @@ class HWWithStyle(BaseModel):
     def onehot(self, label):
         """[L,B] int labels -> [L,B,num_class] float one-hot on the labels' device"""
         if label.is_cuda:
-            rows = ops.onehot_rows(label.to(torch.int32).contiguous(), self.num_class)      # [B,1,L,C]
-            return ops.permute_bl_to_lb(rows)
+            return ops.onehot_both(label.to(torch.int32).contiguous(), self.num_class)      # [L,B,C] (+ its NHWC twin for the networks)
         out = torch.zeros(label.size(0), label.size(1), self.num_class)
         out.view(-1, self.num_class)[torch.arange(label.numel()), label.reshape(-1).long()] = 1
         return out

@@ -201,8 +201,12 @@ class SpacedGenerator(nn.Module):
         """content [T,B,n_class] (time major, as in the reference) or NHWC [B,1,T,n_class]; style [B,style]; -> NCHW [B,1,64,4T]"""
         if content.dim() == 3:
             T, B, C = content.shape
-            content = ops.permute4(content.contiguous(), (B, 1, T, C), (C, 0, B * C, 1)) if not content.requires_grad else \
-                ops.to_nhwc(content.permute(1, 2, 0).unsqueeze(2))
+            twin = ops.nhwc_of(content) if not content.requires_grad else None      # (a one-hot made by ops.onehot_both carries its NHWC rows)
+            if twin is not None:
+                content = twin
+            else:
+                content = ops.permute4(content.contiguous(), (B, 1, T, C), (C, 0, B * C, 1)) if not content.requires_grad else \
+                    ops.to_nhwc(content.permute(1, 2, 0).unsqueeze(2))
         B, _, T, _ = content.shape
         emb = self.embed_style(style)
         x = ops.cat_channels([content, emb], (B, 1, T)) if self.append_style else content

@@ -1081,8 +1081,17 @@ class _Conv2d(Function):
                     # (one output row, H == R: the vertical stride never moves - stride R gives every input row its own class of 1 x S taps
                     # where stride sh pairs each class with R / sh tap rows of which all but one meet nothing; the style extractor's last
                     # 4x4 stride-(2,1) layer)
-                    she = R if (P == 1 and ph == 0 and H == R and R > sh) else sh
-                    dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (she, sw), (ph, pw), (1, 1), H, W, 1)
+                    if P == 1 and ph == 0 and H >= R and R > sh:
+                        # (H > R: rows R.. of the input never met the filter - the style extractor's last block sees 5 rows and uses 4. They
+                        # get zeros; the R live rows run as the stride-R twin instead of sh-strided classes whose second block row is dead:
+                        # 4x1x254x256 -> 4x5x257x256: 81 -> ~50 us)
+                        dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (R, sw), (ph, pw), (1, 1), R, W, 1)
+                        if H > R:
+                            full = torch.empty((N, H, W, C), dtype=torch.float32, device=dx.device)
+                            L.call("hwg_pad2d_fwd", dx, full, N, R, W, C, 0, H - R, 0, 0, 0, 0.0, st)
+                            dx = full
+                    else:
+                        dx = _run_conv(dyin, wp, None, N, P, Q, Kp, C, R, S, (sh, sw), (ph, pw), (1, 1), H, W, 1)
             else:
                 # gradient of a transposed conv is an ordinary (strided) correlation of dy
                 wino = _wino_ok(N, P, Q, Kp, C, R, S, (sh, sw), (ph, pw), (dh, dw), H, W)
@@ -1717,6 +1726,26 @@ def onehot_rows(label_LB, ncls):
     return out
 
 
+def onehot_both(label_LB, ncls):
+    """label int32 [L,B] (device) -> (time-major [L,B,ncls] with the NHWC rows [B,1,L,ncls] hanging on it as `_hwg_nhwc`), one launch: the
+    consumers that read NHWC (generator, spacer) take the attached tensor instead of permuting the time-major one back"""
+    Lr, B = label_LB.shape
+    _chk(label_LB, "label", torch.int32)
+    blc = torch.empty((B, 1, Lr, ncls), dtype=torch.float32, device=label_LB.device)
+    lbc = torch.empty((Lr, B, ncls), dtype=torch.float32, device=label_LB.device)
+    L.call("hwg_onehot_both", label_LB, blc, lbc, Lr, B, ncls, _stream())
+    lbc._hwg_nhwc = blc
+    return lbc
+
+
+def nhwc_of(content_LBC):
+    """the NHWC twin of a time-major tensor made by onehot_both (None for any other tensor, e.g. a slice of it)"""
+    twin = getattr(content_LBC, "_hwg_nhwc", None)
+    if twin is not None and content_LBC.dim() == 3 and twin.shape[0] == content_LBC.shape[1] and twin.shape[2] == content_LBC.shape[0]:
+        return twin
+    return None
+
+
 def permute4(x, dims, strides):
     out = torch.empty(tuple(dims), dtype=torch.float32, device=x.device)
     L.call("hwg_permute4", x, out, dims[0], dims[1], dims[2], dims[3], strides[0], strides[1], strides[2], strides[3], _stream())
@@ -2237,11 +2266,16 @@ class _FusedUpWeight(Function):
         w4 = torch.empty((A, B, 4, 4), dtype=torch.float32, device=w3.device)
         L.call("hwg_fused_upsample_weight_fwd", w3, w4, A * B, mult, _stream())
         ctx.cfg = (A, B, mult)
+        ctx.param_refs = (w3,)
         return w4
 
     @staticmethod
     def backward(ctx, dw4):
         A, B, mult = ctx.cfg
+        (wref,) = ctx.param_refs
+        if _direct(wref):      # a parameter: added where parameter gradients live (the current set or the redirected one), no add launch behind it
+            L.call("hwg_fused_upsample_weight_bwd_acc", dw4.contiguous(), _grad_buffer(wref), A * B, mult, _stream())
+            return None, None
         dw3 = torch.empty((A, B, 3, 3), dtype=torch.float32, device=dw4.device)
         L.call("hwg_fused_upsample_weight_bwd", dw4.contiguous(), dw3, A * B, mult, _stream())
         return dw3, None

@@ -301,9 +301,14 @@ int hwg_pad_channels(const float* src, int C, float* dst, int Cpad, long long ro
 int hwg_reduce_rows(const float* src, int Cs, int soff, float* out, int Cn, int N, int HW, int accumulate, void* stream);
 /* label [L][B] int32 -> out[b][l][doff + cls] one-hot rows of width ncls inside rows of width Cd (HWWithStyle.onehot, hw_with_style.py:333-337) */
 int hwg_onehot(const int* label, float* out, int L, int B, int ncls, int Cd, int doff, void* stream);
+/* the same one-hot in both layouts at once: out_blc [B][L][ncls] (NHWC rows, what the networks read) and out_lbc [L][B][ncls] (the reference's
+ * time-major tensor, hw_with_style.py:333-337) - one launch instead of a one-hot and two permutes */
+int hwg_onehot_both(const int* label, float* out_blc, float* out_lbc, int L, int B, int ncls, void* stream);
 /* FusedUpsample weight transform, model/pure_gen.py:268-276: [A][B][3][3] -> [A][B][4][4] (AB = A*B) and its adjoint */
 int hwg_fused_upsample_weight_fwd(const float* w3, float* w4, long long AB, float mult, void* stream);
 int hwg_fused_upsample_weight_bwd(const float* dw4, float* dw3, long long AB, float mult, void* stream);
+/* the adjoint ADDED into dw3 (the parameter's gradient buffer): saves the add launch behind it */
+int hwg_fused_upsample_weight_bwd_acc(const float* dw4, float* dw3, long long AB, float mult, void* stream);
 int hwg_permute4(const float* in, float* out, int d0, int d1, int d2, int d3, long long s0, long long s1, long long s2, long long s3, void* stream);
 
 /* ------------------------------------------------------------------------------------------
