@@ -84,6 +84,73 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(DirK a, int TP, int n
   }
 }
 
+// ---- C == 1, stride 1, dilation 1 (every first layer: discriminator 7x7, style extractor / perceptual encoder 5x5, recogniser 3x3) ------------
+// The kernel above gathers its im2col tile tap by tap (49 clamped 4-byte loads per pixel, each with its own coordinate arithmetic and bounds
+// test) and is bound by that gather: 83 us for 16x64x512 (1.5 TB/s of output) where the matrix cores need 19 us and the output 30. Here a
+// workgroup owns 128 consecutive output pixels of ONE output row: the R input rows it reads are staged in LDS once (coalesced, zero-filled
+// outside the image: R x (128 + S - 1) floats), a tap (r, s) of pixel m is then rows[r][m + s] - one conflict-free ds_read_b32 per MFMA
+// operand with compile-time offsets - and the filter's B fragments live in registers for the whole launch (TP x BN / 64 values per lane).
+// Wavefront w multiplies pixels 32 w .. 32 w + 31 by all BN output channels: TP / 2 steps of v_mfma_f32_32x32x2_f32 per 32 channels.
+template <int R, int S, int BN>
+__global__ __launch_bounds__(256) void conv_c1_rows_kernel(DirK a, int qtiles, int nseg) {
+  constexpr int T = R * S, TP = (T + 1) & ~1, STEPS = TP / 2, NI = BN / 32, QT = 128, RW = QT + S - 1;
+  __shared__ float rows[R * RW];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  float bf[STEPS][NI];
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int t = 2 * st + lhi, k = ni * 32 + l31;
+      bf[st][ni] = (t < T && k < a.K) ? a.w[t * a.K + k] : 0.f;
+    }
+  float bv[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) bv[ni] = (a.bias && ni * 32 + l31 < a.K) ? a.bias[ni * 32 + l31] : 0.f;
+  for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    const int qt = seg % qtiles, t2 = seg / qtiles;
+    const int p = t2 % a.P, n = t2 / a.P;
+    const int q0 = qt * QT;
+    __syncthreads();                                    // the previous segment's operand reads are done
+    for (int i = tid; i < R * RW; i += 256) {
+      const int r = i / RW, c = i - r * RW;
+      const int ih = p - a.ph + r, iw = q0 - a.pw + c;
+      const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+      rows[i] = ok ? a.x[((long long)n * a.H + ih) * a.W + iw] : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ni][e] = 0.f;
+    const float* base = rows + wid * 32 + l31;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      const int t0 = 2 * st, t1 = 2 * st + 1 < T ? 2 * st + 1 : 2 * st;      // (the padding tap of an odd filter: weight 0, any valid address)
+      const int o0 = (t0 / S) * RW + t0 % S, o1 = (t1 / S) * RW + t1 % S;
+      const float af = base[lhi ? o1 : o0];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[st][ni], acc[ni], 0, 0, 0);
+    }
+    // C/D layout of the 32x32 MFMA: col (k) = lane & 31, row (pixel) = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    const long long rowbase = ((long long)n * a.P + p) * a.Q;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int q = q0 + wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+      if (q >= a.Q) continue;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int k = ni * 32 + l31;
+        if (k >= a.K) continue;
+        float* yo = a.y + (rowbase + q) * a.K + k;
+        const float v = acc[ni][e] + bv[ni];
+        *yo = a.accumulate ? *yo + v : v;
+      }
+    }
+  }
+}
+
 // ---- C == 1 : each thread computes 4 consecutive q pixels x 4 channels; weights [R*S][K] staged in LDS ----
 __global__ __launch_bounds__(256) void conv_c1_kernel(DirK a, int KG, int PG) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];  // [R*S][KG*4]
@@ -392,6 +459,30 @@ bool plan_wd(const hwg_conv_desc* d, WdPlan* p) {
 
 int hwg_conv_c1_fwd_impl(const hwg_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int accumulate, hipStream_t st) {
   HWG_REQUIRE(d->C == 1, "conv_c1: C must be 1");
+  // stride-1 square 3x3 / 5x5 / 7x7 filters with 32 or 64 output channels: input rows staged in LDS, filter in registers (conv_c1_rows_kernel)
+  if (hwg_tune().c1_rows && (d->K == 32 || d->K == 64) && d->R == d->S && (d->R == 3 || d->R == 5 || d->R == 7) && d->stride_h == 1 && d->stride_w == 1 &&
+      d->dil_h == 1 && d->dil_w == 1 && (long long)d->N * d->P * hwg_cdiv(d->Q, 128) < (1ll << 31)) {
+    DirK k;
+    k.x = x; k.w = w; k.bias = bias; k.y = y;
+    k.N = d->N; k.H = d->H; k.W = d->W; k.C = d->C; k.K = d->K; k.R = d->R; k.S = d->S;
+    k.sh = 1; k.sw = 1; k.ph = d->pad_h; k.pw = d->pad_w; k.dh = 1; k.dw = 1;
+    k.P = d->P; k.Q = d->Q; k.accumulate = accumulate;
+    const int qtiles = hwg_cdiv(d->Q, 128);
+    const int nseg = d->N * d->P * qtiles;
+    const int grid = nseg < 2048 ? nseg : 2048;
+    const int prof = hwg_prof_open(HWG_PROF_CONV_DIRECT, 2.0 * d->N * d->P * d->Q * d->K * d->C * d->R * d->S, st);
+#define HWG_C1R(R_, BN_) hipLaunchKernelGGL((conv_c1_rows_kernel<R_, R_, BN_>), dim3(grid), dim3(256), 0, st, k, qtiles, nseg)
+    if (d->R == 3 && d->K == 64) HWG_C1R(3, 64);
+    else if (d->R == 3) HWG_C1R(3, 32);
+    else if (d->R == 5 && d->K == 64) HWG_C1R(5, 64);
+    else if (d->R == 5) HWG_C1R(5, 32);
+    else if (d->K == 64) HWG_C1R(7, 64);
+    else HWG_C1R(7, 32);
+#undef HWG_C1R
+    hwg_prof_close(prof, st);
+    HWG_LAUNCH_CHECK("conv_c1_rows");
+    return HWG_OK;
+  }
   // the matrix-core kernel pays from ~36 taps (7x7: 128 -> 88 us on 16x64x512; 5x5 and 3x3 layers are no faster or slower: tools/probes/probe_r3_c1.txt)
   if (hwg_tune().c1_mfma && (d->K == 32 || d->K == 64) && d->R * d->S <= 64 && d->R * d->S >= 36) {
     DirK k;

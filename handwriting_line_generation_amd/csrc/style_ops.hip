@@ -345,7 +345,7 @@ __global__ __launch_bounds__(1024) void mlp_chain_bwd_kernel(const float* __rest
         const int ii = t % DD, o = t / DD;
         float a = 0.f;
 #pragma unroll
-        for (int b = 0; b < BM; ++b) a += dpre[b * DD + o] * hin[b * DD + ii];
+        for (int b = 0; b < BM; ++b) a = __fmaf_rn(dpre[b * DD + o], hin[b * DD + ii], a);      // (explicit FMA chain: the two-launch variant must produce the same bits)
         gW[t] = gcur[u] + a;
       }
     }
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(1024) void mlp_chain_bwd_kernel(const float* __rest
       const int b = p / DD, ii = p % DD;
       float a = 0.f;
 #pragma unroll 8
-      for (int o = 0; o < DD; ++o) a += dpre[b * DD + o] * ws[o * DD + ii];
+      for (int o = 0; o < DD; ++o) a = __fmaf_rn(dpre[b * DD + o], ws[o * DD + ii], a);
       dnew[p] = a;
     }
     __syncthreads();
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(1024) void mlp_chain_delta_kernel(const float* __re
       const int b = p / DD, ii = p % DD;
       float a = 0.f;
 #pragma unroll 8
-      for (int o = 0; o < DD; ++o) a += dpre[b * DD + o] * ws[o * DD + ii];
+      for (int o = 0; o < DD; ++o) a = __fmaf_rn(dpre[b * DD + o], ws[o * DD + ii], a);
       dnew[p] = a;
     }
     __syncthreads();
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(1024) void mlp_chain_pgrad_kernel(const float* __re
     const int ii = t % DD, o = t / DD;
     float a = 0.f;
 #pragma unroll
-    for (int b = 0; b < BM; ++b) a += dl[b * DD + o] * hl[b * DD + ii];
+    for (int b = 0; b < BM; ++b) a = __fmaf_rn(dl[b * DD + o], hl[b * DD + ii], a);
     gW[t] = gW[t] + a;
   }
   if (gb && blockIdx.x == 0 && tid < DD) {

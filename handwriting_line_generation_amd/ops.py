@@ -1160,12 +1160,12 @@ class _Conv2d(Function):
                 if PROF_SHAPES is not None:
                     _prof_tag((d.N, d.H, d.W, d.C, d.K, R, S, (sh, sw), (ph, pw), (dh, dw), "wgrad", ctx.scope))
                 L.call("hwg_conv_wgrad", d.ptr, up, vp, tmp, Cq * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)
-                valid = tmp[:dK, :dC]
+                # the valid block of the padded result, added to (or copied into) the gradient through the C-ABI: row k of `tmp` holds Cq*R*S floats
+                # of which the first dC*R*S belong to real channels (a torch-side add_ here was invisible to a recorded call list: every RIMES
+                # geometry of the recogniser failed its replay self-check)
+                L.call("hwg_copy_channels", tmp, Cq * R * S, 0, dw_, dC * R * S, 0, dC * R * S, dK, 1, 0, 1 if direct else 0, st)
                 if direct:
-                    dw_.add_(valid.reshape(dw_.shape))
                     dw_ = None
-                else:
-                    dw_ = valid.reshape(weight.shape).contiguous()
             else:
                 ws = dws if dws is not None else workspace(need, x.device)
                 if PROF_SHAPES is not None:

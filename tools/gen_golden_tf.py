@@ -44,7 +44,18 @@ REDUCED = {"gen_dim": 64, "disc_dim": 16, "style_extractor_dim": 8, "char_style_
 CASES = {
     "tf_full": dict(config="iam_gan", reduced=None, B=2, A=2, W=256, L=12, warm=0),
     "tf_trained": dict(config="iam_gan", reduced=REDUCED, B=2, A=2, W=256, L=12, warm=147),
+    # round 6: teacher-forced units for BASELINE configs[2] (a_batch_size = 1: one line per author, so the style extractor
+    # sees single lines and the author batch carries no second line to collapse) and configs[4] (the RIMES config: 78 classes, i.e. the
+    # channel-padded recogniser head / 206-channel generator input, wider lines)
+    "tf_a1": dict(config="iam_gan", reduced=None, B=2, A=1, W=256, L=12, warm=0),
+    # (seeded RIMES weights generate lines too narrow for their 14-character texts in every probed seed - the CTC terms are infeasible and the
+    # reference itself trips its NaN assert in the auto lesson - so the RIMES units start, like tf_trained, from the reference's own
+    # trajectory: two curriculum cycles from seeded weights at reduced widths)
+    "tf_rimes": dict(config="rimes_gan", reduced=REDUCED, B=1, A=2, W=512, L=14, warm=14),
 }
+if os.environ.get("HWG_TF_SEEDS"):      # seed probing for a new case: HWG_TF_SEEDS="case:s0,s1,s2,s3,s4"
+    _c, _s = os.environ["HWG_TF_SEEDS"].split(":")
+    CASES[_c]["unit_seeds"] = [int(v) for v in _s.split(",")]
 UNITS = [[0], [1, 2], [3], [4, 5], [6]]      # curriculum positions (count | gen auto | disc | gen auto | disc)
 N_PREV_STYLES = 20
 
@@ -207,7 +218,7 @@ def run_units(case, wide, out_path, rms_path):
         if c["warm"]:
             sd, prev = base_sd, [t.clone() for t in base_prev]
         else:
-            sd = seeded_sd(model, UNIT_SEEDS[u], wide)
+            sd = seeded_sd(model, c.get("unit_seeds", UNIT_SEEDS)[u], wide)
             prev = tf_state.seeded_prev_styles(N_PREV_STYLES, cfg["model"]["style_dim"], 900 + u)
         model.load_state_dict(sd)
         for opt in (trainer.optimizer, trainer.optimizer_discriminator):
@@ -279,7 +290,7 @@ def main():
                 subprocess.check_call([sys.executable, os.path.abspath(__file__), "--units", case, str(wide), tmp, rms_path])
             res[wide] = json.load(open(tmp))
         out = {"case": case, "config": c["config"], "reduced": c["reduced"], "batch_size": c["B"], "a_batch_size": c["A"], "W": c["W"], "label_len": c["L"],
-               "warm": c["warm"], "wseed_model": WSEED_MODEL, "wseed_enc": WSEED_ENC, "n_prev_styles": N_PREV_STYLES, "unit_seeds": UNIT_SEEDS, "names": res[0]["names"], "units": []}
+               "warm": c["warm"], "wseed_model": WSEED_MODEL, "wseed_enc": WSEED_ENC, "n_prev_styles": N_PREV_STYLES, "unit_seeds": c.get("unit_seeds", UNIT_SEEDS), "names": res[0]["names"], "units": []}
         for u32, u64 in zip(res[0]["units"], res[1]["units"]):
             unit = []
             for a, b in zip(u32, u64):
