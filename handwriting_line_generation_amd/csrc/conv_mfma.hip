@@ -1659,6 +1659,113 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(WgK a) {
     else if (a.bias_on) pout[i] = sres;                    // K bias sums behind the image
   }
 }
+// ---- the same layers on the matrix cores with the input ROWS staged in LDS (round 6, the default) ------------------------------------------------
+// dw[k][tap] = sum_pix dy[pix][k] * x[pix + tap] as a GEMM with M = 64 filters, N = taps, contraction = pixels. The taps-as-N kernel above
+// builds its im2col tile tap by tap (a clamped 4-byte gather with its own coordinate arithmetic per element) and is bound by that gather. Here a
+// workgroup walks 128-pixel segments of ONE gradient row: the R input rows under it are staged in LDS once (coalesced, zero-filled outside the
+// image), lane n owns tap n for the whole launch, so its B operand of pixel pair j is rows[off(n) + j] - one ds_read_b32 at an address that
+// only advances - and the A operand (dy[pixel][k]) comes straight from global memory, 128 contiguous bytes per half-wavefront, all loads of
+// a segment issued before the first MFMA. v_mfma_f32_32x32x2_f32, 2 x ceil(taps / 32) per pixel pair; the bias gradient is the column sum of
+// the A operands. One partial image [tap][64] (+64 bias sums) per workgroup, waves summed in a fixed order.
+template <int R, int S>
+__global__ __launch_bounds__(256) void wgrad_c1_rows_kernel(WgK a, int qtiles, int nseg) {
+  constexpr int T = R * S, NB = (T + 31) / 32, QT = 128, RW = QT + S - 1, STEPS = 16;
+  __shared__ float rows[R * RW];
+  __shared__ float red[3][2 * NB * 16 * 64 + 128];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int set = a.sets > 1 ? (int)blockIdx.x / a.gx : 0;
+  const float* __restrict__ au = a.u + (a.set_on_v ? 0ll : (long long)set * a.Mtot * 64);
+  const float* __restrict__ av = a.v + (a.set_on_v ? (long long)set * a.N * a.H * a.W : 0ll);
+  const int b0 = (int)blockIdx.x - set * a.gx;
+  int toff[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int tap = min(nb * 32 + l31, T - 1);                 // (lanes past the last tap repeat it: their columns are never stored)
+    toff[nb] = (tap / S) * RW + tap % S + wid * 32 + lhi;
+  }
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mb][nb][e] = 0.f;
+  float bsum[2] = {0.f, 0.f};
+  for (int seg = b0; seg < nseg; seg += a.gx) {
+    const int qt = seg % qtiles, t2 = seg / qtiles;
+    const int p = t2 % a.P, n = t2 / a.P;
+    const int q0 = qt * QT;
+    // A operands of this wavefront's 32 pixels: dy[(n, p, q0 + 32 wid + 2 st + lhi)][l31 (+32)], zero past the row's end
+    float af[STEPS][2];
+    const float* dyrow = au + ((long long)(n * a.P + p) * a.Q) * 64;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      const int q = q0 + wid * 32 + 2 * st + lhi;
+      const bool ok = q < a.Q;
+      const float* src = dyrow + (long long)(ok ? q : 0) * 64 + l31;
+      const float v0 = src[0], v1 = src[32];
+      af[st][0] = ok ? v0 : 0.f; af[st][1] = ok ? v1 : 0.f;
+    }
+    __syncthreads();                                    // the previous segment's operand reads are done
+    for (int i = tid; i < R * RW; i += 256) {
+      const int r = i / RW, c = i - r * RW;
+      const int ih = p - a.ph + r, iw = q0 - a.pw + c;
+      const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+      rows[i] = ok ? av[((long long)n * a.H + ih) * a.W + iw] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      bsum[0] += af[st][0]; bsum[1] += af[st][1];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float bfv = rows[toff[nb] + 2 * st];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[st][mb], bfv, acc[mb][nb], 0, 0, 0);
+      }
+    }
+  }
+  // fixed-order sum over the four wavefronts: 3, 2, 1 park their accumulators, wavefront 0 adds them in that order and writes the image
+  bsum[0] += __shfl_xor(bsum[0], 32, 64); bsum[1] += __shfl_xor(bsum[1], 32, 64);
+  __syncthreads();
+  if (wid > 0) {
+    float* slot = red[wid - 1];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) slot[((mb * NB + nb) * 16 + e) * 64 + lane] = acc[mb][nb][e];
+    if (lane < 32) { slot[2 * NB * 16 * 64 + lane] = bsum[0]; slot[2 * NB * 16 * 64 + 32 + lane] = bsum[1]; }
+  }
+  __syncthreads();
+  if (wid == 0) {
+    float* pout = a.part + (long long)blockIdx.x * a.pstride;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = ((mb * NB + nb) * 16 + e) * 64 + lane;
+          const float v = ((acc[mb][nb][e] + red[0][i]) + red[1][i]) + red[2][i];
+          // C/D layout: col (tap) = lane & 31, row (k) = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+          const int tap = nb * 32 + l31, k = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+          if (tap < T) pout[tap * 64 + k] = v;
+        }
+    if (a.bias_on && lane < 32) {
+      const int o = 2 * NB * 16 * 64;
+      pout[T * 64 + lane] = ((bsum[0] + red[0][o + lane]) + red[1][o + lane]) + red[2][o + lane];
+      pout[T * 64 + 32 + lane] = ((bsum[1] + red[0][o + 32 + lane]) + red[1][o + 32 + lane]) + red[2][o + 32 + lane];
+    }
+  }
+}
+static bool wgrad_is_c1_rows(const hwg_conv_desc* d) {
+  return hwg_tune().wgrad_c1 != 1 && hwg_tune().wgrad_c1_rows && d->C == 1 && d->K == 64 && d->R == d->S && (d->R == 3 || d->R == 5 || d->R == 7) &&
+         d->stride_h == 1 && d->stride_w == 1 && d->dil_h == 1 && d->dil_w == 1 && (long long)d->N * d->P * d->Q >= 4096 &&
+         (long long)d->N * d->P * hwg_cdiv(d->Q, 128) < (1ll << 31) && (long long)d->N * d->H * d->W < (1ll << 31);
+}
 static bool wgrad_is_c1_valu(const hwg_conv_desc* d) {
   return hwg_tune().wgrad_c1 && d->C == 1 && d->K == 64 && d->R == d->S && (d->R == 3 || d->R == 5 || d->R == 7) &&
          (long long)d->N * d->P * d->Q >= 4096 && (long long)d->N * d->P * d->Q * 64 < (1ll << 40) && (long long)d->N * d->H * d->W < (1ll << 31);
@@ -1687,6 +1794,13 @@ static WgPlan plan_wgrad_tapn(const hwg_conv_desc* d) {
   WgPlan p;
   p.cfg = 3; p.bmu = 64; p.bnv = 64; p.bkp = 32;
   p.tiles_u = hwg_cdiv(d->K, 64); p.tiles_v = 1;
+  if (wgrad_is_c1_rows(d)) {      // wgrad_c1_rows_kernel: one partial image per workgroup, the workgroups stride over the 128-pixel segments
+    p.cfg = 5;
+    const long long nseg = (long long)d->N * d->P * hwg_cdiv(d->Q, 128);
+    p.nsplit = (int)(nseg < 512 ? nseg : 512);
+    p.chunk = 0;
+    return p;
+  }
   if (wgrad_is_c1_valu(d)) {      // wgrad_c1_kernel: one partial image per workgroup of four wavefronts, three workgroups per CU
     p.cfg = 4;
     wg_split(p, (long long)d->N * d->P * d->Q, 768);
@@ -1901,6 +2015,12 @@ static int conv_wgrad_run(const hwg_conv_desc* d, const float* u, const float* v
   else if (p.cfg == 0) hipLaunchKernelGGL((wgrad_mfma_kernel<128, 128, 32, 4, 4, 1>), grid, dim3(1024), 0, st, k);
   // 64x64: two wave groups split every 32-pixel K step between them (8 waves; 5..10 % over 4 waves on every measured shape)
   else if (p.cfg == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<64, 64, 32, 2, 2, 2>), grid, dim3(512), 0, st, k);
+  else if (p.cfg == 5) {
+    const int qtiles = hwg_cdiv(d->Q, 128), nseg = d->N * d->P * qtiles;
+    if (d->R == 3) hipLaunchKernelGGL((wgrad_c1_rows_kernel<3, 3>), dim3(gx), dim3(256), 0, st, k, qtiles, nseg);
+    else if (d->R == 5) hipLaunchKernelGGL((wgrad_c1_rows_kernel<5, 5>), dim3(gx), dim3(256), 0, st, k, qtiles, nseg);
+    else hipLaunchKernelGGL((wgrad_c1_rows_kernel<7, 7>), dim3(gx), dim3(256), 0, st, k, qtiles, nseg);
+  }
   else if (p.cfg == 4 && d->R == 3) hipLaunchKernelGGL((wgrad_c1_kernel<3, 3>), dim3(gx), dim3(256), 0, st, k);
   else if (p.cfg == 4 && d->R == 5) hipLaunchKernelGGL((wgrad_c1_kernel<5, 5>), dim3(gx), dim3(256), 0, st, k);
   else if (p.cfg == 4) hipLaunchKernelGGL((wgrad_c1_kernel<7, 7>), dim3(gx), dim3(256), 0, st, k);

@@ -74,8 +74,8 @@ struct HwgTune {
   int to1_lanes;         // HWG_TO1_LANES: 0 = one wave per output pixel whenever taps x channel groups > 16 (A/B timing), 1 default = lanes cover one tap's channel groups
   int conv_lds;          // HWG_CONV_LDS: 0 keeps strided layers on the per-tap gather kernel (A/B timing), 1 default
   int wgrad_c1;          // HWG_WGRAD_C1: 0 default = single-channel first-layer weight gradients on the taps-as-N MFMA kernel, 1 = VALU kernel (wgrad_c1_kernel: measured slower, kept for A/B runs)
+  int wgrad_c1_rows;     // HWG_WGRAD_C1_ROWS: 0 = single-channel first-layer weight gradients on the taps-as-N gather kernel (A/B timing), 1 default = input rows staged in LDS
   int c1_rows;           // HWG_C1_ROWS: 0 = single-input-channel forward convs on the gather kernels (A/B timing), 1 default = input rows staged in LDS, filter in registers
-  int norm_big;          // HWG_NORM_BIG: threshold (pixel passes per chunk cap) from which the normalisation kernels run 1024-thread workgroups, 0 = never, default 256
   int wgrad_reduce_rows; // HWG_WGRAD_REDUCE_ROWS: 0 = tap-at-a-time partial-image reduce (A/B timing), 1 default = row-contiguous stores
   char wino_force[32];   // HWG_WINO_FORCE  "cfg[,nsplit]"
   char wino_bal[32];     // HWG_WINO_BAL    balanced schedule of the 64 x 64 Winograd kernel: -1 never, unset / 0 by model, "G[,lead tiles]" forced

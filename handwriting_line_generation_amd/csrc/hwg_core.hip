@@ -52,8 +52,8 @@ const HwgTune& hwg_tune() {
     t->to1_lanes = tune_int("HWG_TO1_LANES", 1);
     t->wgrad_reduce_rows = tune_int("HWG_WGRAD_REDUCE_ROWS", 1);
     t->wgrad_c1 = tune_int("HWG_WGRAD_C1", 0);
-    t->norm_big = tune_int("HWG_NORM_BIG", 256);
     t->c1_rows = tune_int("HWG_C1_ROWS", 1);
+    t->wgrad_c1_rows = tune_int("HWG_WGRAD_C1_ROWS", 1);
     t->conv_wk = tune_int("HWG_CONV_WK", 2);
     t->c1_mfma = tune_int("HWG_C1_MFMA", 1);
     t->conv_dbg = tune_int("HWG_CONV_DBG", 0);

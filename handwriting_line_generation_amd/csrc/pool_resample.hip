@@ -439,6 +439,38 @@ __global__ __launch_bounds__(256) void col2im_taps_kernel(const float* __restric
   dx[((long long)n * H + ih) * W + iw] = acc;
 }
 
+// The same fold through LDS (dilation 1, square 3x3 / 5x5 / 7x7): in the kernel above neighbouring lanes read t[.., q, tap] R*S floats apart - 64
+// cache lines per load instruction, every tap row of the tile re-fetched R x S times through L1 (52 us for 46 MB of t on the
+// discriminator's 7x7 layer). Here a workgroup copies the (TH + R - 1) x (TW + S - 1) pixel block of t it needs into LDS with contiguous
+// loads (pixels of one row are (TW + S - 1) * R*S consecutive floats) and every thread folds its output pixel from LDS: lanes are R*S floats
+// apart there too, an odd stride - conflict free. Taps are added in the same (r, s) order (absent ones as zeros): bit-identical results.
+template <int R, int S, int TH, int TW>
+__global__ __launch_bounds__(256) void col2im_taps_lds_kernel(const float* __restrict__ t, float* __restrict__ dx, int N, int H, int W, int P, int Q, int ph,
+                                                              int pw) {
+  constexpr int RS = R * S, PH = TH + R - 1, PW = TW + S - 1, ROW = PW * RS;
+  __shared__ float tile[PH * ROW];
+  const int iw0 = blockIdx.x * TW, ih0 = blockIdx.y * TH, n = blockIdx.z;
+  const int p_lo = ih0 + ph - (R - 1), q_lo = iw0 + pw - (S - 1);
+  for (int i = threadIdx.x; i < PH * ROW; i += 256) {
+    const int pl = i / ROW, rem = i - pl * ROW;
+    const int p = p_lo + pl, q = q_lo + rem / RS;
+    const bool ok = p >= 0 && p < P && q >= 0 && q < Q;
+    // (row pl of the tile is ROW consecutive floats of t starting at pixel q_lo: rem is the offset inside it)
+    tile[i] = ok ? t[((long long)n * P + p) * Q * RS + (long long)q_lo * RS + rem] : 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x >= TH * TW) return;
+  const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
+  const int iw = iw0 + tx, ih = ih0 + ty;
+  if (iw >= W || ih >= H) return;
+  float acc = 0.f;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int s2 = 0; s2 < S; ++s2) acc += tile[((ty + (R - 1) - r) * PW + (tx + (S - 1) - s2)) * RS + r * S + s2];
+  dx[((long long)n * H + ih) * W + iw] = acc;
+}
+
 }  // namespace
 
 extern "C" int hwg_avgpool_fwd(const float* x, float* y, int N, int H, int W, int C, int kh, int kw, void* stream) {
@@ -634,6 +666,15 @@ extern "C" int hwg_fused_upsample_weight_bwd_acc(const float* dw4, float* dw3, l
 extern "C" int hwg_col2im_taps(const float* t, float* dx, int N, int H, int W, int P, int Q, int R, int S, int pad_h, int pad_w, int dil_h, int dil_w,
                                void* stream) {
   HWG_REQUIRE(t && dx && N > 0 && H > 0 && W > 0 && P > 0 && Q > 0 && R > 0 && S > 0 && dil_h > 0 && dil_w > 0, "col2im_taps: bad arguments");
+  static const int lds_on = [] { const char* e = getenv("HWG_COL2IM_LDS"); return e && *e ? atoi(e) : 1; }();      // 0: the direct gather (A/B timing)
+  if (lds_on && dil_h == 1 && dil_w == 1 && R == S && (R == 3 || R == 5 || R == 7) && (long long)N * P * Q * R * S < (1ll << 31)) {
+    hipStream_t st = (hipStream_t)stream;
+    if (R == 3) hipLaunchKernelGGL((col2im_taps_lds_kernel<3, 3, 8, 32>), dim3(hwg_cdiv(W, 32), hwg_cdiv(H, 8), N), dim3(256), 0, st, t, dx, N, H, W, P, Q, pad_h, pad_w);
+    else if (R == 5) hipLaunchKernelGGL((col2im_taps_lds_kernel<5, 5, 8, 32>), dim3(hwg_cdiv(W, 32), hwg_cdiv(H, 8), N), dim3(256), 0, st, t, dx, N, H, W, P, Q, pad_h, pad_w);
+    else hipLaunchKernelGGL((col2im_taps_lds_kernel<7, 7, 8, 16>), dim3(hwg_cdiv(W, 16), hwg_cdiv(H, 8), N), dim3(256), 0, st, t, dx, N, H, W, P, Q, pad_h, pad_w);
+    HWG_LAUNCH_CHECK("col2im_taps_lds");
+    return HWG_OK;
+  }
   hipLaunchKernelGGL(col2im_taps_kernel, dim3(hwg_cdiv(W, 64), hwg_cdiv(H, 4), N), dim3(256), 0, (hipStream_t)stream, t, dx, N, H, W, P, Q, R, S, pad_h,
                      pad_w, dil_h, dil_w);
   HWG_LAUNCH_CHECK("col2im_taps");

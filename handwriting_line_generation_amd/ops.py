@@ -860,6 +860,9 @@ def _make_wgrad_plan(N, H, W, C, K, R, S, sh, sw, ph, pw, dh, dw, P, Q, transpos
     return d, 2, L.query("hwg_conv_wgrad_workspace", d.ptr), Kq, Cq, tiny_end, tap_gemm
 
 
+ONEROW_TWIN_DEAD_ROWS = bool(int(os.environ.get("HWG_ONEROW_DEAD_ROWS", "1") or 0))     # 0: inputs with dead rows (H > R, one output row) keep the sh-strided classes (A/B)
+
+
 class _Conv2d(Function):
     """y = conv2d(x, w) (+b) or conv_transpose2d(x, w) (+b); x NHWC."""
 
@@ -1081,7 +1084,7 @@ class _Conv2d(Function):
                     # (one output row, H == R: the vertical stride never moves - stride R gives every input row its own class of 1 x S taps
                     # where stride sh pairs each class with R / sh tap rows of which all but one meet nothing; the style extractor's last
                     # 4x4 stride-(2,1) layer)
-                    if P == 1 and ph == 0 and H >= R and R > sh:
+                    if P == 1 and ph == 0 and R > sh and (H == R or (H > R and ONEROW_TWIN_DEAD_ROWS)):
                         # (H > R: rows R.. of the input never met the filter - the style extractor's last block sees 5 rows and uses 4. They
                         # get zeros; the R live rows run as the stride-R twin instead of sh-strided classes whose second block row is dead:
                         # 4x1x254x256 -> 4x5x257x256: 81 -> ~50 us)

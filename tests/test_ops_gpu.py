@@ -83,8 +83,13 @@ CONV_CASES = [
     ("narrow_16to32_4x4s2", 3, 128, 200, 16, 32, 4, 4, (2, 2), (1, 1), (1, 1), False),
     ("narrow_32x32_3x3_pad0", 2, 42, 258, 32, 32, 3, 3, (1, 1), (0, 0), (1, 1), False),
     ("narrow_c20_k24", 2, 64, 161, 20, 24, 3, 3, (1, 1), (1, 1), (1, 1), False),
-    # single-channel first layers with 64 filters and >= 4096 output pixels on the VALU weight-gradient kernel (wgrad_c1_kernel, HWG_WGRAD_C1=1;
+    # single-channel first layers with 64 filters and >= 4096 output pixels: weight gradient with the input rows staged in LDS (c1rows_*, the
+    # default) - ragged last segment, pads 0 / 1 / 2 / 3 - and on the VALU weight-gradient kernel (wgrad_c1_kernel, HWG_WGRAD_C1=1;
     # off by default: measured slower than the taps-as-N MFMA kernel) - ragged last 64-pixel group, pad 0 / 1 / 3, dilation, few and many ranges
+    ("c1rows_3x3", 3, 40, 67, 1, 64, 3, 3, (1, 1), (1, 1), (1, 1), False),
+    ("c1rows_5x5_pad0", 2, 36, 131, 1, 64, 5, 5, (1, 1), (0, 0), (1, 1), False),
+    ("c1rows_7x7", 2, 70, 150, 1, 64, 7, 7, (1, 1), (0, 3), (1, 1), False),
+    ("c1rows_7x7_pad2", 5, 33, 129, 1, 64, 7, 7, (1, 1), (2, 2), (1, 1), False),
     ("c1valu_3x3", 3, 40, 67, 1, 64, 3, 3, (1, 1), (1, 1), (1, 1), False),
     ("c1valu_5x5_pad0", 2, 36, 131, 1, 64, 5, 5, (1, 1), (0, 0), (1, 1), False),
     ("c1valu_7x7_dil2", 2, 70, 150, 1, 64, 7, 7, (1, 1), (3, 6), (1, 2), False),
@@ -104,6 +109,8 @@ def test_conv_fwd_bwd(cuda, case):
         # the library picks Winograd or the direct kernels per geometry from its cost models; these cases must run the Winograd kernels
         with ops.tuning(HWG_WINO="2"):
             return _conv_case(cuda, ops, case, expect_fwd_engine=6)
+    if name.startswith("c1rows_") or name == "c1_7x7_many_chunks":       # the default for >= 4096 output pixels: input rows staged in LDS (wgrad_c1_rows_kernel)
+        return _conv_case(cuda, ops, case, expect_wgrad_cfg=15)
     if name.startswith("c1valu_"):
         with ops.tuning(HWG_WGRAD_C1="1"):
             return _conv_case(cuda, ops, case, expect_wgrad_cfg=14)
