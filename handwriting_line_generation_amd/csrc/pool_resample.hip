@@ -451,12 +451,25 @@ __global__ __launch_bounds__(256) void col2im_taps_lds_kernel(const float* __res
   __shared__ float tile[PH * ROW];
   const int iw0 = blockIdx.x * TW, ih0 = blockIdx.y * TH, n = blockIdx.z;
   const int p_lo = ih0 + ph - (R - 1), q_lo = iw0 + pw - (S - 1);
-  for (int i = threadIdx.x; i < PH * ROW; i += 256) {
-    const int pl = i / ROW, rem = i - pl * ROW;
-    const int p = p_lo + pl, q = q_lo + rem / RS;
-    const bool ok = p >= 0 && p < P && q >= 0 && q < Q;
-    // (row pl of the tile is ROW consecutive floats of t starting at pixel q_lo: rem is the offset inside it)
-    tile[i] = ok ? t[((long long)n * P + p) * Q * RS + (long long)q_lo * RS + rem] : 0.f;
+  // (row pl of the tile is ROW consecutive floats of t starting at pixel q_lo; eight loads per thread in flight: a workgroup copies 12-60 KB and
+  // one load at a time made the copy a chain of 47-59 memory latencies)
+  constexpr int UL = 8;
+  for (int i0 = threadIdx.x; i0 < PH * ROW; i0 += UL * 256) {
+    float v[UL];
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+      const int i = i0 + u * 256;
+      const int ic = i < PH * ROW ? i : i0;
+      const int pl = ic / ROW, rem = ic - pl * ROW;
+      const int p = p_lo + pl, q = q_lo + rem / RS;
+      const bool ok = p >= 0 && p < P && q >= 0 && q < Q;
+      const long long off = ((long long)n * P + (ok ? p : 0)) * Q * RS + (long long)(ok ? q_lo : 0) * RS + (ok ? rem : 0);
+      const float x = t[off];
+      v[u] = ok ? x : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UL; ++u)
+      if (i0 + u * 256 < PH * ROW) tile[i0 + u * 256] = v[u];
   }
   __syncthreads();
   if (threadIdx.x >= TH * TW) return;

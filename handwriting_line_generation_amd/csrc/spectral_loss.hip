@@ -266,6 +266,14 @@ __global__ void scale_scalars_kernel(const float* gout, WSum a, float* out) {
   const int i = threadIdx.x;
   if (i < a.n) out[i] = a.w[i] == 1.f ? *gout : __fmul_rn(*gout, a.w[i]);
 }
+// out[b][d] = bank[ij[b]][d] * w[b] + bank[ij[B + b]][d] * w[B + b]: the trainer's style interpolation (trainer/hw_with_style_trainer.py:974-988) in one
+// launch; both products and the sum rounded to fp32 like the tensor expression it replaces
+__global__ void style_mix_kernel(const float* bank, const int* ij, const float* w, float* out, int B, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, d = i - b * D;
+  out[i] = __fadd_rn(__fmul_rn(bank[(long long)ij[b] * D + d], w[b]), __fmul_rn(bank[(long long)ij[B + b] * D + d], w[B + b]));
+}
 __global__ void tanh_fwd_kernel(const float* x, float* y, long long n) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = tanhf(x[i]);
 }
@@ -454,6 +462,12 @@ extern "C" int hwg_weighted_sum_bwd(const float* grad_out, const float* weights,
   for (int i = 0; i < n; ++i) { a.x[i] = nullptr; a.w[i] = weights[i]; }
   hipLaunchKernelGGL(scale_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, grad_out, a, grads);
   HWG_LAUNCH_CHECK("weighted_sum_bwd");
+  return HWG_OK;
+}
+extern "C" int hwg_style_mix(const float* bank, const int* ij, const float* w, float* out, int K, int B, int D, void* stream) {
+  HWG_REQUIRE(bank && ij && w && out && K > 0 && B > 0 && D > 0, "style_mix: bad arguments");
+  hipLaunchKernelGGL(style_mix_kernel, dim3(hwg_cdiv((long long)B * D, 256)), dim3(256), 0, (hipStream_t)stream, bank, ij, w, out, B, D);
+  HWG_LAUNCH_CHECK("style_mix");
   return HWG_OK;
 }
 extern "C" int hwg_tanh_fwd(const float* x, float* y, long long n, void* stream) {

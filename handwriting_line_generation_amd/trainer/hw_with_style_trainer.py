@@ -656,10 +656,20 @@ class HWWithStyleTrainer(BaseTrainer):
             indexes = np.random.randint(0, len(self.prev_styles), (batch_size, 2))
             mix = np.random.uniform(self.interpolate_gen_styles_low, self.interpolate_gen_styles_high, batch_size)
             bank = torch.stack(self.prev_styles, dim=0)
+            if bank.is_cuda and bank.dtype == torch.float32:
+                # one upload (the two index rows as int32 next to the two weight rows as float32) and one launch (hwg_style_mix) instead of two
+                # uploads, two index gathers, two products and a sum. The reference multiplies float32 tensors by numpy float64 scalars: the
+                # scalar is rounded to float32, the product is float32 - the kernel rounds both products and the sum the same way
+                host = np.empty((4, batch_size), dtype=np.float32)
+                host[:2].view(np.int32)[:] = indexes.T
+                host[2] = mix.astype(np.float32); host[3] = (1 - mix).astype(np.float32)
+                dev_ = ops.h2d(host, device)
+                out = torch.empty((batch_size, bank.shape[1]), dtype=torch.float32, device=device)
+                ops.L.call("hwg_style_mix", bank, dev_[:2].view(torch.int32), dev_[2:], out, bank.shape[0], batch_size, bank.shape[1], ops._stream())
+                return out
             ij = ops.h2d(indexes.T.copy(), device)
             a = bank[ij[0]]
             b = bank[ij[1]]
-            # the reference multiplies float32 tensors by numpy float64 scalars: the scalar is rounded to float32, the product is float32
             mm = ops.h2d(np.stack([mix.astype(np.float32), (1 - mix).astype(np.float32)]), device)
             return (a * mm[0][:, None] + b * mm[1][:, None]).contiguous()
         return ops.h2d(torch.randn(batch_size, self.model.style_dim), device)

@@ -368,6 +368,9 @@ int hwg_pixelnorm_bwd(const float* dy, const float* x, float* dx, int rows, int 
  * rounded like the chain of hwg_axpby launches it replaces; _bwd: grads[i] = weights[i] * *grad_out */
 int hwg_weighted_sum(const void* x_ptrs, const float* weights, int n, float* scaled, float* sum, void* stream);
 int hwg_weighted_sum_bwd(const float* grad_out, const float* weights, int n, float* grads, void* stream);
+/* out[b] = bank[ij[b]] * w[b] + bank[ij[B + b]] * w[B + b] over rows of D floats (bank [K][D], ij int32 [2][B], w [2][B], all on the device): the
+ * interpolation of two stored styles per generated line (trainer/hw_with_style_trainer.py:974-988), products and sum rounded to fp32 */
+int hwg_style_mix(const float* bank, const int* ij, const float* w, float* out, int K, int B, int D, void* stream);
 int hwg_axpby(const float* x, float a, const float* y, float b, float* out, long long n, void* stream);
 /* y = x*scale[c] + shift[c] on x[rows][C] (CountCNN output scaling, count_cnn.py:44); out = a*b elementwise */
 int hwg_channel_affine(const float* x, const float* scale, const float* shift, float* y, long long rows, int C, void* stream);

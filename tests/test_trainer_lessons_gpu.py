@@ -219,8 +219,15 @@ def test_lessons_match_reference_per_tensor(cuda, tmp_path, case):
         strict = sum(1 for g in summary if g[4] == TOL)
         print("\n[%s] %d tensor comparisons in %d groups, %d groups held at %.0e; (iteration, kind, sub-network): tensors, HIP rms error, reference rms error, bound" %
               (case, len(rows), len(summary), strict, TOL))
+        table = ["[%s, chained from seeded weights] %d tensor comparisons in %d groups, %d groups held at %.0e; (iteration, kind, sub-network): tensors, HIP rms error "
+                 "vs fp64, reference fp32 rms error vs fp64, bound" % (case, len(rows), len(summary), strict, TOL)]
         for key, n, rh, rr, bound in summary:
             print("   it%d %-6s %-16s %5d  %.2e  %.2e  %.2e" % (key[0], key[1], key[2], n, rh, rr, bound))
+            table.append("   it%d %-6s %-16s %5d  %.2e  %.2e  %.2e" % (key[0], key[1], key[2], n, rh, rr, bound))
+        if os.environ.get("HWG_PARITY_SUMMARY"):      # (the chained cycles' group table next to the teacher-forced ones)
+            os.makedirs(os.path.dirname(os.path.abspath(os.environ["HWG_PARITY_SUMMARY"])), exist_ok=True)
+            with open(os.environ["HWG_PARITY_SUMMARY"], "a") as fh:
+                fh.write("\n".join(table) + "\n\n")
         if os.environ.get("HWG_LESSON_VERBOSE"):
             seen_k = {}
             for it, kind, top, n, eh, er, cd, sp, _ in sorted([r for r in rows if r[2] != "hwr"], key=lambda r: (r[0], r[1], -r[4])):
@@ -758,6 +765,7 @@ def test_lessons_teacher_forced(cuda, tmp_path, case):
             excl.append("      %-22s signs %d, max-pool winners %d, arg-max columns %d [%d]%s" % (
                 tag_, c["act"], c["pool"], c.get("argmax", 0), c["unit_so_far"], "  (op sequences differed: %d)" % c["mismatch"] if c["mismatch"] else ""))
         f_tol = f_bound = 0
+        f_outside = []
         for key_, errs_ in groups_f.items():
             if key_ in groups:
                 rf_ = math.sqrt(sum(e ** 2 for e in errs_) / len(errs_))
@@ -765,12 +773,16 @@ def test_lessons_teacher_forced(cuda, tmp_path, case):
                 b_ = min(max(TOL, TF_SLACK * rr_), CAP)
                 f_tol += int(rf_ <= TOL); f_bound += int(rf_ <= b_)
                 left_ = sum(c for net, c in forced_unit.get(key_[0], {}).items() if net in gate_records.DOWNSTREAM.get(key_[2], ()))
+                if rf_ > b_:
+                    f_outside.append("      outside its arithmetic bound in the forced pass: %s %s %s: %.2e > %.2e with %d flip(s) LEFT downstream "
+                                     "(gates the record's near-zero / near-tie lists could not locate)" % (key_[0], key_[1], key_[2], rf_, b_, left_))
                 if rf_ > b_ and left_ == 0:
                     # the forced pass is the strict form of the bar: with every gate downstream of a group on the reference's fp64 branch NO
                     # group - flip-labelled in the judged pass or not - may be outside its arithmetic bound
                     bad.append("%s %s %s: forced pass %.2e > bound %.2e with no flip left downstream" % (key_[0], key_[1], key_[2], rf_, b_))
         excl.append("   forced pass, all %d groups: %d within %.0e of the reference's fp64 values, %d within their arithmetic bound (no flip allowance)" % (
             len(groups_f), f_tol, TOL, f_bound))
+        excl.extend(f_outside)
         excl.append("   gate forcing: %d element(s) nudged by 1e-5 onto the reference's fp64 side of their gate in a third pass; %d of the %d flip-labelled groups are within "
                     "their arithmetic bound there (a group with flips LEFT keeps gates the near-zero / near-tie lists of the record could not locate)" % (
                         GATE_FORCED[0], collapsed, flips))
