@@ -32,7 +32,8 @@ struct ConvK {
   int ntm;         // M tiles of the largest parity class
   int ntm_pad;     // ntm rounded up to a multiple of 8 (XCD remap)
   int nsplit;      // split-K: the taps x channel-steps loop is cut into nsplit ranges, one workgroup each (blockIdx.y % nsplit)
-  float* part;     // nsplit > 1: partial outputs [nsplit][N*P*Q*K] in y's layout, summed (+bias) by conv_split_reduce_kernel
+  float* part;     // nsplit > 1: partial outputs [nsplit][N*P*Q*K] in y's layout, summed (+bias) by the last wavefront to arrive (cnt) or by conv_split_reduce_kernel
+  int* cnt;        // nsplit > 1: arrival counters, one per (tile, wavefront sub-tile), zero between launches; nullptr = separate reduce launch
   int dbg;         // ABL kernel only (HWG_CONV_DBG, timing ablations of the 128 x 128 tile - results are garbage): 1 no global loads in the loop, 2 no LDS
                    // stores, 4 no barrier, 8 no MFMAs / fragment reads, 16 no fragment reads (MFMAs on stale registers), 32 nothing (the ABL build itself).
                    // Round 5 (tools/probes/probe_r5_abl7.txt, warm clocks, 4x66x1026x64->128 4x4 stride 2): 147.6 us as shipped; MFMAs alone 130 us
@@ -367,48 +368,75 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
     }
     bv[ni] = (a.bias && a.nsplit == 1 && col < a.KN) ? a.bias[ck[ni]] : 0.f;
   }
-  float* __restrict__ yg = a.nsplit == 1 ? a.y : a.part + (long long)split * ((long long)a.N * a.P * a.Q * a.K);
-  const bool accum = a.accumulate && a.nsplit == 1;
+  // every (accumulator element, output offset) pair this lane owns - the same set for every split of a tile
+  auto for_each_out = [&](auto&& f) {
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-      const int m = m0 + row;
-      if (m >= Mc) continue;
-      if (a.mode == 2) {
-        const int qi = row_q[row], pi = row_p[row], n = row_n[row];
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+        const int m = m0 + row;
+        if (m >= Mc) continue;
+        if (a.mode == 2) {
+          const int qi = row_q[row], pi = row_p[row], n = row_n[row];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const int col = n0 + wn0 + ni * 32 + l31;
+            const int p = a.sh * (pi - c_bh[ni]) + c_p[ni], q = a.sw * (qi - c_bw[ni]) + c_q[ni];
+            if (col < a.KN && pi >= c_bh[ni] && p < a.P && qi >= c_bw[ni] && q < a.Q) f(mi, ni, e, (((long long)n * a.P + p) * a.Q + q) * a.K + ck[ni]);
+          }
+          continue;
+        }
+        long long obase;
+        if (a.mode == 0) {
+          obase = (long long)m * a.K;
+        } else {
+          const int qi = row_q[row], pi = row_p[row], n = row_n[row];
+          obase = (((long long)n * a.P + (cp + a.sh * pi)) * a.Q + (cq + a.sw * qi)) * a.K;
+        }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           const int col = n0 + wn0 + ni * 32 + l31;
-          const int p = a.sh * (pi - c_bh[ni]) + c_p[ni], q = a.sw * (qi - c_bw[ni]) + c_q[ni];
-          if (col < a.KN && pi >= c_bh[ni] && p < a.P && qi >= c_bw[ni] && q < a.Q) {
-            const long long o = (((long long)n * a.P + p) * a.Q + q) * a.K + ck[ni];
-            float v = acc[mi][ni][e] + bv[ni];
-            if (accum) v += yg[o];
-            yg[o] = v;
-          }
-        }
-        continue;
-      }
-      long long obase;
-      if (a.mode == 0) {
-        obase = (long long)m * a.K;
-      } else {
-        const int qi = row_q[row], pi = row_p[row], n = row_n[row];
-        obase = (((long long)n * a.P + (cp + a.sh * pi)) * a.Q + (cq + a.sw * qi)) * a.K;
-      }
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int col = n0 + wn0 + ni * 32 + l31;
-        if (col < a.K) {
-          float v = acc[mi][ni][e] + bv[ni];
-          if (accum) v += yg[obase + col];
-          yg[obase + col] = v;
+          if (col < a.K) f(mi, ni, e, obase + col);
         }
       }
     }
+  };
+  if (a.nsplit == 1) {
+    float* __restrict__ yg = a.y;
+    const bool accum = a.accumulate;
+    for_each_out([&](int mi, int ni, int e, long long o) {
+      float v = acc[mi][ni][e] + bv[ni];
+      if (accum) v += yg[o];
+      yg[o] = v;
+    });
+    return;
   }
+  const long long total = (long long)a.N * a.P * a.Q * a.K;
+  {
+    float* __restrict__ pg = a.part + (long long)split * total;
+    for_each_out([&](int mi, int ni, int e, long long o) { pg[o] = acc[mi][ni][e]; });
+  }
+  if (!a.cnt) return;                                  // partial images summed by conv_split_reduce_kernel
+  // The wavefront that delivers the LAST of a sub-tile's nsplit partial images sums them itself - in split order, then bias, then the old
+  // output: the arithmetic of conv_split_reduce_kernel, bit for bit - and writes the output: no second launch, the partials are read where
+  // they were written (L2). Every split's wavefront of a sub-tile owns the same output offsets, so nothing but the arrival counter crosses
+  // wavefronts (hwg_split_arrive_wave, hwg_common.h).
+  if (!hwg_split_arrive_wave(a.cnt + (((size_t)blockIdx.z * (gridDim.y / a.nsplit) + blockIdx.y / a.nsplit) * gridDim.x + blockIdx.x) * WMN + wmn, a.nsplit)) return;
+  float bl[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) bl[ni] = (a.bias && n0 + wn0 + ni * 32 + l31 < a.KN) ? a.bias[ck[ni]] : 0.f;
+  const float* pr = a.part;
+  float* yg = a.y;
+  const int nsplit = a.nsplit;
+  const bool accum = a.accumulate, has_bias = a.bias != nullptr;
+  for_each_out([&](int, int ni, int, long long o) {
+    float v = pr[o];
+    for (int sp = 1; sp < nsplit; ++sp) v += pr[sp * total + o];
+    if (has_bias) v += bl[ni];
+    if (accum) v += yg[o];
+    yg[o] = v;
+  });
 }
 
 // y[i] = (accumulate ? y[i] : 0) + bias[i % K] + sum_s part[s][i]   (split-K epilogue; fixed summation order -> deterministic)
@@ -1401,11 +1429,19 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
   k.accumulate = accumulate;
   k.nsplit = p.nsplit;
   k.part = (float*)workspace;
+  k.cnt = nullptr;
   k.dbg = hwg_tune().conv_dbg;
   const int bm = p.bm, bn = p.bn, bk = p.bk;
   k.ntm = hwg_cdiv(p.Mc, bm);
   k.ntm_pad = (k.ntm + 7) / 8 * 8;
   dim3 grid(k.ntm_pad, hwg_cdiv(p.KN, bn) * p.nsplit, p.classes);
+  if (p.nsplit > 1 && hwg_tune().split_inkernel) {
+    const int wmn = bm == 64 ? 4 : 4 * (bn / 32);                      // wavefront sub-tiles per tile (WAVES_M x WAVES_N of the cases below)
+    if ((long long)k.ntm_pad * hwg_cdiv(p.KN, bn) * p.classes * wmn <= HWG_SPLIT_COUNTERS) {
+      k.cnt = hwg_split_counters(st);
+      if (!k.cnt) return HWG_ERR_LAUNCH;
+    }
+  }
   // algorithmic work: every output pixel x K x C x taps (transposed: every input pixel feeds RxS outputs)
   const double pix = d->transposed ? (double)d->N * d->H * d->W : (double)d->N * d->P * d->Q;
   const int prof = hwg_prof_open(HWG_PROF_CONV, 2.0 * pix * d->K * d->C * d->R * d->S, st);
@@ -1426,7 +1462,7 @@ extern "C" int hwg_conv_fwd(const hwg_conv_desc* d, const float* x, const float*
   hwg_prof_close(prof, st);
   hwg_note_plan(HWG_PROF_CONV, bm * 1000 + bn + (p.merged ? 1000000 : 0), p.nsplit);      // (+ 1000000: merged parity classes)
   HWG_LAUNCH_CHECK("conv_fwd");
-  if (p.nsplit > 1) {
+  if (p.nsplit > 1 && !k.cnt) {
     const long long total = (long long)d->N * d->P * d->Q * d->K;
     const int prof2 = hwg_prof_open(HWG_PROF_CONV_REDUCE, 4.0 * total * (p.nsplit + 1), st);
     hipLaunchKernelGGL(conv_split_reduce_kernel, dim3(hwg_stream_grid(total / 4 + 1, 256)), dim3(256), 0, st, (const float*)workspace, bias, y, total,

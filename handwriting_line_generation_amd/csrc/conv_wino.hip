@@ -30,6 +30,7 @@ struct WinoK {
   int accumulate;
   int nsplit;          // the C/16 chunk loop is cut into nsplit ranges (blockIdx.z); partial outputs go to `part`
   float* part;         // [nsplit][N*P*Q*K]
+  int* cnt;            // uniform split: arrival counters (hwg_split_counters), nullptr = the partial images are summed by conv_split_reduce_kernel
   int mt, nt;          // workgroup tiles along M and K
   int xcd_order;       // 1: every XCD owns a contiguous run of the (split, n-tile, m-tile) sequence, 0: plain launch order
   int bal;             // > 0 (64 x 64 DMA kernel only): the tiles from `bal_tile0` on are scheduled BALANCED on `bal` workgroups - their (tile, chunk)
@@ -302,6 +303,36 @@ __global__ __launch_bounds__(64 * WGM * WGN) void wino_conv_kernel(WinoK a) {
         float v = y2[i][j] + bv;
         if (accum) v += yg[o];
         yg[o] = v;
+      }
+    }
+  }
+  if (direct || !a.cnt) return;
+  // channel split without a reduce launch: the wavefront that delivers its 16 x 16 block's last partial image sums them (hwg_split_arrive_wave)
+  if (!hwg_split_arrive_wave(a.cnt + ((size_t)ntile * a.mt + mtile) * (WGM * WGN) + wid, a.nsplit)) return;
+  const long long total = (long long)a.N * a.P * a.Q * a.K;
+  const float bl = (a.bias && k < a.K) ? a.bias[k] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int m = m0 + wm * 16 + (lane >> 4) * 4 + e;
+    if (m >= a.M || k >= a.K) continue;
+    const int tj = m % a.TQ;
+    const int t2 = m / a.TQ;
+    const int ti = t2 % a.TP;
+    const int n = t2 / a.TP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = 2 * ti + i;
+      if (p >= a.P) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int q = 2 * tj + j;
+        if (q >= a.Q) continue;
+        const long long o = (((long long)n * a.P + p) * a.Q + q) * a.K + k;
+        float v = a.part[o];
+        for (int sp = 1; sp < a.nsplit; ++sp) v += a.part[sp * total + o];
+        if (a.bias) v += bl;
+        if (a.accumulate) v += a.y[o];
+        a.y[o] = v;
       }
     }
   }
@@ -1098,11 +1129,13 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
   __syncthreads();
   bool direct = a.nsplit == 1;
   int piece = split;
+  int pieces = a.nsplit, slot_id = ntile * a.mt + mtile;      // partial images this tile is written in; its arrival counter
   if (BAL && !whole) {
     const int rel = unit / T_all;
     const int g_first = wino_bal_owner(a.bal, U_bal, rel * T_all), g_last = wino_bal_owner(a.bal, U_bal, rel * T_all + T_all - 1);
     direct = g_first == g_last;
     piece = wg - g_first;
+    pieces = g_last - g_first + 1; slot_id = rel;
   }
   if constexpr ((ABL & 1) != 0) {
     if (a.dbg & 2048) {      // timing ablation: no output transform (the accumulators stay alive through one store that never happens)
@@ -1239,6 +1272,48 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
             if (accum) v += yg[o];
             yg[o] = v;
           }
+        }
+      }
+    }
+  }
+  // Partial images without a reduce launch: the workgroup that delivers its tile's last piece sums them in piece order (hwg_split_arrive_block) -
+  // the arithmetic of conv_split_reduce_kernel (uniform split) / wino_bal_reduce_kernel (a tile cut by the balanced schedule's workgroup
+  // boundaries), bit for bit. Every thread revisits the outputs it stored above (tile_out / tile_ext are still in LDS).
+  if (!direct && a.cnt) {
+    __shared__ int last_flag;
+    if (hwg_split_arrive_block(a.cnt + slot_id, pieces, &last_flag)) {
+      const long long total = (long long)a.N * a.P * a.Q * a.K;
+      const int k = n0 + (tid & 63);
+      const float bl = (a.bias && k < a.K) ? a.bias[k] : 0.f;
+      auto finish = [&](long long o) {
+        float v = BAL ? 0.f : a.part[o];
+        for (int sp = BAL ? 0 : 1; sp < pieces; ++sp) v += a.part[sp * total + o];
+        if (a.bias) v += bl;
+        if (a.accumulate) v += a.y[o];
+        a.y[o] = v;
+      };
+      if constexpr (MT == 2) {
+        for (int tile = tid >> 6; tile < 64; tile += 8) {
+          const int base = tile_out[tile], ext = tile_ext[tile];
+          if (base < 0 || k >= a.K) continue;
+          const long long ob = (long long)base * a.K + k;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if (i && !(ext & 1)) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              if (j && !(ext & 2)) continue;
+              finish(ob + (i * a.Q + j) * a.K);
+            }
+          }
+        }
+      } else {
+        const long long kch = (long long)(k / a.y_kc) * a.y_run + (k % a.y_kc);
+        for (int tile = tid >> 6; tile < 64; tile += 8) {
+          const int base = tile_out[tile], ext = tile_ext[tile];
+          if (base < 0 || k >= a.K) continue;
+          for (int i = 0; i < (ext & 3); ++i)
+            for (int j = 0; j < (ext >> 2); ++j) finish((long long)base + (long long)i * a.y_row + (long long)j * a.y_pix + kch);
         }
       }
     }
@@ -1747,6 +1822,12 @@ extern "C" int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const f
   k.x_img = k.x_row = k.x_pix = k.x_tc = k.x_run = 0;      // (the F(2x2,3x3) kernels address the plain NHWC image themselves)
   k.y_img = d->P * d->Q * d->K; k.y_row = d->Q * d->K; k.y_pix = d->K; k.y_kc = d->K; k.y_run = 0;
   dim3 grid(p.bal > 0 ? p.bal_tile0 + (p.bal + 7) / 8 * 8 : (k.mt * k.nt * p.nsplit + 7) / 8 * 8);
+  k.cnt = nullptr;
+  const bool counted = p.cfg == 0 || p.cfg == 1 || p.cfg == 2 || p.cfg == 7 || (p.cfg == 6 && !hwg_tune().w64_nodma && !(hwg_tune().conv_dbg & 512));
+  if ((p.bal > 0 ? p.bal_pieces > 1 : p.nsplit > 1) && counted && hwg_tune().split_inkernel && (long long)k.mt * k.nt * 8 <= HWG_SPLIT_COUNTERS) {
+    k.cnt = hwg_split_counters(st);        // (8: the most wavefront blocks a workgroup tile of these kernels has)
+    if (!k.cnt) return HWG_ERR_LAUNCH;
+  }
   const int prof = hwg_prof_open(HWG_PROF_CONV_WINO, 2.0 * d->N * d->P * d->Q * (double)d->K * d->C * 9.0, st);
   if (p.cfg == 0) hipLaunchKernelGGL((wino_conv_kernel<4, 2>), grid, dim3(512), 0, st, k);
   else if (p.cfg == 1) hipLaunchKernelGGL((wino_conv_kernel<2, 4>), grid, dim3(512), 0, st, k);
@@ -1761,7 +1842,9 @@ extern "C" int hwg_wino_conv_fwd(const hwg_conv_desc* d, const float* x, const f
   hwg_prof_close(prof, st);
   hwg_note_plan(HWG_PROF_CONV_WINO, p.cfg, p.bal > 0 ? -p.bal : p.nsplit);
   HWG_LAUNCH_CHECK("wino_conv_fwd");
-  if (p.bal > 0 && p.bal_pieces > 1) {
+  if (k.cnt) {
+    // (partial images summed inside the kernel)
+  } else if (p.bal > 0 && p.bal_pieces > 1) {
     const long long total = (long long)d->N * d->P * d->Q * d->K;
     const double cut = (double)(k.mt * k.nt - p.bal_tile0) / (k.mt * k.nt);
     const int prof2 = hwg_prof_open(HWG_PROF_CONV_REDUCE, 4.0 * total * cut * (p.bal_pieces + 1), st);
@@ -1936,6 +2019,11 @@ extern "C" int hwg_wino_s2_conv(const hwg_conv_desc* d, const float* x, const fl
   k.x_img = g.x_img; k.x_row = g.x_row; k.x_pix = g.x_pix; k.x_tc = g.x_tc; k.x_run = g.x_run;
   k.y_img = g.y_img; k.y_row = g.y_row; k.y_pix = g.y_pix; k.y_kc = g.y_kc; k.y_run = g.y_run;
   dim3 grid(p.bal > 0 ? p.bal_tile0 + (p.bal + 7) / 8 * 8 : (k.mt * k.nt * p.nsplit + 7) / 8 * 8);
+  k.cnt = nullptr;
+  if ((p.bal > 0 ? p.bal_pieces > 1 : p.nsplit > 1) && hwg_tune().split_inkernel && (long long)k.mt * k.nt <= HWG_SPLIT_COUNTERS) {
+    k.cnt = hwg_split_counters(st);
+    if (!k.cnt) return HWG_ERR_LAUNCH;
+  }
   const int prof = hwg_prof_open(HWG_PROF_CONV_WINO, g.flops, st);
   if (p.bal > 0) hipLaunchKernelGGL((wino_conv64d_kernel<0, true, 3>), grid, dim3(512), 0, st, k);
   else hipLaunchKernelGGL((wino_conv64d_kernel<0, false, 3>), grid, dim3(512), 0, st, k);
@@ -1943,7 +2031,9 @@ extern "C" int hwg_wino_s2_conv(const hwg_conv_desc* d, const float* x, const fl
   hwg_note_plan(HWG_PROF_CONV_WINO, 36, p.bal > 0 ? -p.bal : p.nsplit);      // (schedule id 36: F(3x3,2x2) on the 64 x 64 DMA kernel)
   HWG_LAUNCH_CHECK("wino_s2_conv");
   const long long total = (long long)d->N * d->P * d->Q * d->K;
-  if (p.bal > 0 && p.bal_pieces > 1) {
+  if (k.cnt) {
+    // (partial images summed inside the kernel)
+  } else if (p.bal > 0 && p.bal_pieces > 1) {
     const double cut = (double)(k.mt * k.nt - p.bal_tile0) / (k.mt * k.nt);
     const int prof2 = hwg_prof_open(HWG_PROF_CONV_REDUCE, 4.0 * total * cut * (p.bal_pieces + 1), st);
     hipLaunchKernelGGL(wino_bal_reduce_kernel<4>, dim3(hwg_stream_grid(total / 4, 256)), dim3(256), 0, st, k, g.Cv / 16);

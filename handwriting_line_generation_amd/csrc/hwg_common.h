@@ -76,6 +76,8 @@ struct HwgTune {
   int wgrad_c1;          // HWG_WGRAD_C1: 0 default = single-channel first-layer weight gradients on the taps-as-N MFMA kernel, 1 = VALU kernel (wgrad_c1_kernel: measured slower, kept for A/B runs)
   int wgrad_c1_rows;     // HWG_WGRAD_C1_ROWS: 0 = single-channel first-layer weight gradients on the taps-as-N gather kernel (A/B timing), 1 default = input rows staged in LDS
   int c1_rows;           // HWG_C1_ROWS: 0 = single-input-channel forward convs on the gather kernels (A/B timing), 1 default = input rows staged in LDS, filter in registers
+  int split_inkernel;    // HWG_SPLIT_INKERNEL: 1 default = the wavefront that delivers a sub-tile's LAST split-K partial sums them (fixed order) and writes the output itself; 0 = separate conv_split_reduce launch (A/B timing)
+  int norm_fused;        // HWG_NORM_FUSED: 1 default = moments and apply pass of the per-sample normalisations (IN / GN / AdaIN) in one launch per direction (norm_act.hip), 0 = two launches (A/B timing)
   int wgrad_reduce_rows; // HWG_WGRAD_REDUCE_ROWS: 0 = tap-at-a-time partial-image reduce (A/B timing), 1 default = row-contiguous stores
   char wino_force[32];   // HWG_WINO_FORCE  "cfg[,nsplit]"
   char wino_bal[32];     // HWG_WINO_BAL    balanced schedule of the 64 x 64 Winograd kernel: -1 never, unset / 0 by model, "G[,lead tiles]" forced
@@ -84,6 +86,43 @@ struct HwgTune {
   char wino_cost6[48];   // HWG_WINO_COST6  "fixed_us,step_us"
 };
 const HwgTune& hwg_tune();
+// Arrival counters of the split-K kernels (one int per (output tile, wavefront sub-tile)): a per-stream device buffer of HWG_SPLIT_COUNTERS ints,
+// zeroed when it is created; the wavefront that finds its counter at nsplit - 1 sets it back to 0, so every launch finds zeros (launches of one
+// stream run in order; two streams never share a buffer). nullptr (with the error set) when the allocation fails.
+constexpr int HWG_SPLIT_COUNTERS = 1 << 18;
+int* hwg_split_counters(hipStream_t st);
+#if defined(__HIPCC__)
+// Arrival protocol of the split kernels (the wavefront / workgroup that delivers a tile's LAST partial image sums all of them itself, in split
+// order - same bits as a separate reduce launch, no second launch, partials read where they were written): partial stores -> release fence at
+// agent scope (the XCDs' L2s are not coherent with each other: the fence writes this one's dirty lines back) -> counter += 1; whoever read
+// `expected - 1` sets the counter back to 0 for the next launch, takes an acquire fence (invalidates L1 and the non-local L2 lines) and may load
+// every split's partials. Both return the same answer to all calling lanes.
+// Wavefront form: the calling wavefront owns its output elements alone (same elements in every split); all 64 lanes call it.
+__device__ __forceinline__ bool hwg_split_arrive_wave(int* slot, int expected) {
+  __threadfence();
+  int arrived = 0;
+  if ((threadIdx.x & 63) == 0) arrived = atomicAdd(slot, 1);
+  arrived = __builtin_amdgcn_readfirstlane(arrived);
+  if (arrived != expected - 1) return false;
+  if ((threadIdx.x & 63) == 0) *slot = 0;
+  __threadfence();
+  return true;
+}
+// Workgroup form: all threads of the workgroup call it (two barriers inside); `flag` is one int of LDS.
+__device__ __forceinline__ bool hwg_split_arrive_block(int* slot, int expected, int* flag) {
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int last = atomicAdd(slot, 1) == expected - 1;
+    if (last) *slot = 0;
+    *flag = last;
+  }
+  __syncthreads();
+  const bool last = *flag != 0;
+  if (last) __threadfence();
+  return last;
+}
+#endif
 // what the calling thread's last convolution-family launch ran: engine (HWG_PROF_* kind), schedule id, split factor
 void hwg_note_plan(int engine, int cfg, int nsplit);
 

@@ -15,6 +15,8 @@ extern "C" const char* hwg_last_error(void) { return g_err; }
 extern "C" int hwg_abi_version(void) { return 6; }
 
 #include <atomic>
+#include <vector>
+#include <utility>
 static std::atomic<unsigned> g_tuning_epoch{1};
 unsigned hwg_tuning_epoch() { return g_tuning_epoch.load(std::memory_order_relaxed); }
 extern "C" int hwg_tuning_reload(void) { g_tuning_epoch.fetch_add(1); return HWG_OK; }
@@ -51,6 +53,8 @@ const HwgTune& hwg_tune() {
     t->conv_lds = tune_int("HWG_CONV_LDS", 1);
     t->to1_lanes = tune_int("HWG_TO1_LANES", 1);
     t->wgrad_reduce_rows = tune_int("HWG_WGRAD_REDUCE_ROWS", 1);
+    t->split_inkernel = tune_int("HWG_SPLIT_INKERNEL", 1);
+    t->norm_fused = tune_int("HWG_NORM_FUSED", 1);
     t->wgrad_c1 = tune_int("HWG_WGRAD_C1", 0);
     t->c1_rows = tune_int("HWG_C1_ROWS", 1);
     t->wgrad_c1_rows = tune_int("HWG_WGRAD_C1_ROWS", 1);
@@ -66,6 +70,20 @@ const HwgTune& hwg_tune() {
   }
   mine = cur;
   return *mine;
+}
+int* hwg_split_counters(hipStream_t st) {
+  static std::mutex mu;
+  static std::vector<std::pair<hipStream_t, int*>> bufs;
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto& b : bufs)
+    if (b.first == st) return b.second;
+  int* p = nullptr;
+  if (hipMalloc(&p, sizeof(int) * HWG_SPLIT_COUNTERS) != hipSuccess || hipMemsetAsync(p, 0, sizeof(int) * HWG_SPLIT_COUNTERS, st) != hipSuccess) {
+    hwg_set_error("split counters: allocation of %zu bytes failed", sizeof(int) * (size_t)HWG_SPLIT_COUNTERS);
+    return nullptr;
+  }
+  bufs.emplace_back(st, p);
+  return p;
 }
 // ---- stream fork / join (weight gradients on a side stream): side waits for main's queue as it stands / main waits for side's ----------
 // One library call each (hipEventRecord + hipStreamWaitEvent on a ring of reusable events) instead of creating, recording and waiting on

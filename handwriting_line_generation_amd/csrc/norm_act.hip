@@ -62,14 +62,31 @@ __device__ __forceinline__ void block_reduce_store(const float4 (&acc)[NV], cons
   }
 }
 
+// wait until *c reaches `expected` (fused launches below: all threads of the workgroup call it; thread 0 polls, then barrier + acquire fence);
+// false after ~1 s without success
+__device__ __forceinline__ bool grid_wait(int* c, int expected) {
+  __shared__ int ok_flag;
+  if (threadIdx.x == 0) {
+    int spins = 0, ok = 1;
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1 << 20)) { ok = 0; break; }
+    }
+    ok_flag = ok;
+  }
+  __syncthreads();
+  __threadfence();
+  return ok_flag != 0;
+}
+
 // ---------------- forward stage 1: moments of x (optionally of u = lrelu(x + nw*noise), which is also written) -------------
 // NOISE: 0 = moments of x, 1 = of u = lrelu(x + nw*noise) with the noise read from a tensor, 2 = the same with the noise DRAWN here: element
 // i of the tensor takes normal i % 4 of Philox counter ctr0 + i / 4 (philox.h) - exactly the value hwg_randn(seed, offset = ctr0) would have
 // written to a noise tensor, without the tensor (forward-only calls: nothing reads the noise again)
 template <int NOISE>
-__global__ __launch_bounds__(256) void moments_fwd_kernel(const float* x, Geo g, double* part,
-                                                          const float* noise, const float* nw, float nscale, float slope, float* u,
-                                                          unsigned long long seed, unsigned long long ctr0) {
+__device__ __forceinline__ void moments_fwd_body(const float* x, const Geo& g, double* part,
+                                                 const float* noise, const float* nw, float nscale, float slope, float* u,
+                                                 unsigned long long seed, unsigned long long ctr0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x;
   const int cl = tid % g.L, pl = tid / g.L;
@@ -115,6 +132,12 @@ __global__ __launch_bounds__(256) void moments_fwd_kernel(const float* x, Geo g,
     }
   }
   block_reduce_store<2>(acc, g, part, sm);
+}
+template <int NOISE>
+__global__ __launch_bounds__(256) void moments_fwd_kernel(const float* x, Geo g, double* part,
+                                                          const float* noise, const float* nw, float nscale, float slope, float* u,
+                                                          unsigned long long seed, unsigned long long ctr0) {
+  moments_fwd_body<NOISE>(x, g, part, noise, nw, nscale, slope, u, seed, ctr0);
 }
 
 // ---------------- forward stage 2 (BatchNorm only): statistics per channel over all samples -> mean[N][C], rstd[N][C] ------------------
@@ -219,9 +242,9 @@ __device__ __forceinline__ float norm_pre(float v, float m, float r, float g, fl
 }
 
 // ---------------- forward stage 3: y = act(mask * (gamma * xhat + beta)) -----------------------------------------------
-__global__ __launch_bounds__(256) void apply_fwd_kernel(const float* x, float* y, Geo g, const float* mean, const float* rstd,
-                                                        const float* gamma, const float* beta, int per_sample,
-                                                        const float* mask, int act, float slope, InlineStats is) {
+__device__ __forceinline__ void apply_fwd_body(const float* x, float* y, const Geo& g, const float* mean, const float* rstd,
+                                               const float* gamma, const float* beta, int per_sample,
+                                               const float* mask, int act, float slope, const InlineStats& is) {
   __shared__ __attribute__((aligned(16))) float s_a[NS_MAXC];
   __shared__ __attribute__((aligned(16))) float s_b[NS_MAXC];
   __shared__ double s_t[2 * NS_MAXC];
@@ -270,12 +293,17 @@ __global__ __launch_bounds__(256) void apply_fwd_kernel(const float* x, float* y
     (void)sc; (void)sh;
   }
 }
+__global__ __launch_bounds__(256) void apply_fwd_kernel(const float* x, float* y, Geo g, const float* mean, const float* rstd,
+                                                        const float* gamma, const float* beta, int per_sample,
+                                                        const float* mask, int act, float slope, InlineStats is) {
+  apply_fwd_body(x, y, g, mean, rstd, gamma, beta, per_sample, mask, act, slope, is);
+}
 
 // ---------------- backward stage 1: partial sums of g and g*xhat, g = dy * act'(y) * mask ---------------------------------
 // `y` == null with act = relu / leaky relu: the gate comes from the recomputed pre-activation (gamma, beta as in the forward call)
-__global__ __launch_bounds__(256) void moments_bwd_kernel(const float* dy, const float* x, const float* y, Geo g, double* part,
-                                                          const float* mean, const float* rstd, const float* mask, int act, float slope,
-                                                          const float* gamma, const float* beta, int per_sample) {
+__device__ __forceinline__ void moments_bwd_body(const float* dy, const float* x, const float* y, const Geo& g, double* part,
+                                                 const float* mean, const float* rstd, const float* mask, int act, float slope,
+                                                 const float* gamma, const float* beta, int per_sample) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x;
   const int cl = tid % g.L, pl = tid / g.L;
@@ -328,6 +356,11 @@ __global__ __launch_bounds__(256) void moments_bwd_kernel(const float* dy, const
   }
   block_reduce_store<2>(acc, g, part, sm);
 }
+__global__ __launch_bounds__(256) void moments_bwd_kernel(const float* dy, const float* x, const float* y, Geo g, double* part,
+                                                          const float* mean, const float* rstd, const float* mask, int act, float slope,
+                                                          const float* gamma, const float* beta, int per_sample) {
+  moments_bwd_body(dy, x, y, g, part, mean, rstd, mask, act, slope, gamma, beta, per_sample);
+}
 
 // ---------------- backward stage 2 (BatchNorm only): coefficients c1,c2 [N][C] and parameter gradients --------------------------------
 // dx = rstd * (g*gamma - c1 - xhat*c2),  c1 = mean(g*gamma), c2 = mean(g*gamma*xhat) over (N,H,W); one wavefront per channel
@@ -373,12 +406,14 @@ __global__ __launch_bounds__(256) void param_grad_kernel(const double* part, Geo
 // ---------------- backward stage 3 -----------------------------------------------------------------------------------------
 // PRE != 0 additionally back-propagates through u = lrelu(x + nw*noise): dt = du * lrelu'(u); writes dx = dt and
 // accumulates per-channel partials of dt (conv bias grad) and dt*noise (noise weight grad) into part2[n][chunk][c][2].
+// `all_arrived` (fused launch only): counter that reaches gridDim.x * gridDim.y once EVERY workgroup's moment partials are in memory - the first
+// sample's workgroups wait for it before they sum the partials of all samples
 template <bool PRE>
-__global__ __launch_bounds__(256) void apply_bwd_kernel(const float* dy, const float* x, const float* y, float* dx, Geo g,
-                                                        const float* mean, const float* rstd, const float* gamma, int per_sample,
-                                                        const float* c1, const float* c2, const float* mask, int act, float slope,
-                                                        const float* noise, float pre_slope, double* part2, InlineStats is, const float* beta,
-                                                        float* pg_gamma, float* pg_beta, int pg_accumulate) {
+__device__ __forceinline__ void apply_bwd_body(const float* dy, const float* x, const float* y, float* dx, const Geo& g,
+                                               const float* mean, const float* rstd, const float* gamma, int per_sample,
+                                               const float* c1, const float* c2, const float* mask, int act, float slope,
+                                               const float* noise, float pre_slope, double* part2, const InlineStats& is, const float* beta,
+                                               float* pg_gamma, float* pg_beta, int pg_accumulate, int* all_arrived) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ __attribute__((aligned(16))) float s_a[NS_MAXC];
   __shared__ __attribute__((aligned(16))) float s_b[NS_MAXC];
@@ -454,6 +489,7 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* dy, const f
   // own between the two passes (param_grad_kernel, 11 launches per training step); now the first sample's workgroups do it behind their
   // streaming work, one wavefront per channel, in the same order (lane-strided items, butterfly) - bit-identical.
   if (!PRE && (pg_gamma || pg_beta) && blockIdx.y == 0 && is.part) {
+    if (all_arrived) grid_wait(all_arrived, gridDim.x * gridDim.y);
     const int lane = tid & 63, wv = tid >> 6;
     const int items = g.N * g.chunks;
     for (int c = blockIdx.x * 4 + wv; c < g.C; c += gridDim.x * 4) {
@@ -469,6 +505,73 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* dy, const f
       }
     }
   }
+}
+template <bool PRE>
+__global__ __launch_bounds__(256) void apply_bwd_kernel(const float* dy, const float* x, const float* y, float* dx, Geo g,
+                                                        const float* mean, const float* rstd, const float* gamma, int per_sample,
+                                                        const float* c1, const float* c2, const float* mask, int act, float slope,
+                                                        const float* noise, float pre_slope, double* part2, InlineStats is, const float* beta,
+                                                        float* pg_gamma, float* pg_beta, int pg_accumulate) {
+  apply_bwd_body<PRE>(dy, x, y, dx, g, mean, rstd, gamma, per_sample, c1, c2, mask, act, slope, noise, pre_slope, part2, is, beta, pg_gamma, pg_beta,
+                      pg_accumulate, nullptr);
+}
+
+// ---------------- per-sample normalisations in ONE launch per direction ------------------------------------------------------------------------
+// The moments pass and the apply pass of IN / GN / AdaIN have the same grid (chunk, sample), and a workgroup of the apply pass needs exactly the
+// partial sums of its own sample's <= 64 workgroups. The fused kernels run the two bodies above back to back in one launch - same code, same
+// partial-sum layout and order: bit-identical - with a barrier over the SAMPLE's workgroups in between (arrival counter per sample in the
+// stream's counter buffer, hwg_split_counters): a launch and a round trip through the command processor less per normalisation and direction,
+// and the second pass reads what this very workgroup streamed a few microseconds earlier.
+// Waiting inside a kernel needs the workgroups waited for to get onto the chip: workgroups are dispatched in linear order (chunk fastest), so when
+// a workgroup of sample n waits, everything ahead of it in the queue belongs to samples <= n - at most 63 workgroups of its own sample, the
+// earlier samples' finish without waiting for anybody - and one sample's workgroups always fit (<= 64 of >= 1024 resident). The first sample's
+// workgroups of the backward kernel also wait - at their very end - for ALL workgroups' partials (shared-affine parameter gradients): the same
+// argument with 64 waiting workgroups. BatchNorm needs every workgroup to wait for every other (grids of 512 on several streams at once): not
+// fused. A wait gives up after ~1 s (the sample's statistics are then poisoned with NaN - the trainer's non-finite check fires) rather than hang.
+// Counters: [2n] arrivals, [2n + 1] departures of sample n; [2N], [2N + 1] the same over the whole grid. The last workgroup to depart sets both
+// back to zero (launches of one stream are ordered, the buffer is per stream).
+__device__ __forceinline__ void grid_arrive(int* a, int* b) {
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) { atomicAdd(a, 1); if (b) atomicAdd(b, 1); }
+}
+__device__ __forceinline__ void grid_depart(int* arrive, int* depart, int expected) {
+  if (threadIdx.x == 0 && atomicAdd(depart, 1) == expected - 1) { atomicExch(arrive, 0); atomicExch(depart, 0); }
+}
+
+template <int NOISE>
+__global__ __launch_bounds__(256) void norm_fwd_fused_kernel(const float* x, float* y, Geo g, double* part, const float* noise, const float* nw,
+                                                             float nscale, float nslope, float* u, unsigned long long seed, unsigned long long ctr0,
+                                                             const float* gamma, const float* beta, int per_sample, const float* mask, int act,
+                                                             float slope, InlineStats is, int* sync) {
+  moments_fwd_body<NOISE>(x, g, part, noise, nw, nscale, nslope, u, seed, ctr0);
+  int* mine = sync + 2 * blockIdx.y;
+  grid_arrive(mine, nullptr);
+  const bool ok = grid_wait(mine, gridDim.x);
+  apply_fwd_body(NOISE ? (const float*)u : x, y, g, is.out_a, is.out_b, gamma, beta, per_sample, mask, act, slope, is);
+  if (!ok && blockIdx.x == 0) { __syncthreads(); for (int c = threadIdx.x; c < g.C; c += 256) is.out_b[blockIdx.y * g.C + c] = __builtin_nanf(""); }
+  grid_depart(mine, mine + 1, gridDim.x);
+}
+
+template <bool PRE>
+__global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const float* dy, const float* x, const float* y, float* dx, Geo g, double* part,
+                                                             const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                                             int per_sample, const float* c1, const float* c2, const float* mask, int act,
+                                                             float slope, const float* noise, float pre_slope, double* part2, InlineStats is,
+                                                             float* pg_gamma, float* pg_beta, int pg_accumulate, int* sync) {
+  // (the moments pass of the generator epilogue's backward takes no gate, mask or affine: hwg_adain_bwd)
+  if (PRE) moments_bwd_body(dy, x, nullptr, g, part, mean, rstd, nullptr, 0, 0.f, nullptr, nullptr, 0);
+  else moments_bwd_body(dy, x, y, g, part, mean, rstd, mask, act, slope, gamma, beta, per_sample);
+  int* mine = sync + 2 * blockIdx.y;
+  int* all = sync + 2 * gridDim.y;
+  const bool fold = !PRE && (pg_gamma || pg_beta);
+  grid_arrive(mine, fold ? all : nullptr);
+  const bool ok = grid_wait(mine, gridDim.x);
+  apply_bwd_body<PRE>(dy, x, y, dx, g, mean, rstd, gamma, per_sample, c1, c2, mask, act, slope, noise, pre_slope, part2, is, beta, pg_gamma, pg_beta,
+                      pg_accumulate, fold ? all : nullptr);
+  if (!ok) { __syncthreads(); for (long long i = threadIdx.x; i < 4; i += 256) dx[i] = __builtin_nanf(""); }
+  grid_depart(mine, mine + 1, gridDim.x);
+  if (fold) grid_depart(all, all + 1, gridDim.x * gridDim.y);
 }
 
 // dbias[c] = sum part2[...][c][0];  dnoise_w[c] = nscale * sum part2[...][c][1]; one wavefront per channel
@@ -590,6 +693,12 @@ size_t red_smem(const Geo& g) { return (size_t)g.PP * g.C * 2 * sizeof(double); 
 
 }  // namespace
 
+// counter buffer of a fused launch (norm_*_fused_kernel), nullptr = run the two-launch path
+static int* fused_sync(int N, hipStream_t st) {
+  if (!hwg_tune().norm_fused || 2 * N + 2 > HWG_SPLIT_COUNTERS) return nullptr;
+  return hwg_split_counters(st);
+}
+
 extern "C" size_t hwg_norm_workspace(int N, int HW, int C) {
   if (N <= 0 || HW <= 0 || C <= 0 || C % 4) return 0;
   Geo g = make_geo(N, HW, C);
@@ -611,6 +720,14 @@ extern "C" int hwg_norm_fwd(const float* x, float* y, int N, int HW, int C, int 
   hipStream_t st = (hipStream_t)stream;
   double* part = (double*)ws;
   dim3 grid(g.chunks, N);
+  if (int* sync = mode != MODE_BN ? fused_sync(N, st) : nullptr) {
+    InlineStats is = {};
+    is.part = part; is.cpg = (mode == MODE_GN) ? C / groups : 1; is.eps = eps; is.out_a = mean; is.out_b = rstd;
+    hipLaunchKernelGGL(norm_fwd_fused_kernel<0>, grid, dim3(256), red_smem(g), st, x, y, g, part, (const float*)nullptr, (const float*)nullptr, 0.f,
+                       0.f, (float*)nullptr, 0ull, 0ull, gamma, beta, affine_per_sample, chan_mask, act, slope, is, sync);
+    HWG_LAUNCH_CHECK("norm_fwd.fused");
+    return HWG_OK;
+  }
   hipLaunchKernelGGL(moments_fwd_kernel<0>, grid, dim3(256), red_smem(g), st, x, g, part, (const float*)nullptr, (const float*)nullptr, 0.f, 0.f,
                      (float*)nullptr, 0ull, 0ull);
   HWG_LAUNCH_CHECK("norm_fwd.moments");
@@ -646,6 +763,17 @@ extern "C" int hwg_norm_bwd(const float* dy, const float* x, const float* y, flo
   float* c1 = (float*)((char*)ws + 2 * part_bytes(g));
   float* c2 = c1 + (size_t)N * C;
   dim3 grid(g.chunks, N);
+  if (int* sync = mode != MODE_BN ? fused_sync(N, st) : nullptr) {
+    InlineStats is = {};
+    is.part = part; is.cpg = (mode == MODE_GN) ? C / groups : 1; is.gamma = gamma; is.per_sample = affine_per_sample;
+    is.out_a = affine_per_sample ? dgamma : nullptr; is.out_b = affine_per_sample ? dbeta : nullptr; is.accumulate = accumulate;
+    const bool fold = !affine_per_sample && (dgamma || dbeta);
+    hipLaunchKernelGGL(norm_bwd_fused_kernel<false>, grid, dim3(256), red_smem(g), st, dy, x, y, dx, g, part, mean, rstd, gamma, beta,
+                       affine_per_sample, (const float*)c1, (const float*)c2, chan_mask, act, slope, (const float*)nullptr, 0.f, (double*)nullptr, is,
+                       fold ? dgamma : (float*)nullptr, fold ? dbeta : (float*)nullptr, accumulate, sync);
+    HWG_LAUNCH_CHECK("norm_bwd.fused");
+    return HWG_OK;
+  }
   hipLaunchKernelGGL(moments_bwd_kernel, grid, dim3(256), red_smem(g), st, dy, x, y, g, part, mean, rstd, chan_mask, act, slope, gamma, beta,
                      affine_per_sample);
   HWG_LAUNCH_CHECK("norm_bwd.moments");
@@ -677,10 +805,16 @@ extern "C" int hwg_adain_fwd(const float* x, const float* noise, const float* no
   hipStream_t st = (hipStream_t)stream;
   double* part = (double*)ws;
   dim3 grid(g.chunks, N);
-  hipLaunchKernelGGL(moments_fwd_kernel<1>, grid, dim3(256), red_smem(g), st, x, g, part, noise, noise_w, noise_scale, slope, u, 0ull, 0ull);
-  HWG_LAUNCH_CHECK("adain_fwd.moments");
   InlineStats is = {};
   is.part = part; is.cpg = 1; is.eps = eps; is.out_a = mean; is.out_b = rstd;
+  if (int* sync = fused_sync(N, st)) {
+    hipLaunchKernelGGL(norm_fwd_fused_kernel<1>, grid, dim3(256), red_smem(g), st, x, y, g, part, noise, noise_w, noise_scale, slope, u, 0ull, 0ull,
+                       gamma, beta, 1, (const float*)nullptr, 0, 0.f, is, sync);
+    HWG_LAUNCH_CHECK("adain_fwd.fused");
+    return HWG_OK;
+  }
+  hipLaunchKernelGGL(moments_fwd_kernel<1>, grid, dim3(256), red_smem(g), st, x, g, part, noise, noise_w, noise_scale, slope, u, 0ull, 0ull);
+  HWG_LAUNCH_CHECK("adain_fwd.moments");
   hipLaunchKernelGGL(apply_fwd_kernel, grid, dim3(256), 0, st, (const float*)u, y, g, (const float*)mean, (const float*)rstd, gamma, beta, 1,
                      (const float*)nullptr, 0, 0.f, is);
   HWG_LAUNCH_CHECK("adain_fwd.apply");
@@ -701,11 +835,17 @@ extern "C" int hwg_adain_fwd_rng(const float* x, unsigned long long seed, unsign
   hipStream_t st = (hipStream_t)stream;
   double* part = (double*)ws;
   dim3 grid(g.chunks, N);
+  InlineStats is = {};
+  is.part = part; is.cpg = 1; is.eps = eps; is.out_a = mean; is.out_b = rstd;
+  if (int* sync = fused_sync(N, st)) {
+    hipLaunchKernelGGL(norm_fwd_fused_kernel<2>, grid, dim3(256), red_smem(g), st, x, y, g, part, (const float*)nullptr, noise_w, noise_scale, slope, u,
+                       (unsigned long long)seed, (unsigned long long)offset, gamma, beta, 1, (const float*)nullptr, 0, 0.f, is, sync);
+    HWG_LAUNCH_CHECK("adain_fwd_rng.fused");
+    return HWG_OK;
+  }
   hipLaunchKernelGGL(moments_fwd_kernel<2>, grid, dim3(256), red_smem(g), st, x, g, part, (const float*)nullptr, noise_w, noise_scale, slope, u,
                      (unsigned long long)seed, (unsigned long long)offset);
   HWG_LAUNCH_CHECK("adain_fwd_rng.moments");
-  InlineStats is = {};
-  is.part = part; is.cpg = 1; is.eps = eps; is.out_a = mean; is.out_b = rstd;
   hipLaunchKernelGGL(apply_fwd_kernel, grid, dim3(256), 0, st, (const float*)u, y, g, (const float*)mean, (const float*)rstd, gamma, beta, 1,
                      (const float*)nullptr, 0, 0.f, is);
   HWG_LAUNCH_CHECK("adain_fwd_rng.apply");
@@ -800,16 +940,23 @@ extern "C" int hwg_adain_bwd(const float* dy, const float* u, const float* noise
   float* c1 = (float*)((char*)ws + 2 * part_bytes(g));
   float* c2 = c1 + (size_t)N * C;
   dim3 grid(g.chunks, N);
-  hipLaunchKernelGGL(moments_bwd_kernel, grid, dim3(256), red_smem(g), st, dy, u, (const float*)nullptr, g, part, mean, rstd,
-                     (const float*)nullptr, 0, 0.f, (const float*)nullptr, (const float*)nullptr, 0);
-  HWG_LAUNCH_CHECK("adain_bwd.moments");
   // dgamma/dbeta are per (n,c) and are NOT accumulated (they feed the style Linear's backward); c1/c2 are formed inside the apply pass
   InlineStats is = {};
   is.part = part; is.cpg = 1; is.gamma = gamma; is.per_sample = 1; is.out_a = dgamma; is.out_b = dbeta; is.accumulate = 0;
-  hipLaunchKernelGGL(apply_bwd_kernel<true>, grid, dim3(256), red_smem(g), st, dy, u, (const float*)nullptr, dx, g, mean, rstd, gamma, 1,
-                     (const float*)c1, (const float*)c2, (const float*)nullptr, 0, 0.f, noise, slope, part2, is, (const float*)nullptr,
-                     (float*)nullptr, (float*)nullptr, 0);
-  HWG_LAUNCH_CHECK("adain_bwd.apply");
+  if (int* sync = fused_sync(N, st)) {
+    hipLaunchKernelGGL(norm_bwd_fused_kernel<true>, grid, dim3(256), red_smem(g), st, dy, u, (const float*)nullptr, dx, g, part, mean, rstd, gamma,
+                       (const float*)nullptr, 1, (const float*)c1, (const float*)c2, (const float*)nullptr, 0, 0.f, noise, slope, part2, is,
+                       (float*)nullptr, (float*)nullptr, 0, sync);
+    HWG_LAUNCH_CHECK("adain_bwd.fused");
+  } else {
+    hipLaunchKernelGGL(moments_bwd_kernel, grid, dim3(256), red_smem(g), st, dy, u, (const float*)nullptr, g, part, mean, rstd,
+                       (const float*)nullptr, 0, 0.f, (const float*)nullptr, (const float*)nullptr, 0);
+    HWG_LAUNCH_CHECK("adain_bwd.moments");
+    hipLaunchKernelGGL(apply_bwd_kernel<true>, grid, dim3(256), red_smem(g), st, dy, u, (const float*)nullptr, dx, g, mean, rstd, gamma, 1,
+                       (const float*)c1, (const float*)c2, (const float*)nullptr, 0, 0.f, noise, slope, part2, is, (const float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, 0);
+    HWG_LAUNCH_CHECK("adain_bwd.apply");
+  }
   if ((dnoise_w || dbias) && defer) {
     PgEntry e;
     e.part2 = part2; e.dbias = dbias; e.dnw = dnoise_w; e.nscale = noise_scale; e.items = g.N * g.chunks; e.C = g.C; e.accumulate = accumulate_params;

@@ -206,6 +206,64 @@ def test_transposed_conv_merged_classes(cuda, case, force):
                 _close(nchw(xcg.grad), xc.grad, "stride-s conv dx through merged classes %s" % (case,), tol=2e-5)
 
 
+# Split-K / channel-split launches without a reduce launch (hwg_split_arrive_wave / _block, hwg_common.h): the wavefront or workgroup that delivers a
+# tile's last partial image sums them in split order. Same arithmetic as conv_split_reduce_kernel, so the outputs must be the SAME BITS as with
+# HWG_SPLIT_INKERNEL=0 - for every tile config of the direct kernel, the by-class and merged transposed modes, the Winograd kernels that take
+# the counters (cfg 0 / 1 / 2 / 7 and the 64 x 64 DMA kernel) and the two-tap kernel; with bias, accumulating into an existing output, and
+# repeatedly (the counters must be back at zero after every launch, also after launches of other geometries in between).
+SPLIT_CASES = [("direct", (2, 9, 40, 64, 96, 3, 3, (1, 1), (1, 1), (1, 1), 0), dict(HWG_WINO="0", HWG_CONV_FORCE="64,64,32,4")),
+               ("direct", (2, 9, 40, 64, 96, 3, 3, (1, 1), (1, 1), (1, 1), 0), dict(HWG_WINO="0", HWG_CONV_FORCE="128,128,32,2")),
+               ("direct", (3, 1, 126, 128, 80, 1, 3, (1, 1), (0, 2), (1, 2), 0), dict(HWG_CONV_FORCE="128,64,32,3")),
+               ("direct", (3, 1, 126, 128, 80, 1, 3, (1, 1), (0, 4), (1, 4), 0), dict(HWG_CONV_FORCE="128,32,16,8")),
+               ("direct", (2, 7, 19, 32, 64, 4, 4, (2, 2), (0, 0), (1, 1), 1), dict(HWG_CONV_MERGE="0", HWG_CONV_FORCE="64,64,32,2")),
+               ("direct", (2, 7, 19, 32, 64, 4, 4, (2, 2), (0, 0), (1, 1), 1), dict(HWG_CONV_MERGE="2", HWG_CONV_FORCE="128,128,32,2")),
+               ("direct", (2, 1, 30, 64, 40, 6, 3, (3, 1), (0, 1), (1, 1), 1), dict(HWG_CONV_MERGE="0", HWG_CONV_FORCE="64,64,16,3")),
+               ("wino", (2, 13, 37, 64, 80, 3, 3, (1, 1), (1, 1), (1, 1), 0), dict(HWG_WINO="2", HWG_WINO_FORCE="0,2")),
+               ("wino", (1, 9, 66, 48, 208, 3, 3, (1, 1), (0, 1), (1, 1), 0), dict(HWG_WINO="2", HWG_WINO_FORCE="1,3")),
+               ("wino", (3, 7, 21, 128, 32, 3, 3, (1, 1), (2, 2), (1, 1), 0), dict(HWG_WINO="2", HWG_WINO_FORCE="2,4")),
+               ("wino", (2, 5, 19, 96, 64, 3, 3, (1, 1), (0, 0), (1, 1), 0), dict(HWG_WINO="2", HWG_WINO_FORCE="7,2")),
+               ("wino", (2, 13, 37, 64, 80, 3, 3, (1, 1), (1, 1), (1, 1), 0), dict(HWG_WINO="2", HWG_WINO_FORCE="6,4", HWG_WINO_BAL="-1")),
+               ("wino", (2, 8, 129, 512, 256, 3, 3, (1, 1), (1, 1), (1, 1), 0), dict(HWG_WINO="2", HWG_WINO_FORCE="6,2", HWG_WINO_BAL="-1")),
+               ("wino", (3, 8, 26, 64, 128, 4, 4, (2, 2), (0, 0), (1, 1), 0), dict(HWG_WINO_S2="2", HWG_WINO_FORCE="6,2")),
+               ("wino", (2, 6, 130, 128, 96, 4, 4, (2, 2), (0, 0), (1, 1), 0), dict(HWG_WINO_S2="2", HWG_WINO_FORCE="6,4"))]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES, ids=lambda c: "x".join(str(v) for v in c[1][:7]) + "_" + "_".join(v.replace(",", ".") for v in c[2].values()))
+def test_split_partials_summed_by_the_last_arrival_are_the_reduce_kernels_bits(cuda, case):
+    from handwriting_line_generation_amd import ops
+    kind, (N, H, W, C, K, R, S, stride, pad, dil, transposed), env = case
+    g = torch.Generator().manual_seed(123)
+    x = nhwc(torch.randn(N, C, H, W, generator=g)).to(cuda)
+    w = (torch.randn((C, K, R, S) if transposed else (K, C, R, S), generator=g) / (C * R * S) ** 0.5).to(cuda)
+    b = torch.randn(K, generator=g).to(cuda)
+    other = nhwc(torch.randn(1, 32, 5, 70, generator=g)).to(cuda); wo = torch.randn(48, 32, 3, 3, generator=g).to(cuda)
+
+    def layer(xin, win, bias):
+        if transposed:
+            return ops.conv_transpose2d(xin, win, bias, stride=stride, padding=pad)
+        return ops.conv2d(xin, win, bias, stride=stride, padding=pad, dilation=dil)
+
+    outs = {}
+    for mode in ("0", "1"):
+        with ops.tuning(HWG_SPLIT_INKERNEL=mode, **env):
+            y = layer(x, w, b)
+            lp = ops.last_plan()
+            assert lp[2] > 1, "%s did not run split: %s" % (case, lp)
+            ys = [y, layer(x, w, None)]
+            ops.conv2d(other, wo, None, 1, (1, 1))              # another geometry on the same stream and counters
+            ys.append(layer(x, w, b))
+            # through the layer twice on one input: the data gradient may split too, and the second one ACCUMULATES into the first (`accumulate`)
+            xg = x.clone().requires_grad_(True)
+            (layer(xg, w, b) + layer(xg, w, None)).backward(torch.ones_like(y))
+            ys.append(xg.grad)
+            outs[mode] = [t.clone() for t in ys]
+    torch.cuda.synchronize()
+    for k, (a_, b_) in enumerate(zip(outs["0"], outs["1"])):
+        assert torch.isfinite(b_).all()
+        assert torch.equal(a_, b_), "%s output %d: %.3e" % (case, k, float((a_ - b_).abs().max()))
+    assert torch.equal(outs["1"][0], outs["1"][2])
+
+
 def test_winograd_agrees_with_direct_engine(cuda):
     """the same 3x3 layer through the F(2x2,3x3) kernels and through the direct implicit-GEMM kernels"""
     from handwriting_line_generation_amd import ops
@@ -732,6 +790,89 @@ def test_adain_epilogue(cuda, shape):
     _close(nchw(xg.grad), xr.grad, "adain.dx", tol=2e-4)
     _close(nwg.grad, nwr.grad, "adain.dnoise_w", tol=2e-4)
     _close(gg.grad, gr.grad, "adain.dgamma", tol=2e-4); _close(bg.grad, br.grad, "adain.dbeta", tol=2e-4)
+
+
+# The per-sample normalisations run their moments pass and their apply pass in ONE launch per direction (norm_*_fused_kernel, norm_act.hip: same two
+# bodies, a barrier over the sample's workgroups in between). Same code, same partial sums in the same order: the outputs, the saved statistics
+# and every gradient must be the SAME BITS as with HWG_NORM_FUSED=0 - GroupNorm with shared affine (parameter gradients folded into the first
+# sample's workgroups: they wait for the whole grid), with mask and gates recomputed in the backward pass, InstanceNorm, the generator epilogue
+# (noise from a tensor / drawn in the kernel), 1 to 64 chunks per sample, 1 to 16 samples, repeated launches (the counters must return to zero).
+FUSED_NORM_CASES = [("gn", 3, 10, 33, 64, 8, "lrelu", True), ("gn", 3, 6, 20, 32, 8, "relu", True), ("gn", 2, 58, 256, 64, 8, "lrelu", False),
+                    ("gn", 2, 1, 60, 512, 8, "relu", False), ("gn", 4, 32, 514, 128, 8, "relu", False), ("gn", 16, 6, 62, 128, 8, "none", False),
+                    ("in", 2, 7, 19, 32, 1, "none", False), ("in", 8, 64, 488, 16, 1, "none", False), ("gn", 1, 64, 1024, 16, 4, "lrelu", True),
+                    ("adain", 2, 4, 61, 256, 1, "", False), ("adain", 8, 64, 488, 16, 1, "", False), ("adain", 3, 16, 122, 128, 1, "", False)]
+
+
+@pytest.mark.parametrize("case", FUSED_NORM_CASES, ids=lambda c: "%s_%dx%dx%dx%d_%s" % (c[0], c[1], c[2], c[3], c[4], c[6] or "epi"))
+def test_one_launch_normalisation_is_the_two_launch_arithmetic(cuda, case):
+    from handwriting_line_generation_amd import ops
+    kind, N, H, W, C, groups, act, use_mask = case
+    g = torch.Generator().manual_seed(17)
+    x = (torch.randn(N, H, W, C, generator=g) * 2 + 0.5).to(cuda)
+    gy = torch.randn(N, H, W, C, generator=g).to(cuda)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(cuda); beta = torch.randn(C, generator=g).to(cuda)
+    mask = ((torch.rand(N, C, generator=g) > 0.3).float() / 0.7).to(cuda) if use_mask else None
+    noise = torch.randn(N, H, W, C, generator=g).to(cuda); nw = (torch.randn(1, C, 1, 1, generator=g) * 0.5).to(cuda)
+    sg = (torch.randn(N, C, generator=g) + 1).to(cuda); sb = torch.randn(N, C, generator=g).to(cuda)
+    actc = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "": 0}[act]
+    outs = {}
+    for mode in ("0", "1"):
+        with ops.tuning(HWG_NORM_FUSED=mode):
+            res = []
+            for rep in range(3):
+                xg = x.clone().requires_grad_(True)
+                if kind == "gn":
+                    gg, bg = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+                    y = ops.group_norm(xg, groups, gg, bg, 1e-5, mask=mask, act=actc, slope=0.1)
+                    y.backward(gy)
+                    res += [y.detach(), xg.grad, gg.grad, bg.grad]
+                elif kind == "in":
+                    y = ops.instance_norm(xg, 1e-5)
+                    y.backward(gy)
+                    res += [y.detach(), xg.grad]
+                else:
+                    nwg, gg, bg = nw.clone().requires_grad_(True), sg.clone().requires_grad_(True), sb.clone().requires_grad_(True)
+                    y = ops.adain_epilogue(xg, noise, nwg, gg, bg, (2.0 / C) ** 0.5, 0.2, 1e-5)
+                    y.backward(gy)
+                    res += [y.detach(), xg.grad, nwg.grad, gg.grad, bg.grad]
+            outs[mode] = [t.clone() for t in res]
+    torch.cuda.synchronize()
+    for k, (a_, b_) in enumerate(zip(outs["0"], outs["1"])):
+        assert torch.isfinite(b_).all(), "%s output %d" % (case, k)
+        assert torch.equal(a_, b_), "%s output %d: %.3e" % (case, k, float((a_ - b_).abs().max()))
+
+
+def test_one_launch_normalisations_on_three_streams_at_once(cuda):
+    """the arrival counters are per stream: the same normalisations and split convolutions enqueued on three streams at once (as the trainer's
+    concurrent style passes do) give the bits of the one-stream run"""
+    from handwriting_line_generation_amd import ops
+    g = torch.Generator().manual_seed(23)
+    xs = [(torch.randn(4, 32, 200 + 37 * i, 128, generator=g) + 0.3).to(cuda) for i in range(3)]
+    gamma = (torch.rand(128, generator=g) + 0.5).to(cuda); beta = torch.randn(128, generator=g).to(cuda)
+    w = (torch.randn(128, 128, 1, 3, generator=g) / 20).to(cuda)
+
+    def work(x):
+        y = x
+        for _ in range(6):
+            y = ops.group_norm(y, 8, gamma, beta, 1e-5, act=ops.ACT_RELU)
+            y = ops.conv2d(y, w, None, 1, (0, 1))
+        return y
+
+    with torch.no_grad(), ops.tuning(HWG_CONV_FORCE="64,64,32,4"):
+        want = [work(x) for x in xs]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in xs]
+        got = [None] * len(xs)
+        for rep in range(3):
+            for i, (x, st) in enumerate(zip(xs, streams)):
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    got[i] = work(x)
+            for st in streams:
+                torch.cuda.current_stream().wait_stream(st)
+            torch.cuda.synchronize()
+            for a_, b_ in zip(want, got):
+                assert torch.equal(a_, b_)
 
 
 def test_bias_act_and_tanh(cuda):
