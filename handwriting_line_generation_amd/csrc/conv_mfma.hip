@@ -415,13 +415,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
   const long long total = (long long)a.N * a.P * a.Q * a.K;
   {
     float* __restrict__ pg = a.part + (long long)split * total;
-    for_each_out([&](int mi, int ni, int e, long long o) { pg[o] = acc[mi][ni][e]; });
+    if (!a.cnt) {                                      // partial images summed by conv_split_reduce_kernel
+      for_each_out([&](int mi, int ni, int e, long long o) { pg[o] = acc[mi][ni][e]; });
+      return;
+    }
+    for_each_out([&](int mi, int ni, int e, long long o) { hwg_store_agent(pg + o, acc[mi][ni][e]); });
   }
-  if (!a.cnt) return;                                  // partial images summed by conv_split_reduce_kernel
   // The wavefront that delivers the LAST of a sub-tile's nsplit partial images sums them itself - in split order, then bias, then the old
   // output: the arithmetic of conv_split_reduce_kernel, bit for bit - and writes the output: no second launch, the partials are read where
-  // they were written (L2). Every split's wavefront of a sub-tile owns the same output offsets, so nothing but the arrival counter crosses
-  // wavefronts (hwg_split_arrive_wave, hwg_common.h).
+  // they were written. Every split's wavefront of a sub-tile owns the same output offsets, so nothing but the arrival counter crosses
+  // wavefronts (hwg_split_arrive_wave, hwg_common.h: the partials travel as agent-scope stores / loads).
   if (!hwg_split_arrive_wave(a.cnt + (((size_t)blockIdx.z * (gridDim.y / a.nsplit) + blockIdx.y / a.nsplit) * gridDim.x + blockIdx.x) * WMN + wmn, a.nsplit)) return;
   float bl[NI];
 #pragma unroll
@@ -431,8 +434,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WK) void conv_mfma_kernel(
   const int nsplit = a.nsplit;
   const bool accum = a.accumulate, has_bias = a.bias != nullptr;
   for_each_out([&](int, int ni, int, long long o) {
-    float v = pr[o];
-    for (int sp = 1; sp < nsplit; ++sp) v += pr[sp * total + o];
+    float v = hwg_load_agent(pr + o);
+    for (int sp = 1; sp < nsplit; ++sp) v += hwg_load_agent(pr + sp * total + o);
     if (has_bias) v += bl[ni];
     if (accum) v += yg[o];
     yg[o] = v;

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void wino_conv_kernel(WinoK a) {
   const bool direct = a.nsplit == 1;
   float* yg = direct ? a.y : a.part + (long long)split * ((long long)a.N * a.P * a.Q * a.K);
   const float bv = (direct && a.bias && k < a.K) ? a.bias[k] : 0.f;
-  const bool accum = direct && a.accumulate;
+  const bool accum = direct && a.accumulate, coh = !direct && a.cnt;      // coh: the partial image is read by another workgroup of this launch
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int m = m0 + wm * 16 + (lane >> 4) * 4 + e;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void wino_conv_kernel(WinoK a) {
         const long long o = (((long long)n * a.P + p) * a.Q + q) * a.K + k;
         float v = y2[i][j] + bv;
         if (accum) v += yg[o];
-        yg[o] = v;
+        if (coh) hwg_store_agent(yg + o, v); else yg[o] = v;
       }
     }
   }
@@ -328,8 +328,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void wino_conv_kernel(WinoK a) {
         const int q = 2 * tj + j;
         if (q >= a.Q) continue;
         const long long o = (((long long)n * a.P + p) * a.Q + q) * a.K + k;
-        float v = a.part[o];
-        for (int sp = 1; sp < a.nsplit; ++sp) v += a.part[sp * total + o];
+        float v = hwg_load_agent(a.part + o);
+        for (int sp = 1; sp < a.nsplit; ++sp) v += hwg_load_agent(a.part + sp * total + o);
         if (a.bias) v += bl;
         if (a.accumulate) v += a.y[o];
         a.y[o] = v;
@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
   const int k = n0 + kk;
   float* yg = direct ? a.y : a.part + (long long)piece * ((long long)a.N * a.P * a.Q * a.K);
   const float bv = (direct && a.bias && k < a.K) ? a.bias[k] : 0.f;
-  const bool accum = direct && a.accumulate;
+  const bool accum = direct && a.accumulate, coh = !direct && a.cnt;      // coh: the partial image is read by another workgroup of this launch
 #pragma unroll 2
   for (int tile = tid >> 6; tile < 64; tile += 8) {
     const int base = tile_out[tile], ext = tile_ext[tile];
@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
         float v = (j == 0 ? y0 : y1) + bv;
         if (accum) v += yg[o];
         if constexpr ((ABL & 1) != 0) { if ((a.dbg & 1024) && v != 123456.789f) continue; }      // timing ablation: no global stores
-        yg[o] = v;
+        if (coh) hwg_store_agent(yg + o, v); else yg[o] = v;
       }
     }
   }
@@ -1222,7 +1222,7 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
     const int k = n0 + kk;
     float* yg = direct ? a.y : a.part + (long long)piece * ((long long)a.N * a.P * a.Q * a.K);
     const float bv = (direct && a.bias && k < a.K) ? a.bias[k] : 0.f;
-    const bool accum = direct && a.accumulate;
+    const bool accum = direct && a.accumulate, coh = !direct && a.cnt;      // coh: the partial image is read by another workgroup of this launch
     const long long kch = (long long)(k / a.y_kc) * a.y_run + (k % a.y_kc);
     if (tid < 64) {
       const int m = m0 + tid;
@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
             const long long o = (long long)base + (long long)i * a.y_row + (long long)j * a.y_pix + kch;
             float v = yv[j] + bv;
             if (accum) v += yg[o];
-            yg[o] = v;
+            if (coh) hwg_store_agent(yg + o, v); else yg[o] = v;
           }
         }
       }
@@ -1286,8 +1286,8 @@ __global__ __launch_bounds__(512) void wino_conv64d_kernel(WinoK a) {
       const int k = n0 + (tid & 63);
       const float bl = (a.bias && k < a.K) ? a.bias[k] : 0.f;
       auto finish = [&](long long o) {
-        float v = BAL ? 0.f : a.part[o];
-        for (int sp = BAL ? 0 : 1; sp < pieces; ++sp) v += a.part[sp * total + o];
+        float v = BAL ? 0.f : hwg_load_agent(a.part + o);
+        for (int sp = BAL ? 0 : 1; sp < pieces; ++sp) v += hwg_load_agent(a.part + sp * total + o);
         if (a.bias) v += bl;
         if (a.accumulate) v += a.y[o];
         a.y[o] = v;

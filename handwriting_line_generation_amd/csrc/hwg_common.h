@@ -76,8 +76,8 @@ struct HwgTune {
   int wgrad_c1;          // HWG_WGRAD_C1: 0 default = single-channel first-layer weight gradients on the taps-as-N MFMA kernel, 1 = VALU kernel (wgrad_c1_kernel: measured slower, kept for A/B runs)
   int wgrad_c1_rows;     // HWG_WGRAD_C1_ROWS: 0 = single-channel first-layer weight gradients on the taps-as-N gather kernel (A/B timing), 1 default = input rows staged in LDS
   int c1_rows;           // HWG_C1_ROWS: 0 = single-input-channel forward convs on the gather kernels (A/B timing), 1 default = input rows staged in LDS, filter in registers
-  int split_inkernel;    // HWG_SPLIT_INKERNEL: 1 default = the wavefront that delivers a sub-tile's LAST split-K partial sums them (fixed order) and writes the output itself; 0 = separate conv_split_reduce launch (A/B timing)
-  int norm_fused;        // HWG_NORM_FUSED: 1 default = moments and apply pass of the per-sample normalisations (IN / GN / AdaIN) in one launch per direction (norm_act.hip), 0 = two launches (A/B timing)
+  int split_inkernel;    // HWG_SPLIT_INKERNEL: 0 default = split-K / channel-split partial images summed by a reduce launch; 1 = by the wavefront / workgroup that delivers a tile's LAST partial (bit-identical; measured SLOWER in the step - what crosses XCDs has to bypass the L2s -, kept for A/B runs: profiles/r06_inkernel_sums.txt)
+  int norm_fused;        // HWG_NORM_FUSED: 0 default = moments pass and apply pass of the per-sample normalisations as two launches; 1 = one launch per direction with a barrier over the sample's workgroups (bit-identical; measured SLOWER in the step, kept for A/B runs: profiles/r06_inkernel_sums.txt)
   int wgrad_reduce_rows; // HWG_WGRAD_REDUCE_ROWS: 0 = tap-at-a-time partial-image reduce (A/B timing), 1 default = row-contiguous stores
   char wino_force[32];   // HWG_WINO_FORCE  "cfg[,nsplit]"
   char wino_bal[32];     // HWG_WINO_BAL    balanced schedule of the 64 x 64 Winograd kernel: -1 never, unset / 0 by model, "G[,lead tiles]" forced
@@ -93,34 +93,42 @@ constexpr int HWG_SPLIT_COUNTERS = 1 << 18;
 int* hwg_split_counters(hipStream_t st);
 #if defined(__HIPCC__)
 // Arrival protocol of the split kernels (the wavefront / workgroup that delivers a tile's LAST partial image sums all of them itself, in split
-// order - same bits as a separate reduce launch, no second launch, partials read where they were written): partial stores -> release fence at
-// agent scope (the XCDs' L2s are not coherent with each other: the fence writes this one's dirty lines back) -> counter += 1; whoever read
-// `expected - 1` sets the counter back to 0 for the next launch, takes an acquire fence (invalidates L1 and the non-local L2 lines) and may load
-// every split's partials. Both return the same answer to all calling lanes.
+// order - same bits as a separate reduce launch, no second launch). What crosses workgroups - the partial images and the counter - is written
+// and read with AGENT-SCOPE relaxed atomics (hwg_store_agent / hwg_load_agent: `sc1` stores write through to the memory side, `sc1` loads do not
+// hit this XCD's possibly stale L2 / L1 lines), ordered by `s_waitcnt vmcnt(0)` between the stores and the counter increment (a store is
+// acknowledged once it is visible at its scope). NOT with __threadfence(): the XCDs' L2s are not coherent with each other, so an agent-scope
+// fence is `buffer_wbl2` + `buffer_inv sc1` - a write-back and an invalidation of the WHOLE L2, per wavefront; measured on the training step:
+// 83 -> 62 steps/s with fences in the split convolutions alone. With the agent-scope accesses it is 90 -> 77: the store acknowledgements from
+// the memory side, the counter round trip and the dependent `sc1` loads sit at the end of every 25 us kernel where a 5 us reduce launch runs
+// at full width. OFF by default (HWG_SPLIT_INKERNEL), kept as a measured alternative: profiles/r06_inkernel_sums.txt.
+__device__ __forceinline__ void hwg_store_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float hwg_load_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hwg_store_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double hwg_load_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hwg_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Both return the same answer to all calling lanes; the counter is set back to zero by whoever read `expected - 1`.
 // Wavefront form: the calling wavefront owns its output elements alone (same elements in every split); all 64 lanes call it.
 __device__ __forceinline__ bool hwg_split_arrive_wave(int* slot, int expected) {
-  __threadfence();
+  hwg_stores_done();
   int arrived = 0;
   if ((threadIdx.x & 63) == 0) arrived = atomicAdd(slot, 1);
   arrived = __builtin_amdgcn_readfirstlane(arrived);
   if (arrived != expected - 1) return false;
-  if ((threadIdx.x & 63) == 0) *slot = 0;
-  __threadfence();
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("" ::: "memory");
   return true;
 }
 // Workgroup form: all threads of the workgroup call it (two barriers inside); `flag` is one int of LDS.
 __device__ __forceinline__ bool hwg_split_arrive_block(int* slot, int expected, int* flag) {
-  __threadfence();
+  hwg_stores_done();
   __syncthreads();
   if (threadIdx.x == 0) {
     const int last = atomicAdd(slot, 1) == expected - 1;
-    if (last) *slot = 0;
+    if (last) __hip_atomic_store(slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *flag = last;
   }
   __syncthreads();
-  const bool last = *flag != 0;
-  if (last) __threadfence();
-  return last;
+  return *flag != 0;
 }
 #endif
 // what the calling thread's last convolution-family launch ran: engine (HWG_PROF_* kind), schedule id, split factor

@@ -53,8 +53,8 @@ const HwgTune& hwg_tune() {
     t->conv_lds = tune_int("HWG_CONV_LDS", 1);
     t->to1_lanes = tune_int("HWG_TO1_LANES", 1);
     t->wgrad_reduce_rows = tune_int("HWG_WGRAD_REDUCE_ROWS", 1);
-    t->split_inkernel = tune_int("HWG_SPLIT_INKERNEL", 1);
-    t->norm_fused = tune_int("HWG_NORM_FUSED", 1);
+    t->split_inkernel = tune_int("HWG_SPLIT_INKERNEL", 0);
+    t->norm_fused = tune_int("HWG_NORM_FUSED", 0);
     t->wgrad_c1 = tune_int("HWG_WGRAD_C1", 0);
     t->c1_rows = tune_int("HWG_C1_ROWS", 1);
     t->wgrad_c1_rows = tune_int("HWG_WGRAD_C1_ROWS", 1);

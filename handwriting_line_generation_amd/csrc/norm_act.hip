@@ -40,7 +40,9 @@ Geo make_geo(int N, int HW, int C) {
 // instead of doubles: NOT the same arithmetic - with the double image the compiler folds the last fp32 accumulate of every lane into the
 // fp64 conversion (contraction across the fpext), the fp32 image rounds it first; 1-ulp differences in rstd that flip a ReLU gate of the
 // count-lesson recogniser path: 2.95e-6 -> 1.42e-4 from fp64, tests/test_pipeline_gpu.py.)
-template <int NV>
+// COH (here and in the bodies below): the partial sums are read by OTHER workgroups of the same launch (fused kernels): they are written and read
+// with agent-scope accesses (hwg_store_agent / hwg_load_agent, hwg_common.h) instead of plain ones - same values, same arithmetic
+template <int NV, bool COH = false>
 __device__ __forceinline__ void block_reduce_store(const float4 (&acc)[NV], const Geo& g, double* part, double* sm) {
   const int tid = threadIdx.x;
   const int cl = tid % g.L, pl = tid / g.L;
@@ -58,7 +60,7 @@ __device__ __forceinline__ void block_reduce_store(const float4 (&acc)[NV], cons
   for (int i = tid; i < g.C * NV; i += 256) {
     double s = 0.0;
     for (int p = 0; p < g.PP; ++p) s += sm[(size_t)p * g.C * NV + i];
-    po[i] = s;
+    if (COH) hwg_store_agent(po + i, s); else po[i] = s;
   }
 }
 
@@ -75,7 +77,6 @@ __device__ __forceinline__ bool grid_wait(int* c, int expected) {
     ok_flag = ok;
   }
   __syncthreads();
-  __threadfence();
   return ok_flag != 0;
 }
 
@@ -83,7 +84,7 @@ __device__ __forceinline__ bool grid_wait(int* c, int expected) {
 // NOISE: 0 = moments of x, 1 = of u = lrelu(x + nw*noise) with the noise read from a tensor, 2 = the same with the noise DRAWN here: element
 // i of the tensor takes normal i % 4 of Philox counter ctr0 + i / 4 (philox.h) - exactly the value hwg_randn(seed, offset = ctr0) would have
 // written to a noise tensor, without the tensor (forward-only calls: nothing reads the noise again)
-template <int NOISE>
+template <int NOISE, bool COH = false>
 __device__ __forceinline__ void moments_fwd_body(const float* x, const Geo& g, double* part,
                                                  const float* noise, const float* nw, float nscale, float slope, float* u,
                                                  unsigned long long seed, unsigned long long ctr0) {
@@ -131,7 +132,7 @@ __device__ __forceinline__ void moments_fwd_body(const float* x, const Geo& g, d
       }
     }
   }
-  block_reduce_store<2>(acc, g, part, sm);
+  block_reduce_store<2, COH>(acc, g, part, sm);
 }
 template <int NOISE>
 __global__ __launch_bounds__(256) void moments_fwd_kernel(const float* x, Geo g, double* part,
@@ -182,8 +183,14 @@ struct InlineStats {
   int per_sample;
   int accumulate;
 };
+template <bool COH>
+__device__ __forceinline__ double2 load_pair(const double2* p) {
+  if (!COH) return *p;
+  const double* d = reinterpret_cast<const double*>(p);
+  return make_double2(hwg_load_agent(d), hwg_load_agent(d + 1));
+}
 // forward: s_a = mean, s_b = rstd.  backward: s_a = c1 = mean_grp(g*gamma), s_b = c2 = mean_grp(g*gamma*xhat)
-template <bool BWD>
+template <bool BWD, bool COH = false>
 __device__ __forceinline__ void sample_stats(const InlineStats& is, const Geo& g, int n, float* s_a, float* s_b, double* s_t) {
   const int tid = threadIdx.x;
   for (int c = tid; c < g.C; c += 256) {
@@ -195,11 +202,11 @@ __device__ __forceinline__ void sample_stats(const InlineStats& is, const Geo& g
     for (; k + 8 <= g.chunks; k += 8) {
       double2 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(k + u) * g.C];
+      for (int u = 0; u < 8; ++u) v[u] = load_pair<COH>(pp + (size_t)(k + u) * g.C);
 #pragma unroll
       for (int u = 0; u < 8; ++u) { s1 += v[u].x; s2 += v[u].y; }
     }
-    for (; k < g.chunks; ++k) { const double2 v = pp[(size_t)k * g.C]; s1 += v.x; s2 += v.y; }
+    for (; k < g.chunks; ++k) { const double2 v = load_pair<COH>(pp + (size_t)k * g.C); s1 += v.x; s2 += v.y; }
     if (BWD) {
       if (blockIdx.x == 0 && is.per_sample) {
         const int idx = n * g.C + c;
@@ -242,6 +249,7 @@ __device__ __forceinline__ float norm_pre(float v, float m, float r, float g, fl
 }
 
 // ---------------- forward stage 3: y = act(mask * (gamma * xhat + beta)) -----------------------------------------------
+template <bool COH = false>
 __device__ __forceinline__ void apply_fwd_body(const float* x, float* y, const Geo& g, const float* mean, const float* rstd,
                                                const float* gamma, const float* beta, int per_sample,
                                                const float* mask, int act, float slope, const InlineStats& is) {
@@ -251,7 +259,7 @@ __device__ __forceinline__ void apply_fwd_body(const float* x, float* y, const G
   const int tid = threadIdx.x;
   const int cl = tid % g.L, pl = tid / g.L;
   const int n = blockIdx.y;
-  if (is.part) sample_stats<false>(is, g, n, s_a, s_b, s_t);
+  if (is.part) sample_stats<false, COH>(is, g, n, s_a, s_b, s_t);
   if (pl >= g.PP) return;
   const int p0 = blockIdx.x * g.cs, p1 = min(p0 + g.cs, g.HW);
   const int c = cl * 4;
@@ -301,6 +309,7 @@ __global__ __launch_bounds__(256) void apply_fwd_kernel(const float* x, float* y
 
 // ---------------- backward stage 1: partial sums of g and g*xhat, g = dy * act'(y) * mask ---------------------------------
 // `y` == null with act = relu / leaky relu: the gate comes from the recomputed pre-activation (gamma, beta as in the forward call)
+template <bool COH = false>
 __device__ __forceinline__ void moments_bwd_body(const float* dy, const float* x, const float* y, const Geo& g, double* part,
                                                  const float* mean, const float* rstd, const float* mask, int act, float slope,
                                                  const float* gamma, const float* beta, int per_sample) {
@@ -354,7 +363,7 @@ __device__ __forceinline__ void moments_bwd_body(const float* dy, const float* x
      }
     }
   }
-  block_reduce_store<2>(acc, g, part, sm);
+  block_reduce_store<2, COH>(acc, g, part, sm);
 }
 __global__ __launch_bounds__(256) void moments_bwd_kernel(const float* dy, const float* x, const float* y, Geo g, double* part,
                                                           const float* mean, const float* rstd, const float* mask, int act, float slope,
@@ -408,7 +417,7 @@ __global__ __launch_bounds__(256) void param_grad_kernel(const double* part, Geo
 // accumulates per-channel partials of dt (conv bias grad) and dt*noise (noise weight grad) into part2[n][chunk][c][2].
 // `all_arrived` (fused launch only): counter that reaches gridDim.x * gridDim.y once EVERY workgroup's moment partials are in memory - the first
 // sample's workgroups wait for it before they sum the partials of all samples
-template <bool PRE>
+template <bool PRE, bool COH = false>
 __device__ __forceinline__ void apply_bwd_body(const float* dy, const float* x, const float* y, float* dx, const Geo& g,
                                                const float* mean, const float* rstd, const float* gamma, int per_sample,
                                                const float* c1, const float* c2, const float* mask, int act, float slope,
@@ -421,7 +430,7 @@ __device__ __forceinline__ void apply_bwd_body(const float* dy, const float* x, 
   const int tid = threadIdx.x;
   const int cl = tid % g.L, pl = tid / g.L;
   const int n = blockIdx.y;
-  if (is.part) sample_stats<true>(is, g, n, s_a, s_b, s_t);
+  if (is.part) sample_stats<true, COH>(is, g, n, s_a, s_b, s_t);
   const int p0 = blockIdx.x * g.cs, p1 = min(p0 + g.cs, g.HW);
   float4 acc[2];
   acc[0] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -495,8 +504,8 @@ __device__ __forceinline__ void apply_bwd_body(const float* dy, const float* x, 
     for (int c = blockIdx.x * 4 + wv; c < g.C; c += gridDim.x * 4) {
       double s1 = 0.0, s2 = 0.0;
       for (int it = lane; it < items; it += 64) {
-        const double* p = is.part + ((size_t)it * g.C + c) * 2;
-        s1 += p[0]; s2 += p[1];
+        const double2 v = load_pair<COH>(reinterpret_cast<const double2*>(is.part) + (size_t)it * g.C + c);
+        s1 += v.x; s2 += v.y;
       }
       s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
       if (lane == 0) {
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* dy, const f
 // Counters: [2n] arrivals, [2n + 1] departures of sample n; [2N], [2N + 1] the same over the whole grid. The last workgroup to depart sets both
 // back to zero (launches of one stream are ordered, the buffer is per stream).
 __device__ __forceinline__ void grid_arrive(int* a, int* b) {
-  __threadfence();
+  hwg_stores_done();
   __syncthreads();
   if (threadIdx.x == 0) { atomicAdd(a, 1); if (b) atomicAdd(b, 1); }
 }
@@ -544,11 +553,11 @@ __global__ __launch_bounds__(256) void norm_fwd_fused_kernel(const float* x, flo
                                                              float nscale, float nslope, float* u, unsigned long long seed, unsigned long long ctr0,
                                                              const float* gamma, const float* beta, int per_sample, const float* mask, int act,
                                                              float slope, InlineStats is, int* sync) {
-  moments_fwd_body<NOISE>(x, g, part, noise, nw, nscale, nslope, u, seed, ctr0);
+  moments_fwd_body<NOISE, true>(x, g, part, noise, nw, nscale, nslope, u, seed, ctr0);
   int* mine = sync + 2 * blockIdx.y;
   grid_arrive(mine, nullptr);
   const bool ok = grid_wait(mine, gridDim.x);
-  apply_fwd_body(NOISE ? (const float*)u : x, y, g, is.out_a, is.out_b, gamma, beta, per_sample, mask, act, slope, is);
+  apply_fwd_body<true>(NOISE ? (const float*)u : x, y, g, is.out_a, is.out_b, gamma, beta, per_sample, mask, act, slope, is);
   if (!ok && blockIdx.x == 0) { __syncthreads(); for (int c = threadIdx.x; c < g.C; c += 256) is.out_b[blockIdx.y * g.C + c] = __builtin_nanf(""); }
   grid_depart(mine, mine + 1, gridDim.x);
 }
@@ -560,15 +569,15 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const float* dy, co
                                                              float slope, const float* noise, float pre_slope, double* part2, InlineStats is,
                                                              float* pg_gamma, float* pg_beta, int pg_accumulate, int* sync) {
   // (the moments pass of the generator epilogue's backward takes no gate, mask or affine: hwg_adain_bwd)
-  if (PRE) moments_bwd_body(dy, x, nullptr, g, part, mean, rstd, nullptr, 0, 0.f, nullptr, nullptr, 0);
-  else moments_bwd_body(dy, x, y, g, part, mean, rstd, mask, act, slope, gamma, beta, per_sample);
+  if (PRE) moments_bwd_body<true>(dy, x, nullptr, g, part, mean, rstd, nullptr, 0, 0.f, nullptr, nullptr, 0);
+  else moments_bwd_body<true>(dy, x, y, g, part, mean, rstd, mask, act, slope, gamma, beta, per_sample);
   int* mine = sync + 2 * blockIdx.y;
   int* all = sync + 2 * gridDim.y;
   const bool fold = !PRE && (pg_gamma || pg_beta);
   grid_arrive(mine, fold ? all : nullptr);
   const bool ok = grid_wait(mine, gridDim.x);
-  apply_bwd_body<PRE>(dy, x, y, dx, g, mean, rstd, gamma, per_sample, c1, c2, mask, act, slope, noise, pre_slope, part2, is, beta, pg_gamma, pg_beta,
-                      pg_accumulate, fold ? all : nullptr);
+  apply_bwd_body<PRE, true>(dy, x, y, dx, g, mean, rstd, gamma, per_sample, c1, c2, mask, act, slope, noise, pre_slope, part2, is, beta, pg_gamma,
+                            pg_beta, pg_accumulate, fold ? all : nullptr);
   if (!ok) { __syncthreads(); for (long long i = threadIdx.x; i < 4; i += 256) dx[i] = __builtin_nanf(""); }
   grid_depart(mine, mine + 1, gridDim.x);
   if (fold) grid_depart(all, all + 1, gridDim.x * gridDim.y);

@@ -18,6 +18,8 @@ def _free_port():
 
 def _worker(rank, world, port, out, workdir):
     import random
+    import faulthandler
+    faulthandler.dump_traceback_later(420, exit=True)      # a rank that hangs says where (the parent gives up after 600 s)
     import numpy as np
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -52,7 +54,11 @@ def _run(world, tmp):
         p.start()
     for p in procs:
         p.join(600)
-        assert p.exitcode == 0
+    codes = [p.exitcode for p in procs]
+    for p in procs:
+        if p.exitcode is None:
+            p.kill()
+    assert codes == [0] * world, codes
     return dict(out)
 
 

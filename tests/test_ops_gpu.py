@@ -215,9 +215,9 @@ SPLIT_CASES = [("direct", (2, 9, 40, 64, 96, 3, 3, (1, 1), (1, 1), (1, 1), 0), d
                ("direct", (2, 9, 40, 64, 96, 3, 3, (1, 1), (1, 1), (1, 1), 0), dict(HWG_WINO="0", HWG_CONV_FORCE="128,128,32,2")),
                ("direct", (3, 1, 126, 128, 80, 1, 3, (1, 1), (0, 2), (1, 2), 0), dict(HWG_CONV_FORCE="128,64,32,3")),
                ("direct", (3, 1, 126, 128, 80, 1, 3, (1, 1), (0, 4), (1, 4), 0), dict(HWG_CONV_FORCE="128,32,16,8")),
-               ("direct", (2, 7, 19, 32, 64, 4, 4, (2, 2), (0, 0), (1, 1), 1), dict(HWG_CONV_MERGE="0", HWG_CONV_FORCE="64,64,32,2")),
-               ("direct", (2, 7, 19, 32, 64, 4, 4, (2, 2), (0, 0), (1, 1), 1), dict(HWG_CONV_MERGE="2", HWG_CONV_FORCE="128,128,32,2")),
-               ("direct", (2, 1, 30, 64, 40, 6, 3, (3, 1), (0, 1), (1, 1), 1), dict(HWG_CONV_MERGE="0", HWG_CONV_FORCE="64,64,16,3")),
+               ("direct", (2, 7, 19, 128, 64, 4, 4, (2, 2), (0, 0), (1, 1), 1), dict(HWG_CONV_MERGE="0", HWG_CONV_FORCE="64,64,32,2")),
+               ("direct", (2, 7, 19, 128, 64, 4, 4, (2, 2), (0, 0), (1, 1), 1), dict(HWG_CONV_MERGE="2", HWG_CONV_FORCE="128,128,32,2")),
+               ("direct", (2, 1, 30, 128, 40, 6, 3, (3, 1), (0, 1), (1, 1), 1), dict(HWG_CONV_MERGE="0", HWG_CONV_FORCE="64,64,16,3")),
                ("wino", (2, 13, 37, 64, 80, 3, 3, (1, 1), (1, 1), (1, 1), 0), dict(HWG_WINO="2", HWG_WINO_FORCE="0,2")),
                ("wino", (1, 9, 66, 48, 208, 3, 3, (1, 1), (0, 1), (1, 1), 0), dict(HWG_WINO="2", HWG_WINO_FORCE="1,3")),
                ("wino", (3, 7, 21, 128, 32, 3, 3, (1, 1), (2, 2), (1, 1), 0), dict(HWG_WINO="2", HWG_WINO_FORCE="2,4")),
