@@ -23,10 +23,12 @@ struct MtArgs {
   int chunk;
 };
 
-__global__ __launch_bounds__(256) void mt_abs_sum_kernel(MtArgs a, double* out) {
+// blockIdx.y = set (hwg_mt_abs_sum_sets: pointer tables [nsets][nt], partials [nsets][nchunks]; one set: the plain call)
+__global__ __launch_bounds__(256) void mt_abs_sum_kernel(MtArgs a, double* out, int nt) {
   __shared__ double sm[16];
   const int t = a.chunk_tensor[blockIdx.x];
-  const float* g = reinterpret_cast<const float*>(a.pa[t]);
+  const float* g = reinterpret_cast<const float*>(a.pa[(size_t)blockIdx.y * nt + t]);
+  out += (size_t)blockIdx.y * gridDim.x;
   if (!g) return;
   const long long off = a.chunk_off[blockIdx.x];
   const long long end = min(off + (long long)a.chunk, a.numel[t]);
@@ -50,6 +52,7 @@ __global__ __launch_bounds__(256) void mt_abs_sum_kernel(MtArgs a, double* out) 
 __global__ __launch_bounds__(256) void mt_abs_sum_final_kernel(const double* part, const int* chunk_tensor, int nchunks, int nt, double* sums) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nt) return;
+  part += (size_t)blockIdx.y * nchunks; sums += (size_t)blockIdx.y * nt;
   // first chunk of tensor t by binary search (chunk_tensor is non-decreasing)
   int lo = 0, hi = nchunks;
   while (lo < hi) {
@@ -123,6 +126,58 @@ __global__ __launch_bounds__(256) void mt_axpy_kernel(MtArgs a, const float* coe
     }
   }
   for (long long i = off + 4 * n4 + threadIdx.x; i < end; i += 256) dst[i] += c * src[i];
+}
+
+// dst += coef[0][t] * src_0, then += coef[1][t] * src_1, ... in ONE pass over dst (hwg_mt_axpy_sets): per element the same chain of fused
+// multiply-adds, in the same order, as nsets launches of mt_axpy_kernel (whose `d += c * v` compiles to v_fma) - dst is read and written once
+// instead of nsets times. a.pb = source tables [nsets][nt]; absent sources and zero coefficients are skipped like the single launches skip them.
+__global__ __launch_bounds__(256) void mt_axpy_sets_kernel(MtArgs a, const float* coef, int nsets, int nt) {
+  const int t = a.chunk_tensor[blockIdx.x];
+  float* dst = reinterpret_cast<float*>(a.pa[t]);
+  if (!dst) return;
+  constexpr int MAXS = 8;
+  const float* src[MAXS];     // (indexed by unrolled loops only: registers)
+  float c[MAXS];
+  bool any = false, al = true;
+  const long long off = a.chunk_off[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < MAXS; ++k) {
+    src[k] = nullptr; c[k] = 0.f;
+    if (k < nsets) {
+      const float* sk = reinterpret_cast<const float*>(a.pb[(size_t)k * nt + t]);
+      const float ck = coef[(size_t)k * nt + t];
+      if (sk && ck != 0.f) {
+        src[k] = sk; c[k] = ck; any = true;
+        al = al && ((reinterpret_cast<uintptr_t>(sk + off)) & 15) == 0;
+      }
+    }
+  }
+  if (!any) return;
+  const long long end = min(off + (long long)a.chunk, a.numel[t]);
+  al = al && ((reinterpret_cast<uintptr_t>(dst + off)) & 15) == 0;
+  const long long n4 = al ? (end - off) >> 2 : 0;
+  float4* d4 = reinterpret_cast<float4*>(dst + off);
+  for (long long j = threadIdx.x; j < n4; j += 256) {
+    float4 d = d4[j];
+    float4 v[MAXS];
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k)
+      if (src[k]) v[k] = reinterpret_cast<const float4*>(src[k] + off)[j];
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k)
+      if (src[k]) {
+        d.x = __fmaf_rn(c[k], v[k].x, d.x); d.y = __fmaf_rn(c[k], v[k].y, d.y);
+        d.z = __fmaf_rn(c[k], v[k].z, d.z); d.w = __fmaf_rn(c[k], v[k].w, d.w);
+      }
+    d4[j] = d;
+  }
+  for (long long i = off + 4 * n4 + threadIdx.x; i < end; i += 256) {
+    float d = dst[i];
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k)
+      if (src[k]) d = __fmaf_rn(c[k], src[k][i], d);
+    dst[i] = d;
+  }
 }
 
 // op 0: a = 0 ; 1: a = clamp(a, -c, c) ; 2: flag |= any(!finite(a)) ; 3: b = a (copy) ; 4: b = a, a = 0 (stash)
@@ -388,10 +443,25 @@ extern "C" int hwg_mt_abs_sum(const void* ptrs, const void* numel, const void* c
     hwg_set_error("mt_abs_sum: memset failed");
     return HWG_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(mt_abs_sum_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a, chunk_partials);
+  hipLaunchKernelGGL(mt_abs_sum_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a, chunk_partials, nt);
   hipLaunchKernelGGL(mt_abs_sum_final_kernel, dim3(hwg_cdiv(nt, 256)), dim3(256), 0, (hipStream_t)stream, (const double*)chunk_partials,
                      (const int*)chunk_tensor, nchunks, nt, out_sums);
   HWG_LAUNCH_CHECK("mt_abs_sum");
+  return HWG_OK;
+}
+extern "C" int hwg_mt_abs_sum_sets(const void* ptrs, int nsets, const void* numel, const void* chunk_tensor, const void* chunk_off, int nchunks,
+                                   int chunk, int nt, double* chunk_partials, double* out_sums, void* stream) {
+  HWG_REQUIRE(ptrs && numel && chunk_tensor && chunk_off && chunk_partials && out_sums && nchunks > 0 && chunk > 0 && nt > 0 && nsets > 0 &&
+              nsets <= 64, "mt_abs_sum_sets: bad arguments");
+  MtArgs a = make_mt(ptrs, nullptr, nullptr, nullptr, numel, chunk_tensor, chunk_off, chunk);
+  if (hipMemsetAsync(chunk_partials, 0, (size_t)nsets * nchunks * sizeof(double), (hipStream_t)stream) != hipSuccess) {
+    hwg_set_error("mt_abs_sum_sets: memset failed");
+    return HWG_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(mt_abs_sum_kernel, dim3(nchunks, nsets), dim3(256), 0, (hipStream_t)stream, a, chunk_partials, nt);
+  hipLaunchKernelGGL(mt_abs_sum_final_kernel, dim3(hwg_cdiv(nt, 256), nsets), dim3(256), 0, (hipStream_t)stream, (const double*)chunk_partials,
+                     (const int*)chunk_tensor, nchunks, nt, out_sums);
+  HWG_LAUNCH_CHECK("mt_abs_sum_sets");
   return HWG_OK;
 }
 extern "C" int hwg_mt_balance_coef(const double* sumD, const double* sumR, const void* numel, const void* ptr_grad, const void* ptr_R,
@@ -408,6 +478,15 @@ extern "C" int hwg_mt_axpy(const void* ptrs_dst, const void* ptrs_src, const flo
   MtArgs a = make_mt(ptrs_dst, ptrs_src, nullptr, nullptr, numel, chunk_tensor, chunk_off, chunk);
   hipLaunchKernelGGL(mt_axpy_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a, coef);
   HWG_LAUNCH_CHECK("mt_axpy");
+  return HWG_OK;
+}
+extern "C" int hwg_mt_axpy_sets(const void* ptrs_dst, const void* ptrs_src, const float* coef, int nsets, int nt, const void* numel,
+                                const void* chunk_tensor, const void* chunk_off, int nchunks, int chunk, void* stream) {
+  HWG_REQUIRE(ptrs_dst && ptrs_src && coef && numel && chunk_tensor && chunk_off && nchunks > 0 && chunk > 0 && nt > 0 && nsets > 0 && nsets <= 8,
+              "mt_axpy_sets: bad arguments (at most 8 sets)");
+  MtArgs a = make_mt(ptrs_dst, ptrs_src, nullptr, nullptr, numel, chunk_tensor, chunk_off, chunk);
+  hipLaunchKernelGGL(mt_axpy_sets_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a, coef, nsets, nt);
+  HWG_LAUNCH_CHECK("mt_axpy_sets");
   return HWG_OK;
 }
 extern "C" int hwg_mt_unary(const void* ptrs_a, const void* ptrs_b, int op, float c, int* flag, const void* numel, const void* chunk_tensor,

@@ -24,6 +24,7 @@ from .. import _lib as L
 from .. import ops
 
 CHUNK = 65536
+BALANCE_SETS = bool(int(os.environ.get("HWG_BALANCE_SETS", "1") or 1))      # 0: one abs-sum / one add launch per stashed set (A/B, tests)
 
 
 class FlatParams:
@@ -194,24 +195,36 @@ class FlatParams:
         if not stashes:
             return
         ops.join_side_stream()
-        sumD = self.abs_sums(self.flat_grad, self.touched)
         ns = len(stashes)
-        sumR = torch.empty((ns, self.nt), dtype=torch.float64, device=self.device)
-        ptrR = np.zeros((ns, self.nt), dtype=np.int64)
+        # one pointer table for everything: row 0 the current gradients, rows 1.. the stashed sets (0 = no gradient)
+        tab = np.zeros((ns + 1, self.nt), dtype=np.int64)
+        tab[0] = self.base_ptrs(self.flat_grad) * self.touched.astype(np.int64)
         for k, st in enumerate(stashes):
             buf, tm = st[0], st[1]
-            sumR[k] = self.abs_sums(buf, tm)
-            ptrR[k] = self.base_ptrs(buf) * tm.astype(np.int64)
+            tab[k + 1] = self.base_ptrs(buf) * tm.astype(np.int64)
             if (tm & ~self.touched).any():
                 raise RuntimeError("a stashed gradient exists for a parameter whose current gradient is None (the reference would raise here too)")
-        d_ptrR = ops.h2d(ptrR, self.device)
-        d_ptrG = self.masked_ptrs(self.flat_grad, self.touched)
+        d_tab = ops.h2d(tab, self.device)
         xs = ops.h2d(np.array([float(multipliers[k]) for k in range(ns)], dtype=np.float32), self.device)
         coef = torch.empty((ns, self.nt), dtype=torch.float32, device=self.device)
-        L.call("hwg_mt_balance_coef", sumD, sumR, self.d_numel, d_ptrG, d_ptrR, xs, ns, self.nt, coef, self._st())
+        if BALANCE_SETS and ns <= 8:
+            # mean |.| of the current gradients and of every set in two launches, the balanced adds of all sets in one pass over the gradients
+            # (hwg_mt_abs_sum_sets / hwg_mt_axpy_sets: per set / per element the arithmetic of the one-set calls below, bit for bit)
+            sums = torch.empty((ns + 1, self.nt), dtype=torch.float64, device=self.device)
+            part = torch.empty((ns + 1) * self.nchunks, dtype=torch.float64, device=self.device)
+            L.call("hwg_mt_abs_sum_sets", d_tab, ns + 1, self.d_numel, self.d_chunk_tensor, self.d_chunk_off, self.nchunks, CHUNK, self.nt, part, sums,
+                   self._st())
+            L.call("hwg_mt_balance_coef", sums[0], sums[1:], self.d_numel, d_tab[0], d_tab[1:], xs, ns, self.nt, coef, self._st())
+            L.call("hwg_mt_axpy_sets", d_tab[0], d_tab[1:], coef, ns, self.nt, self.d_numel, self.d_chunk_tensor, self.d_chunk_off, self.nchunks, CHUNK,
+                   self._st())
+            return
+        sums = torch.empty((ns + 1, self.nt), dtype=torch.float64, device=self.device)
+        part = torch.empty(self.nchunks, dtype=torch.float64, device=self.device)
+        for k in range(ns + 1):
+            L.call("hwg_mt_abs_sum", d_tab[k], self.d_numel, self.d_chunk_tensor, self.d_chunk_off, self.nchunks, CHUNK, self.nt, part, sums[k], self._st())
+        L.call("hwg_mt_balance_coef", sums[0], sums[1:], self.d_numel, d_tab[0], d_tab[1:], xs, ns, self.nt, coef, self._st())
         for k in range(ns):
-            L.call("hwg_mt_axpy", d_ptrG, d_ptrR[k].contiguous(), coef[k].contiguous(), self.d_numel, self.d_chunk_tensor, self.d_chunk_off,
-                   self.nchunks, CHUNK, self._st())
+            L.call("hwg_mt_axpy", d_tab[0], d_tab[k + 1], coef[k], self.d_numel, self.d_chunk_tensor, self.d_chunk_off, self.nchunks, CHUNK, self._st())
 
     def clip_(self, value):
         """torch.nn.utils.clip_grad_value_ over every parameter that has a gradient"""

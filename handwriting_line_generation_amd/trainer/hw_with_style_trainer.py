@@ -294,7 +294,7 @@ class HWWithStyleTrainer(BaseTrainer):
             if self.balance_loss:
                 for pos, part in enumerate((autoGenLoss, recogLoss)):
                     if not isinstance(part, int):
-                        part.backward(retain_graph=True)
+                        part.backward(self._one(part), retain_graph=True)
                         ops.join_side_stream()
                         if taped:
                             st = self.flat.stash()                        # its all-reduce starts once the taped networks' share has been added
@@ -306,7 +306,7 @@ class HWWithStyleTrainer(BaseTrainer):
                     if not isinstance(part, int):
                         loss = part if isinstance(loss, int) else ops.add(loss, part)
             if not isinstance(loss, int):
-                loss.backward()
+                loss.backward(self._one(loss))
                 ops.join_side_stream()
             if taped:
                 sets.append((None, None, self._take_leaf_grads(gtapes, stapes)))
@@ -649,6 +649,16 @@ class HWWithStyleTrainer(BaseTrainer):
                      "gen_spaced", "spaced_style", "mu", "sigma"):
             setattr(model, attr, None)
         return ret
+
+    def _one(self, like):
+        """the seed of a backward pass: autograd's implicit one is a fill launch per call; a cached tensor of the loss's shape is read-only there"""
+        key = (like.shape, like.dtype, like.device)
+        hit = self._ones.get(key) if hasattr(self, "_ones") else None
+        if hit is None:
+            if not hasattr(self, "_ones"):
+                self._ones = {}
+            hit = self._ones[key] = torch.ones(like.shape, dtype=like.dtype, device=like.device)
+        return hit
 
     def get_style_gen(self, batch_size, device):
         """mix two stored styles per line with a weight in [low, high] (trainer :974-988); the style bank stays on the GPU"""

@@ -444,10 +444,19 @@ int hwg_segment_accumulate_ptr(const float* rows, const int* seg_start, const in
  * nchunks doubles of scratch), then the chunks of a tensor - consecutive entries of the chunk table - are added in table order. */
 int hwg_mt_abs_sum(const void* ptrs, const void* numel, const void* chunk_tensor, const void* chunk_off, int nchunks, int chunk,
                    int nt, double* chunk_partials, double* out_sums, void* stream);
+/* the same for nsets tensor lists at once (ptrs [nsets][nt], chunk_partials [nsets][nchunks], out_sums [nsets][nt]): the current gradients and
+ * every stashed set of a balanced lesson (trainer :340-359) in two launches instead of two per set; per set the arithmetic of hwg_mt_abs_sum */
+int hwg_mt_abs_sum_sets(const void* ptrs, int nsets, const void* numel, const void* chunk_tensor, const void* chunk_off, int nchunks,
+                        int chunk, int nt, double* chunk_partials, double* out_sums, void* stream);
 int hwg_mt_balance_coef(const double* sumD, const double* sumR, const void* numel, const void* ptr_grad, const void* ptr_R,
                         const float* xs, int nsets, int nt, float* coef, void* stream);
 int hwg_mt_axpy(const void* ptrs_dst, const void* ptrs_src, const float* coef, const void* numel, const void* chunk_tensor,
                 const void* chunk_off, int nchunks, int chunk, void* stream);
+/* dst_t += coef[0][t] * src_0t, then += coef[1][t] * src_1t, ...: the balanced adds of all stashed sets (trainer :360-377) in ONE pass over the
+ * gradients (ptrs_src, coef: [nsets][nt], nsets <= 8) - per element the same chain of fused multiply-adds in the same order as nsets calls of
+ * hwg_mt_axpy, bit for bit */
+int hwg_mt_axpy_sets(const void* ptrs_dst, const void* ptrs_src, const float* coef, int nsets, int nt, const void* numel,
+                     const void* chunk_tensor, const void* chunk_off, int nchunks, int chunk, void* stream);
 /* op 0: a=0, 1: clamp(a,-c,c), 2: flag |= any non-finite, 3: b=a, 4: b=a then a=0 */
 int hwg_mt_unary(const void* ptrs_a, const void* ptrs_b, int op, float c, int* flag, const void* numel, const void* chunk_tensor,
                  const void* chunk_off, int nchunks, int chunk, void* stream);

@@ -121,6 +121,7 @@ def test_fused_step_and_masked_zero_grad_train_to_the_same_bits(cuda, tmp_path):
     and after zero_grad of both optimizers nothing but zeros is left outside the 'rest' group (no writer bypasses the touched marks)."""
     from handwriting_line_generation_amd import rng
     from handwriting_line_generation_amd.harness import build_gan_trainer
+    from handwriting_line_generation_amd.trainer import flat_params
     outs = []
     for new in (False, True):
         rng.set_mode("device", seed=11)
@@ -128,6 +129,7 @@ def test_fused_step_and_masked_zero_grad_train_to_the_same_bits(cuda, tmp_path):
         trainer, _ = build_gan_trainer("iam_gan", 2, 2, width=256, label_len=12, workdir=str(tmp_path / ("f%d" % new)))
         trainer._fused_step = new
         trainer.flat._zero_all = not new
+        flat_params.BALANCE_SETS = new      # (iii) the balanced adds of all stashed sets in one pass (hwg_mt_abs_sum_sets / hwg_mt_axpy_sets) vs a launch per set
         torch.manual_seed(5); np.random.seed(5); random.seed(5)
         logs = [trainer._train_iteration(it) for it in range(14)]
         torch.cuda.synchronize()
@@ -141,6 +143,7 @@ def test_fused_step_and_masked_zero_grad_train_to_the_same_bits(cuda, tmp_path):
         end = int(f.offsets[a]) if b > a else f.total
         extra["left"] = float(f.flat_grad[:end].abs().max())
         outs.append((logs, state, extra))
+    flat_params.BALANCE_SETS = True
     (la, sa, ea), (lb, sb, eb) = outs
     for it, (a, b) in enumerate(zip(la, lb)):
         assert a == b, "iteration %d: %s vs %s" % (it, a, b)
