@@ -90,6 +90,13 @@ def run(path, timing=False):
                 need = L.query("hwg_conv_wgrad_workspace", d.ptr)
                 ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
                 call = lambda: L.call("hwg_conv_wgrad", d.ptr, u, x, dw, C * R * S, R * S, S, 1, 0, None, 0, ws, ws.numel(), st)  # noqa: E731
+        elif kind == "wino_conv_kernel" and R == 4 and S == 4:      # F(3x3,2x2) on the space-to-depth image (4x4 stride 2, either direction)
+            # (the filter image is sized by the FORWARD layer's (K, C): for the data-gradient form that is this product's (C, K))
+            w = torch.randn(L.query("hwg_wino_s2_weight_floats", C if transposed else K, K if transposed else C, transposed), generator=g).to(dev)
+            y = torch.empty(N, P, Q, K, dtype=torch.float32, device=dev)
+            need = L.query("hwg_wino_s2_workspace", d.ptr)
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+            call = lambda: L.call("hwg_wino_s2_conv", d.ptr, x, w, None, y, 0, ws, ws.numel(), st)  # noqa: E731
         elif (kind == "wino_conv_kernel" if not os.environ.get("PMC_FREE_CHOICE") else
               (not transposed and L.query("hwg_wino_supported", d.ptr) and L.query("hwg_wino_preferred", d.ptr))):
             w = torch.randn(L.query("hwg_wino_weight_floats", K, C), generator=g).to(dev)
