@@ -154,8 +154,13 @@ class Matcher:
         self.feed_seq = 0          # feed() calls so far (the other side's gated tensors, in its own order)
         self.sites = []            # flips located through the near-zero lists: (record name, feed_seq, other side's sample, index in the sample, fp64 margin, fp64 decision code)
 
-    def feed(self, kind, dec, optional=False):
-        """dec: uint8 [N][M] decisions of one gated tensor of the other implementation"""
+    def feed(self, kind, dec, optional=False, margin=None, alt=None):
+        """dec: uint8 [N][M] decisions of one gated tensor of the other implementation. margin (sign gates only): float [N][M], the other side's own
+        pre-activation (any monotone image of it): a block whose hash differs and whose flips the record's near-zero list does not explain is
+        then SEARCHED - the decisions of the other side's smallest-|margin| elements of the block are toggled, one at a time and in pairs, until
+        the block's hash equals the reference's (a 64-bit hash: a match is the located flip, not a guess) - see _search_blocks. Pool windows:
+        margin = maximum minus runner-up (or the maximum itself where that is nearer zero), alt uint8 [N][M] = the decision the window would
+        take if that margin had the other sign (runner-up's code, or 0 = no positive maximum)"""
         N, M = dec.shape
         seq = self.feed_seq
         self.feed_seq += 1
@@ -193,9 +198,64 @@ class Matcher:
                         exact += 1
                         self.sites.append((r["name"], seq, n, int(i - lo), float(v), code))
             name = r["name"]
+            if differ and margin is not None and (kind == "act" or alt is not None):
+                exact += self._search_blocks(r, j, dec[n], margin[n], h[n], seq, n, None if alt is None else alt[n])
             self.flips[name] = self.flips.get(name, 0) + max(differ, exact)
             b = self.blocks.get(name, (0, 0))
             self.blocks[name] = (b[0] + differ, b[1] + nblk)
+
+    SEARCH_SINGLE, SEARCH_PAIR = 24, 10
+    SEARCH_MAX_MARGIN = 1e-4      # only decisions THIS close to flipping on the other side are candidates: a flip with a larger margin is not a
+                                  # rounding flip but the consequence of one upstream (or of a forcing nudge), and forcing it would move values
+                                  # by that margin
+
+    def _search_blocks(self, r, j, dec, margin, h, seq, n, alt=None):
+        """hash-verified location of the flips the near-zero list missed: -> sites added"""
+        M = dec.size
+        bs = block_size(M)
+        ref_h = r["hashes"][j]
+        added = 0
+
+        def hash_of(blk):          # block_hashes' arithmetic for ONE block of the tensor's block size
+            buf = np.zeros(bs, dtype=np.uint8)
+            buf[:blk.size] = blk
+            with np.errstate(over="ignore"):
+                v = (buf.view(np.uint64) * _multipliers()[: bs // 8]).sum(dtype=np.uint64)
+                return v ^ (v >> np.uint64(29))
+
+        for b in np.nonzero(ref_h != h)[0]:
+            lo, hi = int(b) * bs, min((int(b) + 1) * bs, M)
+            blk = dec[lo:hi].copy()
+            for (nm, sq, nn, idx, _v, code) in self.sites:          # flips of this block the near-zero list has located already
+                if nm == r["name"] and sq == seq and nn == n and lo <= idx < hi:
+                    blk[idx - lo] = code
+            if hash_of(blk) == ref_h[b]:
+                continue
+            cand = np.argsort(np.abs(margin[lo:hi]), kind="stable")[:self.SEARCH_SINGLE]
+            cand = cand[np.abs(margin[lo:hi][cand]) <= self.SEARCH_MAX_MARGIN]
+            hit = None
+            other = (blk ^ 1) if alt is None else alt[lo:hi]        # what each decision becomes if its margin changes sign
+            for c in cand:
+                t = blk.copy(); t[c] = other[c]
+                if hash_of(t) == ref_h[b]:
+                    hit = [int(c)]
+                    break
+            if hit is None:
+                pc = cand[:self.SEARCH_PAIR]
+                for a_ in range(len(pc)):
+                    for b_ in range(a_ + 1, len(pc)):
+                        t = blk.copy(); t[pc[a_]] = other[pc[a_]]; t[pc[b_]] = other[pc[b_]]
+                        if hash_of(t) == ref_h[b]:
+                            hit = [int(pc[a_]), int(pc[b_])]
+                            break
+                    if hit:
+                        break
+            if hit:
+                for c in hit:
+                    self.sites.append((r["name"], seq, n, lo + c, float(margin[lo + c]), int(other[c])))
+                    self.searched = getattr(self, "searched", 0) + 1
+                    added += 1
+        return added
 
     def unmatched_reference(self):
         """[(record name, samples never matched)]"""

@@ -169,3 +169,27 @@ def test_seq_known_answers():
         dec = json.loads(str(kat["dec%d" % n]))
         for b in range(pred.shape[1]):
             assert seq_oracle.naive_decode(pred[:, b].numpy())[0] == dec[b]
+
+
+def test_gate_matcher_locates_flips_beyond_the_near_zero_lists_by_hash_search():
+    """oracle/gates.py Matcher.feed(margin=...): a block whose hash differs from the record's is searched by toggling the other side's
+    smallest-|pre-activation| decisions until the 64-bit block hash equals the reference's - single flips, two flips in one block, several
+    samples; with an EMPTY near-zero list in the record (the case the search exists for)."""
+    from oracle import gates
+    rng = np.random.default_rng(0)
+    N, M = 2, 20000
+    pre64 = rng.standard_normal((N, M))
+    dec64 = (pre64 > 0).astype(np.uint8)
+    rec = {"name": "net.layer", "kind": "act", "N": N, "M": M, "hashes": gates.block_hashes(dec64), "nz_idx": np.full(gates.NZ, -1),
+           "nz_val": np.zeros(gates.NZ), "nz_code": np.zeros(gates.NZ, np.uint8), "ref32_flips": 0}
+    flips = [(0, 123), (0, 9000), (1, 17000), (1, 5), (1, 77)]            # the last two share a block
+    pre32 = pre64.copy()
+    for k, (n, i) in enumerate(flips):
+        pre32[n, i] = -np.sign(pre64[n, i]) * (1 + k) * 1e-7
+    m = gates.Matcher([rec])
+    m.feed("act", (pre32 > 0).astype(np.uint8), margin=pre32)
+    assert sorted((s[2], s[3], s[5]) for s in m.sites) == sorted((n, i, int(dec64[n, i])) for n, i in flips)
+    assert m.flips == {"net.layer": 5}
+    m2 = gates.Matcher([rec])                                              # without margins nothing can be located, the blocks still count
+    m2.feed("act", (pre32 > 0).astype(np.uint8))
+    assert m2.sites == [] and m2.flips == {"net.layer": 4}

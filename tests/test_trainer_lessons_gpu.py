@@ -345,6 +345,13 @@ def _tf_collect(kind, tag, names, got, ref32, ref64, bad, rows, skipped, fps=Non
 
 
 GATE_FORCED = [0]      # elements nudged by the gate-forcing passes (diagnostic)
+# Forcing passes per case. One: the flips the JUDGED run's matcher located (rounding-size margins by construction) are forced. More passes (each adds
+# what the previous forcing pass's own matcher located; HWG_TF_FORCING_PASSES) were tried in round 6: they bring tf_trained and tf_rimes to 33 / 33
+# groups, but a nudge upstream of the style path (the recogniser's gates on the real line feed the character-specific style extractor) moves the
+# generated image by ~1e-5, the discriminator then flips other gates, and on tf_full the second pass left `u1.auto+auto-gen grad discriminator`
+# 2.5e-4 out with every discriminator gate on the reference's branch - an interaction of the harness that was not understood, so the plain
+# single pass stays the judged one.
+FORCING_PASSES = int(os.environ.get("HWG_TF_FORCING_PASSES", "1") or 1)
 
 
 class _GateRecorder:
@@ -364,14 +371,18 @@ class _GateRecorder:
         self.matcher = None       # oracle.gates.Matcher over the REFERENCE's fp64 decisions of the current iteration (judged run only)
         self.force = {}           # gate forcing: feed sequence number of a gated tensor -> [(sample, index in the sample, fp64 margin, fp64 decision code)]
 
-    def _feed64(self, kind, t, live=None, geom=None, optional=False):
-        """the decisions of one gated tensor, in the reference's element order [sample][channel][spatial], to the fp64 matcher"""
+    def _feed64(self, kind, t, live=None, geom=None, optional=False, margin=None):
+        """the decisions of one gated tensor, in the reference's element order [sample][channel][spatial], to the fp64 matcher. margin: this side's
+        pre-activation (or a sign- and order-preserving image of it, e.g. a LeakyReLU output) for the hash-verified flip search (oracle/gates.py)"""
         if self.cur is None or self.matcher is None:
             return
         from oracle import gates
         N = t.shape[0]
         if kind == "act":
             dec = (t > 0).movedim(-1, 1).reshape(N, -1).to(torch.uint8).cpu().numpy()
+            if margin is not None:
+                self.matcher.feed(kind, dec, optional=optional, margin=margin.detach().movedim(-1, 1).reshape(N, -1).float().cpu().numpy())
+                return
         else:
             H, W, kh, kw, sh, sw, ph, pw, P, Q = geom
             idx = t.long()
@@ -379,7 +390,29 @@ class _GateRecorder:
             ow = (torch.arange(Q, device=t.device) * sw - pw).view(1, 1, Q, 1)
             winner = (idx // W - oh) * kw + (idx % W - ow)
             dec = torch.where(live, winner + 1, torch.zeros_like(winner)).movedim(-1, 1).reshape(N, -1).to(torch.uint8).cpu().numpy()
+            if margin is not None:          # (margin, alt) [N, P, Q, C] of this side's windows: see _pool_margins
+                mg, alt = margin
+                self.matcher.feed(kind, dec, optional=optional, margin=mg.movedim(-1, 1).reshape(N, -1).float().cpu().numpy(),
+                                  alt=alt.movedim(-1, 1).reshape(N, -1).to(torch.uint8).cpu().numpy())
+                return
         self.matcher.feed(kind, dec, optional=optional)
+
+    @staticmethod
+    def _pool_margins(x, kernel, stride, padding):
+        """per pool window of x [N, H, W, C]: how far the window's decision (position of the maximum + 1, or 0 = no positive maximum) is from the
+        nearest other one, and what that other decision is: the runner-up's position if the two largest are closer to each other than the largest
+        is to zero, else 0 / the present winner (liveness). -> (margin [N, P, Q, C], alt code [N, P, Q, C])"""
+        (kh, kw), (sh, sw), (ph, pw) = kernel, stride, padding
+        xp = torch.nn.functional.pad(x, (0, 0, pw, pw, ph, ph), value=float("-inf"))
+        win = xp.unfold(1, kh, sh).unfold(2, kw, sw)                      # [N, P, Q, C, kh, kw]
+        flat = win.reshape(*win.shape[:4], kh * kw)
+        top, pos = flat.topk(2, dim=-1)
+        gap, zero = top[..., 0] - top[..., 1], top[..., 0].abs()
+        live = top[..., 0] > 0
+        tie = gap < zero
+        alt = torch.where(tie, torch.where(top[..., 1] > 0, pos[..., 1] + 1, torch.zeros_like(pos[..., 1])),
+                          torch.where(live, torch.zeros_like(pos[..., 0]), pos[..., 0] + 1))
+        return torch.where(tie, gap, zero), alt
 
     def _put(self, kind, a, live=None):
         if self.cur is None:
@@ -449,7 +482,24 @@ class _GateRecorder:
                     y = f(ctx, *a)
                 if gated:
                     rec._put("act", y > 0)
-                    rec._feed64("act", y)
+                    pre = None
+                    if rec.matcher is not None:          # this side's pre-activation, for the flip search of the fp64 matcher
+                        N_, C_ = a[0].shape[0], a[0].shape[-1]
+                        bc = lambda v: None if v is None else (v.view(N_, *([1] * (a[0].dim() - 2)), C_) if v.dim() == 2 else v)      # noqa: E731
+                        if cls is ops._BiasAct:
+                            pre = a[0] if a[1] is None else a[0] + a[1]
+                            if a[2] is not None:
+                                pre = pre * bc(a[2])
+                        else:
+                            saved = ctx.to_save if hasattr(ctx, "to_save") else ctx.saved_tensors
+                            pre = (a[0] - bc(saved[4])) * bc(saved[5])
+                            if a[1] is not None:
+                                pre = pre * bc(a[1])
+                            if a[2] is not None:
+                                pre = pre + bc(a[2])
+                            if a[6] is not None:
+                                pre = pre * bc(a[6])
+                    rec._feed64("act", y, margin=pre)
                 return y
             return staticmethod(fwd)
 
@@ -479,8 +529,9 @@ class _GateRecorder:
             rec._put("pool", idx.clone(), y > 0)
             # the recogniser applies its ReLU behind the pool (relu(max) == max(relu)): the sign map the reference's ReLU in FRONT of the pool
             # saw is the sign of the pool's input (optional: where a ReLU already ran in front of the pool this is a second look at its record)
-            rec._feed64("act", x, optional=True)
-            rec._feed64("pool", idx, live=y > 0, geom=(H, W, kh, kw, sh, sw, ph, pw, y.shape[1], y.shape[2]))
+            rec._feed64("act", x, optional=True, margin=x)
+            rec._feed64("pool", idx, live=y > 0, geom=(H, W, kh, kw, sh, sw, ph, pw, y.shape[1], y.shape[2]),
+                        margin=rec._pool_margins(x, a[1], a[2], a[3]) if rec.matcher is not None else None)
             return y
 
         def fwd_adain(ctx, *a):
@@ -490,14 +541,14 @@ class _GateRecorder:
             y = rec.saved[ops._AdaIN](ctx, *a)
             u = (ctx.to_save if hasattr(ctx, "to_save") else ctx.saved_tensors)[0]
             rec._put("act", u > 0)
-            rec._feed64("act", u)
+            rec._feed64("act", u, margin=u)                      # (LeakyReLU output: sign and order of the pre-activation)
             return y
 
         def fwd_chain(ctx, *a):
             y = rec.saved[ops._MLPChain](ctx, *a)
             acts = (ctx.to_save if hasattr(ctx, "to_save") else ctx.saved_tensors)[0]
             for l in range(1, acts.shape[0]):
-                rec._feed64("act", acts[l])
+                rec._feed64("act", acts[l], margin=acts[l])
             return y
 
         def fwd_ggn(ctx, *a):
@@ -514,7 +565,7 @@ class _GateRecorder:
             if gated:
                 pre = x if mask is None else x * mask.view(x.shape[0], 1, 1, x.shape[3])
                 rec._put("act", pre > 0)
-                rec._feed64("act", pre)
+                rec._feed64("act", pre, margin=pre)
             return y
         ops._ActAvgPool.forward = staticmethod(fwd_actpool)
         ops._BiasAct.forward = wrap_act(ops._BiasAct, 3)
@@ -619,8 +670,25 @@ def test_lessons_teacher_forced(cuda, tmp_path, case):
         ref_gates = gate_records.load(gpath)          # the reference's fp64 decisions per iteration ("unit:position"), tools/gen_golden_tf.py
         flips64 = {}          # tag -> {"iter": {network: HIP-vs-fp64 flips in this iteration}, "unit": the same summed over the unit so far, ...}
         forced = ([], [], {})
+        left_layers, searched = {}, [0]        # tag -> gates still differing in the forced run; flips located by the block-hash search (judged run)
+        forced_passes = [0]
+        added_log = []
+        forced_history = []      # rows of the forcing passes before the last one
         force_map, flips64_forced = {}, {}     # tag -> {feed sequence number: sites} found by the judged run; tag -> flips left in the forced run
-        for variant in ("alt", "judged", "forced"):
+        new_sites = 0
+        for pass_no, variant in enumerate(("alt", "judged") + ("forced",) * FORCING_PASSES):
+            if variant == "forced":
+                # up to three forcing passes: a nudge of 1e-5 moves the values behind it by more than rounding, so a forced pass has a few flips of
+                # its own; what its matcher locates is added to the force map and the pass is repeated (the LAST pass is the one that is judged)
+                if pass_no > 2 and new_sites == 0:
+                    break
+                if forced[1]:
+                    forced_history.append(forced[1])
+                forced = ([], [], {})
+                flips64_forced.clear(); left_layers.clear()
+                GATE_FORCED[0] = 0
+                new_sites = 0
+                forced_passes[0] += 1
             # "alt": the same units on another valid schedule of the same kernels (ALT_TUNING) - only its fingerprints are kept, as the
             # yardstick of how far two correct fp32 evaluations of THIS implementation are apart (see SELF_SLACK)
             # "forced": the judged schedule once more with every LOCATED flip (near-zero pre-activations, near-tie pool windows of the reference's
@@ -657,6 +725,15 @@ def test_lessons_teacher_forced(cuda, tmp_path, case):
                         gates.force = {}
                         if m64 is not None and variant == "forced":
                             flips64_forced[tag] = m64.flips_by_network()
+                            left_layers[tag] = {k: v for k, v in m64.flips.items() if v}
+                            fm = force_map.setdefault(tag, {})
+                            for name_, seq_, n_, idx_, v_, code_ in m64.sites:          # flips of THIS pass that can be located: forced in the next one
+                                if not any(s_[0] == n_ and s_[1] == idx_ for s_ in fm.get(seq_, ())):
+                                    fm.setdefault(seq_, []).append((n_, idx_, v_, code_))
+                                    new_sites += 1
+                                    added_log.append("pass %d %s %s seq %d sample %d idx %d margin %+.2e code %d" % (forced_passes[0], tag, name_, seq_, n_, idx_, v_, code_))
+                        if m64 is not None and variant == "judged":
+                            searched[0] += getattr(m64, "searched", 0)
                         if m64 is not None and variant == "judged":
                             fm = force_map.setdefault(tag, {})
                             for name_, seq_, n_, idx_, v_, code_ in m64.sites:
@@ -748,6 +825,12 @@ def test_lessons_teacher_forced(cuda, tmp_path, case):
                 left = sum(c for net, c in forced_unit.get(key[0], {}).items() if net in gate_records.DOWNSTREAM.get(key[2], ()))
                 collapsed += int(rms_f <= bound)
                 note = "   forced: %.2e%s, %d flips left" % (rms_f, " (within the bound)" if rms_f <= bound else "", left)
+                if forced_history:
+                    earlier = []
+                    for rows_ in forced_history:
+                        e_ = [r_[4] for r_ in rows_ if (r_[0], r_[1], r_[2]) == key]
+                        earlier.append("%.2e" % math.sqrt(sum(v * v for v in e_) / max(len(e_), 1)))
+                    note += " (earlier forcing passes: %s)" % ", ".join(earlier)
                 if left == 0 and rms_f > bound:
                     bad.append("%s %s %s: every gate downstream of the group is on the reference's fp64 branch in the forced run, yet the group is %.2e from "
                                "fp64 (bound %.2e): the excess is not a gate flip" % (key[0], key[1], key[2], rms_f, bound))
@@ -799,6 +882,11 @@ def test_lessons_teacher_forced(cuda, tmp_path, case):
         excl.append("   gate forcing: %d element(s) nudged by 1e-5 onto the reference's fp64 side of their gate in a third pass; %d of the %d flip-labelled groups are within "
                     "their arithmetic bound there (a group with flips LEFT keeps gates the near-zero / near-tie lists of the record could not locate)" % (
                         GATE_FORCED[0], collapsed, flips))
+        excl.extend("      added by a forcing pass: " + l_ for l_ in added_log)
+        excl.append("   forcing passes: %d (each adds the flips its own matcher located); located beyond the record's near-zero lists by the block-hash search "
+                    "of the judged run (oracle/gates.py Matcher._search_blocks): %d; gates still off the "
+                    "reference's branch in the last forced pass: %s" % (forced_passes[0], searched[0], "; ".join("%s %s" % (t_, ", ".join("%s %d" % kv for kv in sorted(l_.items())))
+                                                                                        for t_, l_ in left_layers.items() if l_) or "none"))
         excl.append("   HIP-vs-fp64 decisions (the judged run against the reference's fp64 record, tests/golden/%s_gates.npz), per iteration and network; in brackets "
                     "what the reference's OWN fp32 run flips against its fp64 run:" % case)
         for tag_, f in flips64.items():
